@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the CoDA hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload sa|model]
+
+A "step" is one forward+backward pass of the hot path over one batch of 8
+synthetic SUN-RGBD-shaped scenes (20 000 points) per GPU, inputs resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0 (see the task contract):
+scenes/s over all ranks, plus
+
+* ``roofline``     for the ball_query(+group) kernel: algorithmic bytes
+                   (3 126 016 B/scene) / its average launch duration,
+                   measured live with HIP events on the launch stream inside the
+                   timed region; ``traffic`` comes from a separate rocprofv3 --pmc
+                   pass and is null here.
+* ``cpu_baseline`` the CPU oracle port (C ops + torch-CPU layers) on the host
+                   cores, bounded sample, rank 0 at N=1 only.
+
+Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL); scenes
+shard data-parallel (weak scaling, 8 scenes per GPU); the only exchange is the
+DDP gradient all-reduce (+ SyncBatchNorm statistics), as in the reference
+(main.py:993-996).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from coda_neurips2023_amd.pointnet2 import _ext, pointnet2_modules  # noqa: E402
+from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402
+
+B_PER_GPU = 8
+N_POINTS = 20000
+M_CENTRES = 2048
+NSAMPLE = 64
+RADIUS = 0.2
+# ball_query 12N+12M+4MS, group (C=3) 4MS+12N+12MS, per scene
+BQ_GROUP_BYTES_PER_SCENE = (12 * N_POINTS + 12 * M_CENTRES + 4 * M_CENTRES * NSAMPLE) + \
+                           (4 * M_CENTRES * NSAMPLE + 12 * N_POINTS + 12 * M_CENTRES * NSAMPLE)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="auto", choices=["auto", "sa", "model"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def build_workload(kind, dev):
+    """Returns (module, step_fn(model, batch) -> loss, description, kind)."""
+    if kind == "auto":
+        try:
+            from coda_neurips2023_amd import model_3detr  # noqa: F401
+            kind = "model"
+        except ImportError:
+            kind = "sa"
+    if kind == "model":
+        from coda_neurips2023_amd.model_3detr import build_bench_model
+        return build_bench_model(dev)
+    torch.manual_seed(0)
+    mod = pointnet2_modules.PointnetSAModuleVotes(radius=RADIUS, nsample=NSAMPLE, npoint=M_CENTRES,
+                                                  mlp=[0, 64, 128, 256], normalize_xyz=True).to(dev)
+    mod.train()
+
+    def step(model, batch):
+        _, feat, _ = model(batch["point_clouds"])
+        return feat.square().mean()
+
+    desc = ("configs[1]: PointNet++ SA (FPS 20000->2048 + ball_query r=0.2 nsample=64 + group + "
+            "SharedMLP[3,64,128,256]+BN+ReLU + max-pool) fwd+bwd, batch=8/GPU, fp32")
+    return mod, step, desc, "sa"
+
+
+def cpu_baseline(kind):
+    """CPU oracle port of the same step on the host cores, bounded sample (1 scene)."""
+    from oracle import pointnet2_oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pc, _, _ = make_batch(1, N_POINTS, seed=4242)
+    torch.manual_seed(0)
+    mlp = pointnet2_modules.PointnetSAModuleVotes(radius=RADIUS, nsample=NSAMPLE, npoint=M_CENTRES,
+                                                  mlp=[0, 64, 128, 256], normalize_xyz=True).mlp_module
+    mlp.train()
+
+    def one():
+        inds = O.furthest_point_sampling(pc, M_CENTRES)
+        new = np.take_along_axis(pc, inds[..., None].astype(np.int64).repeat(3, -1), 1)
+        idx = O.ball_query(new, pc, RADIUS, NSAMPLE)
+        g = O.group_points(np.ascontiguousarray(pc.transpose(0, 2, 1)), idx)
+        g = (g - new.transpose(0, 2, 1)[..., None]) / np.float32(RADIUS)
+        feat = mlp(torch.from_numpy(g)).max(-1)[0]
+        feat.square().mean().backward()
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+        one()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(1.0 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x 1 scene (20000 pts): oracle C FPS+ball_query+group (OpenMP) + "
+                      f"torch-CPU SharedMLP fwd+bwd; SA stage only"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    mod, step_fn, desc, kind = build_workload(args.workload, dev)
+    model = mod
+    if world > 1:
+        # reference: SyncBatchNorm + DDP (main.py:993-996)
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(mod)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+
+    # synthetic inputs, resident in HBM before timing; a few distinct batches cycle
+    pool = []
+    for i in range(4):
+        pc, mn, mx = make_batch(B_PER_GPU, N_POINTS, seed=1234 + rank * 1000 + i)
+        pool.append({"point_clouds": torch.from_numpy(pc).to(dev),
+                     "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
+                     "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+
+    def one_step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = step_fn(model, pool[i % len(pool)])
+        loss.backward()
+        opt.step()
+
+    for i in range(args.warmup):
+        one_step(i)
+
+    timing = _ext.enable_kernel_timing(["query_and_group_xyz", "ball_query", "furthest_point_sampling"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _ext.disable_kernel_timing()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def avg_ms(name):
+        ev = timing.get(name, [])
+        return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
+
+    if rank == 0:
+        bq_ms = avg_ms("query_and_group_xyz") or avg_ms("ball_query")
+        fps_ev = timing.get("furthest_point_sampling", [])
+        # two FPS calls per step in the model workload (20000->2048, 2048->nq): report the large one
+        fps_ms = max((s.elapsed_time(e) for s, e in fps_ev), default=None)
+        bytes_per_launch = BQ_GROUP_BYTES_PER_SCENE * B_PER_GPU
+        achieved = bytes_per_launch / (bq_ms * 1e-3) / 1e9 if bq_ms else None
+        out = {
+            "metric": "scenes/sec fwd+bwd (20k pts, 256 queries)",
+            "value": round(world * B_PER_GPU * args.steps / dt, 3),
+            "unit": "scenes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": N_POINTS,
+                       "parallelism": f"dp{world}", "optimizer": "AdamW (in timed region)"},
+            "roofline": {
+                "kernel": "ball_query_scan_kernel (fused ball_query + group xyz)",
+                "bound": "hbm",
+                "achieved": round(achieved, 3) if achieved else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                "traffic": None,
+                "bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
+            },
+            "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""ctypes loader for ``libcoda_hip.so`` (the C ABI in ``include/*.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C coda_neurips2023_amd/csrc`` and is the ONLY compute back end of this
+package.  Loading fails loudly; nothing falls back to PyTorch or the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoda_hip.so")
+
+CODA_OK = 0
+CODA_EINVAL = -1
+CODA_ENOSPC = -2
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/coda_pointnet2.h one to one.
+_P = _c_void_p
+SIGNATURES = {
+    "coda_version": (ctypes.c_char_p, []),
+    "coda_furthest_point_sampling_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "coda_furthest_point_sampling_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _P]),
+    "coda_gather_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_gather_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_ball_query_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "coda_ball_query_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _P, _c_size_t, _P]),
+    "coda_group_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_group_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_query_and_group_xyz_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _P, _c_size_t, _P]),
+    "coda_three_nn_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
+    "coda_three_interpolate_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_three_interpolate_grad_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+}
+
+_lib = None
+
+
+class CodaLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcoda_hip.so once and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CodaLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # stale build
+            raise CodaLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    """Turn a C-ABI status into a Python exception (the reference exit(-1)s)."""
+    if status == CODA_OK:
+        return
+    if status == CODA_EINVAL:
+        raise RuntimeError(f"{what}: invalid argument (CODA_EINVAL)")
+    if status == CODA_ENOSPC:
+        raise RuntimeError(f"{what}: workspace too small (CODA_ENOSPC)")
+    raise RuntimeError(f"{what}: HIP kernel launch failed (hipError_t={status})")

@@ -1,0 +1,305 @@
+// fps.hip -- furthest point sampling for gfx950 (MI355X).
+//
+// Replaces the reference's one-512-thread-block-per-scene CUDA kernel
+// (third_party_pointnet2/pointnet2/_ext_src/src/sampling_gpu.cu:72-232).
+//
+// Design (MI355X-first):
+//  * FPS is m-1 strictly dependent arg-max rounds; the bound is the latency of
+//    one round, not HBM.  One workgroup (up to 16 wave64s = one CU) owns a
+//    scene and keeps the WHOLE cloud plus the running min-distances in VGPRs
+//    (P points per thread) for all rounds: HBM is read once (12 N bytes/scene),
+//    written once (4 m bytes/scene).
+//  * One s_barrier per round: wave-level arg-max with DPP row shifts /
+//    row broadcasts on a 64-bit composite key, 16 wave results exchanged
+//    through a double-buffered LDS slot, re-reduced redundantly by every wave.
+//  * The composite key (dist bits, ~tie-rank, index) makes the arg-max
+//    independent of the reduction topology while reproducing the reference's
+//    tie-break exactly: the reference's 2^k-thread strided scan keeps the
+//    lowest k per thread (strict '>', :111-112) and its LDS tree keeps slot
+//    idx1 on ties (:60-68), so among equal distances the winner is the point
+//    with the smallest bit-reversed (k mod T), then the smallest k, where
+//    T = min(512, 2^floor(log2 N)) (include/cuda_utils.h:17-21).
+#include "common.hip.h"
+
+#include <cmath>
+
+namespace coda {
+namespace {
+
+// `(double)mag <= 1e-3` (sampling_gpu.cu:104) for a float mag is `mag <= T`
+// with T the largest float not above the double 0.001: 1e-3f rounds UP to
+// 0x3A83126F (0.00100000005), so T = 0x3A83126E.
+__device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
+  const float mag = sqdist3(x, y, z);
+  return mag <= __uint_as_float(0x3A83126Eu);
+}
+
+__device__ __forceinline__ uint32_t bitrev_low(uint32_t v, int bits) {
+  return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+// Tie rank of point k (smaller wins among equal distances).
+__device__ __forceinline__ uint32_t tie_rank(uint32_t k, int log2T) {
+  const uint32_t kmod = k & ((1u << log2T) - 1u);
+  return (bitrev_low(kmod, log2T) << 23) | (k >> log2T);
+}
+__device__ __forceinline__ uint32_t rank_to_index(uint32_t r, int log2T) {
+  const uint32_t kdiv = r & ((1u << 23) - 1u);
+  const uint32_t kmod = bitrev_low(r >> 23, log2T);
+  return (kdiv << log2T) | kmod;
+}
+
+// One DPP step of a 64-bit unsigned max: partner value comes from the lane
+// selected by CTRL; lanes without a valid partner see key 0 (the identity).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void kmax_step(uint32_t &hi, uint32_t &lo) {
+  const uint32_t ohi = __builtin_amdgcn_update_dpp(0u, hi, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t olo = __builtin_amdgcn_update_dpp(0u, lo, CTRL, ROW_MASK, 0xf, false);
+  const uint64_t mine = (static_cast<uint64_t>(hi) << 32) | lo;
+  const uint64_t other = (static_cast<uint64_t>(ohi) << 32) | olo;
+  if (other > mine) {
+    hi = ohi;
+    lo = olo;
+  }
+}
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
+              DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// Max over the 64 lanes; result valid in lane 63 and returned wave-uniform.
+__device__ __forceinline__ void wave_kmax(uint32_t &hi, uint32_t &lo) {
+  kmax_step<DPP_ROW_SHR1, 0xf>(hi, lo);
+  kmax_step<DPP_ROW_SHR2, 0xf>(hi, lo);
+  kmax_step<DPP_ROW_SHR4, 0xf>(hi, lo);
+  kmax_step<DPP_ROW_SHR8, 0xf>(hi, lo);
+  kmax_step<DPP_ROW_BCAST15, 0xa>(hi, lo);
+  kmax_step<DPP_ROW_BCAST31, 0xc>(hi, lo);
+  hi = __builtin_amdgcn_readlane(hi, 63);
+  lo = __builtin_amdgcn_readlane(lo, 63);
+}
+
+// Max over the first NW lanes of a 16-lane row (NW power of two <= 16);
+// returned wave-uniform.
+template <int NW>
+__device__ __forceinline__ void row_kmax(uint32_t &hi, uint32_t &lo) {
+  if (NW > 1) kmax_step<DPP_ROW_SHR1, 0xf>(hi, lo);
+  if (NW > 2) kmax_step<DPP_ROW_SHR2, 0xf>(hi, lo);
+  if (NW > 4) kmax_step<DPP_ROW_SHR4, 0xf>(hi, lo);
+  if (NW > 8) kmax_step<DPP_ROW_SHR8, 0xf>(hi, lo);
+  hi = __builtin_amdgcn_readlane(hi, NW - 1);
+  lo = __builtin_amdgcn_readlane(lo, NW - 1);
+}
+
+// Exchange the per-wave keys through LDS (slot parity = round parity; one
+// barrier per round is enough, see the header comment) and reduce them.
+template <int NW>
+__device__ __forceinline__ uint32_t block_argmax(uint32_t hi, uint32_t lo, uint2 (*s_key)[NW],
+                                                 int parity, int log2T) {
+  wave_kmax(hi, lo);
+  if (NW > 1) {
+    if (lane_id() == 0) s_key[parity][wave_id()] = make_uint2(hi, lo);
+    __syncthreads();
+    const uint2 kk = s_key[parity][lane_id() & (NW - 1)];
+    hi = kk.x;
+    lo = kk.y;
+    row_kmax<NW>(hi, lo);
+  }
+  // hi == 0: no thread saw a participating point -> reference yields besti = 0.
+  return hi == 0u ? 0u : rank_to_index(~lo, log2T);
+}
+
+// ---- register-resident kernel: P points per thread, THREADS per scene --------
+template <int P, int THREADS>
+__global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restrict__ xyz, int n,
+                                                          int m, int log2T,
+                                                          int32_t *__restrict__ idx) {
+  constexpr int NW = THREADS / kWave;
+  __shared__ uint2 s_key[2][NW];
+
+  const int tid = threadIdx.x;
+  const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
+  int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
+
+  float x[P], y[P], z[P], t[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int k = tid + i * THREADS;
+    if (k < n) {
+      x[i] = pts[k * 3 + 0];
+      y[i] = pts[k * 3 + 1];
+      z[i] = pts[k * 3 + 2];
+      // running min distance: 1e10 (sampling.cpp:75-77); -1 marks a point that
+      // never takes part (skip rule :103-104): fminf(d, -1) stays -1 and
+      // `-1 > best` is false for best >= -1.
+      t[i] = fps_skipped(x[i], y[i], z[i]) ? -1.0f : 1e10f;
+    } else {
+      x[i] = y[i] = z[i] = 0.0f;
+      t[i] = -1.0f;
+    }
+  }
+
+  if (tid == 0) out[0] = 0;  // :88-89
+  float cx = pts[0], cy = pts[1], cz = pts[2];
+
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;  // :94
+    int besti = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const float d = sqdist3(__fsub_rn(x[i], cx), __fsub_rn(y[i], cy), __fsub_rn(z[i], cz));
+      const float d2 = fminf(d, t[i]);  // :109
+      t[i] = d2;                        // :110
+      // strict '>' in ascending i: thread-local ties keep the lowest k, and
+      // all k of a thread share (k mod T) because T divides THREADS.
+      if (d2 > best) {
+        best = d2;
+        besti = i;
+      }
+    }
+    uint32_t hi = 0u, lo = 0u;
+    if (best >= 0.0f) {
+      hi = __float_as_uint(best) + 1u;  // non-negative floats order like uints
+      lo = ~tie_rank(static_cast<uint32_t>(tid + besti * THREADS), log2T);
+    }
+    const uint32_t old = block_argmax<NW>(hi, lo, s_key, j & 1, log2T);
+    if (tid == 0) out[j] = static_cast<int32_t>(old);  // :173-174
+    cx = pts[old * 3 + 0];  // wave-uniform address -> scalar loads
+    cy = pts[old * 3 + 1];
+    cz = pts[old * 3 + 2];
+  }
+}
+
+// ---- streaming fallback: any n; running distances in LDS or in workspace -------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fps_stream_kernel(const float *__restrict__ xyz, int n,
+                                                             int m, int log2T,
+                                                             float *__restrict__ temp_global,
+                                                             int32_t *__restrict__ idx) {
+  constexpr int NW = THREADS / kWave;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint2(*s_key)[NW] = reinterpret_cast<uint2(*)[NW]>(smem);
+  float *temp = temp_global ? temp_global + static_cast<size_t>(blockIdx.x) * n
+                            : reinterpret_cast<float *>(smem + sizeof(uint2) * 2 * NW);
+
+  const int tid = threadIdx.x;
+  const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
+  int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
+
+  for (int k = tid; k < n; k += THREADS)
+    temp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
+  if (tid == 0) out[0] = 0;
+  float cx = pts[0], cy = pts[1], cz = pts[2];
+
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;
+    int bestk = 0;
+    for (int k = tid; k < n; k += THREADS) {  // each thread only touches its own temp[k]
+      const float d = sqdist3(__fsub_rn(pts[k * 3 + 0], cx), __fsub_rn(pts[k * 3 + 1], cy),
+                              __fsub_rn(pts[k * 3 + 2], cz));
+      const float d2 = fminf(d, temp[k]);
+      temp[k] = d2;
+      if (d2 > best) {
+        best = d2;
+        bestk = k;
+      }
+    }
+    uint32_t hi = 0u, lo = 0u;
+    if (best >= 0.0f) {
+      hi = __float_as_uint(best) + 1u;
+      lo = ~tie_rank(static_cast<uint32_t>(bestk), log2T);
+    }
+    const uint32_t old = block_argmax<NW>(hi, lo, s_key, j & 1, log2T);
+    if (tid == 0) out[j] = static_cast<int32_t>(old);
+    cx = pts[old * 3 + 0];
+    cy = pts[old * 3 + 1];
+    cz = pts[old * 3 + 2];
+  }
+}
+
+template <int P, int THREADS>
+void launch_reg(const float *xyz, int b, int n, int m, int log2T, int32_t *idx, hipStream_t s) {
+  hipLaunchKernelGGL((fps_reg_kernel<P, THREADS>), dim3(b), dim3(THREADS), 0, s, xyz, n, m, log2T,
+                     idx);
+}
+
+// 256 threads serve the small clouds (query sampling, N <= 2048); 1024 threads
+// (16 waves = 4 per SIMD, 128 VGPRs each) hold up to 24 points per thread.
+bool dispatch_reg_small(int p, const float *xyz, int b, int n, int m, int log2T, int32_t *idx,
+                        hipStream_t s) {
+  if (p <= 1) launch_reg<1, 256>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 2) launch_reg<2, 256>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 4) launch_reg<4, 256>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 8) launch_reg<8, 256>(xyz, b, n, m, log2T, idx, s);
+  else return false;
+  return true;
+}
+
+bool dispatch_reg_large(int p, const float *xyz, int b, int n, int m, int log2T, int32_t *idx,
+                        hipStream_t s) {
+  if (p <= 4) launch_reg<4, 1024>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 8) launch_reg<8, 1024>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 12) launch_reg<12, 1024>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 16) launch_reg<16, 1024>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 20) launch_reg<20, 1024>(xyz, b, n, m, log2T, idx, s);
+  else if (p <= 24) launch_reg<24, 1024>(xyz, b, n, m, log2T, idx, s);
+  else return false;
+  return true;
+}
+
+// include/cuda_utils.h:17-21, evaluated exactly like the reference (double log).
+int reference_block_log2(int n) {
+  int pow_2 = static_cast<int>(std::log(static_cast<double>(n)) / std::log(2.0));
+  if (pow_2 > 9) pow_2 = 9;  // TOTAL_THREADS = 512
+  if (pow_2 < 0) pow_2 = 0;
+  return pow_2;
+}
+
+constexpr int kStreamThreads = 1024;
+constexpr size_t kLdsBudget = 160 * 1024;
+constexpr size_t kStreamKeyBytes = sizeof(uint2) * 2 * (kStreamThreads / kWave);
+
+}  // namespace
+}  // namespace coda
+
+CODA_API size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
+  (void)m;
+  if (b <= 0 || n <= 0) return 0;
+  const size_t lds_need = coda::kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
+  if (n <= 1024 * 24 || lds_need <= coda::kLdsBudget) return 0;
+  return sizeof(float) * static_cast<size_t>(b) * n;
+}
+
+CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m, int32_t *idx,
+                                              void *workspace, size_t workspace_bytes,
+                                              void *stream) {
+  using namespace coda;
+  if (b < 0 || n <= 0 || m < 0 || (b > 0 && (!xyz || (m > 0 && !idx)))) return CODA_EINVAL;
+  if (b == 0 || m == 0) return CODA_OK;  // sampling_gpu.cu:75
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int log2T = reference_block_log2(n);
+
+  bool done = false;
+  if (n <= 256 * 8) {
+    done = dispatch_reg_small(ceil_div(n, 256), xyz, b, n, m, log2T, idx, s);
+  } else if (n <= 1024 * 24) {
+    done = dispatch_reg_large(ceil_div(n, 1024), xyz, b, n, m, log2T, idx, s);
+  }
+  if (!done) {
+    const size_t lds_need = kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
+    auto kern = fps_stream_kernel<kStreamThreads>;
+    if (lds_need <= kLdsBudget) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds_need));
+      if (e != hipSuccess) return static_cast<int>(e);
+      hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), lds_need, s, xyz, n, m, log2T,
+                         static_cast<float *>(nullptr), idx);
+    } else {
+      if (!workspace || workspace_bytes < sizeof(float) * static_cast<size_t>(b) * n)
+        return CODA_ENOSPC;
+      hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), kStreamKeyBytes, s, xyz, n, m, log2T,
+                         static_cast<float *>(workspace), idx);
+    }
+  }
+  return launch_status();
+}

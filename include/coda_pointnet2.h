@@ -1,0 +1,132 @@
+/*
+ * coda_pointnet2.h -- C ABI of libcoda_hip.so, the MI355X (gfx950) point-cloud
+ * operators of the CoDA / 3DETR set-abstraction path.
+ *
+ * Each entry point replaces one function of the reference's pybind11 module
+ * `pointnet2._ext` (third_party_pointnet2/pointnet2/_ext_src/src/bindings.cpp:9-22);
+ * the per-function comments cite the reference C++ wrapper and CUDA kernel.
+ *
+ * Conventions
+ *  - Plain device pointers + sizes, no torch types.  All tensors are dense,
+ *    row-major ("contiguous"), float32 / int32, resident in HBM of the current
+ *    device.  Inputs are borrowed and never written.
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *    on that stream (no allocation, no synchronisation, graph-capture safe).
+ *  - Outputs are fully written by the call (the reference relies on
+ *    torch::zeros pre-fill; here the kernels write the fill values themselves),
+ *    so callers may pass uninitialised memory.
+ *  - Return value: 0 on success; a positive hipError_t if the launch failed;
+ *    CODA_EINVAL (-1) for invalid arguments, CODA_ENOSPC (-2) if `workspace`
+ *    is too small.  (The reference prints and exit(-1)s on launch failure,
+ *    include/cuda_utils.h:32-41; the binding raises instead.)
+ *  - Re-entrant and thread-safe: no global mutable state.
+ *
+ * Arithmetic contract (parity): distances are evaluated in fp32, source order
+ * of the reference expression, one rounding per operation, no FMA contraction:
+ *   d2 = ((dx*dx + dy*dy) + dz*dz).
+ */
+#ifndef CODA_POINTNET2_H
+#define CODA_POINTNET2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODA_OK 0
+#define CODA_EINVAL (-1)
+#define CODA_ENOSPC (-2)
+
+/* Library identification: returns "coda_hip gfx950 <abi-version>". */
+const char *coda_version(void);
+
+/* ---- furthest_point_sampling ------------------------------------------------
+ * Replaces furthest_point_sampling(points (B,N,3) f32, nsamples) -> (B,m) i32
+ *   wrapper  src/sampling.cpp:67-88, kernel src/sampling_gpu.cu:72-232.
+ * Semantics kept bit-exactly (given the arithmetic contract):
+ *   start at index 0; points with x*x+y*y+z*z <= 1e-3 (double literal) never
+ *   take part; running min distance starts at 1e10; arg-max ties resolve like
+ *   the reference's 2^k-thread strided scan + LDS tree:  smallest
+ *   bit-reversed (k mod T) first, then smallest k, with
+ *   T = min(512, 2^floor(log2 N))  (include/cuda_utils.h:17-21).
+ * The running distances live in registers (N <= 24576) or LDS (N <= ~40000);
+ * only larger clouds need `workspace` (B*N floats, the reference's `tmp`
+ * tensor, sampling.cpp:75-77): coda_..._workspace_bytes() returns 0 otherwise
+ * and NULL/0 may be passed.                                               */
+size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m);
+int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
+                                     int32_t *idx, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
+/* ---- gather_points / gather_points_grad --------------------------------------
+ * out[b,c,j] = points[b,c,idx[b,j]]            src/sampling_gpu.cu:11-33
+ * grad_points[b,c,idx[b,j]] += grad_out[b,c,j] src/sampling_gpu.cu:37-60
+ * (grad_points (B,C,N) is zeroed by the call; fp32 atomics, so the summation
+ *  order for repeated indices is unspecified, as in the reference).         */
+int coda_gather_points_f32(const float *points, const int32_t *idx, float *out,
+                           int b, int c, int n, int m, void *stream);
+int coda_gather_points_grad_f32(const float *grad_out, const int32_t *idx,
+                                float *grad_points, int b, int c, int n, int m,
+                                void *stream);
+
+/* ---- ball_query ---------------------------------------------------------------
+ * Replaces ball_query(new_xyz (B,M,3), xyz (B,N,3), radius, nsample) -> (B,M,S) i32
+ *   wrapper src/ball_query.cpp:11-35, kernel src/ball_query_gpu.cu:12-57.
+ * Row j = the nsample smallest point indices k (ascending) with
+ * d2(new_xyz[j], xyz[k]) < radius*radius (strict, fp32), padded with the first
+ * hit; all zeros when the ball is empty.
+ * `workspace` (device, >= coda_ball_query_workspace_bytes) holds the per-scene
+ * uniform grid of the cell-binned search; pass NULL/0 to force the brute-force
+ * scan.                                                                      */
+size_t coda_ball_query_workspace_bytes(int b, int n, int m, int nsample);
+int coda_ball_query_f32(const float *new_xyz, const float *xyz, int32_t *idx,
+                        int b, int n, int m, float radius, int nsample,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- group_points / group_points_grad ------------------------------------------
+ * out[b,c,j,k] = points[b,c,idx[b,j,k]]                 src/group_points_gpu.cu:11-42
+ * grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k]      src/group_points_gpu.cu:46-78
+ * (grad_points zeroed by the call; fp32 atomics -> order unspecified).      */
+int coda_group_points_f32(const float *points, const int32_t *idx, float *out,
+                          int b, int c, int n, int npoints, int nsample,
+                          void *stream);
+int coda_group_points_grad_f32(const float *grad_out, const int32_t *idx,
+                               float *grad_points, int b, int c, int n,
+                               int npoints, int nsample, void *stream);
+
+/* ---- query_and_group_xyz (fused QueryAndGroup, xyz branch) ---------------------
+ * Fuses ball_query + grouping of the coordinates + centring (+ optional 1/radius
+ * normalisation) of QueryAndGroup.forward (pointnet2_utils.py:331-349):
+ *   idx          (B,M,S) i32   as coda_ball_query_f32
+ *   grouped_xyz  (B,3,M,S) f32 = (xyz[idx] - new_xyz[j]) [/ radius if normalize]
+ * The subtraction and the division are the same two fp32 operations the
+ * reference performs with torch (`-=` then `/=`).                           */
+int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz,
+                                 int32_t *idx, float *grouped_xyz, int b, int n,
+                                 int m, float radius, int nsample, int normalize,
+                                 void *workspace, size_t workspace_bytes,
+                                 void *stream);
+
+/* ---- three_nn / three_interpolate / three_interpolate_grad ---------------------
+ * three_nn: 3 nearest `known` (B,m,3) of each `unknown` (B,n,3); strict `<`
+ *   insertion in ascending k (ties -> lowest k); writes squared distances
+ *   dist2 (B,n,3) and idx (B,n,3).            src/interpolate_gpu.cu:12-71
+ * three_interpolate: out[b,c,j] = (p[i1]*w1 + p[i2]*w2) + p[i3]*w3
+ *                                             src/interpolate_gpu.cu:75-115
+ * three_interpolate_grad: scatter-add of grad_out*w into zeroed (B,C,m)
+ *                                             src/interpolate_gpu.cu:119-158 */
+int coda_three_nn_f32(const float *unknown, const float *known, float *dist2,
+                      int32_t *idx, int b, int n, int m, void *stream);
+int coda_three_interpolate_f32(const float *points, const int32_t *idx,
+                               const float *weight, float *out, int b, int c,
+                               int m, int n, void *stream);
+int coda_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
+                                    const float *weight, float *grad_points,
+                                    int b, int c, int n, int m, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODA_POINTNET2_H */

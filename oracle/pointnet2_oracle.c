@@ -1,0 +1,272 @@
+/*
+ * pointnet2_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, fp32, scalar) of the nine pointnet2 operators of
+ * the reference's `pointnet2._ext` module.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the shipped path
+ * (coda_neurips2023_amd/csrc, libcoda_hip.so) never links or calls it.
+ *
+ * The reference implements these operators ONLY as CUDA kernels
+ * (`AT_ASSERT(false, "CPU not supported")` in every C++ wrapper, e.g.
+ * third_party_pointnet2/pointnet2/_ext_src/src/ball_query.cpp:30-32) and there
+ * is no nvcc in this image, so the reference binary cannot be run here:
+ * bit-level parity against the CUDA binary is UNPINNED.  What is pinned is the
+ * semantics of the .cu sources, restated here statement by statement, and the
+ * known-answer inputs of the reference's own test (pointnet2_test.py:15-30).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * third_party_pointnet2/pointnet2/_ext_src/).
+ *
+ * Floating point: the canonical arithmetic is source order, one rounding per
+ * operation (build with -ffp-contract=off).  The reference is built by nvcc
+ * with the default -fmad=true (setup.py:22-25 passes no flag), whose
+ * contraction of `a*a + b*b + c*c` is not recoverable without nvcc;
+ * `fma_mode` selects the two plausible contractions for sensitivity studies:
+ *   0  none (canonical):        (a*a + b*b) + c*c
+ *   1  fma(c,c, fma(a,a, b*b))  (LLVM DAGCombiner order)
+ *   2  fma(c,c, fma(b,b, a*a))
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+static int g_fma_mode = 0;
+
+ORACLE_API void oracle_set_fma_mode(int mode) { g_fma_mode = mode; }
+ORACLE_API int oracle_get_fma_mode(void) { return g_fma_mode; }
+
+/* a*a' + b*b' + c*c' in the selected rounding order. */
+static inline float dot3(float a, float a2, float b, float b2, float c, float c2) {
+  switch (g_fma_mode) {
+    case 1:
+      return fmaf(c, c2, fmaf(a, a2, b * b2));
+    case 2:
+      return fmaf(c, c2, fmaf(b, b2, a * a2));
+    default: /* -ffp-contract=off: one rounding per operation, source order */
+      return (a * a2 + b * b2) + c * c2;
+  }
+}
+
+/* include/cuda_utils.h:17-21 -- largest power of two <= work_size, capped 512 */
+ORACLE_API int oracle_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 512) t = 512;
+  if (t < 1) t = 1;
+  return t;
+}
+
+/* ------------------------------------------------------------------------- */
+/* furthest_point_sampling: src/sampling_gpu.cu:72-176 (kernel),             */
+/* src/sampling.cpp:67-88 (zero-filled idxs, temp filled with 1e10).         */
+/* Literal emulation of the block: `bs` threads, strided scan, LDS tree.     */
+/* ------------------------------------------------------------------------- */
+static void fps_one(const float *dataset, int n, int m, float *temp, int32_t *idxs,
+                    int bs, float *dists, int *dists_i) {
+  if (m <= 0) return;                                   /* :75  */
+  int old = 0;                                          /* :88  */
+  idxs[0] = old;                                        /* :89  */
+  for (int j = 1; j < m; j++) {                         /* :92  */
+    float x1 = dataset[old * 3 + 0];
+    float y1 = dataset[old * 3 + 1];
+    float z1 = dataset[old * 3 + 2];
+    /* Per-thread strided scan (:93-115).  Thread `tid` owns k = tid, tid+bs, ...
+     * in ascending order; iterating k-major with tid = k mod bs visits every
+     * thread's points in that same order (bs is a power of two). */
+    for (int tid = 0; tid < bs; tid++) {
+      dists[tid] = -1;                                  /* best  :94 */
+      dists_i[tid] = 0;                                 /* besti :93 */
+    }
+    for (int k = 0; k < n; k++) {                       /* :98  */
+      const int tid = k & (bs - 1);
+      float x2 = dataset[k * 3 + 0];
+      float y2 = dataset[k * 3 + 1];
+      float z2 = dataset[k * 3 + 2];
+      float mag = dot3(x2, x2, y2, y2, z2, z2);         /* :103 */
+      if ((double)mag <= 1e-3) continue;                /* :104 float vs double literal */
+      float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+      float d = dot3(dx, dx, dy, dy, dz, dz);           /* :106-107 */
+      float d2 = fminf(d, temp[k]);                     /* :109 */
+      temp[k] = d2;                                     /* :110 */
+      if (d2 > dists[tid]) {                            /* :111-112 */
+        dists_i[tid] = k;
+        dists[tid] = d2;
+      }
+    }
+    /* :118-171 -- tree reduction, __update (:60-68) keeps slot idx1 on ties */
+    for (int s = bs / 2; s >= 1; s >>= 1) {
+      for (int tid = 0; tid < s; tid++) {
+        const float v1 = dists[tid], v2 = dists[tid + s];
+        const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+        dists[tid] = v1 > v2 ? v1 : v2;                 /* max(v1, v2) */
+        dists_i[tid] = v2 > v1 ? i2 : i1;
+      }
+    }
+    old = dists_i[0];                                   /* :173 */
+    idxs[j] = old;                                      /* :174 */
+  }
+}
+
+ORACLE_API void oracle_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                               int32_t *idxs) {
+  const int bs = oracle_opt_n_threads(n);               /* :181 */
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < b; i++) {
+    float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    float dists[512];
+    int dists_i[512];
+    for (int k = 0; k < n; k++) temp[k] = 1e10f;        /* sampling.cpp:75-77 */
+    memset(idxs + (size_t)i * m, 0, sizeof(int32_t) * (size_t)m); /* torch::zeros :71 */
+    fps_one(dataset + (size_t)i * n * 3, n, m, temp, idxs + (size_t)i * m, bs, dists, dists_i);
+    free(temp);
+  }
+}
+
+/* gather_points: src/sampling_gpu.cu:11-23 */
+ORACLE_API void oracle_gather_points(int b, int c, int n, int m, const float *points,
+                                     const int32_t *idx, float *out) {
+  for (int i = 0; i < b; i++)
+    for (int l = 0; l < c; l++)
+      for (int j = 0; j < m; j++) {
+        int a = idx[i * m + j];
+        out[((size_t)i * c + l) * m + j] = points[((size_t)i * c + l) * n + a];
+      }
+}
+
+/* gather_points_grad: src/sampling_gpu.cu:37-50 (atomicAdd -> serial j order here) */
+ORACLE_API void oracle_gather_points_grad(int b, int c, int n, int m, const float *grad_out,
+                                          const int32_t *idx, float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * n); /* sampling.cpp:52-54 */
+  for (int i = 0; i < b; i++)
+    for (int l = 0; l < c; l++)
+      for (int j = 0; j < m; j++) {
+        int a = idx[i * m + j];
+        grad_points[((size_t)i * c + l) * n + a] += grad_out[((size_t)i * c + l) * m + j];
+      }
+}
+
+/* ball_query: src/ball_query_gpu.cu:12-47; zero-filled idx ball_query.cpp:20-22 */
+ORACLE_API void oracle_ball_query(int b, int n, int m, float radius, int nsample,
+                                  const float *new_xyz, const float *xyz, int32_t *idx) {
+  memset(idx, 0, sizeof(int32_t) * (size_t)b * m * nsample);
+  const float radius2 = radius * radius;                /* :25 */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; bi++) {
+    for (int j = 0; j < m; j++) {                       /* :26 */
+      const float *X = xyz + (size_t)bi * n * 3;
+      int32_t *row = idx + ((size_t)bi * m + j) * nsample;
+      float new_x = new_xyz[((size_t)bi * m + j) * 3 + 0];
+      float new_y = new_xyz[((size_t)bi * m + j) * 3 + 1];
+      float new_z = new_xyz[((size_t)bi * m + j) * 3 + 2];
+      for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) { /* :30 */
+        float dx = new_x - X[k * 3 + 0];
+        float dy = new_y - X[k * 3 + 1];
+        float dz = new_z - X[k * 3 + 2];
+        float d2 = dot3(dx, dx, dy, dy, dz, dz);        /* :34-35 */
+        if (d2 < radius2) {                             /* :36 */
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) row[l] = k; /* :37-41 */
+          row[cnt] = k;                                 /* :42 */
+          ++cnt;
+        }
+      }
+    }
+  }
+}
+
+/* group_points: src/group_points_gpu.cu:11-31 */
+ORACLE_API void oracle_group_points(int b, int c, int n, int npoints, int nsample,
+                                    const float *points, const int32_t *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; bi++)
+    for (int l = 0; l < c; l++)
+      for (int j = 0; j < npoints; j++)
+        for (int k = 0; k < nsample; k++) {
+          int ii = idx[((size_t)bi * npoints + j) * nsample + k];
+          out[(((size_t)bi * c + l) * npoints + j) * nsample + k] =
+              points[((size_t)bi * c + l) * n + ii];
+        }
+}
+
+/* group_points_grad: src/group_points_gpu.cu:46-67 (atomicAdd -> serial (j,k) order) */
+ORACLE_API void oracle_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                         const float *grad_out, const int32_t *idx,
+                                         float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * n); /* group_points.cpp:50-52 */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; bi++)
+    for (int l = 0; l < c; l++)
+      for (int j = 0; j < npoints; j++)
+        for (int k = 0; k < nsample; k++) {
+          int ii = idx[((size_t)bi * npoints + j) * nsample + k];
+          grad_points[((size_t)bi * c + l) * n + ii] +=
+              grad_out[(((size_t)bi * c + l) * npoints + j) * nsample + k];
+        }
+}
+
+/* three_nn: src/interpolate_gpu.cu:12-62 (double running bests initialised 1e40) */
+ORACLE_API void oracle_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                                float *dist2, int32_t *idx) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; bi++)
+    for (int j = 0; j < n; j++) {
+      const float *U = unknown + ((size_t)bi * n + j) * 3;
+      const float *K = known + (size_t)bi * m * 3;
+      float ux = U[0], uy = U[1], uz = U[2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;  /* :30 */
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float dx = ux - K[k * 3 + 0], dy = uy - K[k * 3 + 1], dz = uz - K[k * 3 + 2];
+        float d = dot3(dx, dx, dy, dy, dz, dz);         /* :36 */
+        if (d < best1) {                                /* :37-52 */
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      float *D = dist2 + ((size_t)bi * n + j) * 3;
+      int32_t *I = idx + ((size_t)bi * n + j) * 3;
+      D[0] = (float)best1; D[1] = (float)best2; D[2] = (float)best3; /* :54-56 */
+      I[0] = besti1; I[1] = besti2; I[2] = besti3;                   /* :58-60 */
+    }
+}
+
+/* three_interpolate: src/interpolate_gpu.cu:75-104 */
+ORACLE_API void oracle_three_interpolate(int b, int c, int m, int n, const float *points,
+                                         const int32_t *idx, const float *weight, float *out) {
+  for (int bi = 0; bi < b; bi++)
+    for (int l = 0; l < c; l++)
+      for (int j = 0; j < n; j++) {
+        const float *W = weight + ((size_t)bi * n + j) * 3;
+        const int32_t *I = idx + ((size_t)bi * n + j) * 3;
+        const float *P = points + ((size_t)bi * c + l) * m;
+        out[((size_t)bi * c + l) * n + j] =
+            dot3(P[I[0]], W[0], P[I[1]], W[1], P[I[2]], W[2]); /* :101-102 */
+      }
+}
+
+/* three_interpolate_grad: src/interpolate_gpu.cu:119-146 (atomicAdd -> serial j order) */
+ORACLE_API void oracle_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                              const int32_t *idx, const float *weight,
+                                              float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * m); /* interpolate.cpp:86-88 */
+  for (int bi = 0; bi < b; bi++)
+    for (int l = 0; l < c; l++)
+      for (int j = 0; j < n; j++) {
+        const float *W = weight + ((size_t)bi * n + j) * 3;
+        const int32_t *I = idx + ((size_t)bi * n + j) * 3;
+        float g = grad_out[((size_t)bi * c + l) * n + j];
+        float *G = grad_points + ((size_t)bi * c + l) * m;
+        G[I[0]] += g * W[0];                            /* :142-144 */
+        G[I[1]] += g * W[1];
+        G[I[2]] += g * W[2];
+      }
+}

@@ -1,0 +1,249 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI
+(coda_neurips2023_amd.pointnet2._ext -> libcoda_hip.so), against the CPU oracle
+on the same seeded inputs, against the golden fixtures generated from the
+reference's Python layers, and at the full BASELINE sizes.
+
+Bar: bit-exact for indices and pure gathers; fp32 sums that go through atomics
+(order unspecified, as in the reference) within 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from coda_neurips2023_amd.pointnet2 import _ext, pointnet2_utils
+from coda_neurips2023_amd.synthetic_scenes import make_batch, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def sample_centres(pc, fps_idx):
+    return np.take_along_axis(pc, fps_idx[..., None].astype(np.int64).repeat(3, -1), 1)
+
+
+# ---------------------------------------------------------------------------- FPS
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 9, 2), (1, 2, 5), (3, 63, 17), (2, 64, 64),
+                                   (2, 65, 30), (2, 300, 40), (1, 511, 64), (2, 512, 100),
+                                   (2, 1024, 128), (2, 2048, 256), (1, 2049, 33), (2, 5000, 200),
+                                   (1, 12345, 300)])
+def test_fps_matches_oracle(dev, oracle, b, n, m):
+    rng = np.random.default_rng(n * 31 + m)
+    x = (rng.standard_normal((b, n, 3)) * 1.5).astype(np.float32)
+    got = _ext.furthest_point_sampling(cu(x, dev), m).cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (b, m)
+    assert np.array_equal(got, oracle.furthest_point_sampling(x, m))
+
+
+@pytest.mark.parametrize("n", [700, 1200, 4000, 20000])
+def test_fps_tie_rule_with_duplicates(dev, oracle, n):
+    rng = np.random.default_rng(n)
+    base = (rng.random((50, 3), dtype=np.float32) * 3 + 1).astype(np.float32)
+    x = base[rng.integers(0, 50, (2, n))]
+    got = _ext.furthest_point_sampling(cu(x, dev), 80).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(x, 80))
+
+
+def test_fps_skip_rule(dev, oracle):
+    x = np.zeros((2, 10, 3), np.float32)
+    x[0, 3] = (0.03, 0, 0)
+    x[0, 7] = (0.04, 0, 0)
+    x[0, 5] = (np.sqrt(np.float32(1e-3)), 0, 0)
+    # scene 1: every point within the skip radius -> all zeros
+    got = _ext.furthest_point_sampling(cu(x, dev), 4).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(x, 4))
+    assert not got[1].any()
+
+
+def test_fps_short_scene_golden_and_synthetic(dev, oracle, golden_ops):
+    for tag in ["small", "mid"]:
+        xyz = golden_ops[f"{tag}_xyz"]
+        m = golden_ops[f"{tag}_fps"].shape[1]
+        got = _ext.furthest_point_sampling(cu(xyz, dev), m).cpu().numpy()
+        assert np.array_equal(got, golden_ops[f"{tag}_fps"])
+    pts = np.stack([make_scene(6000, seed=s, short_fraction=1.0) for s in (1, 2)])
+    got = _ext.furthest_point_sampling(cu(pts, dev), 512).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(pts, 512))
+
+
+@pytest.mark.parametrize("n,m", [(30000, 300), (50000, 200)])
+def test_fps_streaming_paths(dev, oracle, n, m):
+    """n > 24576: running distances in LDS (<= ~40000) or in the workspace."""
+    pc, _, _ = make_batch(2, n, seed=n)
+    got = _ext.furthest_point_sampling(cu(pc, dev), m).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(pc, m))
+
+
+def test_fps_full_size_bit_exact(dev, oracle):
+    """BASELINE shape: B=8, N=20000 -> 2048, then 2048 -> 256 (query sampling)."""
+    pc, _, _ = make_batch(8, 20000, seed=1234)
+    got = _ext.furthest_point_sampling(cu(pc, dev), 2048).cpu().numpy()
+    ref = oracle.furthest_point_sampling(pc, 2048)
+    assert np.array_equal(got, ref)
+    assert all(len(np.unique(r)) == 2048 for r in got)  # no duplicates in these scenes
+    enc_xyz = sample_centres(pc, got)
+    got2 = _ext.furthest_point_sampling(cu(enc_xyz, dev), 256).cpu().numpy()
+    assert np.array_equal(got2, oracle.furthest_point_sampling(enc_xyz, 256))
+
+
+# --------------------------------------------------------------------- ball query
+@pytest.mark.parametrize("b,n,m,r,s", [(1, 1, 1, 0.5, 1), (2, 9, 2, 5.0, 3), (2, 9, 2, 10.0, 6),
+                                       (2, 70, 5, 0.8, 4), (2, 1000, 37, 0.3, 16),
+                                       (2, 3000, 130, 0.25, 64), (1, 5000, 64, 0.4, 32),
+                                       (1, 2000, 40, 0.5, 200), (1, 600, 9, 10.0, 700),
+                                       (1, 300, 5, 10.0, 3000)])
+def test_ball_query_matches_oracle(dev, oracle, b, n, m, r, s):
+    if n >= 600:
+        pc, _, _ = make_batch(b, n, seed=n + s)
+    else:
+        pc = (np.random.default_rng(n).standard_normal((b, n, 3))).astype(np.float32)
+    new = pc[:, np.random.default_rng(m).integers(0, n, m)].copy()
+    new[:, 0] += 100.0  # an empty ball per scene -> all-zero row
+    got = _ext.ball_query(cu(new, dev), cu(pc, dev), r, s).cpu().numpy()
+    ref = oracle.ball_query(new, pc, r, s)
+    assert got.dtype == np.int32 and np.array_equal(got, ref)
+    assert not got[:, 0].any()
+
+
+def test_ball_query_golden(dev, golden_ops):
+    for tag in ["small", "mid"]:
+        got = _ext.ball_query(cu(golden_ops[f"{tag}_new_xyz"], dev), cu(golden_ops[f"{tag}_xyz"], dev),
+                              float(golden_ops[f"{tag}_radius"]), int(golden_ops[f"{tag}_nsample"]))
+        assert np.array_equal(got.cpu().numpy(), golden_ops[f"{tag}_ball_idx"])
+
+
+def test_ball_query_and_fused_group_full_size(dev, oracle):
+    """BASELINE shape: B=8, N=20000, M=2048, r=0.2, nsample=64 + fused grouping."""
+    pc, _, _ = make_batch(8, 20000, seed=1234)
+    fps = oracle.furthest_point_sampling(pc, 2048)
+    new = sample_centres(pc, fps)
+    d_pc, d_new = cu(pc, dev), cu(new, dev)
+    ref = oracle.ball_query(new, pc, 0.2, 64)
+    got = _ext.ball_query(d_new, d_pc, 0.2, 64)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    idx, grouped = _ext.query_and_group_xyz(d_new, d_pc, 0.2, 64, True)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    # properties: rows ascending up to the pad, the centre itself is always a member
+    r = idx.cpu().numpy()
+    assert (r[..., 0][..., None] <= r).all()
+    assert ((r == fps[..., None]).any(-1) | (np.diff(r, axis=-1) >= 0).all(-1)).all()
+    # grouped = (xyz[idx] - centre) * (1/0.2f) in fp32 (torch's GPU div-by-scalar)
+    exp = (np.take_along_axis(pc[:, None], r.reshape(8, -1, 1).astype(np.int64).repeat(3, -1)[:, None], 2)
+           .reshape(8, 2048, 64, 3) - new[:, :, None, :]) * (np.float32(1.0) / np.float32(0.2))
+    np.testing.assert_array_equal(grouped.cpu().numpy(), exp.transpose(0, 3, 1, 2))
+    assert np.abs(grouped.cpu().numpy()).max() < 1.0 + 1e-5  # inside the unit ball
+
+
+def test_fused_group_equals_unfused_sequence(dev):
+    pc, _, _ = make_batch(2, 4000, seed=3)
+    d_pc = cu(pc, dev)
+    d_new = d_pc[:, :300].contiguous()
+    for normalize in (False, True):
+        idx, grouped = _ext.query_and_group_xyz(d_new, d_pc, 0.3, 32, normalize)
+        idx2 = _ext.ball_query(d_new, d_pc, 0.3, 32)
+        g2 = _ext.group_points(d_pc.transpose(1, 2).contiguous(), idx2)
+        g2 = g2 - d_new.transpose(1, 2).unsqueeze(-1)
+        if normalize:
+            g2 = g2 * (1.0 / torch.tensor(0.3, dtype=torch.float32)).item()
+        assert torch.equal(idx, idx2)
+        torch.testing.assert_close(grouped, g2, rtol=2e-7, atol=0)
+
+
+# ------------------------------------------------------------ gathers / scatter-adds
+@pytest.mark.parametrize("b,c,n,m,s", [(1, 1, 1, 1, 1), (2, 3, 50, 7, 5), (2, 6, 1024, 128, 64),
+                                       (1, 19, 333, 21, 9), (2, 256, 2048, 64, 32)])
+def test_group_and_gather_exact(dev, oracle, b, c, n, m, s):
+    rng = np.random.default_rng(c * 7 + n)
+    pts = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, s)).astype(np.int32)
+    got = _ext.group_points(cu(pts, dev), cu(idx, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.group_points(pts, idx))
+    idx1 = rng.integers(0, n, (b, m)).astype(np.int32)
+    got = _ext.gather_points(cu(pts, dev), cu(idx1, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.gather_points(pts, idx1))
+
+
+@pytest.mark.parametrize("b,c,n,m,s", [(2, 3, 50, 7, 5), (2, 6, 1024, 128, 64), (1, 19, 333, 21, 9)])
+def test_scatter_add_grads(dev, oracle, b, c, n, m, s):
+    rng = np.random.default_rng(c + n)
+    idx = rng.integers(0, n, (b, m, s)).astype(np.int32)
+    go = rng.standard_normal((b, c, m, s)).astype(np.float32)
+    got = _ext.group_points_grad(cu(go, dev), cu(idx, dev), n).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.group_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+    idx1 = rng.integers(0, n, (b, m)).astype(np.int32)
+    go1 = rng.standard_normal((b, c, m)).astype(np.float32)
+    got = _ext.gather_points_grad(cu(go1, dev), cu(idx1, dev), n).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.gather_points_grad(go1, idx1, n), rtol=1e-5, atol=1e-5)
+    # unique indices -> no atomics collisions -> bit exact
+    perm = np.stack([rng.permutation(n)[:m] for _ in range(b)]).astype(np.int32)
+    got = _ext.gather_points_grad(cu(go1, dev), cu(perm, dev), n).cpu().numpy()
+    assert np.array_equal(got, oracle.gather_points_grad(go1, perm, n))
+
+
+# ----------------------------------------------------------- three_nn / interpolate
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 50, 2), (2, 50, 30), (2, 1024, 128), (1, 3000, 1500)])
+def test_three_nn_matches_oracle(dev, oracle, b, n, m):
+    rng = np.random.default_rng(n + m)
+    u = rng.random((b, n, 3), dtype=np.float32)
+    k = rng.random((b, m, 3), dtype=np.float32)
+    if m > 5:
+        k[:, 5] = k[:, 2]  # tie -> lower index first
+    d2, idx = _ext.three_nn(cu(u, dev), cu(k, dev))
+    rd2, ridx = oracle.three_nn(u, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)  # inf where m < 3
+
+
+def test_three_interpolate_known_answer_and_golden(dev, oracle, golden_ops):
+    g = golden_ops
+    out = _ext.three_interpolate(cu(g["kat_feats"], dev), cu(g["kat_idx"], dev), cu(g["kat_weight"], dev))
+    assert np.array_equal(out.cpu().numpy(), g["kat_interp"])
+    grad = _ext.three_interpolate_grad(torch.ones_like(out), cu(g["kat_idx"], dev), cu(g["kat_weight"], dev), 4)
+    assert np.array_equal(grad.cpu().numpy(), g["kat_grad"])
+    for tag in ["small", "mid"]:
+        out = _ext.three_interpolate(cu(g[f"{tag}_known_feats"], dev), cu(g[f"{tag}_nn_idx"], dev),
+                                     cu(g[f"{tag}_nn_weight"], dev))
+        assert np.array_equal(out.cpu().numpy(), g[f"{tag}_interp"])
+        m = g[f"{tag}_known_feats"].shape[2]
+        grad = _ext.three_interpolate_grad(cu(g[f"{tag}_interp_gw"], dev), cu(g[f"{tag}_nn_idx"], dev),
+                                           cu(g[f"{tag}_nn_weight"], dev), m)
+        np.testing.assert_allclose(grad.cpu().numpy(), g[f"{tag}_interp_grad"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------- autograd functions vs the reference
+def test_autograd_functions_against_reference_golden(dev, golden_ops):
+    g = golden_ops
+    for tag in ["small", "mid"]:
+        xyz = cu(g[f"{tag}_xyz"], dev)
+        feats = cu(g[f"{tag}_feats"], dev).requires_grad_(True)
+        m = g[f"{tag}_fps"].shape[1]
+        inds = pointnet2_utils.furthest_point_sample(xyz, m)
+        assert np.array_equal(inds.cpu().numpy(), g[f"{tag}_fps"])
+        new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        assert np.array_equal(new_xyz.cpu().numpy(), g[f"{tag}_new_xyz"])
+        idx = pointnet2_utils.ball_query(float(g[f"{tag}_radius"]), int(g[f"{tag}_nsample"]), xyz, new_xyz)
+        grouped = pointnet2_utils.grouping_operation(feats, idx)
+        assert np.array_equal(grouped.detach().cpu().numpy(), g[f"{tag}_grouped"])
+        (grouped * cu(g[f"{tag}_group_gw"], dev)).sum().backward()
+        np.testing.assert_allclose(feats.grad.cpu().numpy(), g[f"{tag}_group_grad"], rtol=1e-4, atol=1e-5)
+        feats.grad = None
+        gathered = pointnet2_utils.gather_operation(feats, inds)
+        assert np.array_equal(gathered.detach().cpu().numpy(), g[f"{tag}_gathered"])
+        (gathered * cu(g[f"{tag}_gather_gw"], dev)).sum().backward()
+        np.testing.assert_allclose(feats.grad.cpu().numpy(), g[f"{tag}_gather_grad"], rtol=1e-4, atol=1e-5)
+        dist, nn_idx = pointnet2_utils.three_nn(xyz, new_xyz)
+        assert np.array_equal(nn_idx.cpu().numpy(), g[f"{tag}_nn_idx"])
+        np.testing.assert_allclose(dist.cpu().numpy(), g[f"{tag}_nn_dist"], rtol=2.4e-7)
+        assert not inds.requires_grad and not idx.requires_grad
+
+
+def test_runs_on_non_default_stream(dev, oracle):
+    pc, _, _ = make_batch(2, 3000, seed=21)
+    d_pc = cu(pc, dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        got = _ext.furthest_point_sampling(d_pc, 128)
+    s.synchronize()
+    assert np.array_equal(got.cpu().numpy(), oracle.furthest_point_sampling(pc, 128))
