@@ -127,6 +127,7 @@ int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *gro
   const float r2 = radius * radius;  // ball_query_gpu.cu:25 (fp32 product)
   const float inv_radius = 1.0f / radius;
   dim3 grid(ceil_div(m, kBqWaves * C), b);
+  clear_sticky_error();
   hipLaunchKernelGGL(kern, grid, dim3(kBqWaves * kWave), lds, s, new_xyz, xyz, idx, grouped, n, m,
                      r2, inv_radius, nsample, normalize);
   return launch_status();

@@ -13,6 +13,11 @@ constexpr int kWave = 64;  // CDNA wavefront width (hard-coded: gfx950 only)
 
 // Launch-status helper: the C ABI returns hipError_t values instead of the
 // reference's print + exit(-1) (include/cuda_utils.h:32-41).
+// hipGetLastError() is sticky per thread: clear what earlier, unrelated runtime
+// calls (e.g. the framework's device probing) may have left behind before a
+// launch whose status is going to be reported.
+inline void clear_sticky_error() { (void)hipGetLastError(); }
+
 inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CODA_OK : static_cast<int>(e);

@@ -222,22 +222,26 @@ void launch_reg(const float *xyz, int b, int n, int m, int log2T, int32_t *idx, 
                      idx);
 }
 
-// 256 threads serve the small clouds (query sampling, N <= 2048); 1024 threads
-// (16 waves = 4 per SIMD, 128 VGPRs each) hold up to 24 points per thread.
-bool dispatch_reg_small(int p, const float *xyz, int b, int n, int m, int log2T, int32_t *idx,
-                        hipStream_t s) {
-  if (p <= 1) launch_reg<1, 256>(xyz, b, n, m, log2T, idx, s);
-  else if (p <= 2) launch_reg<2, 256>(xyz, b, n, m, log2T, idx, s);
-  else if (p <= 4) launch_reg<4, 256>(xyz, b, n, m, log2T, idx, s);
-  else if (p <= 8) launch_reg<8, 256>(xyz, b, n, m, log2T, idx, s);
-  else return false;
-  return true;
-}
-
-bool dispatch_reg_large(int p, const float *xyz, int b, int n, int m, int log2T, int32_t *idx,
-                        hipStream_t s) {
-  if (p <= 4) launch_reg<4, 1024>(xyz, b, n, m, log2T, idx, s);
-  else if (p <= 8) launch_reg<8, 1024>(xyz, b, n, m, log2T, idx, s);
+// The thread-local strict '>' scan is only rank-ordered when every point of a
+// thread shares (k mod T), i.e. when T divides THREADS: 256 threads for
+// n < 512 (T <= 256), 512 threads up to 4096 points, 1024 threads (16 waves =
+// 4 per SIMD, 128 VGPRs each) up to 24 points per thread.
+bool dispatch_reg(const float *xyz, int b, int n, int m, int log2T, int32_t *idx, hipStream_t s) {
+  if (n < 512) {
+    if (n <= 256) launch_reg<1, 256>(xyz, b, n, m, log2T, idx, s);
+    else launch_reg<2, 256>(xyz, b, n, m, log2T, idx, s);
+    return true;
+  }
+  if (n <= 4096) {
+    const int p = ceil_div(n, 512);
+    if (p <= 1) launch_reg<1, 512>(xyz, b, n, m, log2T, idx, s);
+    else if (p <= 2) launch_reg<2, 512>(xyz, b, n, m, log2T, idx, s);
+    else if (p <= 4) launch_reg<4, 512>(xyz, b, n, m, log2T, idx, s);
+    else launch_reg<8, 512>(xyz, b, n, m, log2T, idx, s);
+    return true;
+  }
+  const int p = ceil_div(n, 1024);
+  if (p <= 8) launch_reg<8, 1024>(xyz, b, n, m, log2T, idx, s);
   else if (p <= 12) launch_reg<12, 1024>(xyz, b, n, m, log2T, idx, s);
   else if (p <= 16) launch_reg<16, 1024>(xyz, b, n, m, log2T, idx, s);
   else if (p <= 20) launch_reg<20, 1024>(xyz, b, n, m, log2T, idx, s);
@@ -278,12 +282,8 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int log2T = reference_block_log2(n);
 
-  bool done = false;
-  if (n <= 256 * 8) {
-    done = dispatch_reg_small(ceil_div(n, 256), xyz, b, n, m, log2T, idx, s);
-  } else if (n <= 1024 * 24) {
-    done = dispatch_reg_large(ceil_div(n, 1024), xyz, b, n, m, log2T, idx, s);
-  }
+  (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated HIP calls
+  const bool done = dispatch_reg(xyz, b, n, m, log2T, idx, s);
   if (!done) {
     const size_t lds_need = kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
     auto kern = fps_stream_kernel<kStreamThreads>;

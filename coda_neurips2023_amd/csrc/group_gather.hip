@@ -55,6 +55,7 @@ int gather_rows(const float *points, const int32_t *idx, float *out, int b, int 
                 long long e_count, hipStream_t s) {
   if (e_count > 0x7fffffffLL) return CODA_EINVAL;
   dim3 grid(ceil_div(static_cast<int>(e_count), kThreads), ceil_div(c, kCh), b);
+  clear_sticky_error();
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(kThreads), 0, s, points, idx, out, c, n,
                      static_cast<int>(e_count));
   return launch_status();
@@ -67,6 +68,7 @@ int scatter_add_rows(const float *grad_out, const int32_t *idx, float *grad_poin
   if (e != hipSuccess) return static_cast<int>(e);
   if (e_count == 0) return CODA_OK;
   dim3 grid(ceil_div(static_cast<int>(e_count), kThreads), ceil_div(c, kCh), b);
+  clear_sticky_error();
   hipLaunchKernelGGL(scatter_add_rows_kernel, grid, dim3(kThreads), 0, s, grad_out, idx,
                      grad_points, c, n, static_cast<int>(e_count));
   return launch_status();

@@ -109,6 +109,7 @@ CODA_API int coda_three_nn_f32(const float *unknown, const float *known, float *
   if (b < 0 || n < 0 || m < 0) return CODA_EINVAL;
   if (b == 0 || n == 0) return CODA_OK;
   if (!unknown || !dist2 || !idx || (m > 0 && !known)) return CODA_EINVAL;
+  clear_sticky_error();
   hipLaunchKernelGGL(three_nn_kernel, dim3(ceil_div(n, kThreads), b), dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), unknown, known, dist2, idx, n, m);
   return launch_status();
@@ -122,6 +123,7 @@ CODA_API int coda_three_interpolate_f32(const float *points, const int32_t *idx,
   if (b == 0 || c == 0 || n == 0) return CODA_OK;
   if (!points || !idx || !weight || !out || m == 0) return CODA_EINVAL;
   dim3 grid(ceil_div(n, kThreads), c < 64 ? c : 64, b);
+  clear_sticky_error();
   hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kThreads), 0,
                      static_cast<hipStream_t>(stream), points, idx, weight, out, c, m, n);
   return launch_status();
@@ -139,6 +141,7 @@ CODA_API int coda_three_interpolate_grad_f32(const float *grad_out, const int32_
   if (e != hipSuccess) return static_cast<int>(e);
   if (n == 0) return CODA_OK;
   dim3 grid(ceil_div(n, kThreads), c < 64 ? c : 64, b);
+  clear_sticky_error();
   hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(kThreads), 0, s, grad_out, idx,
                      weight, grad_points, c, n, m);
   return launch_status();

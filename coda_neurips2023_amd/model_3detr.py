@@ -1,0 +1,367 @@
+"""CoDA / 3DETR detector: the forward hot path.
+
+Mirror of models/model_3detr.py for the model the CoDA scripts build
+(``Model3DETRPredictedBoxDistillationHead``, :130-1833) restricted to the hot
+path of SURVEY.md section 8: ``run_encoder`` (:535-555), the encoder->decoder
+projection (:409-419, 1770-1772), ``get_query_embeddings`` (:513-526), the
+decoder call (:1784-1792), ``get_box_predictions`` (:1634-1740),
+``get_class_scores`` (:1742-1764), ``BoxProcessor`` (:56-127) and the builders
+(:3935-4074).  Class names, constructor keywords, the ``forward`` signature, the
+output dictionary keys and every ``state_dict`` key of the trunk are the
+reference's, so ``main.py`` / ``engine.py`` can call it unchanged.
+
+Out of scope here (SURVEY.md 8f "next"): the CLIP towers and the image-crop
+distillation branch (``get_predicted_box_clip_embedding*``, :902-1632), which
+need weights that are not available.  Their PRODUCTS enter the hot path through
+two seams: ``text_features_fg_norm`` (the normalised text embeddings, computed
+once at init in the reference, :339-342) and ``region_embedding_provider`` (a
+callable that adds ``gt_text_correlation_embedding(_mask)`` etc. to the output
+dictionary like the crop branch does, :1102-1103).
+"""
+import math
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .helpers import GenericMLP
+from .pointnet2.pointnet2_modules import PointnetSAModuleVotes
+from .pointnet2.pointnet2_utils import furthest_point_sample
+from .position_embedding import PositionEmbeddingCoordsSine, scale_points, shift_scale_points
+from .transformer import (MaskedTransformerEncoder, TransformerDecoder, TransformerDecoderLayer,
+                          TransformerEncoder, TransformerEncoderLayer)
+
+
+class BoxProcessor(object):
+    """Converts the MLP-head outputs into boxes (models/model_3detr.py:56-127)."""
+
+    def __init__(self, dataset_config):
+        self.dataset_config = dataset_config
+
+    def compute_predicted_center(self, center_offset, query_xyz, point_cloud_dims):
+        center_unnormalized = query_xyz + center_offset
+        center_normalized = shift_scale_points(center_unnormalized, src_range=point_cloud_dims)
+        return center_normalized, center_unnormalized
+
+    def compute_predicted_size(self, size_normalized, point_cloud_dims):
+        scene_scale = point_cloud_dims[1] - point_cloud_dims[0]
+        scene_scale = torch.clamp(scene_scale, min=1e-1)
+        return scale_points(size_normalized, mult_factor=scene_scale)
+
+    def compute_predicted_angle(self, angle_logits, angle_residual):
+        if angle_logits.shape[-1] == 1:
+            # datasets without rotation: keep the heads in the graph (:80-85)
+            angle = angle_logits * 0 + angle_residual * 0
+            return angle.squeeze(-1).clamp(min=0)
+        angle_per_cls = 2 * np.pi / self.dataset_config.num_angle_bin
+        pred_angle_class = angle_logits.argmax(dim=-1).detach()
+        angle_center = angle_per_cls * pred_angle_class
+        angle = angle_center + angle_residual.gather(2, pred_angle_class.unsqueeze(-1)).squeeze(-1)
+        mask = angle > np.pi
+        angle[mask] = angle[mask] - 2 * np.pi
+        return angle
+
+    def compute_objectness_and_cls_prob(self, cls_logits):
+        cls_prob = torch.nn.functional.softmax(cls_logits, dim=-1)
+        objectness_prob = 1 - cls_prob[..., -1]
+        return cls_prob[..., :-1], objectness_prob
+
+    def box_parametrization_to_corners(self, box_center_unnorm, box_size_unnorm, box_angle):
+        return self.dataset_config.box_parametrization_to_corners(box_center_unnorm, box_size_unnorm,
+                                                                  box_angle)
+
+    def box_parametrization_to_corners_xyz(self, box_center_unnorm, box_size_unnorm, box_angle):
+        return self.dataset_config.box_parametrization_to_corners_xyz(box_center_unnorm,
+                                                                      box_size_unnorm, box_angle)
+
+
+class Model3DETRPredictedBoxDistillationHead(nn.Module):
+    """pre_encoder (set abstraction) -> encoder -> projection -> query embeddings ->
+    decoder -> MLP heads (box parameters + 512-d CLIP-space region embedding)."""
+
+    def __init__(self, pre_encoder, encoder, decoder, dataset_config, image_text_encoder=None,
+                 encoder_dim=256, decoder_dim=256, position_embedding="fourier", mlp_dropout=0.3,
+                 num_queries=256, if_with_clip=False, if_use_gt_box=False, if_expand_box=False,
+                 if_with_clip_embed=False, if_with_clip_train=True, num_cls_predict=1,
+                 if_with_fake_classes=False, pooling_methods="average", if_clip_more_prompts=False,
+                 if_keep_box=False, if_select_box_by_objectness=False, keep_objectness=0.5,
+                 online_nms_update_novel_label=False, online_nms_update_accumulate_novel_label=False,
+                 online_nms_update_accumulate_epoch=10, distillation_box_num=32, args=None,
+                 text_features_fg_norm=None, region_embedding_provider=None):
+        super().__init__()
+        self.if_with_fake_classes = if_with_fake_classes
+        self.num_cls_predict = num_cls_predict
+        self.pre_encoder = pre_encoder
+        self.encoder = encoder
+        self.args = args
+        self.if_with_clip = if_with_clip
+        self.if_with_clip_train = if_with_clip_train
+        self.if_keep_box = if_keep_box  # poked by main.py:356
+        self.if_select_box_by_objectness = if_select_box_by_objectness
+        self.keep_objectness = keep_objectness
+        self.distillation_box_num = distillation_box_num
+        self.eval_layer_id = getattr(args, "eval_layer_id", -1) if args is not None else -1
+        self.if_clip_superset = False
+
+        # Products of the (out-of-scope) CLIP text tower: normalised prompt embeddings and the
+        # frozen temperature (reference: clip_model.logit_scale, :367).
+        self.region_embedding_provider = region_embedding_provider
+        if text_features_fg_norm is not None:
+            self.register_buffer("text_features_fg_norm", text_features_fg_norm.to(torch.float32),
+                                 persistent=False)
+            self.train_range_max = text_features_fg_norm.shape[0]
+            self.test_range_max = text_features_fg_norm.shape[0]
+            self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07), requires_grad=False)
+        else:
+            self.text_features_fg_norm = None
+
+        self.encoder_to_decoder_projection = GenericMLP(
+            input_dim=256, hidden_dims=[512, 512], output_dim=decoder_dim, norm_fn_name="bn1d",
+            activation="relu", use_conv=True, output_use_activation=True, output_use_norm=True,
+            output_use_bias=False)
+        self.pos_embedding = PositionEmbeddingCoordsSine(d_pos=decoder_dim, pos_type=position_embedding,
+                                                         normalize=True)
+        self.query_projection = GenericMLP(input_dim=decoder_dim, hidden_dims=[decoder_dim],
+                                           output_dim=decoder_dim, use_conv=True,
+                                           output_use_activation=True, hidden_use_bias=True)
+        self.decoder = decoder
+        self.build_mlp_heads(dataset_config, decoder_dim, mlp_dropout)
+        self.num_queries = num_queries
+        self.box_processor = BoxProcessor(dataset_config)
+
+    def build_mlp_heads(self, dataset_config, decoder_dim, mlp_dropout):
+        mlp_func = partial(GenericMLP, norm_fn_name="bn1d", activation="relu", use_conv=True,
+                           hidden_dims=[decoder_dim, decoder_dim], dropout=mlp_dropout,
+                           input_dim=decoder_dim)
+        if self.if_with_fake_classes:
+            self.num_cls_predict += 1
+        # +1: background / not-an-object class
+        semcls_head = mlp_func(output_dim=self.num_cls_predict + 1)
+        text_correlation_head = mlp_func(output_dim=512)  # CLIP joint space
+        center_head = mlp_func(output_dim=3)
+        size_head = mlp_func(output_dim=3)
+        angle_cls_head = mlp_func(output_dim=dataset_config.num_angle_bin)
+        angle_reg_head = mlp_func(output_dim=dataset_config.num_angle_bin)
+        self.mlp_heads = nn.ModuleDict([
+            ("sem_cls_head", semcls_head),
+            ("center_head", center_head),
+            ("size_head", size_head),
+            ("angle_cls_head", angle_cls_head),
+            ("angle_residual_head", angle_reg_head),
+            ("text_correlation_head", text_correlation_head),
+        ])
+
+    def get_query_embeddings(self, encoder_xyz, point_cloud_dims):
+        query_inds = furthest_point_sample(encoder_xyz, self.num_queries).long()
+        query_xyz = torch.gather(encoder_xyz, 1, query_inds.unsqueeze(-1).expand(-1, -1, 3))
+        pos_embed = self.pos_embedding(query_xyz, input_range=point_cloud_dims)
+        query_embed = self.query_projection(pos_embed)
+        return query_xyz, query_embed
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def run_encoder(self, point_clouds):
+        xyz, features = self._break_up_pc(point_clouds)
+        pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features)
+        # (B, C, npoints) -> (npoints, B, C) for the seq-first transformer
+        pre_enc_features = pre_enc_features.permute(2, 0, 1)
+        enc_xyz, enc_features, enc_inds = self.encoder(pre_enc_features, xyz=pre_enc_xyz)
+        if enc_inds is None:
+            enc_inds = pre_enc_inds  # no down-sampling inside the encoder
+        else:
+            enc_inds = torch.gather(pre_enc_inds, 1, enc_inds.long())
+        return enc_xyz, enc_features, enc_inds
+
+    def get_box_predictions(self, query_xyz, point_cloud_dims, box_features, point_clouds=None,
+                            inputs=None):
+        """box_features: (num_layers, num_queries, batch, channel) -> output dicts."""
+        box_features = box_features.permute(0, 2, 3, 1)
+        num_layers, batch, channel, num_queries = box_features.shape
+        box_features = box_features.reshape(num_layers * batch, channel, num_queries)
+
+        heads = self.mlp_heads
+        cls_logits = heads["sem_cls_head"](box_features).transpose(1, 2)
+        text_correlation_embedding = heads["text_correlation_head"](box_features).transpose(1, 2)
+        center_offset = heads["center_head"](box_features).sigmoid().transpose(1, 2) - 0.5
+        size_normalized = heads["size_head"](box_features).sigmoid().transpose(1, 2)
+        angle_logits = heads["angle_cls_head"](box_features).transpose(1, 2)
+        angle_residual_normalized = heads["angle_residual_head"](box_features).transpose(1, 2)
+
+        def split(t):
+            return t.reshape(num_layers, batch, num_queries, -1)
+
+        cls_logits = split(cls_logits)
+        text_correlation_embedding = split(text_correlation_embedding)
+        center_offset = split(center_offset)
+        size_normalized = split(size_normalized)
+        angle_logits = split(angle_logits)
+        angle_residual_normalized = split(angle_residual_normalized)
+        angle_residual = angle_residual_normalized * (np.pi / angle_residual_normalized.shape[-1])
+
+        outputs = []
+        for l in range(num_layers):
+            center_normalized, center_unnormalized = self.box_processor.compute_predicted_center(
+                center_offset[l], query_xyz, point_cloud_dims)
+            angle_continuous = self.box_processor.compute_predicted_angle(angle_logits[l],
+                                                                          angle_residual[l])
+            size_unnormalized = self.box_processor.compute_predicted_size(size_normalized[l],
+                                                                          point_cloud_dims)
+            box_corners = self.box_processor.box_parametrization_to_corners(
+                center_unnormalized, size_unnormalized, angle_continuous)
+            box_corners_xyz = self.box_processor.box_parametrization_to_corners_xyz(
+                center_unnormalized, size_unnormalized, angle_continuous)
+            with torch.no_grad():  # matching / mAP only
+                semcls_prob, objectness_prob = self.box_processor.compute_objectness_and_cls_prob(
+                    cls_logits[l])
+            outputs.append({
+                "sem_cls_logits": cls_logits[l],
+                "text_correlation_embedding": text_correlation_embedding[l],
+                "center_normalized": center_normalized.contiguous(),
+                "center_unnormalized": center_unnormalized,
+                "size_normalized": size_normalized[l],
+                "size_unnormalized": size_unnormalized,
+                "angle_logits": angle_logits[l],
+                "angle_residual": angle_residual[l],
+                "angle_residual_normalized": angle_residual_normalized[l],
+                "angle_continuous": angle_continuous,
+                "objectness_prob": objectness_prob,
+                "sem_cls_prob": semcls_prob,
+                "box_corners": box_corners,
+                "box_corners_xyz": box_corners_xyz,
+                "point_clouds": point_clouds,
+            })
+        return {"outputs": outputs[-1], "aux_outputs": outputs[:-1]}
+
+    def get_class_scores(self, box_predictions):
+        """Open-vocabulary class scores: softmax(normalised embedding @ text^T * scale)
+        (models/model_3detr.py:1742-1764)."""
+        if self.eval_layer_id != -1:
+            for key in box_predictions["aux_outputs"][self.eval_layer_id].keys():
+                box_predictions["outputs"][key] = box_predictions["aux_outputs"][self.eval_layer_id][key]
+        outputs = box_predictions["outputs"]
+        text_features_clip = outputs["text_features_clip"].to(torch.float32)
+        temperature_param = outputs["logit_scale"]
+        emb = outputs["text_correlation_embedding"]
+        emb = emb / (emb.norm(dim=-1, keepdim=True) + 1e-32)
+        correlation_map = torch.bmm(emb, text_features_clip.permute(0, 2, 1)) * temperature_param
+        scores = torch.nn.functional.softmax(correlation_map, dim=-1)
+        outputs["sem_cls_prob"] = scores
+        return box_predictions, outputs["sem_cls_prob"], outputs["objectness_prob"]
+
+    def forward(self, inputs, encoder_only=False, if_test=False, if_real_test=False, curr_epoch=-1,
+                if_cmp_class=False):
+        point_clouds = inputs["point_clouds"]
+        enc_xyz, enc_features, enc_inds = self.run_encoder(point_clouds)
+        enc_features = self.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+        if encoder_only:
+            return enc_xyz, enc_features.transpose(0, 1)
+        point_cloud_dims = [inputs["point_cloud_dims_min"], inputs["point_cloud_dims_max"]]
+        query_xyz, query_embed = self.get_query_embeddings(enc_xyz, point_cloud_dims)
+        enc_pos = self.pos_embedding(enc_xyz, input_range=point_cloud_dims)
+        enc_pos = enc_pos.permute(2, 0, 1)
+        query_embed = query_embed.permute(2, 0, 1)
+        tgt = torch.zeros_like(query_embed)
+        box_features = self.decoder(tgt, enc_features, query_pos=query_embed, pos=enc_pos)[0]
+        box_predictions = self.get_box_predictions(query_xyz, point_cloud_dims, box_features,
+                                                   point_clouds, inputs)
+        if self.text_features_fg_norm is None:
+            return box_predictions
+
+        outputs = box_predictions["outputs"]
+        outputs["logit_scale"] = torch.clip(self.logit_scale.exp(), min=None, max=100)
+        bsz = point_clouds.shape[0]
+        if (not if_real_test) and (not if_cmp_class) and (not if_test):
+            outputs["text_features_clip"] = self.text_features_fg_norm[:self.train_range_max, :] \
+                .unsqueeze(0).repeat(bsz, 1, 1)
+            if self.region_embedding_provider is not None:
+                box_predictions["outputs"] = self.region_embedding_provider(inputs, outputs,
+                                                                            curr_epoch=curr_epoch)
+        if if_real_test:
+            outputs["text_features_clip"] = self.text_features_fg_norm.unsqueeze(0).repeat(bsz, 1, 1)
+            box_predictions, _, _ = self.get_class_scores(box_predictions)
+        return box_predictions
+
+
+# ---- builders (models/model_3detr.py:3935-3996, 4018-4048; models/__init__.py:3-10) ----------
+def build_preencoder(args):
+    mlp_dims = [3 * int(args.use_color), 64, 128, args.enc_dim]
+    return PointnetSAModuleVotes(radius=0.2, nsample=64, npoint=args.preenc_npoints, mlp=mlp_dims,
+                                 normalize_xyz=True)
+
+
+def build_encoder(args):
+    if args.enc_type == "vanilla":
+        encoder_layer = TransformerEncoderLayer(d_model=args.enc_dim, nhead=args.enc_nhead,
+                                                dim_feedforward=args.enc_ffn_dim,
+                                                dropout=args.enc_dropout,
+                                                activation=args.enc_activation)
+        return TransformerEncoder(encoder_layer=encoder_layer, num_layers=args.enc_nlayers)
+    if args.enc_type in ["masked"]:
+        encoder_layer = TransformerEncoderLayer(d_model=args.enc_dim, nhead=args.enc_nhead,
+                                                dim_feedforward=args.enc_ffn_dim,
+                                                dropout=args.enc_dropout,
+                                                activation=args.enc_activation)
+        interim_downsampling = PointnetSAModuleVotes(radius=0.4, nsample=32,
+                                                     npoint=args.preenc_npoints // 2,
+                                                     mlp=[args.enc_dim, 256, 256, args.enc_dim],
+                                                     normalize_xyz=True)
+        masking_radius = [math.pow(x, 2) for x in [0.4, 0.8, 1.2]]
+        return MaskedTransformerEncoder(encoder_layer=encoder_layer, num_layers=3,
+                                        interim_downsampling=interim_downsampling,
+                                        masking_radius=masking_radius)
+    raise ValueError(f"Unknown encoder type {args.enc_type}")
+
+
+def build_decoder(args):
+    decoder_layer = TransformerDecoderLayer(d_model=args.dec_dim, nhead=args.dec_nhead,
+                                            dim_feedforward=args.dec_ffn_dim,
+                                            dropout=args.dec_dropout)
+    return TransformerDecoder(decoder_layer, num_layers=args.dec_nlayers, return_intermediate=True)
+
+
+def build_3detr_predictedbox_distillation_head(args, dataset_config, **extra):
+    pre_encoder = build_preencoder(args)
+    encoder = build_encoder(args)
+    decoder = build_decoder(args)
+    g = lambda k, d=False: getattr(args, k, d)  # noqa: E731  (flags of main.py:37-304)
+    model = Model3DETRPredictedBoxDistillationHead(
+        pre_encoder, encoder, decoder, dataset_config, encoder_dim=args.enc_dim,
+        decoder_dim=args.dec_dim, mlp_dropout=args.mlp_dropout, num_queries=args.nqueries,
+        if_with_clip=g("if_with_clip"), if_with_clip_embed=g("if_with_clip_embed"),
+        if_use_gt_box=g("if_use_gt_box"), if_expand_box=g("if_expand_box"),
+        if_with_fake_classes=g("if_with_fake_classes"), pooling_methods=g("pooling_methods", "average"),
+        if_clip_more_prompts=g("if_clip_more_prompts"), if_keep_box=g("if_keep_box"),
+        if_select_box_by_objectness=g("if_select_box_by_objectness"),
+        keep_objectness=g("keep_objectness", 0.5),
+        online_nms_update_novel_label=g("online_nms_update_novel_label"),
+        online_nms_update_accumulate_novel_label=g("online_nms_update_accumulate_novel_label"),
+        online_nms_update_accumulate_epoch=g("online_nms_update_accumulate_epoch", 10),
+        distillation_box_num=g("distillation_box_num", 32), args=args, **extra)
+    return model, BoxProcessor(dataset_config)
+
+
+MODEL_FUNCS = {
+    "3detr_predictedbox_distillation": build_3detr_predictedbox_distillation_head,
+}
+
+
+def build_model(args, dataset_config, **extra):
+    """models/__init__.py:8-10."""
+    return MODEL_FUNCS[args.model_name](args, dataset_config, **extra)
+
+
+def default_args(**overrides):
+    """The hot-path flags with main.py's defaults (main.py:64-74,127-148)."""
+    from types import SimpleNamespace
+    ns = SimpleNamespace(model_name="3detr_predictedbox_distillation", use_color=False, enc_type="vanilla",
+                         enc_nlayers=3, enc_dim=256, enc_ffn_dim=128, enc_dropout=0.1, enc_nhead=4,
+                         enc_activation="relu", dec_nlayers=8, dec_dim=256, dec_ffn_dim=256,
+                         dec_dropout=0.1, dec_nhead=4, mlp_dropout=0.3, preenc_npoints=2048,
+                         nqueries=256, eval_layer_id=-1, dataset_name="sunrgbd")
+    for k, v in overrides.items():
+        setattr(ns, k, v)
+    return ns

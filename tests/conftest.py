@@ -36,6 +36,8 @@ def golden_sa():
 @pytest.fixture(scope="session")
 def dev():
     import torch
+    if os.environ.get("CODA_DEBUG_CPU_DEVICE") == "1":  # local debugging of pure-torch layers only
+        return torch.device("cpu")
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test running without a GPU; use -m 'not gpu' on CPU-only hosts")
     return torch.device("cuda:0")

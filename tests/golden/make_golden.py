@@ -194,10 +194,240 @@ def golden_sa_module():
     _save("sa_module.npz", **out)
 
 
+def _args(**over):
+    from types import SimpleNamespace
+    ns = SimpleNamespace(use_color=False, enc_dim=256, preenc_npoints=128, enc_type="vanilla", enc_nhead=4,
+                         enc_ffn_dim=64, enc_dropout=0.0, enc_activation="relu", enc_nlayers=2, dec_dim=64,
+                         dec_nhead=4, dec_ffn_dim=64, dec_dropout=0.0, dec_nlayers=3, mlp_dropout=0.0,
+                         nqueries=32, dataset_name="sunrgbd", begin_keep_epoch=1,
+                         online_nms_update_save_novel_label_clip_driven_with_cate_confidence=False,
+                         save_objectness=0.3, online_nms_update_save_epoch=50, clip_driven_keep_thres=0.3,
+                         eval_layer_id=-1, if_clip_weak_labels=False, if_accumulate_former_pseudo_labels=False,
+                         if_use_v1=True, image_size_width=730, image_size_height=531, test_range_min=0,
+                         test_range_max=10, train_range_min=0, train_range_max=10)
+    for k, v in over.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def golden_transformer():
+    """TransformerEncoder / MaskedTransformerEncoder / TransformerDecoder stacks
+    (models/transformer.py) at d=64 with full gradient digests, plus single layers at
+    the real width d=256, h=4.  dropout=0 so train-mode graphs are deterministic."""
+    from golden.weights import fill_deterministic, grad_digest
+    import models.transformer as RT  # the REFERENCE module
+    import pointnet2_modules as RM
+
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    # --- encoder stack, d=64
+    layer = RT.TransformerEncoderLayer(d_model=64, nhead=4, dim_feedforward=32, dropout=0.0)
+    enc = fill_deterministic(RT.TransformerEncoder(layer, 3), seed=1).train()
+    src = torch.randn(96, 2, 64, generator=g).requires_grad_(True)
+    _, y, _ = enc(src)
+    gw = torch.randn(y.shape, generator=g)
+    (y * gw).sum().backward()
+    out.update({"enc_src": _np(src), "enc_out": _np(y), "enc_gw": _np(gw), "enc_src_grad": _np(src.grad)})
+    for k, v in grad_digest(enc).items():
+        out[f"enc_grad/{k}"] = v
+    # --- masked encoder with interim set-abstraction down-sampling, d=64
+    pc, _, _ = make_batch(2, 64, seed=77)
+    xyz = torch.from_numpy(pc)
+    layer = RT.TransformerEncoderLayer(d_model=64, nhead=4, dim_feedforward=32, dropout=0.0)
+    interim = RM.PointnetSAModuleVotes(radius=0.6, nsample=8, npoint=32, mlp=[64, 32, 64], normalize_xyz=True)
+    menc = fill_deterministic(RT.MaskedTransformerEncoder(layer, 3, masking_radius=[0.8, 1.6, 2.4],
+                                                          interim_downsampling=interim), seed=2).train()
+    src = torch.randn(64, 2, 64, generator=g).requires_grad_(True)
+    mxyz, my, minds = menc(src, xyz=xyz)
+    gw = torch.randn(my.shape, generator=g)
+    (my * gw).sum().backward()
+    out.update({"menc_xyz_in": _np(xyz), "menc_src": _np(src), "menc_out": _np(my), "menc_xyz": _np(mxyz),
+                "menc_inds": _np(minds), "menc_gw": _np(gw), "menc_src_grad": _np(src.grad)})
+    for k, v in grad_digest(menc).items():
+        out[f"menc_grad/{k}"] = v
+    # --- decoder stack, d=64, 4 layers, intermediate outputs
+    dl = RT.TransformerDecoderLayer(d_model=64, nhead=4, dim_feedforward=48, dropout=0.0)
+    dec = fill_deterministic(RT.TransformerDecoder(dl, 4, return_intermediate=True), seed=3).train()
+    memory = torch.randn(96, 2, 64, generator=g).requires_grad_(True)
+    pos = torch.randn(96, 2, 64, generator=g)
+    qpos = torch.randn(24, 2, 64, generator=g).requires_grad_(True)
+    tgt = torch.zeros(24, 2, 64)
+    y, attns = dec(tgt, memory, query_pos=qpos, pos=pos, return_attn_weights=True)
+    gw = torch.randn(y.shape, generator=g)
+    (y * gw).sum().backward()
+    out.update({"dec_memory": _np(memory), "dec_pos": _np(pos), "dec_qpos": _np(qpos), "dec_out": _np(y),
+                "dec_attns": _np(attns), "dec_gw": _np(gw), "dec_memory_grad": _np(memory.grad),
+                "dec_qpos_grad": _np(qpos.grad)})
+    for k, v in grad_digest(dec).items():
+        out[f"dec_grad/{k}"] = v
+    # --- single layers at the real width (d=256, h=4), outputs + input grads
+    el = fill_deterministic(RT.TransformerEncoderLayer(d_model=256, nhead=4, dim_feedforward=128, dropout=0.0),
+                            seed=4).train()
+    src = torch.randn(160, 2, 256, generator=g).requires_grad_(True)
+    y = el(src)
+    gw = torch.randn(y.shape, generator=g)
+    (y * gw).sum().backward()
+    out.update({"el_src": _np(src), "el_out": _np(y), "el_gw": _np(gw), "el_src_grad": _np(src.grad)})
+    dl = fill_deterministic(RT.TransformerDecoderLayer(d_model=256, nhead=4, dim_feedforward=256, dropout=0.0),
+                            seed=5).train()
+    tgt = torch.randn(40, 2, 256, generator=g).requires_grad_(True)
+    memory = torch.randn(160, 2, 256, generator=g).requires_grad_(True)
+    pos = torch.randn(160, 2, 256, generator=g)
+    qpos = torch.randn(40, 2, 256, generator=g)
+    y, _ = dl(tgt, memory, pos=pos, query_pos=qpos)
+    gw = torch.randn(y.shape, generator=g)
+    (y * gw).sum().backward()
+    out.update({"dl_tgt": _np(tgt), "dl_memory": _np(memory), "dl_pos": _np(pos), "dl_qpos": _np(qpos),
+                "dl_out": _np(y), "dl_gw": _np(gw), "dl_tgt_grad": _np(tgt.grad),
+                "dl_memory_grad": _np(memory.grad)})
+    _save("transformer.npz", **out)
+
+
+def golden_model():
+    """Whole detector at a tiny configuration through the reference's own methods
+    (models/model_3detr.py:1767-1794; the CLIP branch is gated off, weights absent):
+    N=1024 points, 128 encoder tokens, 32 queries, enc 2 layers d=256, dec 3 layers d=64."""
+    from golden.weights import fill_deterministic, grad_digest
+    import models.model_3detr as M  # the REFERENCE module
+    from datasets.sunrgbd_anonymous_aligned_image import SunrgbdAnonymousAlignedImageDatasetConfig
+
+    args = _args()
+    cfg = SunrgbdAnonymousAlignedImageDatasetConfig(if_print=False, args=args)
+    pre, enc, dec = M.build_preencoder(args), M.build_encoder(args), M.build_decoder(args)
+    model = M.Model3DETRPredictedBoxDistillationHead(pre, enc, dec, cfg, encoder_dim=256, decoder_dim=args.dec_dim,
+                                                     mlp_dropout=0.0, num_queries=args.nqueries,
+                                                     if_with_clip_train=False, args=args)
+    fill_deterministic(model, seed=9)
+    out = {"state_keys": np.array(sorted(model.state_dict().keys())),
+           "state_shapes": np.array([str(tuple(model.state_dict()[k].shape)) for k in sorted(model.state_dict())])}
+    pc, mn, mx = make_batch(2, 1024, seed=31)
+    inputs = {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
+              "point_cloud_dims_max": torch.from_numpy(mx)}
+    for mode in ["train", "eval"]:
+        model.train(mode == "train")
+        model.zero_grad()
+        point_clouds = inputs["point_clouds"]
+        enc_xyz, enc_features, enc_inds = model.run_encoder(point_clouds)
+        enc_features = model.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+        dims = [inputs["point_cloud_dims_min"], inputs["point_cloud_dims_max"]]
+        query_xyz, query_embed = model.get_query_embeddings(enc_xyz, dims)
+        enc_pos = model.pos_embedding(enc_xyz, input_range=dims).permute(2, 0, 1)
+        query_embed = query_embed.permute(2, 0, 1)
+        tgt = torch.zeros_like(query_embed)
+        box_features = model.decoder(tgt, enc_features, query_pos=query_embed, pos=enc_pos)[0]
+        pred = model.get_box_predictions(query_xyz, dims, box_features, point_clouds, inputs)
+        o = pred["outputs"]
+        out.update({f"{mode}_enc_xyz": _np(enc_xyz), f"{mode}_enc_inds": _np(enc_inds),
+                    f"{mode}_enc_features": _np(enc_features), f"{mode}_query_xyz": _np(query_xyz),
+                    f"{mode}_box_features": _np(box_features)})
+        for k, v in o.items():
+            if k != "point_clouds":
+                out[f"{mode}_out/{k}"] = _np(v)
+        for li, aux in enumerate(pred["aux_outputs"]):
+            for k in ["sem_cls_logits", "center_normalized", "box_corners", "text_correlation_embedding"]:
+                out[f"{mode}_aux{li}/{k}"] = _np(aux[k])
+        if mode == "train":
+            gen = torch.Generator().manual_seed(3)
+            loss = 0
+            for k in ["sem_cls_logits", "text_correlation_embedding", "center_normalized", "size_normalized",
+                      "angle_logits", "angle_residual", "box_corners"]:
+                w = torch.randn(o[k].shape, generator=gen)
+                out[f"train_lossw/{k}"] = _np(w)
+                loss = loss + (o[k] * w).sum()
+                for aux in pred["aux_outputs"]:
+                    loss = loss + 0.5 * (aux[k] * w).sum()
+            loss.backward()
+            out["train_loss"] = _np(loss)
+            for k, v in grad_digest(model).items():
+                out[f"train_grad/{k}"] = v
+    # open-vocabulary scores (get_class_scores, :1742-1764) on synthetic unit-norm text embeddings
+    gen = torch.Generator().manual_seed(4)
+    text = torch.nn.functional.normalize(torch.randn(10, 512, generator=gen), dim=-1)
+    pred["outputs"]["text_features_clip"] = text.unsqueeze(0).repeat(2, 1, 1)
+    pred["outputs"]["logit_scale"] = torch.clip(torch.tensor(np.log(1 / 0.07)).exp(), max=100).float()
+    _, scores, obj = model.get_class_scores(pred)
+    out.update({"text_features": _np(text), "class_scores": _np(scores), "pc": pc, "dims_min": mn, "dims_max": mx})
+    _save("model_tiny.npz", **out)
+
+
+def golden_criterion():
+    """The live loss terms of criterion.py through the reference's own methods, with the
+    reference Hungarian Matcher (cost_class=1, cost_center=... as main.py defaults) on
+    synthetic predictions / targets.  SetCriterion.__init__ hard-codes .to('cuda')
+    (criterion.py:97), so the object is assembled with __new__ + attributes."""
+    import criterion as RC  # the REFERENCE module
+    from types import SimpleNamespace
+
+    gen = torch.Generator().manual_seed(21)
+    B, nq, ngt, ncls, nbin = 3, 24, 8, 10, 12
+    outputs = {
+        "sem_cls_logits": torch.randn(B, nq, 2, generator=gen).requires_grad_(True),
+        "text_correlation_embedding": torch.randn(B, nq, 512, generator=gen).requires_grad_(True),
+        "center_normalized": torch.rand(B, nq, 3, generator=gen).requires_grad_(True),
+        "size_normalized": torch.rand(B, nq, 3, generator=gen).requires_grad_(True),
+        "angle_logits": torch.randn(B, nq, nbin, generator=gen).requires_grad_(True),
+        "angle_residual_normalized": torch.randn(B, nq, nbin, generator=gen).requires_grad_(True),
+    }
+    probs = torch.softmax(outputs["sem_cls_logits"].detach(), -1)
+    outputs["sem_cls_prob"] = probs[..., :-1]
+    outputs["objectness_prob"] = 1 - probs[..., -1]
+    nactual = torch.tensor([5, 0, 8])
+    present = (torch.arange(ngt)[None] < nactual[:, None]).float()
+    targets = {
+        "gt_box_present": present,
+        "gt_box_sem_cls_label": torch.zeros(B, ngt, dtype=torch.int64),
+        "gt_box_centers_normalized": torch.rand(B, ngt, 3, generator=gen),
+        "gt_box_sizes_normalized": torch.rand(B, ngt, 3, generator=gen),
+        "gt_angle_class_label": torch.randint(0, nbin, (B, ngt), generator=gen),
+        "gt_angle_residual_label": (torch.rand(B, ngt, generator=gen) - 0.5) * 0.2,
+        "gt_box_seen_sem_cls_label": torch.randint(0, ncls, (B, ngt), generator=gen),
+        "gt_box_seen_sem_cls_confi": torch.rand(B, ngt, generator=gen),
+        "text_features_clip": torch.nn.functional.normalize(torch.randn(ncls, 512, generator=gen), dim=-1)
+        .unsqueeze(0).repeat(B, 1, 1),
+        "logit_scale": torch.tensor(1 / 0.07).clamp(max=100),
+        "gt_text_correlation_embedding": torch.nn.functional.normalize(torch.randn(B, nq, 512, generator=gen), dim=-1),
+        "gt_text_correlation_embedding_mask": (torch.rand(B, nq, 1, generator=gen) < 0.25).float(),
+        "weak_box_cate_label": torch.randint(0, ncls, (B, nq), generator=gen),
+        "weak_confidence_weight": torch.rand(B, nq, generator=gen) * (torch.rand(B, nq, generator=gen) < 0.5),
+    }
+    targets["nactual_gt"] = present.sum(1).long()
+    targets["num_boxes"] = float(max(int(targets["nactual_gt"].sum()), 1))
+    targets["num_boxes_replica"] = int(targets["nactual_gt"].sum())
+    crit = RC.SetCriterion.__new__(RC.SetCriterion)
+    torch.nn.Module.__init__(crit)
+    crit.dataset_config = SimpleNamespace(num_semcls=1, num_angle_bin=nbin)
+    crit.register_buffer("semcls_percls_weights", torch.tensor([1.0, 0.25]))
+    crit.confidence_type = "clip-max-prob"
+    matcher = RC.Matcher(cost_class=1, cost_objectness=0, cost_giou=0, cost_center=1)
+    outputs["gious"] = torch.zeros(B, nq, ngt)
+    outputs["center_dist"] = torch.cdist(outputs["center_normalized"], targets["gt_box_centers_normalized"], p=1)
+    assignments = matcher(outputs, targets)
+    res = {}
+    for name in ["loss_sem_cls_softmax_skip_none_gt_sample", "loss_angle", "loss_center", "loss_size",
+                 "loss_cardinality", "loss_predicted_region_embed_l1",
+                 "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi"]:
+        res.update(getattr(crit, name)(outputs, targets, assignments))
+    total = sum(v for k, v in res.items() if k != "loss_cardinality")
+    total.backward()
+    out = {}
+    for k, v in outputs.items():
+        out[f"out/{k}"] = _np(v)
+        if v.requires_grad and v.grad is not None:
+            out[f"grad/{k}"] = _np(v.grad)
+    for k, v in targets.items():
+        out[f"tgt/{k}"] = _np(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    out["assign/per_prop_gt_inds"] = _np(assignments["per_prop_gt_inds"])
+    out["assign/proposal_matched_mask"] = _np(assignments["proposal_matched_mask"])
+    for k, v in res.items():
+        out[f"loss/{k}"] = _np(v)
+    _save("criterion.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     install_reference()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "sa_module"]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion"]
     for w in which:
         globals()["golden_" + w]()

@@ -1,0 +1,83 @@
+"""Whole detector (tiny configuration) on the GPU against the reference's own
+methods (golden fixture model_tiny.npz): indices bit-exact, every output key
+within 1e-3 relative, parameter-gradient digests, open-vocabulary class scores."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from golden.weights import fill_deterministic, grad_digest  # noqa: E402
+from test_model_structure import tiny_args  # noqa: E402
+
+from coda_neurips2023_amd.dataset_config import HotPathDatasetConfig  # noqa: E402
+from coda_neurips2023_amd.model_3detr import build_model  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_tiny.npz"))
+RTOL = 1e-3
+
+
+def close(got, ref, what, rtol=RTOL):
+    got = got.detach().cpu().numpy()
+    err = np.abs(got.astype(np.float64) - ref).max() / (np.abs(ref).max() + 1e-12)
+    assert err < rtol, f"{what}: max err / max|ref| = {err:.3e}"
+
+
+def _inputs(dev):
+    return {"point_clouds": torch.from_numpy(G["pc"]).to(dev),
+            "point_cloud_dims_min": torch.from_numpy(G["dims_min"]).to(dev),
+            "point_cloud_dims_max": torch.from_numpy(G["dims_max"]).to(dev)}
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_tiny_model_matches_reference(dev, mode):
+    model, _ = build_model(tiny_args(), HotPathDatasetConfig())
+    fill_deterministic(model, seed=9)
+    model.to(dev).train(mode == "train")
+    inputs = _inputs(dev)
+    enc_xyz, enc_features, enc_inds = model.run_encoder(inputs["point_clouds"])
+    assert np.array_equal(enc_inds.cpu().numpy(), G[f"{mode}_enc_inds"])
+    assert np.array_equal(enc_xyz.cpu().numpy(), G[f"{mode}_enc_xyz"])
+    pred = model(inputs)
+    o = pred["outputs"]
+    int_keys = []
+    for k in [f for f in G.files if f.startswith(f"{mode}_out/")]:
+        name = k.split("/", 1)[1]
+        close(o[name], G[k], f"{mode} outputs[{name}]")
+    assert len(pred["aux_outputs"]) == 2
+    for li, aux in enumerate(pred["aux_outputs"]):
+        for name in ["sem_cls_logits", "center_normalized", "box_corners", "text_correlation_embedding"]:
+            close(aux[name], G[f"{mode}_aux{li}/{name}"], f"{mode} aux{li}[{name}]")
+    if mode == "train":
+        loss = 0
+        for name in ["sem_cls_logits", "text_correlation_embedding", "center_normalized", "size_normalized",
+                     "angle_logits", "angle_residual", "box_corners"]:
+            w = torch.from_numpy(G[f"train_lossw/{name}"]).to(dev)
+            loss = loss + (o[name] * w).sum()
+            for aux in pred["aux_outputs"]:
+                loss = loss + 0.5 * (aux[name] * w).sum()
+        loss.backward()
+        assert abs(float(loss) - float(G["train_loss"])) < RTOL * abs(float(G["train_loss"])) + 1e-2
+        dig = grad_digest(model)
+        for k in [f for f in G.files if f.startswith("train_grad/")]:
+            name = k.split("/", 1)[1]
+            ref = G[k]
+            scale = max(abs(ref[1]), 1e-6)
+            assert abs(dig[name][1] - ref[1]) < 3e-3 * scale + 1e-6, f"grad norm {name}"
+            assert np.abs(dig[name][2:] - ref[2:]).max() < 3e-3 * max(np.abs(ref[2:]).max(), scale / 10) + 1e-6, name
+
+
+def test_open_vocabulary_class_scores(dev):
+    text = torch.from_numpy(G["text_features"])
+    model, _ = build_model(tiny_args(), HotPathDatasetConfig(), text_features_fg_norm=text)
+    fill_deterministic(model, seed=9)
+    with torch.no_grad():
+        model.logit_scale.fill_(float(np.log(1 / 0.07)))
+    model.to(dev).eval()
+    with torch.no_grad():
+        pred = model(_inputs(dev), if_real_test=True)
+    close(pred["outputs"]["sem_cls_prob"], G["class_scores"], "get_class_scores", rtol=2e-3)
+    assert pred["outputs"]["text_features_clip"].shape == (2, 10, 512)
