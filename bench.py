@@ -152,36 +152,41 @@ def build_model_workload(dev):
 
 
 def cpu_baseline(kind):
-    """CPU oracle port of the same step on the host cores, bounded sample (1 scene)."""
+    """The same step on the host cores: the product's host-side module graph with the CPU
+    oracle (oracle/pointnet2_oracle.c ops, plain torch attention) patched into its kernel
+    seams (oracle/cpu_port.py), torch CPU threads = all cores, bounded sample (1 scene)."""
+    from oracle import cpu_port
     from oracle import pointnet2_oracle as O
     O.build()
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    pc, _, _ = make_batch(1, N_POINTS, seed=4242)
-    torch.manual_seed(0)
-    mlp = pointnet2_modules.PointnetSAModuleVotes(radius=RADIUS, nsample=NSAMPLE, npoint=M_CENTRES,
-                                                  mlp=[0, 64, 128, 256], normalize_xyz=True).mlp_module
-    mlp.train()
+    global B_PER_GPU
+    saved_b = B_PER_GPU
+    B_PER_GPU = 1  # bounded sample: one scene per step
+    try:
+        cpu = torch.device("cpu")
+        mod, step_fn, _, _ = build_workload(kind, cpu)
+        pc, mn, mx = make_batch(1, N_POINTS, seed=4242)
+        batch = {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
+                 "point_cloud_dims_max": torch.from_numpy(mx)}
 
-    def one():
-        inds = O.furthest_point_sampling(pc, M_CENTRES)
-        new = np.take_along_axis(pc, inds[..., None].astype(np.int64).repeat(3, -1), 1)
-        idx = O.ball_query(new, pc, RADIUS, NSAMPLE)
-        g = O.group_points(np.ascontiguousarray(pc.transpose(0, 2, 1)), idx)
-        g = (g - new.transpose(0, 2, 1)[..., None]) / np.float32(RADIUS)
-        feat = mlp(torch.from_numpy(g)).max(-1)[0]
-        feat.square().mean().backward()
+        def one():
+            mod.zero_grad(set_to_none=True)
+            step_fn(mod, batch).backward()
 
-    one()  # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 20):
-        one()
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
+        with cpu_port.patched():
+            one()  # warm-up
+            t0 = time.perf_counter()
+            reps = 0
+            while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+                one()
+                reps += 1
+            dt = (time.perf_counter() - t0) / reps
+    finally:
+        B_PER_GPU = saved_b
     return {"value": round(1.0 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x 1 scene (20000 pts): oracle C FPS+ball_query+group (OpenMP) + "
-                      f"torch-CPU SharedMLP fwd+bwd; SA stage only"}
+            "sample": f"{reps} x 1 scene (20000 pts) fwd+bwd of the same workload: oracle C ops (scalar, "
+                      f"OpenMP over scenes) + torch-CPU layers on {cores} threads"}
 
 
 def main():

@@ -1,0 +1,59 @@
+"""CPU execution of the hot path for the reported baseline -- TEST INFRASTRUCTURE.
+
+``patched()`` temporarily replaces the two kernel seams of the product package
+(``pointnet2._ext`` operators and ``attention_core.attention``) with the CPU
+oracle (C restatement of the ops, plain torch fp32 attention), so that the SAME
+host-side module graph can be timed / checked on the host cores.  Only
+``bench.py``'s cpu_baseline leg and ``tests/`` use it; the product never imports
+this module and has no CPU path of its own.
+"""
+import contextlib
+
+import torch
+
+from . import pointnet2_oracle as O
+
+
+def attention_ref(q, k, v, mask, scale, dropout_p, need_weights):
+    """Plain fp32 softmax(q*scale @ k^T + mask) [dropout] @ v on (L,B,h,d) inputs."""
+    qh, kh, vh = (t.permute(1, 2, 0, 3) for t in (q, k, v))
+    scores = torch.matmul(qh * scale, kh.transpose(-1, -2))
+    if mask is not None:
+        scores = scores.masked_fill(mask, float("-inf"))
+    probs = torch.softmax(scores, dim=-1)
+    if dropout_p > 0.0:
+        probs = torch.nn.functional.dropout(probs, p=dropout_p)
+    out = torch.matmul(probs, vh)
+    return out.permute(2, 0, 1, 3), (probs if need_weights else None)
+
+
+@contextlib.contextmanager
+def patched():
+    from coda_neurips2023_amd import attention_core
+    from coda_neurips2023_amd.pointnet2 import _ext
+
+    ext = O.TorchExt()
+    names = ["gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
+             "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
+             "group_points_grad"]
+    saved = {n: getattr(_ext, n) for n in names + ["query_and_group_xyz"]}
+    saved_attn = attention_core.attention
+
+    def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz):
+        idx = ext.ball_query(new_xyz, xyz, radius, nsample)
+        grouped = ext.group_points(xyz.transpose(1, 2).contiguous(), idx)
+        grouped = grouped - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if normalize_xyz:
+            grouped = grouped / radius
+        return idx, grouped
+
+    try:
+        for n in names:
+            setattr(_ext, n, getattr(ext, n))
+        _ext.query_and_group_xyz = query_and_group_xyz
+        attention_core.attention = attention_ref
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(_ext, n, f)
+        attention_core.attention = saved_attn
