@@ -20,6 +20,12 @@
 #include "common.hip.h"
 
 namespace coda {
+
+// ball_query_grid.hip
+int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b, int n,
+                    int m, float radius, int nsample, int normalize, void *workspace, hipStream_t s);
+size_t ball_query_grid_workspace(int b, int n, int nsample);
+
 namespace {
 
 constexpr int kBqWaves = 4;  // waves per workgroup
@@ -134,7 +140,12 @@ int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *gro
 }
 
 int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b,
-                        int n, int m, float radius, int nsample, int normalize, hipStream_t s) {
+                        int n, int m, float radius, int nsample, int normalize, void *workspace,
+                        size_t workspace_bytes, hipStream_t s) {
+  // cell-binned search when the caller provided the workspace it was told to provide
+  const size_t need = ball_query_grid_workspace(b, n, nsample);
+  if (workspace && need > 0 && workspace_bytes >= need && radius > 0.0f)
+    return ball_query_grid(new_xyz, xyz, idx, grouped, b, n, m, radius, nsample, normalize, workspace, s);
   // LDS rows: waves * C * nsample * 4 B must fit the 160 KiB CU.
   const size_t per_centre = sizeof(int32_t) * kBqWaves * static_cast<size_t>(nsample);
   if (per_centre * 8 <= 64 * 1024)
@@ -150,29 +161,29 @@ int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, fl
 }  // namespace coda
 
 CODA_API size_t coda_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
-  (void)b; (void)n; (void)m; (void)nsample;
-  return 0;
+  (void)m;
+  if (b <= 0 || n <= 0 || nsample <= 0) return 0;
+  return coda::ball_query_grid_workspace(b, n, nsample);
 }
 
 CODA_API int coda_ball_query_f32(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n,
                                  int m, float radius, int nsample, void *workspace,
                                  size_t workspace_bytes, void *stream) {
-  (void)workspace; (void)workspace_bytes;
   if (b < 0 || n <= 0 || m < 0 || nsample <= 0) return CODA_EINVAL;
   if (b == 0 || m == 0) return CODA_OK;
   if (!new_xyz || !xyz || !idx) return CODA_EINVAL;
-  return coda::ball_query_dispatch(new_xyz, xyz, idx, nullptr, b, n, m, radius, nsample, 0,
-                                   static_cast<hipStream_t>(stream));
+  return coda::ball_query_dispatch(new_xyz, xyz, idx, nullptr, b, n, m, radius, nsample, 0, workspace,
+                                   workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 CODA_API int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz, int32_t *idx,
                                           float *grouped_xyz, int b, int n, int m, float radius,
                                           int nsample, int normalize, void *workspace,
                                           size_t workspace_bytes, void *stream) {
-  (void)workspace; (void)workspace_bytes;
   if (b < 0 || n <= 0 || m < 0 || nsample <= 0) return CODA_EINVAL;
   if (b == 0 || m == 0) return CODA_OK;
   if (!new_xyz || !xyz || !idx || !grouped_xyz) return CODA_EINVAL;
   return coda::ball_query_dispatch(new_xyz, xyz, idx, grouped_xyz, b, n, m, radius, nsample,
-                                   normalize, static_cast<hipStream_t>(stream));
+                                   normalize, workspace, workspace_bytes,
+                                   static_cast<hipStream_t>(stream));
 }

@@ -22,6 +22,7 @@
 #include "common.hip.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace coda {
 namespace {
@@ -169,6 +170,160 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
   }
 }
 
+// ---- v2: 512 threads == T (the reference block size), packed pairs, 32-bit DPP ------
+//
+// With THREADS == T == 512 every thread owns exactly one residue (k mod T = tid), so
+// the cross-thread tie order is bitrev9(tid) alone and the arg-max splits into two
+// cheap 32-bit wave reductions (float max, then u32 min of bitrev9(tid) among the
+// lanes that hold the max) done with DPP-fused VALU ops.  The per-point update is
+// written on float2 pairs (v_pk_add/v_pk_mul, still one rounding per operation), the
+// running minimum uses a bare v_min_f32 and the thread maximum v_max3_f32 (no
+// canonicalisation moves), and the slot index of the maximum is recovered with an
+// equality chain instead of being dragged through the update loop.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// Wave-wide max of a float; valid in lane 63 (returned uniform).  DPP needs two wait
+// states after the VALU write of its source, hence the s_nop 1 between the steps.
+__device__ __forceinline__ float wave_max_f32(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int P>  // points per thread (even); 512 threads, n in [512, 512*P]
+__global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__ xyz, int n, int m,
+                                                       int32_t *__restrict__ idx) {
+  constexpr int THREADS = 512, H = P / 2;
+  __shared__ unsigned long long s_slot[3];
+
+  const int tid = threadIdx.x;
+  const int lane = lane_id();
+  const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
+  int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
+  const uint32_t brev = __brev(static_cast<uint32_t>(tid)) >> 23;  // bitrev9(tid)
+
+  f32x2 x[H], y[H], z[H];
+  float t[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    const int k = tid + i * THREADS;
+    float px = 0.0f, py = 0.0f, pz = 0.0f, pt = -1.0f;
+    if (k < n) {
+      px = pts[k * 3 + 0];
+      py = pts[k * 3 + 1];
+      pz = pts[k * 3 + 2];
+      pt = fps_skipped(px, py, pz) ? -1.0f : 1e10f;  // see fps_reg_kernel
+    }
+    x[i / 2][i % 2] = px;
+    y[i / 2][i % 2] = py;
+    z[i / 2][i % 2] = pz;
+    t[i] = pt;
+  }
+  if (tid < 3) s_slot[tid] = 0ull;
+  if (tid == 0) out[0] = 0;
+  float cx = pts[0], cy = pts[1], cz = pts[2];
+  __syncthreads();
+
+  for (int j = 1; j < m; ++j) {
+    const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+    float best = -1.0f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const f32x2 dx = x[h] - cx2, dy = y[h] - cy2, dz = z[h] - cz2;
+      const f32x2 d = (dx * dx + dy * dy) + dz * dz;  // -ffp-contract=off: source order, no FMA
+      t[2 * h] = vmin(d[0], t[2 * h]);
+      t[2 * h + 1] = vmin(d[1], t[2 * h + 1]);
+      best = vmax3(best, t[2 * h], t[2 * h + 1]);
+    }
+    int besti = 0;  // lowest slot holding the thread maximum (= lowest k of the thread)
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) besti = (t[i] == best) ? i : besti;
+
+    const float wmax = wave_max_f32(best);
+    const uint32_t cand = (best == wmax) ? brev : 0xffffu;
+    const uint32_t wrank = wave_min_u32(cand);
+    const uint64_t owner = __ballot(cand == wrank);
+    const int owner_lane = __ffsll(static_cast<unsigned long long>(owner)) - 1;
+    const uint32_t wbesti = __builtin_amdgcn_readlane(static_cast<uint32_t>(besti), owner_lane);
+    if (lane == 0 && wmax >= 0.0f) {
+      const unsigned long long key =
+          (static_cast<unsigned long long>(__float_as_uint(wmax) + 1u) << 32) |
+          static_cast<uint32_t>(~((wrank << 23) | wbesti));
+      atomicMax(&s_slot[j % 3], key);
+    }
+    __syncthreads();
+    const unsigned long long key = s_slot[j % 3];
+    if (tid == 0) s_slot[(j + 2) % 3] = 0ull;  // next use is two barriers away
+    const uint32_t rk = ~static_cast<uint32_t>(key);
+    uint32_t old = ((rk & 0x7fffffu) << 9) | (__brev(rk >> 23) >> 23);
+    if ((key >> 32) == 0ull) old = 0u;  // nothing participated: reference besti = 0
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (tid == 0) out[j] = static_cast<int32_t>(old);
+    cx = pts[old * 3 + 0];
+    cy = pts[old * 3 + 1];
+    cz = pts[old * 3 + 2];
+  }
+}
+
+template <int P>
+void launch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStream_t s) {
+  hipLaunchKernelGGL((fps_t512_kernel<P>), dim3(b), dim3(512), 0, s, xyz, n, m, idx);
+}
+
+bool dispatch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStream_t s) {
+  if (n < 512 || n > 512 * 40) return false;
+  const int p = ceil_div(n, 512);
+  if (p <= 2) launch_t512<2>(xyz, b, n, m, idx, s);
+  else if (p <= 4) launch_t512<4>(xyz, b, n, m, idx, s);
+  else if (p <= 8) launch_t512<8>(xyz, b, n, m, idx, s);
+  else if (p <= 16) launch_t512<16>(xyz, b, n, m, idx, s);
+  else if (p <= 24) launch_t512<24>(xyz, b, n, m, idx, s);
+  else if (p <= 32) launch_t512<32>(xyz, b, n, m, idx, s);
+  else launch_t512<40>(xyz, b, n, m, idx, s);
+  return true;
+}
+
 // ---- streaming fallback: any n; running distances in LDS or in workspace -------
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void fps_stream_kernel(const float *__restrict__ xyz, int n,
@@ -283,7 +438,10 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   const int log2T = reference_block_log2(n);
 
   (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated HIP calls
-  const bool done = dispatch_reg(xyz, b, n, m, log2T, idx, s);
+  // variant 0 (default): v2 kernel where it applies; 1: force the v1 register kernel (A/B, tests)
+  static const int variant = [] { const char *e = getenv("CODA_FPS_VARIANT"); return e ? atoi(e) : 0; }();
+  bool done = variant == 0 && dispatch_t512(xyz, b, n, m, idx, s);
+  if (!done) done = dispatch_reg(xyz, b, n, m, log2T, idx, s);
   if (!done) {
     const size_t lds_need = kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
     auto kern = fps_stream_kernel<kStreamThreads>;

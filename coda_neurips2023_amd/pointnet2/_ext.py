@@ -132,13 +132,19 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
-def _ball_query_workspace(lib, b, n, m, nsample, device):
-    ws_bytes = lib.coda_ball_query_workspace_bytes(b, n, m, nsample)
+def _ball_query_workspace(lib, b, n, m, nsample, device, algorithm):
+    """Workspace of the cell-binned search; ``algorithm='scan'`` passes none, which makes the
+    C ABI fall back to the brute-force scan kernel (same results, used by the parity tests)."""
+    if algorithm not in ("auto", "scan", "grid"):
+        raise ValueError(f"unknown ball_query algorithm {algorithm!r}")
+    ws_bytes = 0 if algorithm == "scan" else lib.coda_ball_query_workspace_bytes(b, n, m, nsample)
+    if algorithm == "grid" and ws_bytes == 0:
+        raise RuntimeError("grid ball_query not applicable to this shape (n < 1024 or nsample > 128)")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device) if ws_bytes else None
     return ws, ws_bytes
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+def ball_query(new_xyz, xyz, radius, nsample, algorithm="auto"):
     """(B,M,3), (B,N,3), radius, nsample -> (B,M,nsample) i32.  ball_query.cpp:11-35."""
     _check_contiguous(new_xyz, "new_xyz")
     _check_contiguous(xyz, "xyz")
@@ -149,7 +155,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     b, n = xyz.size(0), xyz.size(1)
     m = new_xyz.size(1)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
-    ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device)
+    ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
     with torch.cuda.device(new_xyz.device), _timed("ball_query"):
         st = lib.coda_ball_query_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), b, n, m, float(radius),
                                      int(nsample), _ptr(ws), ws_bytes, _stream())
@@ -253,7 +259,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
 
 # ---- fused entry points of this build (not in the reference module) ------------------
 
-def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz):
+def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz, algorithm="auto"):
     """ball_query + xyz grouping + centring (+ 1/radius) in one kernel.
 
     Returns (idx (B,M,S) i32, grouped_xyz (B,3,M,S) f32); replaces the
@@ -270,7 +276,7 @@ def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz):
     m = new_xyz.size(1)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     grouped = torch.empty((b, 3, m, nsample), dtype=torch.float32, device=new_xyz.device)
-    ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device)
+    ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
     with torch.cuda.device(new_xyz.device), _timed("query_and_group_xyz"):
         st = lib.coda_query_and_group_xyz_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(grouped),
                                               b, n, m, float(radius), int(nsample),

@@ -106,6 +106,46 @@ def test_ball_query_matches_oracle(dev, oracle, b, n, m, r, s):
     assert not got[:, 0].any()
 
 
+@pytest.mark.parametrize("algorithm", ["scan", "grid"])
+@pytest.mark.parametrize("n,m,r,s", [(1024, 100, 0.3, 16), (3000, 130, 0.25, 64), (20000, 500, 0.2, 64),
+                                     (20000, 300, 0.4, 32), (5000, 64, 1.5, 128), (40000, 256, 0.2, 64)])
+def test_ball_query_scan_and_grid_paths(dev, oracle, algorithm, n, m, r, s):
+    pc, _, _ = make_batch(2, n, seed=n + m)
+    rng = np.random.default_rng(s)
+    new = pc[:, rng.integers(0, n, m)].copy()
+    new[:, 0] += 100.0                      # far outside the cloud: empty ball
+    new[:, 1] = pc.min(1) - 0.05            # just outside the bounding box corner
+    new[:, 2] += rng.normal(0, 0.05, 3).astype(np.float32)   # not a cloud point
+    ref = oracle.ball_query(new, pc, r, s)
+    d_new, d_pc = cu(new, dev), cu(pc, dev)
+    got = _ext.ball_query(d_new, d_pc, r, s, algorithm=algorithm)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    idx, grouped = _ext.query_and_group_xyz(d_new, d_pc, r, s, True, algorithm=algorithm)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    exp = np.take_along_axis(pc, ref.reshape(2, -1, 1).astype(np.int64).repeat(3, -1), 1).reshape(2, m, s, 3)
+    exp = (exp - new[:, :, None, :]) * (np.float32(1.0) / np.float32(r))
+    np.testing.assert_array_equal(grouped.cpu().numpy(), exp.transpose(0, 3, 1, 2))
+
+
+def test_ball_query_grid_stress(dev, oracle):
+    """Balls holding far more hits than the LDS hit buffer (rank-and-keep overflow path),
+    duplicate points, non-finite points, a far outlier that stretches the grid."""
+    rng = np.random.default_rng(0)
+    n = 6000
+    pc = (rng.standard_normal((2, n, 3)) * 0.15).astype(np.float32)       # ~all within r of the origin
+    pc[:, 100:200] = pc[:, 0:100]                                           # exact duplicates
+    pc[0, 7] = (np.nan, 0, 0)
+    pc[0, 8] = (np.inf, 0, 0)
+    pc[1, 9] = (1e6, -1e6, 3e5)                                             # outlier
+    new = np.concatenate([np.zeros((2, 1, 3), np.float32), pc[:, 1000:1063]], 1)
+    for r, s in [(0.5, 64), (0.2, 16), (2.0, 128)]:
+        ref = oracle.ball_query(new, pc, r, s)
+        got = _ext.ball_query(cu(new, dev), cu(pc, dev), r, s, algorithm="grid")
+        assert np.array_equal(got.cpu().numpy(), ref), (r, s)
+        got = _ext.ball_query(cu(new, dev), cu(pc, dev), r, s, algorithm="scan")
+        assert np.array_equal(got.cpu().numpy(), ref), (r, s)
+
+
 def test_ball_query_golden(dev, golden_ops):
     for tag in ["small", "mid"]:
         got = _ext.ball_query(cu(golden_ops[f"{tag}_new_xyz"], dev), cu(golden_ops[f"{tag}_xyz"], dev),

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Per-operator device timings at the BASELINE shapes (HIP events, median of runs).
+
+    python tools/bench_ops.py [fps] [bq] [gather] ...
+
+Development aid for kernel A/B comparisons; the judged numbers come from bench.py
+and rocprofv3.  CODA_FPS_VARIANT=1 selects the v1 FPS kernel."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from coda_neurips2023_amd.pointnet2 import _ext  # noqa: E402
+from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def main():
+    which = sys.argv[1:] or ["fps", "bq", "group"]
+    dev = torch.device("cuda:0")
+    pc, _, _ = make_batch(8, 20000, seed=1234)
+    xyz = torch.from_numpy(pc).to(dev)
+    inds = _ext.furthest_point_sampling(xyz, 2048)
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    if "fps" in which:
+        for b in (1, 8, 64):
+            x = xyz[:1].repeat(b, 1, 1) if b != 8 else xyz
+            med, mn = timeit(lambda: _ext.furthest_point_sampling(x, 2048), reps=10)
+            print(f"fps 20000->2048 B={b:3d} variant={os.environ.get('CODA_FPS_VARIANT', '0')}: "
+                  f"median {med:.3f} ms  min {mn:.3f} ms  ({med / 2047 * 1e3:.3f} us/round)")
+        med, mn = timeit(lambda: _ext.furthest_point_sampling(new_xyz, 256))
+        print(f"fps 2048->256 B=8: median {med:.4f} ms  min {mn:.4f} ms ({med / 255 * 1e3:.3f} us/round)")
+    if "bq" in which:
+        nbytes = 8 * (12 * 20000 + 12 * 2048 + 4 * 2048 * 64)
+        gbytes = 8 * 3126016
+        for alg in ("scan", "grid"):
+            med, mn = timeit(lambda: _ext.ball_query(new_xyz, xyz, 0.2, 64, algorithm=alg))
+            print(f"ball_query {alg}: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
+                  f"({nbytes / med / 1e6:.1f} GB/s algorithmic)")
+            med, mn = timeit(lambda: _ext.query_and_group_xyz(new_xyz, xyz, 0.2, 64, True, algorithm=alg))
+            print(f"query_and_group_xyz {alg}: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
+                  f"({gbytes / med / 1e6:.1f} GB/s algorithmic, bq+group bytes)")
+    if "group" in which:
+        idx = _ext.ball_query(new_xyz, xyz, 0.2, 64)
+        xyz_t = xyz.transpose(1, 2).contiguous()
+        med, mn = timeit(lambda: _ext.group_points(xyz_t, idx))
+        print(f"group_points C=3: median {med * 1e3:.1f} us ({8 * 2337152 / med / 1e6:.1f} GB/s)")
+        feats = torch.randn(8, 256, 2048, device=dev)
+        idx2 = torch.randint(0, 2048, (8, 1024, 32), device=dev, dtype=torch.int32)
+        by = 8 * (4 * 1024 * 32 + 4 * 256 * 2048 + 4 * 256 * 1024 * 32)
+        med, mn = timeit(lambda: _ext.group_points(feats, idx2))
+        print(f"group_points C=256 M=1024 S=32: median {med * 1e3:.1f} us ({by / med / 1e6:.1f} GB/s)")
+        go = torch.randn(8, 256, 1024, 32, device=dev)
+        med, mn = timeit(lambda: _ext.group_points_grad(go, idx2, 2048))
+        print(f"group_points_grad C=256: median {med * 1e3:.1f} us ({by / med / 1e6:.1f} GB/s)")
+
+
+if __name__ == "__main__":
+    main()
