@@ -35,6 +35,11 @@ SIGNATURES = {
     "coda_three_nn_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_grad_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    # include/coda_attention.h
+    "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P]),
+    "coda_mha_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
+                                  _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P]),
 }
 
 _lib = None
@@ -54,6 +59,15 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no fallback path."
         )
+    # The HIP runtime must be the one PyTorch-ROCm brought (torch bundles its own
+    # libamdhip64): load torch first so that libcoda_hip.so binds to the SAME runtime and
+    # its launches see torch's device context and streams.  Loading this library before
+    # torch puts a second runtime in the process and every launch fails with
+    # hipErrorNoDevice.
+    import torch  # noqa: F401
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:

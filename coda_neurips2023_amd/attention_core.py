@@ -1,13 +1,21 @@
 """Scaled-dot-product attention core of the 3DETR encoder/decoder.
 
 ``attention(q, k, v, mask, scale, dropout_p, need_weights)`` takes the
-seq-first projections ``q (L,B,h,d)``, ``k/v (S,B,h,d)`` and returns
-``out (L,B,h,d)`` (+ ``probs (B,h,L,S)`` when asked).  Semantics are those of
-``torch.nn.functional.multi_head_attention_forward`` as the reference uses it:
-softmax(q*scale @ k^T + mask) -> dropout(p) -> @ v.
+seq-first projections ``q (L,B,h,d)``, ``k/v (S,B,h,d)`` (dense or slices of a
+packed in-projection) and returns ``out (L,B,h,d)`` (+ ``probs (B,h,L,S)`` when
+asked).  Semantics are those of ``torch.nn.functional.multi_head_attention_forward``
+as the reference uses it: softmax(q*scale @ k^T + mask) -> dropout(p) -> @ v.
+
+The core runs in ``libcoda_hip.so`` (``include/coda_attention.h``: fused fp32-MFMA
+forward and backward, the (B,h,L,S) probability tensor is never materialised).
+GPU tensors only -- there is no CPU or PyTorch fallback for the core.  Only the
+optional, off-hot-path ``need_weights=True`` output (head-averaged attention
+maps for visualisation, transformer.py:126-137) is produced by a plain torch
+softmax next to the fused output.
 """
 import torch
-import torch.nn.functional as F
+
+from . import _lib
 
 
 def merge_masks(attn_mask, key_padding_mask, bsz, h, tgt_len, src_len):
@@ -27,16 +35,88 @@ def merge_masks(attn_mask, key_padding_mask, bsz, h, tgt_len, src_len):
     return mask
 
 
+def _row_layout(t):
+    """(rows, B, h, d) tensor -> (tensor, ld): element (r,b,hh,c) at (r*B + b)*ld + hh*d + c.
+    Accepts dense tensors and last-dim slices of a packed projection; copies otherwise."""
+    rows, b, h, d = t.shape
+    st = t.stride()
+    if st[3] == 1 and st[2] == d and st[0] == b * st[1] and st[1] >= h * d and st[1] % 4 == 0 \
+            and t.data_ptr() % 16 == 0:
+        return t, st[1]
+    t = t.contiguous()
+    return t, h * d
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _FusedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask_u8, scale, dropout_p):
+        if not q.is_cuda:
+            raise RuntimeError("CPU not supported")  # same contract as the pointnet2 ops
+        if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32:
+            raise RuntimeError("attention core expects float32 tensors")
+        lib = _lib.load()
+        l, b, h, d = q.shape
+        s = k.shape[0]
+        q, ldq = _row_layout(q)
+        k, ldk = _row_layout(k)
+        v, ldv = _row_layout(v)
+        out = torch.empty((l, b, h, d), dtype=torch.float32, device=q.device)
+        lse = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
+        seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if dropout_p > 0.0 else 0
+        with torch.cuda.device(q.device):
+            st = lib.coda_mha_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
+                                      b, h, l, s, d, ldq, ldk, ldv, float(scale), float(dropout_p), seed,
+                                      torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "mha_fwd")
+        ctx.save_for_backward(q, k, v, mask_u8, out, lse)
+        ctx.meta = (ldq, ldk, ldv, float(scale), float(dropout_p), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, mask_u8, out, lse = ctx.saved_tensors
+        ldq, ldk, ldv, scale, dropout_p, seed = ctx.meta
+        lib = _lib.load()
+        l, b, h, d = q.shape
+        s = k.shape[0]
+        dout = dout.contiguous()
+        dq = torch.empty((l, b, h, d), dtype=torch.float32, device=q.device)
+        dk = torch.empty((s, b, h, d), dtype=torch.float32, device=q.device)
+        dv = torch.empty((s, b, h, d), dtype=torch.float32, device=q.device)
+        delta = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            st = lib.coda_mha_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
+                                      _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
+                                      ldq, ldk, ldv, scale, dropout_p, seed,
+                                      torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "mha_bwd")
+        return dq, dk, dv, None, None, None
+
+
 def attention(q, k, v, mask, scale, dropout_p, need_weights):
-    # (L,B,h,d) -> (B,h,L,d)
-    qh = q.permute(1, 2, 0, 3)
-    kh = k.permute(1, 2, 0, 3)
-    vh = v.permute(1, 2, 0, 3)
-    scores = torch.matmul(qh * scale, kh.transpose(-1, -2))
+    mask_u8 = None
     if mask is not None:
-        scores = scores.masked_fill(mask, float("-inf"))
-    probs = torch.softmax(scores, dim=-1)
-    if dropout_p > 0.0:
-        probs = F.dropout(probs, p=dropout_p)
-    out = torch.matmul(probs, vh)  # (B,h,L,d)
-    return out.permute(2, 0, 1, 3), (probs if need_weights else None)
+        mask_u8 = mask.contiguous().to(torch.uint8)
+    d = q.shape[-1]
+    if d in (64, 128):
+        out = _FusedAttention.apply(q, k, v, mask_u8, scale, dropout_p)
+    elif d < 128:
+        # the kernels are specialised for the head dims of the model (64: dec_dim 256, 128:
+        # dec_dim 512); other widths are zero-padded, which changes neither scores nor outputs
+        pad = (64 if d < 64 else 128) - d
+        qp, kp, vp = (torch.nn.functional.pad(t, (0, pad)) for t in (q, k, v))
+        out = _FusedAttention.apply(qp, kp, vp, mask_u8, scale, dropout_p)[..., :d]
+    else:
+        raise RuntimeError(f"head_dim {d} > 128 is not supported by the fused attention core")
+    probs = None
+    if need_weights:
+        with torch.no_grad():  # visualisation output only; not part of the differentiated path
+            scores = torch.einsum("lbhd,sbhd->bhls", q * scale, k)
+            if mask is not None:
+                scores = scores.masked_fill(mask, float("-inf"))
+            probs = torch.softmax(scores, dim=-1)
+    return out, probs

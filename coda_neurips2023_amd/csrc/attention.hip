@@ -1,0 +1,563 @@
+// attention.hip -- fused multi-head attention core (forward + backward), fp32 MFMA.
+//
+// Replaces the baddbmm / softmax / dropout / bmm sequence inside
+// torch.nn.MultiheadAttention that the reference's encoder / decoder layers call
+// (models/transformer.py:470-471,566-573): the (B*h, L, S) fp32 probability
+// tensor (67 MB per scene per encoder layer) is never materialised.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32: A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31],
+// C/D col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):
+//  * Both GEMMs of the forward are evaluated TRANSPOSED so that a lane always owns
+//    one query column: S^T = K Q^T (A = K rows, B = Q rows) puts 16 keys of one
+//    query in the 16 accumulator registers of a lane -> the online-softmax row
+//    reductions are in-register plus ONE cross-half shuffle; O^T = V^T P^T takes
+//    those same registers unchanged as its B operand and keeps O with lane = query,
+//    so the rescale by exp(m_old - m_new) is a per-lane scalar multiply.
+//  * The two k-slots of a k-step are mapped to head-dim components (kk, D/2 + kk):
+//    a lane's A/B fragment is D/2 CONSECUTIVE floats of one row -> ds_read_b128 /
+//    global float4 loads, LDS rows padded by 16 B (conflict-free b128 reads).
+//  * In O^T = V^T P^T the output row i <-> head-dim component is free; choosing
+//    dv = (D/32)*i + tile lets one ds_read_b64/b128 feed all D/32 output tiles.
+// The backward runs as two kernels (dK/dV owned per key block, dQ owned per query
+// block): no atomics, deterministic, at the price of recomputing S twice.
+#include "coda_attention.h"
+#include "common.hip.h"
+
+namespace coda {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 32;  // keys (or queries) per MFMA tile
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Counter-based dropout decision, identical in forward and backward.
+__device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t bh, uint32_t q, uint32_t key,
+                                             uint32_t s_len, uint32_t thresh24) {
+  uint32_t x = (q * s_len + key) ^ (bh * 0x9E3779B9u) ^ seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  x += bh; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+  return (x >> 8) >= thresh24;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct MhaParams {
+  const float *q, *k, *v;
+  const uint8_t *mask;
+  float *out, *lse;
+  int b, h, l, s;
+  int ldq, ldk, ldv;  // floats between consecutive batch rows of q / k / v (H*D when dense)
+  float scale, inv_keep;
+  uint32_t thresh24, seed;
+};
+
+// Cooperative copy of `rows` x D floats (row stride `gstride` floats) into a padded LDS tile.
+template <int D, int THREADS>
+__device__ __forceinline__ void load_tile(float *lds, const float *g, size_t gstride, int row0,
+                                          int nrows_total, int tid) {
+  constexpr int LS = D + 4;
+  for (int i = tid; i < kTile * D / 4; i += THREADS) {
+    const int row = i / (D / 4), c4 = i % (D / 4);
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows_total)
+      val = *reinterpret_cast<const float4 *>(g + static_cast<size_t>(row0 + row) * gstride + c4 * 4);
+    *reinterpret_cast<float4 *>(lds + row * LS + c4 * 4) = val;
+  }
+}
+
+template <int D, int QW>
+__global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
+  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
+  __shared__ __attribute__((aligned(16))) float s_k[kTile * LS];
+  __shared__ __attribute__((aligned(16))) float s_v[kTile * LS];
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = (blockIdx.x * QW + w) * kTile;
+  const int myq = q0 + l31;
+  const bool wave_active = q0 < p.l;  // wave-uniform
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;  // dense outputs
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float qf[HD];
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (myq < p.l)
+      t = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
+    qf[c] = t.x * p.scale; qf[c + 1] = t.y * p.scale; qf[c + 2] = t.z * p.scale; qf[c + 3] = t.w * p.scale;
+  }
+
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const bool use_drop = p.thresh24 != 0u;
+
+  for (int s0 = 0; s0 < p.s; s0 += kTile) {
+    __syncthreads();
+    load_tile<D, THREADS>(s_k, kbase, kstride, s0, p.s, tid);
+    load_tile<D, THREADS>(s_v, vbase, vstride, s0, p.s, tid);
+    __syncthreads();
+    if (!wave_active) continue;
+
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kf = *reinterpret_cast<const float4 *>(s_k + l31 * LS + half * HD + c);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c + 1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c + 2], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c + 3], sacc, 0, 0, 0);
+    }
+    // sacc[r] = scale * <q[myq], k[s0 + crow(r, half)]>
+    float pr[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = s0 + crow(r, half);
+      bool dead = key >= p.s;
+      if (p.mask && !dead && myq < p.l)
+        dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
+      pr[r] = dead ? -INFINITY : sacc[r];
+      tmax = fmaxf(tmax, pr[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = fast_exp2((m - m_safe) * kLog2e);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float e = fast_exp2((pr[r] - m_safe) * kLog2e);
+      rs += e;
+      if (use_drop) {
+        const int key = s0 + crow(r, half);
+        e = dropout_keep(p.seed, bh, myq, key, p.s, p.thresh24) ? e * p.inv_keep : 0.f;
+      }
+      pr[r] = e;
+    }
+    lsum = lsum * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float *vrow = s_v + crow(r, half) * LS + NT * l31;
+      if (NT == 2) {
+        const float2 vv = *reinterpret_cast<const float2 *>(vrow);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, pr[r], o[1], 0, 0, 0);
+      } else {
+        const float4 vv = *reinterpret_cast<const float4 *>(vrow);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, pr[r], o[1], 0, 0, 0);
+        o[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, pr[r], o[2 % NT], 0, 0, 0);
+        o[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, pr[r], o[3 % NT], 0, 0, 0);
+      }
+    }
+  }
+
+  lsum += __shfl_xor(lsum, 32);
+  if (myq < p.l) {
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dv = NT * crow(r, half);
+      if (NT == 2) {
+        *reinterpret_cast<float2 *>(orow + dv) = make_float2(o[0][r] * inv, o[1][r] * inv);
+      } else {
+        *reinterpret_cast<float4 *>(orow + dv) =
+            make_float4(o[0][r] * inv, o[1][r] * inv, o[2 % NT][r] * inv, o[3 % NT][r] * inv);
+      }
+    }
+    if (half == 0)
+      p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m + __logf(lsum) : -INFINITY;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward.  delta[b,h,q] = sum_dv dout * out  (row-wise), then
+//   P  = exp(scale*QK^T - lse)         Pd = dropout(P)
+//   dV = Pd^T dO      dP = dO V^T (dropout-masked, /keep)     dS = P * (dP - delta) * scale
+//   dK = dS^T Q       dQ = dS K
+struct MhaBwdParams {
+  const float *q, *k, *v, *out, *lse, *dout;
+  const uint8_t *mask;
+  float *dq, *dk, *dv, *delta;
+  int b, h, l, s;
+  int ldq, ldk, ldv;
+  float scale, inv_keep;
+  uint32_t thresh24, seed;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
+  // one thread per (q, b, h) row
+  const size_t row = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
+  if (row >= nrows) return;
+  const float *o = p.out + row * D, *g = p.dout + row * D;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < D; c += 4) {
+    const float4 a = *reinterpret_cast<const float4 *>(o + c);
+    const float4 d = *reinterpret_cast<const float4 *>(g + c);
+    acc += a.x * d.x + a.y * d.y + a.z * d.z + a.w * d.w;
+  }
+  const int hh = row % p.h, bb = (row / p.h) % p.b, qq = row / (static_cast<size_t>(p.h) * p.b);
+  p.delta[(static_cast<size_t>(bb) * p.h + hh) * p.l + qq] = acc;
+}
+
+// dK / dV: a wave owns 32 keys (K, V fragments in registers), loops over query tiles.
+// S = Q K^T is evaluated UN-transposed here (A = Q rows, B = K rows): a lane then owns one
+// key column and 16 queries in registers, which is the A-operand layout of dV = Pd^T dO and
+// dK = dS^T Q (k-dimension = query).
+template <int D, int KW>
+__global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p) {
+  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
+  __shared__ __attribute__((aligned(16))) float s_q[kTile * LS];
+  __shared__ __attribute__((aligned(16))) float s_do[kTile * LS];
+  __shared__ float s_lse[kTile], s_delta[kTile];
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
+  const int k0 = (blockIdx.x * KW + w) * kTile;
+  const int mykey = k0 + l31;
+  const bool wave_active = k0 < p.s;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const bool use_drop = p.thresh24 != 0u;
+
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float kf[HD], vf[HD];  // B operands: K[mykey][half*HD + c], V[mykey][half*HD + c]
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a;
+    if (mykey < p.s) {
+      a = *reinterpret_cast<const float4 *>(kbase + static_cast<size_t>(mykey) * kstride + half * HD + c);
+      b4 = *reinterpret_cast<const float4 *>(vbase + static_cast<size_t>(mykey) * vstride + half * HD + c);
+    }
+    kf[c] = a.x; kf[c + 1] = a.y; kf[c + 2] = a.z; kf[c + 3] = a.w;
+    vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
+  }
+  f32x16 dk[NT], dv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  for (int q0 = 0; q0 < p.l; q0 += kTile) {
+    __syncthreads();
+    load_tile<D, THREADS>(s_q, qbase, qstride, q0, p.l, tid);
+    load_tile<D, THREADS>(s_do, p.dout + head_off, rstride, q0, p.l, tid);
+    if (tid < kTile) {
+      const int qq = q0 + tid;
+      s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+      s_delta[tid] = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+
+    // S[q][key] and dP[q][key]: A = Q / dO rows (lane = query), B = K / V rows (lane = key)
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 qa = *reinterpret_cast<const float4 *>(s_q + l31 * LS + half * HD + c);
+      const float4 ga = *reinterpret_cast<const float4 *>(s_do + l31 * LS + half * HD + c);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kf[c], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vf[c], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kf[c + 1], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vf[c + 1], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kf[c + 2], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vf[c + 2], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kf[c + 3], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vf[c + 3], pacc, 0, 0, 0);
+    }
+    // lane: key = mykey, register r: query q0 + crow(r, half)
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = crow(r, half), qq = q0 + qi;
+      bool dead = qq >= p.l || mykey >= p.s;
+      if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
+      const float lse = s_lse[qi];
+      float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
+      float keep = 1.f;
+      if (use_drop) keep = dropout_keep(p.seed, bh, qq, mykey, p.s, p.thresh24) ? p.inv_keep : 0.f;
+      pd[r] = prob * keep;
+      ds[r] = prob * (pacc[r] * keep - s_delta[qi]) * p.scale;
+    }
+    // dV^T? no: dV[key][dv] += sum_q Pd[q][key] dO[q][dv]  (A = Pd^T: lane = key, k = query)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = crow(r, half);
+      const float *grow = s_do + qi * LS + NT * l31;
+      const float *qrow = s_q + qi * LS + NT * l31;
+      if (NT == 2) {
+        const float2 g2 = *reinterpret_cast<const float2 *>(grow);
+        const float2 q2 = *reinterpret_cast<const float2 *>(qrow);
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.x, dv[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.y, dv[1], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.x, dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.y, dk[1], 0, 0, 0);
+      } else {
+        const float4 g4 = *reinterpret_cast<const float4 *>(grow);
+        const float4 q4 = *reinterpret_cast<const float4 *>(qrow);
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g4.x, dv[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g4.y, dv[1], 0, 0, 0);
+        dv[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g4.z, dv[2 % NT], 0, 0, 0);
+        dv[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g4.w, dv[3 % NT], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q4.x, dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q4.y, dk[1], 0, 0, 0);
+        dk[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q4.z, dk[2 % NT], 0, 0, 0);
+        dk[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q4.w, dk[3 % NT], 0, 0, 0);
+      }
+    }
+  }
+
+  // dk[t][r]: row i = crow(r, half) = key within the tile, column j = l31 <-> component NT*l31 + t
+  if (wave_active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + crow(r, half);
+      if (key < p.s) {
+        float *dkrow = p.dk + static_cast<size_t>(key) * rstride + head_off + NT * l31;
+        float *dvrow = p.dv + static_cast<size_t>(key) * rstride + head_off + NT * l31;
+        if (NT == 2) {
+          *reinterpret_cast<float2 *>(dkrow) = make_float2(dk[0][r], dk[1][r]);
+          *reinterpret_cast<float2 *>(dvrow) = make_float2(dv[0][r], dv[1][r]);
+        } else {
+          *reinterpret_cast<float4 *>(dkrow) = make_float4(dk[0][r], dk[1][r], dk[2 % NT][r], dk[3 % NT][r]);
+          *reinterpret_cast<float4 *>(dvrow) = make_float4(dv[0][r], dv[1][r], dv[2 % NT][r], dv[3 % NT][r]);
+        }
+      }
+    }
+  }
+}
+
+// dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
+// the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
+template <int D, int QW>
+__global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) {
+  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
+  __shared__ __attribute__((aligned(16))) float s_k[kTile * LS];
+  __shared__ __attribute__((aligned(16))) float s_v[kTile * LS];
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = (blockIdx.x * QW + w) * kTile;
+  const int myq = q0 + l31;
+  const bool wave_active = q0 < p.l;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const bool use_drop = p.thresh24 != 0u;
+
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float qf[HD], gf[HD];
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), g = a;
+    if (myq < p.l) {
+      a = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
+      g = *reinterpret_cast<const float4 *>(p.dout + static_cast<size_t>(myq) * rstride + head_off + half * HD + c);
+    }
+    qf[c] = a.x * p.scale; qf[c + 1] = a.y * p.scale; qf[c + 2] = a.z * p.scale; qf[c + 3] = a.w * p.scale;
+    gf[c] = g.x; gf[c + 1] = g.y; gf[c + 2] = g.z; gf[c + 3] = g.w;
+  }
+  float lse = 0.f, delta = 0.f;
+  if (myq < p.l) {
+    lse = p.lse[static_cast<size_t>(bh) * p.l + myq];
+    delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
+  }
+  f32x16 dq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+
+  for (int s0 = 0; s0 < p.s; s0 += kTile) {
+    __syncthreads();
+    load_tile<D, THREADS>(s_k, kbase, kstride, s0, p.s, tid);
+    load_tile<D, THREADS>(s_v, vbase, vstride, s0, p.s, tid);
+    __syncthreads();
+    if (!wave_active) continue;
+
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 ka = *reinterpret_cast<const float4 *>(s_k + l31 * LS + half * HD + c);
+      const float4 va = *reinterpret_cast<const float4 *>(s_v + l31 * LS + half * HD + c);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qf[c], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, gf[c], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qf[c + 1], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, gf[c + 1], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qf[c + 2], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, gf[c + 2], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qf[c + 3], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, gf[c + 3], pacc, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = s0 + crow(r, half);
+      bool dead = key >= p.s || myq >= p.l;
+      if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
+      const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] - lse) * kLog2e);
+      float keep = 1.f;
+      if (use_drop) keep = dropout_keep(p.seed, bh, myq, key, p.s, p.thresh24) ? p.inv_keep : 0.f;
+      ds[r] = prob * (pacc[r] * keep - delta) * p.scale;
+    }
+    // dQ[q][d] += sum_key dS[q][key] K[key][d]   (A = dS: lane = query, k = key)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float *krow = s_k + crow(r, half) * LS + NT * l31;
+      if (NT == 2) {
+        const float2 k2 = *reinterpret_cast<const float2 *>(krow);
+        dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k2.x, dq[0], 0, 0, 0);
+        dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k2.y, dq[1], 0, 0, 0);
+      } else {
+        const float4 k4 = *reinterpret_cast<const float4 *>(krow);
+        dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.x, dq[0], 0, 0, 0);
+        dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.y, dq[1], 0, 0, 0);
+        dq[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.z, dq[2 % NT], 0, 0, 0);
+        dq[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.w, dq[3 % NT], 0, 0, 0);
+      }
+    }
+  }
+  if (wave_active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + crow(r, half);
+      if (qq < p.l) {
+        float *row = p.dq + static_cast<size_t>(qq) * rstride + head_off + NT * l31;
+        if (NT == 2) {
+          *reinterpret_cast<float2 *>(row) = make_float2(dq[0][r], dq[1][r]);
+        } else {
+          *reinterpret_cast<float4 *>(row) = make_float4(dq[0][r], dq[1][r], dq[2 % NT][r], dq[3 % NT][r]);
+        }
+      }
+    }
+  }
+}
+
+uint32_t drop_threshold(float p) {
+  if (!(p > 0.f)) return 0u;
+  double t = static_cast<double>(p) * 16777216.0;
+  if (t < 1.0) t = 1.0;
+  if (t > 16777215.0) t = 16777215.0;
+  return static_cast<uint32_t>(t);
+}
+
+template <int D>
+int launch_fwd(const MhaParams &p, hipStream_t s) {
+  clear_sticky_error();
+  if (p.l >= 1024) {
+    dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
+    hipLaunchKernelGGL((mha_fwd_kernel<D, 4>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
+    hipLaunchKernelGGL((mha_fwd_kernel<D, 1>), grid, dim3(64), 0, s, p);
+  }
+  return launch_status();
+}
+
+template <int D>
+int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
+  clear_sticky_error();
+  const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
+  hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+  if (p.s >= 1024) {
+    hipLaunchKernelGGL((mha_bwd_dkv_kernel<D, 4>), dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((mha_bwd_dkv_kernel<D, 1>), dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(64), 0, s, p);
+  }
+  if (p.l >= 1024) {
+    hipLaunchKernelGGL((mha_bwd_dq_kernel<D, 4>), dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((mha_bwd_dq_kernel<D, 1>), dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(64), 0, s, p);
+  }
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace coda
+
+CODA_API int coda_mha_fwd_f32(const float *q, const float *k, const float *v, const uint8_t *mask,
+                              float *out, float *lse, int b, int h, int l, int s, int d, int ldq, int ldk,
+                              int ldv, float scale, float dropout_p, uint64_t seed, void *stream) {
+  using namespace coda;
+  if (b < 0 || h <= 0 || l < 0 || s < 0 || (d != 64 && d != 128) || dropout_p < 0.f || dropout_p >= 1.f ||
+      ldq < h * d || ldk < h * d || ldv < h * d || (ldq | ldk | ldv) % 4 != 0)
+    return CODA_EINVAL;
+  if (b == 0 || l == 0) return CODA_OK;
+  if (!q || !out || !lse || (s > 0 && (!k || !v))) return CODA_EINVAL;
+  MhaParams p;
+  p.q = q; p.k = k; p.v = v; p.mask = mask; p.out = out; p.lse = lse;
+  p.b = b; p.h = h; p.l = l; p.s = s;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.scale = scale;
+  p.thresh24 = drop_threshold(dropout_p);
+  p.inv_keep = 1.0f / (1.0f - dropout_p);
+  p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return d == 64 ? launch_fwd<64>(p, st) : launch_fwd<128>(p, st);
+}
+
+CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, const uint8_t *mask,
+                              const float *out, const float *lse, const float *dout, float *dq,
+                              float *dk, float *dv, float *delta, int b, int h, int l, int s, int d,
+                              int ldq, int ldk, int ldv, float scale, float dropout_p, uint64_t seed,
+                              void *stream) {
+  using namespace coda;
+  if (b < 0 || h <= 0 || l < 0 || s < 0 || (d != 64 && d != 128) || dropout_p < 0.f || dropout_p >= 1.f ||
+      ldq < h * d || ldk < h * d || ldv < h * d || (ldq | ldk | ldv) % 4 != 0)
+    return CODA_EINVAL;
+  if (b == 0 || (l == 0 && s == 0)) return CODA_OK;
+  if (l == 0 || s == 0) return CODA_EINVAL;
+  if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta) return CODA_EINVAL;
+  MhaBwdParams p;
+  p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.dout = dout; p.mask = mask;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.delta = delta;
+  p.b = b; p.h = h; p.l = l; p.s = s;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.scale = scale;
+  p.thresh24 = drop_threshold(dropout_p);
+  p.inv_keep = 1.0f / (1.0f - dropout_p);
+  p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return d == 64 ? launch_bwd<64>(p, st) : launch_bwd<128>(p, st);
+}

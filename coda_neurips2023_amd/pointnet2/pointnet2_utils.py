@@ -170,7 +170,9 @@ class QueryAndGroup(nn.Module):
                 grouped_xyz /= self.radius
 
         if features is not None:
-            grouped_features = grouping_operation(features, idx)
+            # the masked encoder hands over a permuted view (transformer.py:199-201); the
+            # reference op would assert on it, here it is made dense
+            grouped_features = grouping_operation(features.contiguous(), idx)
             if self.use_xyz:
                 new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
             else:

@@ -1,0 +1,59 @@
+/*
+ * coda_attention.h -- C ABI of the fused multi-head attention core (gfx950, fp32 MFMA).
+ *
+ * Replaces the scaled-dot-product core inside torch.nn.MultiheadAttention as the
+ * reference's 3DETR layers use it (models/transformer.py:422,470-471,506-507,
+ * 566-573 -> torch.nn.functional.multi_head_attention_forward):
+ *     P = softmax(scale * Q K^T  [masked -> -inf]);  O = dropout_p(P) V
+ * for the three shapes of the path: encoder self-attention (2048 x 2048), decoder
+ * self-attention (nq x nq) and decoder cross-attention (nq x 2048), 4 heads,
+ * head_dim 64 (dec_dim 256) or 128 (dec_dim 512).
+ *
+ * Layout: the SEQUENCE-FIRST projections are read in place,
+ *     q (L, B, H, D),  k / v (S, B, H, D),  out (L, B, H, D)   float32,
+ * element (l, b, h, c) of q at (l*B + b)*ldq + h*D + c (same for k / ldk, v / ldv):
+ * ld* = H*D for dense (L,B,E) tensors, 3*H*D for the slices of a packed in-projection
+ * (no copy of the chunks is needed).  out, dout, dq, dk, dv are dense (ld = H*D).  lse (B, H, L) float32 keeps log-sum-exp of the
+ * scaled scores for the backward pass.  mask: optional uint8 (B, H, L, S), non-zero
+ * = key not attended (the boolean radius mask of MaskedTransformerEncoder,
+ * transformer.py:154-190), or NULL.
+ *
+ * Dropout: keep(b,h,l,s) is a counter-based hash of (seed, b*H+h, l, s) evaluated
+ * identically in forward and backward; kept probabilities are scaled by 1/(1-p).
+ * p = 0 disables it (eval mode).
+ *
+ * Numerics: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf
+ * chain), fp32 online softmax; parity target 1e-3 relative vs the fp32 reference.
+ * Rows whose keys are ALL masked produce 0 (torch produces NaN).
+ *
+ * Return values and stream semantics as in coda_pointnet2.h.  head_dim must be 64
+ * or 128 (CODA_EINVAL otherwise).
+ */
+#ifndef CODA_ATTENTION_H
+#define CODA_ATTENTION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int coda_mha_fwd_f32(const float *q, const float *k, const float *v,
+                     const uint8_t *mask, float *out, float *lse, int b, int h,
+                     int l, int s, int d, int ldq, int ldk, int ldv, float scale,
+                     float dropout_p, uint64_t seed, void *stream);
+
+/* dq (L,B,H,D), dk / dv (S,B,H,D) are fully written.  `delta` is a (B,H,L) float
+ * scratch provided by the caller (rowsum(dout * out)). */
+int coda_mha_bwd_f32(const float *q, const float *k, const float *v,
+                     const uint8_t *mask, const float *out, const float *lse,
+                     const float *dout, float *dq, float *dk, float *dv,
+                     float *delta, int b, int h, int l, int s, int d, int ldq,
+                     int ldk, int ldv, float scale, float dropout_p, uint64_t seed,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODA_ATTENTION_H */

@@ -1,0 +1,121 @@
+"""Fused fp32-MFMA attention core (coda_mha_fwd_f32 / coda_mha_bwd_f32 through
+attention_core) against a plain torch fp32 reference of the same op
+(oracle/cpu_port.attention_ref, evaluated on the GPU): the three shapes of the path,
+ragged sizes, packed / dense layouts, boolean masks, head_dim 64 and 128, gradients,
+and the dropout path (mask recovered with V = I, consistency of forward and backward).
+Tolerance 1e-3 relative (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from coda_neurips2023_amd import attention_core
+from oracle.cpu_port import attention_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def make_qkv(dev, l, s, b, h, d, packed, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if packed and l == s:
+        qkv = torch.randn(l, b, 3 * h * d, generator=g).to(dev).requires_grad_(True)
+        q, k, v = (t.reshape(l, b, h, d) for t in qkv.chunk(3, dim=-1))
+        return (qkv,), q, k, v
+    q = torch.randn(l, b, h, d, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(s, b, h, d, generator=g).to(dev).requires_grad_(True)
+    v = torch.randn(s, b, h, d, generator=g).to(dev).requires_grad_(True)
+    return (q, k, v), q, k, v
+
+
+@pytest.mark.parametrize("l,s,b,h,d,packed,masked", [
+    (2048, 2048, 2, 4, 64, True, False),    # encoder self-attention
+    (256, 256, 2, 4, 64, True, False),      # decoder self-attention
+    (256, 2048, 2, 4, 64, False, False),    # decoder cross-attention
+    (100, 77, 3, 2, 64, False, True),       # ragged + mask
+    (33, 31, 1, 1, 64, False, False),
+    (1024, 1024, 1, 4, 64, True, True),     # masked encoder after interim down-sampling
+    (40, 160, 2, 4, 128, False, False),     # dec_dim 512
+    (128, 128, 2, 4, 128, True, True),
+])
+def test_forward_backward_match_torch_reference(dev, l, s, b, h, d, packed, masked):
+    leaves, q, k, v = make_qkv(dev, l, s, b, h, d, packed, seed=l + s)
+    scale = d ** -0.5
+    mask = None
+    if masked:
+        mask = torch.rand(b, h, l, s, device=dev) < 0.3
+        mask[..., 0] = False  # no fully-masked rows (torch gives NaN there, the kernel 0)
+    out, _ = attention_core.attention(q, k, v, mask, scale, 0.0, False)
+    ref, _ = attention_ref(q, k, v, mask, scale, 0.0, False)
+    assert out.shape == (l, b, h, d)
+    assert rel(out, ref) < 1e-3
+    gw = torch.randn(out.shape, device=dev)
+    grads = torch.autograd.grad((out * gw).sum(), leaves)
+    grads_ref = torch.autograd.grad((ref * gw).sum(), leaves)
+    for g, gr in zip(grads, grads_ref):
+        assert rel(g, gr) < 1e-3
+
+
+def test_need_weights_output(dev):
+    _, q, k, v = make_qkv(dev, 64, 96, 2, 4, 64, False, seed=3)
+    out, probs = attention_core.attention(q, k, v, None, 0.125, 0.0, True)
+    ref, probs_ref = attention_ref(q, k, v, None, 0.125, 0.0, True)
+    assert rel(out, ref) < 1e-3 and rel(probs, probs_ref) < 1e-4
+    assert torch.allclose(probs.sum(-1), torch.ones_like(probs.sum(-1)), atol=1e-5)
+
+
+def test_fully_masked_rows_give_zero(dev):
+    _, q, k, v = make_qkv(dev, 40, 50, 1, 2, 64, False, seed=4)
+    mask = torch.zeros(1, 2, 40, 50, dtype=torch.bool, device=dev)
+    mask[:, :, 7] = True
+    out, _ = attention_core.attention(q, k, v, mask, 0.125, 0.0, False)
+    assert torch.isfinite(out).all() and out[7].abs().max() == 0
+    (gq,) = torch.autograd.grad(out.sum(), q)
+    assert torch.isfinite(gq).all()
+
+
+def test_dropout_mask_statistics_and_backward_consistency(dev):
+    l, s, b, h, d, p = 96, 64, 2, 4, 64, 0.3
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(l, b, h, d, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(s, b, h, d, generator=g).to(dev).requires_grad_(True)
+    eye = torch.eye(s, d).view(s, 1, 1, d).expand(s, b, h, d).contiguous().to(dev).requires_grad_(True)
+    scale = d ** -0.5
+    torch.manual_seed(123)
+    a_drop, _ = attention_core.attention(q, k, eye, None, scale, p, False)   # = dropout(P) itself
+    probs = attention_ref(q, k, eye, None, scale, 0.0, True)[1].permute(2, 0, 1, 3)  # (l,b,h,s)
+    kept = a_drop != 0
+    frac = kept.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.02, frac
+    assert rel(a_drop[kept], (probs / (1 - p))[kept]) < 1e-3            # kept entries are P/(1-p)
+    # per-(b,h) keep rates are similar: the hash decorrelates heads
+    per_head = kept.float().mean(dim=(0, 3))
+    assert (per_head - (1 - p)).abs().max() < 0.05
+    # same seed -> same mask; different seed -> different mask
+    torch.manual_seed(123)
+    again, _ = attention_core.attention(q, k, eye, None, scale, p, False)
+    assert torch.equal(again, a_drop)
+    torch.manual_seed(124)
+    other, _ = attention_core.attention(q, k, eye, None, scale, p, False)
+    assert not torch.equal(other, a_drop)
+    # backward uses the same mask: compare with autograd through the explicit masked formula
+    v = torch.randn(s, b, h, d, generator=g).to(dev).requires_grad_(True)
+    torch.manual_seed(123)
+    out, _ = attention_core.attention(q, k, v, None, scale, p, False)
+    keep_mask = kept.float() / (1 - p)                                     # (l,b,h,s)
+    scores = torch.einsum("lbhd,sbhd->lbhs", q * scale, k)
+    ref = torch.einsum("lbhs,sbhd->lbhd", torch.softmax(scores, -1) * keep_mask, v)
+    assert rel(out, ref) < 1e-3
+    gw = torch.randn(out.shape, device=dev)
+    grads = torch.autograd.grad((out * gw).sum(), (q, k, v))
+    grads_ref = torch.autograd.grad((ref * gw).sum(), (q, k, v))
+    for a, r in zip(grads, grads_ref):
+        assert rel(a, r) < 1e-3
+
+
+def test_cpu_tensors_rejected():
+    q = torch.randn(8, 1, 1, 64)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        attention_core.attention(q, q, q, None, 0.125, 0.0, False)
