@@ -35,6 +35,13 @@ SIGNATURES = {
     "coda_three_nn_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_grad_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    # include/coda_sa_mlp.h
+    "coda_sa_col_stats_f32": (_c_int, [_P, _P, ctypes.c_longlong, _c_int, _P, _P]),
+    "coda_sa_bn_relu_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
+    "coda_sa_col_stats_pool_f32": (_c_int, [_P, ctypes.c_longlong, _c_int, _c_int, _P, _P, _P, _P, _P, _P]),
+    "coda_sa_bn_bwd_sparse_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_int, _P, _P]),
+    "coda_sa_relu_bn_bwd_stats_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
+    "coda_sa_relu_bn_bwd_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P, _P]),
     # include/coda_attention.h
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P]),

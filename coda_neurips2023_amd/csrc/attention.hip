@@ -55,11 +55,11 @@ struct MhaParams {
 };
 
 // Cooperative copy of `rows` x D floats (row stride `gstride` floats) into a padded LDS tile.
-template <int D, int THREADS>
+template <int D, int THREADS, int ROWS = kTile>
 __device__ __forceinline__ void load_tile(float *lds, const float *g, size_t gstride, int row0,
                                           int nrows_total, int tid) {
   constexpr int LS = D + 4;
-  for (int i = tid; i < kTile * D / 4; i += THREADS) {
+  for (int i = tid; i < ROWS * D / 4; i += THREADS) {
     const int row = i / (D / 4), c4 = i % (D / 4);
     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + row < nrows_total)
@@ -68,16 +68,25 @@ __device__ __forceinline__ void load_tile(float *lds, const float *g, size_t gst
   }
 }
 
-template <int D, int QW>
+// SPLIT = false: every wave owns its own block of 32 queries and all waves share one K/V tile
+//                 per step (long query sequences: the encoder).
+// SPLIT = true:  all QW waves work on the SAME 32 queries and split the keys (QW tiles are
+//                 staged per step, wave w takes tile w); the partial (m, l, O) are merged
+//                 through LDS at the end.  This is what fills the chip for the decoder, whose
+//                 256 queries give only 8 query blocks per (scene, head).
+template <int D, int QW, bool SPLIT>
 __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  __shared__ __attribute__((aligned(16))) float s_k[kTile * LS];
-  __shared__ __attribute__((aligned(16))) float s_v[kTile * LS];
+  constexpr int TILES = SPLIT ? QW : 1;  // K/V tiles staged per step
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *s_k = s_dyn;
+  float *s_v = s_dyn + TILES * kTile * LS;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = (blockIdx.x * QW + w) * kTile;
+  const int q0 = SPLIT ? blockIdx.x * kTile : (blockIdx.x * QW + w) * kTile;
+  const int my_tile = SPLIT ? w : 0;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;  // wave-uniform
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;  // dense outputs
@@ -105,19 +114,21 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   float m = -INFINITY, lsum = 0.f;
   const bool use_drop = p.thresh24 != 0u;
 
-  for (int s0 = 0; s0 < p.s; s0 += kTile) {
+  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
     __syncthreads();
-    load_tile<D, THREADS>(s_k, kbase, kstride, s0, p.s, tid);
-    load_tile<D, THREADS>(s_v, vbase, vstride, s0, p.s, tid);
+    load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
+    load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
     __syncthreads();
-    if (!wave_active) continue;
+    const int s0 = sbase + my_tile * kTile;
+    if (!wave_active || s0 >= p.s) continue;
+    const float *tk = s_k + my_tile * kTile * LS, *tv = s_v + my_tile * kTile * LS;
 
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      const float4 kf = *reinterpret_cast<const float4 *>(s_k + l31 * LS + half * HD + c);
+      const float4 kf = *reinterpret_cast<const float4 *>(tk + l31 * LS + half * HD + c);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c + 1], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c + 2], sacc, 0, 0, 0);
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float *vrow = s_v + crow(r, half) * LS + NT * l31;
+      const float *vrow = tv + crow(r, half) * LS + NT * l31;
       if (NT == 2) {
         const float2 vv = *reinterpret_cast<const float2 *>(vrow);
         o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
@@ -175,6 +186,40 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   }
 
   lsum += __shfl_xor(lsum, 32);
+  if (SPLIT && QW > 1) {
+    // merge the per-wave partial softmax states: slot layout [wave-1][NT*16 + 2][64 lanes]
+    __syncthreads();  // everyone is done with the K/V tiles
+    float *slot = s_dyn + static_cast<size_t>(w > 0 ? w - 1 : 0) * (NT * 16 + 2) * kWave;
+    if (w > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * kWave + lane] = o[t][r];
+      slot[(NT * 16) * kWave + lane] = m;
+      slot[(NT * 16 + 1) * kWave + lane] = lsum;
+    }
+    __syncthreads();
+    if (w > 0) return;
+    float m_all = m;
+    for (int ww = 1; ww < QW; ++ww) m_all = fmaxf(m_all, s_dyn[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
+    const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
+    const float f0 = fast_exp2((m - m_ref) * kLog2e);
+    lsum *= f0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= f0;
+    for (int ww = 1; ww < QW; ++ww) {
+      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
+      const float fw = fast_exp2((sl[(NT * 16) * kWave + lane] - m_ref) * kLog2e);
+      lsum += sl[(NT * 16 + 1) * kWave + lane] * fw;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] += sl[(t * 16 + r) * kWave + lane] * fw;
+    }
+    m = m_all;
+  }
   if (myq < p.l) {
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
     float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
@@ -363,16 +408,19 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
 
 // dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
 // the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
-template <int D, int QW>
+template <int D, int QW, bool SPLIT>
 __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  __shared__ __attribute__((aligned(16))) float s_k[kTile * LS];
-  __shared__ __attribute__((aligned(16))) float s_v[kTile * LS];
+  constexpr int TILES = SPLIT ? QW : 1;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *s_k = s_dyn;
+  float *s_v = s_dyn + TILES * kTile * LS;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = (blockIdx.x * QW + w) * kTile;
+  const int q0 = SPLIT ? blockIdx.x * kTile : (blockIdx.x * QW + w) * kTile;
+  const int my_tile = SPLIT ? w : 0;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
@@ -407,20 +455,22 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
 
-  for (int s0 = 0; s0 < p.s; s0 += kTile) {
+  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
     __syncthreads();
-    load_tile<D, THREADS>(s_k, kbase, kstride, s0, p.s, tid);
-    load_tile<D, THREADS>(s_v, vbase, vstride, s0, p.s, tid);
+    load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
+    load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
     __syncthreads();
-    if (!wave_active) continue;
+    const int s0 = sbase + my_tile * kTile;
+    if (!wave_active || s0 >= p.s) continue;
+    const float *tk = s_k + my_tile * kTile * LS, *tv = s_v + my_tile * kTile * LS;
 
     f32x16 sacc, pacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      const float4 ka = *reinterpret_cast<const float4 *>(s_k + l31 * LS + half * HD + c);
-      const float4 va = *reinterpret_cast<const float4 *>(s_v + l31 * LS + half * HD + c);
+      const float4 ka = *reinterpret_cast<const float4 *>(tk + l31 * LS + half * HD + c);
+      const float4 va = *reinterpret_cast<const float4 *>(tv + l31 * LS + half * HD + c);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qf[c], sacc, 0, 0, 0);
       pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, gf[c], pacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qf[c + 1], sacc, 0, 0, 0);
@@ -444,7 +494,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
     // dQ[q][d] += sum_key dS[q][key] K[key][d]   (A = dS: lane = query, k = key)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float *krow = s_k + crow(r, half) * LS + NT * l31;
+      const float *krow = tk + crow(r, half) * LS + NT * l31;
       if (NT == 2) {
         const float2 k2 = *reinterpret_cast<const float2 *>(krow);
         dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k2.x, dq[0], 0, 0, 0);
@@ -456,6 +506,25 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
         dq[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.z, dq[2 % NT], 0, 0, 0);
         dq[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.w, dq[3 % NT], 0, 0, 0);
       }
+    }
+  }
+  if (SPLIT && QW > 1) {  // sum the per-wave partial dQ through LDS: [wave-1][NT*16][64 lanes]
+    __syncthreads();
+    if (w > 0) {
+      float *slot = s_dyn + static_cast<size_t>(w - 1) * (NT * 16) * kWave;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * kWave + lane] = dq[t][r];
+    }
+    __syncthreads();
+    if (w > 0) return;
+    for (int ww = 1; ww < QW; ++ww) {
+      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16) * kWave;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[t][r] += sl[(t * 16 + r) * kWave + lane];
     }
   }
   if (wave_active) {
@@ -482,15 +551,28 @@ uint32_t drop_threshold(float p) {
   return static_cast<uint32_t>(t);
 }
 
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return CODA_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  return e == hipSuccess ? CODA_OK : static_cast<int>(e);
+}
+
 template <int D>
 int launch_fwd(const MhaParams &p, hipStream_t s) {
+  constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
   clear_sticky_error();
   if (p.l >= 1024) {
+    auto kern = mha_fwd_kernel<D, 4, false>;
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
-    hipLaunchKernelGGL((mha_fwd_kernel<D, 4>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), kTileBytes, s, p);
   } else {
+    auto kern = mha_fwd_kernel<D, 4, true>;
+    int st = set_lds(kern, 4 * kTileBytes);
+    if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
-    hipLaunchKernelGGL((mha_fwd_kernel<D, 1>), grid, dim3(64), 0, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
   }
   return launch_status();
 }
@@ -505,10 +587,15 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   } else {
     hipLaunchKernelGGL((mha_bwd_dkv_kernel<D, 1>), dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(64), 0, s, p);
   }
+  constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);
   if (p.l >= 1024) {
-    hipLaunchKernelGGL((mha_bwd_dq_kernel<D, 4>), dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 0, s, p);
+    auto kern = mha_bwd_dq_kernel<D, 4, false>;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), kTileBytes, s, p);
   } else {
-    hipLaunchKernelGGL((mha_bwd_dq_kernel<D, 1>), dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(64), 0, s, p);
+    auto kern = mha_bwd_dq_kernel<D, 4, true>;
+    int st = set_lds(kern, 4 * kTileBytes);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   }
   return launch_status();
 }

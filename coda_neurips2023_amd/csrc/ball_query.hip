@@ -103,16 +103,21 @@ __global__ __launch_bounds__(kBqWaves * kWave) void ball_query_scan_kernel(
           float gx = __fsub_rn(pts[v * 3 + 0], cx[c]);
           float gy = __fsub_rn(pts[v * 3 + 1], cy[c]);
           float gz = __fsub_rn(pts[v * 3 + 2], cz[c]);
-          if (normalize) {
+          if (normalize & 1) {
             gx = __fmul_rn(gx, inv_radius);
             gy = __fmul_rn(gy, inv_radius);
             gz = __fmul_rn(gz, inv_radius);
           }
-          const size_t plane = static_cast<size_t>(m) * nsample;
-          float *g = grouped + static_cast<size_t>(bi) * 3 * plane + static_cast<size_t>(j) * nsample + s;
-          g[0] = gx;
-          g[plane] = gy;
-          g[2 * plane] = gz;
+          if (normalize & 2) {  // channels-last (B,M,S,3): feeds the fused shared MLP
+            float *g = grouped + ((static_cast<size_t>(bi) * m + j) * nsample + s) * 3;
+            g[0] = gx; g[1] = gy; g[2] = gz;
+          } else {              // (B,3,M,S): the reference layout
+            const size_t plane = static_cast<size_t>(m) * nsample;
+            float *g = grouped + static_cast<size_t>(bi) * 3 * plane + static_cast<size_t>(j) * nsample + s;
+            g[0] = gx;
+            g[plane] = gy;
+            g[2 * plane] = gz;
+          }
         }
       }
     }

@@ -28,6 +28,7 @@ namespace coda {
 
 constexpr int kCellMax = 32768;       // cells per scene (128 KiB of LDS counters)
 constexpr int kGridThreads = 1024;
+constexpr int kGridUnroll = 8;         // points per thread whose loads are in flight together
 constexpr int kHitCap = 256;          // LDS hit records per wave (4 KiB)
 constexpr int kQueryWaves = 4;
 constexpr int kGridMinPoints = 1024;  // below this the scan kernel is cheaper than building a grid
@@ -44,6 +45,8 @@ inline size_t grid_scene_bytes(int n) {
 
 namespace {
 
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
+
 __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }
@@ -57,6 +60,14 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv, int g) {
   return static_cast<int>(u);
 }
 
+// LDS counter index with one pad word per 32 counters: thread t scanning its 32 consecutive
+// counters then touches banks (t + i) mod 32 -- conflict-free -- instead of a single bank.
+__device__ __forceinline__ int cidx(int c) { return c + (c >> 5); }
+constexpr int kCntWords = kCellMax + (kCellMax >> 5);
+
+// The three passes over the points (bounding box, histogram, scatter) are latency-bound
+// loops (load -> dependent LDS atomic), so each pass handles kGridUnroll points per thread
+// per iteration with all their loads issued up front.
 __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *__restrict__ xyz,
                                                                   int n, float radius,
                                                                   unsigned char *__restrict__ ws,
@@ -65,9 +76,9 @@ __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int *s_cnt = reinterpret_cast<int *>(smem);
   float(*s_red)[kGridThreads / kWave] =
-      reinterpret_cast<float(*)[kGridThreads / kWave]>(smem + sizeof(int) * kCellMax);
-  int *s_wave_sum = reinterpret_cast<int *>(smem + sizeof(int) * kCellMax + sizeof(float) * 6 * (kGridThreads / kWave));
-  GridHeader &s_hdr = *reinterpret_cast<GridHeader *>(smem + sizeof(int) * kCellMax +
+      reinterpret_cast<float(*)[kGridThreads / kWave]>(smem + sizeof(int) * kCntWords);
+  int *s_wave_sum = reinterpret_cast<int *>(smem + sizeof(int) * kCntWords + sizeof(float) * 6 * (kGridThreads / kWave));
+  GridHeader &s_hdr = *reinterpret_cast<GridHeader *>(smem + sizeof(int) * kCntWords +
                                                       sizeof(float) * 7 * (kGridThreads / kWave));
 
   const int tid = threadIdx.x;
@@ -79,16 +90,32 @@ __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *_
   int *cell_start = reinterpret_cast<int *>(base + sizeof(GridHeader));
   float4 *records = reinterpret_cast<float4 *>(base + sizeof(GridHeader) + sizeof(int) * (kCellMax + 1));
 
+  // for_each_point(f): f(k, x, y, z) for every point of the scene, kGridUnroll loads in flight
+  auto for_each_point = [&](auto &&f) {
+    for (int base = 0; base < n; base += kGridThreads * kGridUnroll) {
+      float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
+#pragma unroll
+      for (int u = 0; u < kGridUnroll; ++u) {
+        const int k = base + u * kGridThreads + tid;
+        // out-of-range slots become non-finite and are skipped like NaN/Inf points
+        x[u] = k < n ? pts[k * 3 + 0] : INFINITY;
+        y[u] = k < n ? pts[k * 3 + 1] : INFINITY;
+        z[u] = k < n ? pts[k * 3 + 2] : INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < kGridUnroll; ++u) f(base + u * kGridThreads + tid, x[u], y[u], z[u]);
+    }
+  };
+
   // ---- 1. bounding box of the finite points
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k = tid; k < n; k += kGridThreads) {
-    const float x = pts[k * 3 + 0], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+  for_each_point([&](int, float x, float y, float z) {
     if (finite3(x, y, z)) {
       lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
       lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
       lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
     }
-  }
+  });
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -100,7 +127,7 @@ __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *_
       s_red[3 + a][w] = hi[a];
     }
   }
-  for (int c = tid; c < kCellMax; c += kGridThreads) s_cnt[c] = 0;
+  for (int c = tid; c < kCntWords; c += kGridThreads) s_cnt[c] = 0;
   __syncthreads();
   if (tid == 0) {
     float mn[3], mx[3];
@@ -144,25 +171,21 @@ __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *_
   const int ncell = h.gx * h.gy * h.gz;
 
   // ---- 2. histogram
-  for (int k = tid; k < n; k += kGridThreads) {
-    const float x = pts[k * 3 + 0], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+  for_each_point([&](int, float x, float y, float z) {
     if (finite3(x, y, z)) {
       const int c = (cell_coord(z, h.oz, h.inv_cell, h.gz) * h.gy + cell_coord(y, h.oy, h.inv_cell, h.gy)) * h.gx +
                     cell_coord(x, h.ox, h.inv_cell, h.gx);
-      atomicAdd(&s_cnt[c], 1);
+      atomicAdd(&s_cnt[cidx(c)], 1);
     }
-  }
+  });
   __syncthreads();
 
-  // ---- 3. exclusive scan over kCellMax counters (16 consecutive per thread)
+  // ---- 3. exclusive scan over kCellMax counters (32 consecutive per thread)
   constexpr int kPer = kCellMax / kGridThreads;
-  int local[kPer];
+  static_assert(kPer == 32, "cidx() padding assumes 32 counters per thread");
   int sum = 0;
-#pragma unroll
-  for (int i = 0; i < kPer; ++i) {
-    local[i] = s_cnt[tid * kPer + i];
-    sum += local[i];
-  }
+#pragma unroll 8
+  for (int i = 0; i < kPer; ++i) sum += s_cnt[cidx(tid * kPer + i)];
   int incl = sum;
   for (int off = 1; off < kWave; off <<= 1) {
     const int v = __shfl_up(incl, off);
@@ -173,12 +196,13 @@ __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *_
   int wave_off = 0;
   for (int i = 0; i < w; ++i) wave_off += s_wave_sum[i];
   int run = wave_off + incl - sum;
-#pragma unroll
+#pragma unroll 8
   for (int i = 0; i < kPer; ++i) {
     const int c = tid * kPer + i;
-    s_cnt[c] = run;  // becomes the scatter cursor
+    const int cnt = s_cnt[cidx(c)];
+    s_cnt[cidx(c)] = run;  // becomes the scatter cursor
     if (c <= ncell) cell_start[c] = run;
-    run += local[i];
+    run += cnt;
   }
   if (tid == kGridThreads - 1) {
     if (ncell == kCellMax) cell_start[kCellMax] = run;
@@ -190,15 +214,14 @@ __global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *_
 
   // ---- 4. scatter (x, y, z, index) records into cell order (order inside a cell is
   //         arbitrary; the query ranks hits by index)
-  for (int k = tid; k < n; k += kGridThreads) {
-    const float x = pts[k * 3 + 0], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+  for_each_point([&](int k, float x, float y, float z) {
     if (finite3(x, y, z)) {
       const int c = (cell_coord(z, h.oz, h.inv_cell, h.gz) * h.gy + cell_coord(y, h.oy, h.inv_cell, h.gy)) * h.gx +
                     cell_coord(x, h.ox, h.inv_cell, h.gx);
-      const int pos = atomicAdd(&s_cnt[c], 1);
+      const int pos = atomicAdd(&s_cnt[cidx(c)], 1);
       records[pos] = make_float4(x, y, z, __int_as_float(k));
     }
-  }
+  });
 }
 
 // Keep only the `keep` smallest-index records of buf[0..h): all-pairs rank in LDS.
@@ -319,13 +342,18 @@ __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
     idx[row_off + s] = v;
     if (grouped) {
       float gx = __fsub_rn(p.x, cx), gy = __fsub_rn(p.y, cy), gz = __fsub_rn(p.z, cz);
-      if (normalize) {
+      if (normalize & 1) {
         gx = __fmul_rn(gx, inv_radius); gy = __fmul_rn(gy, inv_radius); gz = __fmul_rn(gz, inv_radius);
       }
-      float *g = grouped + static_cast<size_t>(bi) * 3 * plane + static_cast<size_t>(j) * nsample + s;
-      g[0] = gx;
-      g[plane] = gy;
-      g[2 * plane] = gz;
+      if (normalize & 2) {  // channels-last (B,M,S,3)
+        float *g = grouped + (row_off + s) * 3;
+        g[0] = gx; g[1] = gy; g[2] = gz;
+      } else {
+        float *g = grouped + static_cast<size_t>(bi) * 3 * plane + static_cast<size_t>(j) * nsample + s;
+        g[0] = gx;
+        g[plane] = gy;
+        g[2 * plane] = gz;
+      }
     }
   }
 }
@@ -338,11 +366,16 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
   const size_t stride = (grid_scene_bytes(n) + 255) & ~static_cast<size_t>(255);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   clear_sticky_error();
-  const size_t lds = sizeof(int) * kCellMax + sizeof(float) * 7 * (kGridThreads / kWave) + sizeof(GridHeader);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(grid_build_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(grid_build_kernel, dim3(b), dim3(kGridThreads), lds, s, xyz, n, radius, ws, stride);
+  const size_t lds = sizeof(int) * kCntWords + sizeof(float) * 7 * (kGridThreads / kWave) + sizeof(GridHeader);
+  auto launch_build = [&](auto kern) -> int {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(kGridThreads), lds, s, xyz, n, radius, ws, stride);
+    return CODA_OK;
+  };
+  const int st = launch_build(grid_build_kernel);
+  if (st != CODA_OK) return st;
   const float r2 = radius * radius;
   hipLaunchKernelGGL(grid_query_kernel, dim3(ceil_div(m, kQueryWaves), b), dim3(kQueryWaves * kWave), 0, s,
                      new_xyz, xyz, n, ws, stride, idx, grouped, m, r2, 1.0f / radius, nsample, normalize);

@@ -259,10 +259,12 @@ def three_interpolate_grad(grad_out, idx, weight, m):
 
 # ---- fused entry points of this build (not in the reference module) ------------------
 
-def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz, algorithm="auto"):
+def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz, algorithm="auto",
+                        channels_last=False):
     """ball_query + xyz grouping + centring (+ 1/radius) in one kernel.
 
-    Returns (idx (B,M,S) i32, grouped_xyz (B,3,M,S) f32); replaces the
+    Returns (idx (B,M,S) i32, grouped_xyz (B,3,M,S) f32, or (B,M,S,3) when
+    ``channels_last``); replaces the
     ball_query / transpose / group_points / sub / div sequence of
     QueryAndGroup.forward (pointnet2_utils.py:331-349).
     """
@@ -275,12 +277,14 @@ def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz, algorithm=
     b, n = xyz.size(0), xyz.size(1)
     m = new_xyz.size(1)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
-    grouped = torch.empty((b, 3, m, nsample), dtype=torch.float32, device=new_xyz.device)
+    shape = (b, m, nsample, 3) if channels_last else (b, 3, m, nsample)
+    grouped = torch.empty(shape, dtype=torch.float32, device=new_xyz.device)
     ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
     with torch.cuda.device(new_xyz.device), _timed("query_and_group_xyz"):
         st = lib.coda_query_and_group_xyz_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(grouped),
                                               b, n, m, float(radius), int(nsample),
-                                              1 if normalize_xyz else 0, _ptr(ws), ws_bytes,
+                                              (1 if normalize_xyz else 0) | (2 if channels_last else 0),
+                                              _ptr(ws), ws_bytes,
                                               _stream())
     _lib.check(st, "query_and_group_xyz")
     return idx, grouped

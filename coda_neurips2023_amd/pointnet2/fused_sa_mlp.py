@@ -1,0 +1,231 @@
+"""Fused shared-MLP + max-pool of the set-abstraction layer (xyz-only input).
+
+Computes exactly what ``SharedMLP`` (1x1 Conv2d, no bias -> BatchNorm2d -> ReLU, per
+layer) followed by ``F.max_pool2d`` over the nsample axis computes in the reference
+(pointnet2_modules.py:247-253, pytorch_utils.py:8-117), including train-mode batch
+statistics, running-statistics updates and SyncBatchNorm semantics, but on
+channels-last activations with the streaming kernels of ``csrc/sa_mlp.hip`` around plain
+library GEMMs (``torch.mm`` -> rocBLAS).  The parameters stay in the reference modules
+(``mlp_module.layer{i}.conv.weight``, ``...bn.bn.*``); this file only holds the autograd
+function that reads them.
+"""
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args, _stream()), name)
+
+
+def _is_sync(bn):
+    return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
+        and dist.get_world_size(bn.process_group) > 1
+
+
+def _all_reduce(t, bn):
+    if _is_sync(bn):
+        dist.all_reduce(t, group=bn.process_group)
+    return t
+
+
+class _FusedMlpPool(torch.autograd.Function):
+    """x (P,3) grouped xyz channels-last, P = groups * nsample.  Returns (groups, C_last)."""
+
+    @staticmethod
+    def forward(ctx, x, groups, nsample, bns, training, *params):
+        # params: for each layer: conv weight (Cout, Cin[,1,1]), bn weight, bn bias
+        nl = len(bns)
+        dev = x.device
+        p = x.shape[0]
+        ws = [params[3 * i].reshape(params[3 * i].shape[0], -1) for i in range(nl)]
+        gammas = [params[3 * i + 1] for i in range(nl)]
+        betas = [params[3 * i + 2] for i in range(nl)]
+        world = [dist.get_world_size(bn.process_group) if _is_sync(bn) else 1 for bn in bns]
+
+        saved_pre, saved_act, stats = [], [], []
+        sums = torch.empty(2 * max(w.shape[0] for w in ws), dtype=torch.float64, device=dev)
+        cur = x  # input of layer i (post-activation of layer i-1)
+        pool = None
+        for i in range(nl):
+            c = ws[i].shape[0]
+            last = i == nl - 1
+            w1 = ws[0].contiguous() if i == 0 else None
+            if i == 0:
+                pre = None  # recomputed on the fly from x
+                src = x
+            else:
+                pre = torch.mm(cur, ws[i].t())  # (P, Cin) @ (Cin, Cout): plain library GEMM
+                src = pre
+            s = sums[:2 * c]
+            if last:
+                ymax = torch.empty((groups, c), dtype=torch.float32, device=dev)
+                ymin = torch.empty_like(ymax)
+                amax = torch.empty((groups, c), dtype=torch.int32, device=dev)
+                amin = torch.empty_like(amax)
+                if i == 0:
+                    raise RuntimeError("fused SA MLP needs at least two layers")
+                _call("coda_sa_col_stats_pool_f32", _p(src), groups, nsample, c, _p(s), _p(ymax), _p(ymin),
+                      _p(amax), _p(amin))
+                pool = (ymax, ymin, amax, amin)
+            elif training:
+                _call("coda_sa_col_stats_f32", _p(src), _p(w1), p, c, _p(s))
+            bn = bns[i]
+            if training:
+                tot = _all_reduce(s.clone(), bn)
+                n = float(p * world[i])
+                mean = tot[:c] / n
+                var = (tot[c:] / n - mean * mean).clamp_(min=0.0)
+                invstd = torch.rsqrt(var + bn.eps)
+                with torch.no_grad():
+                    if bn.track_running_stats and bn.running_mean is not None:
+                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                        bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32), alpha=mom)
+                        bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(torch.float32),
+                                                          alpha=mom)
+                        bn.num_batches_tracked += 1
+                mean = mean.to(torch.float32)
+                invstd = invstd.to(torch.float32)
+            else:
+                mean = bn.running_mean
+                invstd = torch.rsqrt(bn.running_var + bn.eps)
+            scale = (gammas[i] * invstd).contiguous()
+            shift = (betas[i] - mean * scale).contiguous()
+            stats.append((mean.contiguous(), invstd.contiguous(), scale, shift))
+            saved_pre.append(pre)
+            if not last:
+                act = torch.empty((p, c), dtype=torch.float32, device=dev)
+                _call("coda_sa_bn_relu_apply_f32", _p(src), _p(w1), _p(scale), _p(shift), p, c, _p(act))
+                saved_act.append(act)
+                cur = act
+
+        ymax, ymin, amax, amin = pool
+        scale, shift = stats[-1][2], stats[-1][3]
+        pos = scale >= 0
+        ysel = torch.where(pos, ymax, ymin)      # BN is monotone per channel: pool the pre-BN values
+        sel = torch.where(pos, amax, amin)
+        out = torch.relu(ysel * scale + shift)   # (groups, C)
+
+        ctx.meta = (groups, nsample, bns, training, nl, world)
+        ctx.wshape = [params[3 * i].shape for i in range(nl)]
+        ctx.stats = stats
+        ctx.save_for_backward(x, ysel, sel, out, *[t for t in saved_pre if t is not None], *saved_act, *ws, *gammas)
+        ctx.n_pre = sum(t is not None for t in saved_pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        groups, nsample, bns, training, nl, world = ctx.meta
+        saved = ctx.saved_tensors
+        x, ysel, sel, out = saved[:4]
+        pres = [None] + list(saved[4:4 + ctx.n_pre])              # pre-BN activations of layers 1..nl-1
+        acts = list(saved[4 + ctx.n_pre:4 + ctx.n_pre + nl - 1])  # post-activation of layers 0..nl-2
+        ws = list(saved[4 + ctx.n_pre + nl - 1:4 + ctx.n_pre + 2 * nl - 1])
+        gammas = list(saved[4 + ctx.n_pre + 2 * nl - 1:])
+        dev = x.device
+        p = x.shape[0]
+        grads = [None] * (3 * nl)
+
+        # ---- last layer: max-pool + ReLU + BN backward
+        i = nl - 1
+        c = ws[i].shape[0]
+        mean, invstd, scale, shift = ctx.stats[i]
+        d = (gout * (out > 0)).contiguous()                      # (groups, C) at sample sel
+        xhat_sel = (ysel - mean) * invstd
+        sum_d = d.sum(0, dtype=torch.float64)
+        sum_dx = (d * xhat_sel).sum(0, dtype=torch.float64)
+        grads[3 * i + 2] = sum_d.to(torch.float32)               # d beta
+        grads[3 * i + 1] = sum_dx.to(torch.float32)              # d gamma
+        if training:
+            tot = _all_reduce(torch.cat([sum_d, sum_dx]), bns[i])
+            n = float(p * world[i])
+            m1 = (tot[:c] / n).to(torch.float32)
+            m2 = (tot[c:] / n).to(torch.float32)
+        else:
+            m1 = torch.zeros(c, device=dev)
+            m2 = torch.zeros(c, device=dev)
+        coef = torch.stack([gammas[i] * invstd, m1, m2, mean, invstd]).contiguous()
+        dy = torch.empty((p, c), dtype=torch.float32, device=dev)
+        _call("coda_sa_bn_bwd_sparse_f32", _p(pres[i]), _p(d), _p(sel.contiguous()), _p(coef), groups, nsample, c,
+              _p(dy))
+
+        # ---- hidden layers, top down
+        while True:
+            a_in = acts[i - 1]                                    # input of layer i
+            grads[3 * i] = torch.mm(dy.t(), a_in).reshape(ctx.wshape[i])   # dW_i = dY^T A_{i-1}
+            da = torch.mm(dy, ws[i])                              # dA_{i-1} = dY W_i
+            del dy
+            i -= 1
+            c = ws[i].shape[0]
+            mean, invstd, scale, shift = ctx.stats[i]
+            first = i == 0
+            src = x if first else pres[i]
+            w1 = ws[0].contiguous() if first else None
+            prm4 = torch.stack([scale, shift, mean, invstd]).contiguous()
+            sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+            _call("coda_sa_relu_bn_bwd_stats_f32", _p(da), _p(src), _p(w1), _p(prm4), p, c, _p(sums))
+            grads[3 * i + 2] = sums[:c].to(torch.float32)
+            grads[3 * i + 1] = sums[c:].to(torch.float32)
+            if training:
+                tot = _all_reduce(sums.clone(), bns[i])
+                n = float(p * world[i])
+                m1 = (tot[:c] / n).to(torch.float32)
+                m2 = (tot[c:] / n).to(torch.float32)
+            else:
+                m1 = torch.zeros(c, device=dev)
+                m2 = torch.zeros(c, device=dev)
+            prm7 = torch.stack([scale, shift, mean, invstd, gammas[i] * invstd, m1, m2]).contiguous()
+            if first:
+                dw1 = torch.empty(3 * c, dtype=torch.float64, device=dev)
+                _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), _p(w1), _p(prm7), p, c, None, _p(dw1))
+                grads[0] = dw1.view(3, c).t().to(torch.float32).reshape(ctx.wshape[0])
+                break
+            _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), None, _p(prm7), p, c, _p(da), None)
+            dy = da
+        return (None, None, None, None, None, *grads)
+
+
+def fused_mlp_pool(x_cl, groups, nsample, mlp_module):
+    """x_cl (P,3) float32 cuda; mlp_module: the reference-shaped SharedMLP.  -> (groups, C_last)."""
+    layers = list(mlp_module.children())
+    bns = [layer.bn.bn for layer in layers]
+    params = []
+    for layer in layers:
+        params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
+    training = bns[0].training
+    return _FusedMlpPool.apply(x_cl, groups, nsample, bns, training, *params)
+
+
+def eligible(mlp_module, features, use_xyz, pooling, xyz):
+    """The fused path covers the pre-encoder of the model: xyz-only input, max pooling,
+    >= 2 layers of bias-free 1x1 Conv2d + BatchNorm2d + ReLU, fp32 on the GPU."""
+    if features is not None or not use_xyz or pooling != "max" or not xyz.is_cuda or xyz.dtype != torch.float32:
+        return False
+    layers = list(mlp_module.children())
+    if len(layers) < 2:
+        return False
+    for i, layer in enumerate(layers):
+        names = [n for n, _ in layer.named_children()]
+        if names != ["conv", "bn", "activation"]:
+            return False
+        conv, bn = layer.conv, layer.bn.bn
+        if conv.bias is not None or conv.kernel_size != (1, 1) or not isinstance(layer.activation, torch.nn.ReLU):
+            return False
+        if not isinstance(bn, (torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm)) or not bn.affine:
+            return False
+        c = conv.out_channels
+        if c % 4 or 1024 % c or (i == 0 and conv.in_channels != 3):
+            return False
+        if not bn.training and bn.running_mean is None:
+            return False
+    return True

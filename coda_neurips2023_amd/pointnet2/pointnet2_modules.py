@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import pointnet2_utils
+from . import _ext, fused_sa_mlp, pointnet2_utils
 from . import pytorch_utils as pt_utils
 
 
@@ -66,6 +66,19 @@ class PointnetSAModuleVotes(nn.Module):
             new_xyz = new_xyz.transpose(1, 2).contiguous()
         else:
             new_xyz = None
+
+        if (self.npoint is not None and not self.ret_unique_cnt and not self.grouper.sample_uniformly
+                and not xyz.requires_grad
+                and fused_sa_mlp.eligible(self.mlp_module, features, self.use_xyz, self.pooling, xyz)):
+            # xyz-only set abstraction (the model's pre-encoder): fused ball query + grouping into
+            # channels-last, then the fused shared MLP + batch norm + ReLU + max-pool
+            _, grouped_cl = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample,
+                                                     self.normalize_xyz, channels_last=True)
+            b, npoint = new_xyz.shape[0], new_xyz.shape[1]
+            pooled = fused_sa_mlp.fused_mlp_pool(grouped_cl.view(-1, 3), b * npoint, self.nsample,
+                                                 self.mlp_module)
+            new_features = pooled.view(b, npoint, -1).permute(0, 2, 1)  # (B, mlp[-1], npoint)
+            return new_xyz, new_features, inds
 
         if not self.ret_unique_cnt:
             grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)

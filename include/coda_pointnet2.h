@@ -100,9 +100,11 @@ int coda_group_points_grad_f32(const float *grad_out, const int32_t *idx,
  * Fuses ball_query + grouping of the coordinates + centring (+ optional 1/radius
  * normalisation) of QueryAndGroup.forward (pointnet2_utils.py:331-349):
  *   idx          (B,M,S) i32   as coda_ball_query_f32
- *   grouped_xyz  (B,3,M,S) f32 = (xyz[idx] - new_xyz[j]) [/ radius if normalize]
- * The subtraction and the division are the same two fp32 operations the
- * reference performs with torch (`-=` then `/=`).                           */
+ *   grouped_xyz  (B,3,M,S) f32 = (xyz[idx] - new_xyz[j]) [/ radius if normalize & 1]
+ * `normalize` bit 1 (value 2) selects the channels-last layout (B,M,S,3) consumed by
+ * the fused shared MLP (coda_sa_mlp.h).  The subtraction and the 1/radius scaling are
+ * the same fp32 operations torch performs on the GPU (`-=`, then a multiply by the
+ * fp32 reciprocal for `/= radius`).                                          */
 int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz,
                                  int32_t *idx, float *grouped_xyz, int b, int n,
                                  int m, float radius, int nsample, int normalize,

@@ -1,0 +1,59 @@
+/*
+ * coda_sa_mlp.h -- C ABI of the streaming kernels of the set-abstraction shared MLP.
+ *
+ * Together with plain library GEMMs they replace the per-layer
+ * Conv2d(1x1) + BatchNorm2d + ReLU stack and the max-pool over nsample of
+ * PointnetSAModuleVotes (pointnet2_modules.py:247-253, pytorch_utils.py:8-117) on
+ * CHANNELS-LAST activations: a matrix of P = B*npoint*nsample rows and C channels,
+ * row p = (b, centre, sample).  C must be a multiple of 4 that divides 1024.
+ *
+ * Conventions as in coda_pointnet2.h (raw device pointers, stream, status codes).
+ * `w1` selects the first layer: when non-NULL, `src` is the grouped xyz (P,3) and the
+ * pre-BN activation is recomputed on the fly as x . w1[c] (w1 is (C,3) row-major);
+ * when NULL, `src` is the stored pre-BN activation (P,C).
+ * Statistics (`sums`, 2*C doubles: per-channel sum, then sum of squares / or sum d,
+ * then sum d*xhat in the backward) are zeroed by the call.
+ */
+#ifndef CODA_SA_MLP_H
+#define CODA_SA_MLP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sums[0:C] = sum_p y, sums[C:2C] = sum_p y^2 */
+int coda_sa_col_stats_f32(const float *src, const float *w1, long long p, int c,
+                          double *sums, void *stream);
+/* dst = relu(y * scale + shift) */
+int coda_sa_bn_relu_apply_f32(const float *src, const float *w1, const float *scale,
+                              const float *shift, long long p, int c, float *dst,
+                              void *stream);
+/* last layer: statistics + per-(group, channel) max / min over the s_len rows of a group
+ * and the row index (0..s_len-1) where they occur (lowest on ties) */
+int coda_sa_col_stats_pool_f32(const float *y, long long groups, int s_len, int c,
+                               double *sums, float *ymax, float *ymin,
+                               int32_t *amax, int32_t *amin, void *stream);
+/* backward of max-pool + ReLU + BN of the last layer; coef = [a, m1, m2, mean, invstd][C]:
+ * dy[p][c] = a * ((row == sel ? d : 0) - m1 - (y - mean) * invstd * m2) */
+int coda_sa_bn_bwd_sparse_f32(const float *y, const float *d, const int32_t *sel,
+                              const float *coef, long long groups, int s_len, int c,
+                              float *dy, void *stream);
+/* hidden layers, prm = [scale, shift, mean, invstd][C]; d = da where scale*y+shift > 0:
+ * sums[0:C] = sum d, sums[C:2C] = sum d * (y - mean) * invstd */
+int coda_sa_relu_bn_bwd_stats_f32(const float *da, const float *src, const float *w1,
+                                  const float *prm, long long p, int c, double *sums,
+                                  void *stream);
+/* prm = [scale, shift, mean, invstd, a, m1, m2][C]; dy = a * (d - m1 - xhat * m2).
+ * w1 == NULL: dy (P,C) is written (may alias da).  w1 != NULL (first layer): dy is not
+ * stored, dw1[k*C + c] = sum_p dy[p][c] * x[p][k] (3*C doubles, zeroed by the call). */
+int coda_sa_relu_bn_bwd_apply_f32(const float *da, const float *src, const float *w1,
+                                  const float *prm, long long p, int c, float *dy,
+                                  double *dw1, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODA_SA_MLP_H */
