@@ -44,9 +44,10 @@ SIGNATURES = {
     "coda_sa_relu_bn_bwd_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P, _P]),
     # include/coda_attention.h
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                  _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P]),
+                                  _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _P]),
     "coda_mha_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
-                                  _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P]),
+                                  _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P,
+                                  _P]),
 }
 
 _lib = None

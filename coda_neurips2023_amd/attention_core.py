@@ -51,6 +51,28 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+# Dropout seeding.  Eager mode: a fresh host seed per call from torch's CPU generator.
+# Graph mode (`use_device_seed(tensor)`): the per-call host value only separates the calls of
+# one step; the device word is folded in by the kernels and must be bumped between replays
+# (e.g. `seed_tensor += 1` captured in the same graph), so replays draw fresh masks.
+_DEVICE_SEED = None
+_CALL_COUNTER = 0
+
+
+def use_device_seed(seed_tensor):
+    """seed_tensor: 1-element int64 CUDA tensor (or None to go back to host seeds)."""
+    global _DEVICE_SEED
+    _DEVICE_SEED = seed_tensor
+
+
+def _next_seed():
+    global _CALL_COUNTER
+    if _DEVICE_SEED is None:
+        return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()), None
+    _CALL_COUNTER += 1
+    return (_CALL_COUNTER * 0x9E3779B97F4A7C15) & (2 ** 63 - 1), _DEVICE_SEED
+
+
 class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask_u8, scale, dropout_p):
@@ -66,20 +88,20 @@ class _FusedAttention(torch.autograd.Function):
         v, ldv = _row_layout(v)
         out = torch.empty((l, b, h, d), dtype=torch.float32, device=q.device)
         lse = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
-        seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if dropout_p > 0.0 else 0
+        seed, seed_dev = _next_seed() if dropout_p > 0.0 else (0, None)
         with torch.cuda.device(q.device):
             st = lib.coda_mha_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
                                       b, h, l, s, d, ldq, ldk, ldv, float(scale), float(dropout_p), seed,
-                                      torch.cuda.current_stream().cuda_stream)
+                                      _ptr(seed_dev), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "mha_fwd")
         ctx.save_for_backward(q, k, v, mask_u8, out, lse)
-        ctx.meta = (ldq, ldk, ldv, float(scale), float(dropout_p), seed)
+        ctx.meta = (ldq, ldk, ldv, float(scale), float(dropout_p), seed, seed_dev)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, mask_u8, out, lse = ctx.saved_tensors
-        ldq, ldk, ldv, scale, dropout_p, seed = ctx.meta
+        ldq, ldk, ldv, scale, dropout_p, seed, seed_dev = ctx.meta
         lib = _lib.load()
         l, b, h, d = q.shape
         s = k.shape[0]
@@ -91,7 +113,7 @@ class _FusedAttention(torch.autograd.Function):
         with torch.cuda.device(q.device):
             st = lib.coda_mha_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
                                       _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
-                                      ldq, ldk, ldv, scale, dropout_p, seed,
+                                      ldq, ldk, ldv, scale, dropout_p, seed, _ptr(seed_dev),
                                       torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "mha_bwd")
         return dq, dk, dv, None, None, None

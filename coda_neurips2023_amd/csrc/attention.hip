@@ -52,7 +52,14 @@ struct MhaParams {
   int ldq, ldk, ldv;  // floats between consecutive batch rows of q / k / v (H*D when dense)
   float scale, inv_keep;
   uint32_t thresh24, seed;
+  const uint64_t *seed_dev;  // optional device-resident seed (graph replays draw fresh masks)
 };
+
+__device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint64_t *seed_dev) {
+  if (!seed_dev) return seed;
+  const uint64_t v = *seed_dev;
+  return seed ^ static_cast<uint32_t>(v) ^ static_cast<uint32_t>(v >> 32) * 0x9E3779B9u;
+}
 
 // Cooperative copy of `rows` x D floats (row stride `gstride` floats) into a padded LDS tile.
 template <int D, int THREADS, int ROWS = kTile>
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
   const bool use_drop = p.thresh24 != 0u;
+  const uint32_t seed = use_drop ? effective_seed(p.seed, p.seed_dev) : 0u;
 
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
     __syncthreads();
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       rs += e;
       if (use_drop) {
         const int key = s0 + crow(r, half);
-        e = dropout_keep(p.seed, bh, myq, key, p.s, p.thresh24) ? e * p.inv_keep : 0.f;
+        e = dropout_keep(seed, bh, myq, key, p.s, p.thresh24) ? e * p.inv_keep : 0.f;
       }
       pr[r] = e;
     }
@@ -251,6 +259,7 @@ struct MhaBwdParams {
   int ldq, ldk, ldv;
   float scale, inv_keep;
   uint32_t thresh24, seed;
+  const uint64_t *seed_dev;
 };
 
 template <int D>
@@ -291,6 +300,7 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
   const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
   const bool use_drop = p.thresh24 != 0u;
+  const uint32_t seed = use_drop ? effective_seed(p.seed, p.seed_dev) : 0u;
 
   const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
                vstride = static_cast<size_t>(p.b) * p.ldv;
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
       const float lse = s_lse[qi];
       float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
       float keep = 1.f;
-      if (use_drop) keep = dropout_keep(p.seed, bh, qq, mykey, p.s, p.thresh24) ? p.inv_keep : 0.f;
+      if (use_drop) keep = dropout_keep(seed, bh, qq, mykey, p.s, p.thresh24) ? p.inv_keep : 0.f;
       pd[r] = prob * keep;
       ds[r] = prob * (pacc[r] * keep - s_delta[qi]) * p.scale;
     }
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
   const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
   const bool use_drop = p.thresh24 != 0u;
+  const uint32_t seed = use_drop ? effective_seed(p.seed, p.seed_dev) : 0u;
 
   const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
                vstride = static_cast<size_t>(p.b) * p.ldv;
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
       if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
       const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] - lse) * kLog2e);
       float keep = 1.f;
-      if (use_drop) keep = dropout_keep(p.seed, bh, myq, key, p.s, p.thresh24) ? p.inv_keep : 0.f;
+      if (use_drop) keep = dropout_keep(seed, bh, myq, key, p.s, p.thresh24) ? p.inv_keep : 0.f;
       ds[r] = prob * (pacc[r] * keep - delta) * p.scale;
     }
     // dQ[q][d] += sum_key dS[q][key] K[key][d]   (A = dS: lane = query, k = key)
@@ -551,12 +562,18 @@ uint32_t drop_threshold(float p) {
   return static_cast<uint32_t>(t);
 }
 
+// Raise the dynamic-LDS limit of a kernel once per process (idempotent; kept out of the
+// steady-state launch path so that launches can be captured into hipGraphs).
 template <typename K>
 int set_lds(K kern, size_t bytes) {
   if (bytes <= 64 * 1024) return CODA_OK;
+  static bool done = false;  // one instance per kernel type K
+  if (done) return CODA_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-  return e == hipSuccess ? CODA_OK : static_cast<int>(e);
+  if (e != hipSuccess) return static_cast<int>(e);
+  done = true;
+  return CODA_OK;
 }
 
 template <int D>
@@ -605,7 +622,8 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
 
 CODA_API int coda_mha_fwd_f32(const float *q, const float *k, const float *v, const uint8_t *mask,
                               float *out, float *lse, int b, int h, int l, int s, int d, int ldq, int ldk,
-                              int ldv, float scale, float dropout_p, uint64_t seed, void *stream) {
+                              int ldv, float scale, float dropout_p, uint64_t seed,
+                              const uint64_t *seed_dev, void *stream) {
   using namespace coda;
   if (b < 0 || h <= 0 || l < 0 || s < 0 || (d != 64 && d != 128) || dropout_p < 0.f || dropout_p >= 1.f ||
       ldq < h * d || ldk < h * d || ldv < h * d || (ldq | ldk | ldv) % 4 != 0)
@@ -620,6 +638,7 @@ CODA_API int coda_mha_fwd_f32(const float *q, const float *k, const float *v, co
   p.thresh24 = drop_threshold(dropout_p);
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
+  p.seed_dev = seed_dev;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return d == 64 ? launch_fwd<64>(p, st) : launch_fwd<128>(p, st);
 }
@@ -628,7 +647,7 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
                               const float *out, const float *lse, const float *dout, float *dq,
                               float *dk, float *dv, float *delta, int b, int h, int l, int s, int d,
                               int ldq, int ldk, int ldv, float scale, float dropout_p, uint64_t seed,
-                              void *stream) {
+                              const uint64_t *seed_dev, void *stream) {
   using namespace coda;
   if (b < 0 || h <= 0 || l < 0 || s < 0 || (d != 64 && d != 128) || dropout_p < 0.f || dropout_p >= 1.f ||
       ldq < h * d || ldk < h * d || ldv < h * d || (ldq | ldk | ldv) % 4 != 0)
@@ -645,6 +664,7 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
   p.thresh24 = drop_threshold(dropout_p);
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
+  p.seed_dev = seed_dev;
   hipStream_t st = static_cast<hipStream_t>(stream);
   return d == 64 ? launch_bwd<64>(p, st) : launch_bwd<128>(p, st);
 }

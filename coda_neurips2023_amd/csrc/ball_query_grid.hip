@@ -368,9 +368,13 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
   clear_sticky_error();
   const size_t lds = sizeof(int) * kCntWords + sizeof(float) * 7 * (kGridThreads / kWave) + sizeof(GridHeader);
   auto launch_build = [&](auto kern) -> int {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
+    static bool lds_set = false;  // once per process: keeps the launch path graph-capturable
+    if (!lds_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return static_cast<int>(e);
+      lds_set = true;
+    }
     hipLaunchKernelGGL(kern, dim3(b), dim3(kGridThreads), lds, s, xyz, n, radius, ws, stride);
     return CODA_OK;
   };

@@ -9,6 +9,8 @@ library GEMMs (``torch.mm`` -> rocBLAS).  The parameters stay in the reference m
 (``mlp_module.layer{i}.conv.weight``, ``...bn.bn.*``); this file only holds the autograd
 function that reads them.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -210,6 +212,8 @@ def eligible(mlp_module, features, use_xyz, pooling, xyz):
     """The fused path covers the pre-encoder of the model: xyz-only input, max pooling,
     >= 2 layers of bias-free 1x1 Conv2d + BatchNorm2d + ReLU, fp32 on the GPU."""
     if features is not None or not use_xyz or pooling != "max" or not xyz.is_cuda or xyz.dtype != torch.float32:
+        return False
+    if os.environ.get("CODA_SA_MLP", "fused") == "layers":  # A/B switch: per-layer library ops
         return False
     layers = list(mlp_module.children())
     if len(layers) < 2:

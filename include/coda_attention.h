@@ -20,7 +20,9 @@
  *
  * Dropout: keep(b,h,l,s) is a counter-based hash of (seed, b*H+h, l, s) evaluated
  * identically in forward and backward; kept probabilities are scaled by 1/(1-p).
- * p = 0 disables it (eval mode).
+ * p = 0 disables it (eval mode).  `seed_dev` (optional, device memory) is XOR-folded
+ * into `seed` inside the kernels: a captured hipGraph whose replays bump that word
+ * draws a fresh mask per replay while `seed` keeps the calls of one step apart.
  *
  * Numerics: fp32 inputs, fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf
  * chain), fp32 online softmax; parity target 1e-3 relative vs the fp32 reference.
@@ -42,7 +44,8 @@ extern "C" {
 int coda_mha_fwd_f32(const float *q, const float *k, const float *v,
                      const uint8_t *mask, float *out, float *lse, int b, int h,
                      int l, int s, int d, int ldq, int ldk, int ldv, float scale,
-                     float dropout_p, uint64_t seed, void *stream);
+                     float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                     void *stream);
 
 /* dq (L,B,H,D), dk / dv (S,B,H,D) are fully written.  `delta` is a (B,H,L) float
  * scratch provided by the caller (rowsum(dout * out)). */
@@ -51,7 +54,7 @@ int coda_mha_bwd_f32(const float *q, const float *k, const float *v,
                      const float *dout, float *dq, float *dk, float *dv,
                      float *delta, int b, int h, int l, int s, int d, int ldq,
                      int ldk, int ldv, float scale, float dropout_p, uint64_t seed,
-                     void *stream);
+                     const uint64_t *seed_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: fused SA shared-MLP vs the per-layer library path, same weights/inputs."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from coda_neurips2023_amd.pointnet2 import pointnet2_modules  # noqa: E402
+from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+pc, _, _ = make_batch(2, 4096, seed=5)
+xyz = torch.from_numpy(pc).to(dev)
+
+
+def run(kind, dtype=torch.float32):
+    os.environ["CODA_SA_MLP"] = kind
+    torch.manual_seed(1)
+    mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=256, radius=0.2, nsample=64,
+                                                  normalize_xyz=True).to(dev).train()
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            if "bn" in k:
+                p.copy_(torch.rand_like(p) + 0.5 if k.endswith("weight") else torch.randn_like(p) * 0.1)
+    _, feat, _ = mod(xyz)
+    g = torch.Generator().manual_seed(2)
+    gw = torch.randn(feat.shape, generator=g).to(dev)
+    (feat * gw).sum().backward()
+    return feat.detach(), {k: p.grad.clone() for k, p in mod.named_parameters()}, \
+        {k: v.clone() for k, v in mod.state_dict().items() if "running" in k}
+
+
+f1, g1, s1 = run("fused")
+f2, g2, s2 = run("layers")
+print("feat rel err", float((f1 - f2).abs().max() / f2.abs().max()))
+for k in g1:
+    print(f"{k:45s} rel err {float((g1[k] - g2[k]).abs().max() / g2[k].abs().max()):.3e}  |g| {float(g2[k].norm()):.3e}")
+for k in s1:
+    print(f"{k:45s} rel err {float((s1[k] - s2[k]).abs().max() / (s2[k].abs().max() + 1e-12)):.3e}")
