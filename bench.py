@@ -263,7 +263,9 @@ def main():
                 step_fn(model, static).backward()
                 opt.step()
         except Exception as e:  # noqa: BLE001 -- capture is an optimisation; the eager loop is the fallback
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            import traceback
+            traceback.print_exc(limit=12)
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
             graph = None
             from coda_neurips2023_amd import attention_core
             attention_core.use_device_seed(None)

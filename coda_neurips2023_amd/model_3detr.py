@@ -58,9 +58,9 @@ class BoxProcessor(object):
         pred_angle_class = angle_logits.argmax(dim=-1).detach()
         angle_center = angle_per_cls * pred_angle_class
         angle = angle_center + angle_residual.gather(2, pred_angle_class.unsqueeze(-1)).squeeze(-1)
-        mask = angle > np.pi
-        angle[mask] = angle[mask] - 2 * np.pi
-        return angle
+        # reference: `angle[mask] = angle[mask] - 2*pi` (boolean indexing = host sync); same values
+        # without the sync, so the step stays capturable in a hipGraph
+        return torch.where(angle > np.pi, angle - 2 * np.pi, angle)
 
     def compute_objectness_and_cls_prob(self, cls_logits):
         cls_prob = torch.nn.functional.softmax(cls_logits, dim=-1)

@@ -57,6 +57,9 @@ def run(tag):
     print(tag, "grad worst:", worst[:8])
 
 
-run("fused-attention")
+os.environ["CODA_SA_MLP"] = "fused"
+run("fused-SA  fused-attn")
+os.environ["CODA_SA_MLP"] = "layers"
+run("layers-SA fused-attn")
 attention_core.attention = attention_ref
-run("torch-attention ")
+run("layers-SA torch-attn")

@@ -12,14 +12,15 @@ from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-pc, _, _ = make_batch(2, 4096, seed=5)
+N = int(os.environ.get("DIAG_N", 4096)); NP = int(os.environ.get("DIAG_NPOINT", 256))
+pc, _, _ = make_batch(2, N, seed=int(os.environ.get("DIAG_SEED", 5)))
 xyz = torch.from_numpy(pc).to(dev)
 
 
 def run(kind, dtype=torch.float32):
     os.environ["CODA_SA_MLP"] = kind
     torch.manual_seed(1)
-    mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=256, radius=0.2, nsample=64,
+    mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=NP, radius=0.2, nsample=64,
                                                   normalize_xyz=True).to(dev).train()
     with torch.no_grad():
         for k, p in mod.named_parameters():
