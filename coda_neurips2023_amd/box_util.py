@@ -16,7 +16,7 @@ _SIGNS_CAM = ((1, 1, 1), (1, 1, -1), (-1, 1, -1), (-1, 1, 1),
 
 
 def rotz_tensor_batch(t):
-    out = torch.zeros(tuple(t.shape) + (3, 3), dtype=torch.float32, device=t.device)
+    out = torch.zeros(tuple(t.shape) + (3, 3), dtype=t.dtype, device=t.device)
     c, s = torch.cos(t), torch.sin(t)
     out[..., 0, 0] = c
     out[..., 0, 1] = -s
@@ -27,7 +27,7 @@ def rotz_tensor_batch(t):
 
 
 def roty_batch_tensor(t):
-    out = torch.zeros(tuple(t.shape) + (3, 3), dtype=torch.float32, device=t.device)
+    out = torch.zeros(tuple(t.shape) + (3, 3), dtype=t.dtype, device=t.device)
     c, s = torch.cos(t), torch.sin(t)
     out[..., 0, 0] = c
     out[..., 0, 2] = s
@@ -39,10 +39,21 @@ def roty_batch_tensor(t):
 
 def flip_axis_to_camera_tensor(pc):
     """depth (X right, Y forward, Z up) -> camera (X right, Y down, Z forward)."""
-    pc2 = torch.clone(pc)
-    pc2[..., [0, 1, 2]] = pc2[..., [0, 2, 1]]
-    pc2[..., 1] *= -1
-    return pc2
+    # reference: clone, index-permute (x, z, y), negate the middle component; written
+    # without list indexing (a host->device index copy that cannot be graph-captured)
+    return torch.stack((pc[..., 0], -pc[..., 2], pc[..., 1]), dim=-1)
+
+
+_SIGN_CACHE = {}
+
+
+def _sign_tensor(signs, dtype, device):
+    """Constant (8,3) sign pattern, created once per (pattern, dtype, device): no host->device
+    copy in the steady state (keeps the step graph-capturable)."""
+    key = (signs, dtype, str(device))
+    if key not in _SIGN_CACHE:
+        _SIGN_CACHE[key] = torch.tensor(signs, dtype=dtype, device=device)
+    return _SIGN_CACHE[key]
 
 
 def _corners(box_size, angle, center, signs, dims, rot_fn):
@@ -55,7 +66,7 @@ def _corners(box_size, angle, center, signs, dims, rot_fn):
         center = center.reshape(-1, 3)
     rot = rot_fn(angle)
     half = torch.stack([box_size[..., d] for d in dims], -1) / 2  # (..., 3) in corner-axis order
-    sign = torch.tensor(signs, dtype=torch.float32, device=box_size.device)  # (8, 3)
+    sign = _sign_tensor(signs, box_size.dtype, box_size.device)  # (8, 3)
     corners = half.unsqueeze(-2) * sign  # (..., 8, 3)
     corners = torch.matmul(corners, rot.transpose(-1, -2))
     corners = corners + center.unsqueeze(-2)
