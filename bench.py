@@ -229,7 +229,7 @@ def main():
         pool.append({"point_clouds": torch.from_numpy(pc).to(dev),
                      "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    use_graph = args.graph == "on"  # measured: the step is GPU-bound, replay gives no gain (profiles/README.md)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph)
 
     def one_step_eager(i):

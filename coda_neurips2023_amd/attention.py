@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import attention_core as _core
+from .linear_fn import linear as _linear
 
 
 class MultiheadAttention(nn.Module):
@@ -52,12 +53,12 @@ class MultiheadAttention(nn.Module):
         if b is not None:
             bq, bk, bv = b[:e], b[e:2 * e], b[2 * e:]
         if key is value and query is key:
-            return F.linear(query, w, b).chunk(3, dim=-1)
-        q = F.linear(query, w[:e], bq)
+            return _linear(query, w, b).chunk(3, dim=-1)
+        q = _linear(query, w[:e], bq)
         if key is value:
-            k, v = F.linear(key, w[e:], b[e:] if b is not None else None).chunk(2, dim=-1)
+            k, v = _linear(key, w[e:], b[e:] if b is not None else None).chunk(2, dim=-1)
             return q, k, v
-        return q, F.linear(key, w[e:2 * e], bk), F.linear(value, w[2 * e:], bv)
+        return q, _linear(key, w[e:2 * e], bk), _linear(value, w[2 * e:], bv)
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None,
                 average_attn_weights=True):
@@ -73,7 +74,7 @@ class MultiheadAttention(nn.Module):
                                        v.reshape(src_len, bsz, h, d), mask,
                                        1.0 / math.sqrt(d), self.dropout if self.training else 0.0,
                                        need_weights)
-        out = self.out_proj(out.reshape(tgt_len, bsz, e))
+        out = _linear(out.reshape(tgt_len, bsz, e), self.out_proj.weight, self.out_proj.bias)
         if need_weights and average_attn_weights:
             weights = weights.mean(dim=1)
         return out, weights

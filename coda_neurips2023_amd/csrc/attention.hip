@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_tile(float *lds, const float *g, size_t gst
 template <int D, int QW, bool SPLIT>
 __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  constexpr int TILES = SPLIT ? QW : 1;  // K/V tiles staged per step
+  constexpr int TILES = QW;  // K/V tiles staged per barrier pair (SPLIT: one per wave; else all waves walk all)
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
@@ -127,9 +127,10 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
     load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
     __syncthreads();
-    const int s0 = sbase + my_tile * kTile;
-    if (!wave_active || s0 >= p.s) continue;
-    const float *tk = s_k + my_tile * kTile * LS, *tv = s_v + my_tile * kTile * LS;
+    for (int tile = SPLIT ? my_tile : 0; tile < (SPLIT ? my_tile + 1 : TILES); ++tile) {
+    const int s0 = sbase + tile * kTile;
+    if (!wave_active || s0 >= p.s) break;
+    const float *tk = s_k + tile * kTile * LS, *tv = s_v + tile * kTile * LS;
 
     f32x16 sacc;
 #pragma unroll
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
         o[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, pr[r], o[3 % NT], 0, 0, 0);
       }
     }
+    }  // tile
   }
 
   lsum += __shfl_xor(lsum, 32);
@@ -287,9 +289,10 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 template <int D, int KW>
 __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
-  __shared__ __attribute__((aligned(16))) float s_q[kTile * LS];
-  __shared__ __attribute__((aligned(16))) float s_do[kTile * LS];
-  __shared__ float s_lse[kTile], s_delta[kTile];
+  constexpr int QT = 2;  // query tiles staged per barrier pair
+  __shared__ __attribute__((aligned(16))) float s_q[QT * kTile * LS];
+  __shared__ __attribute__((aligned(16))) float s_do[QT * kTile * LS];
+  __shared__ float s_lse[QT * kTile], s_delta[QT * kTile];
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
@@ -325,17 +328,22 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
 
-  for (int q0 = 0; q0 < p.l; q0 += kTile) {
+  for (int qbase0 = 0; qbase0 < p.l; qbase0 += kTile * QT) {
     __syncthreads();
-    load_tile<D, THREADS>(s_q, qbase, qstride, q0, p.l, tid);
-    load_tile<D, THREADS>(s_do, p.dout + head_off, rstride, q0, p.l, tid);
-    if (tid < kTile) {
-      const int qq = q0 + tid;
+    load_tile<D, THREADS, kTile * QT>(s_q, qbase, qstride, qbase0, p.l, tid);
+    load_tile<D, THREADS, kTile * QT>(s_do, p.dout + head_off, rstride, qbase0, p.l, tid);
+    if (tid < kTile * QT) {
+      const int qq = qbase0 + tid;
       s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
       s_delta[tid] = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
     }
     __syncthreads();
     if (!wave_active) continue;
+    for (int qt = 0; qt < QT; ++qt) {
+    const int q0 = qbase0 + qt * kTile;
+    if (q0 >= p.l) break;
+    const float *tq = s_q + qt * kTile * LS, *tdo = s_do + qt * kTile * LS;
+    const float *t_lse = s_lse + qt * kTile, *t_delta = s_delta + qt * kTile;
 
     // S[q][key] and dP[q][key]: A = Q / dO rows (lane = query), B = K / V rows (lane = key)
     f32x16 sacc, pacc;
@@ -343,8 +351,8 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      const float4 qa = *reinterpret_cast<const float4 *>(s_q + l31 * LS + half * HD + c);
-      const float4 ga = *reinterpret_cast<const float4 *>(s_do + l31 * LS + half * HD + c);
+      const float4 qa = *reinterpret_cast<const float4 *>(tq + l31 * LS + half * HD + c);
+      const float4 ga = *reinterpret_cast<const float4 *>(tdo + l31 * LS + half * HD + c);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kf[c], sacc, 0, 0, 0);
       pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vf[c], pacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kf[c + 1], sacc, 0, 0, 0);
@@ -361,19 +369,19 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
       const int qi = crow(r, half), qq = q0 + qi;
       bool dead = qq >= p.l || mykey >= p.s;
       if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
-      const float lse = s_lse[qi];
+      const float lse = t_lse[qi];
       float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
       float keep = 1.f;
       if (use_drop) keep = dropout_keep(seed, bh, qq, mykey, p.s, p.thresh24) ? p.inv_keep : 0.f;
       pd[r] = prob * keep;
-      ds[r] = prob * (pacc[r] * keep - s_delta[qi]) * p.scale;
+      ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
     }
     // dV^T? no: dV[key][dv] += sum_q Pd[q][key] dO[q][dv]  (A = Pd^T: lane = key, k = query)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = crow(r, half);
-      const float *grow = s_do + qi * LS + NT * l31;
-      const float *qrow = s_q + qi * LS + NT * l31;
+      const float *grow = tdo + qi * LS + NT * l31;
+      const float *qrow = tq + qi * LS + NT * l31;
       if (NT == 2) {
         const float2 g2 = *reinterpret_cast<const float2 *>(grow);
         const float2 q2 = *reinterpret_cast<const float2 *>(qrow);
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
         dk[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q4.w, dk[3 % NT], 0, 0, 0);
       }
     }
+    }  // query tile
   }
 
   // dk[t][r]: row i = crow(r, half) = key within the tile, column j = l31 <-> component NT*l31 + t
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
 template <int D, int QW, bool SPLIT>
 __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  constexpr int TILES = SPLIT ? QW : 1;
+  constexpr int TILES = QW;
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
@@ -471,9 +480,10 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
     load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
     load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
     __syncthreads();
-    const int s0 = sbase + my_tile * kTile;
-    if (!wave_active || s0 >= p.s) continue;
-    const float *tk = s_k + my_tile * kTile * LS, *tv = s_v + my_tile * kTile * LS;
+    for (int tile = SPLIT ? my_tile : 0; tile < (SPLIT ? my_tile + 1 : TILES); ++tile) {
+    const int s0 = sbase + tile * kTile;
+    if (!wave_active || s0 >= p.s) break;
+    const float *tk = s_k + tile * kTile * LS, *tv = s_v + tile * kTile * LS;
 
     f32x16 sacc, pacc;
 #pragma unroll
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
         dq[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], k4.w, dq[3 % NT], 0, 0, 0);
       }
     }
+    }  // tile
   }
   if (SPLIT && QW > 1) {  // sum the per-wave partial dQ through LDS: [wave-1][NT*16][64 lanes]
     __syncthreads();
@@ -582,8 +593,10 @@ int launch_fwd(const MhaParams &p, hipStream_t s) {
   clear_sticky_error();
   if (p.l >= 1024) {
     auto kern = mha_fwd_kernel<D, 4, false>;
+    int st = set_lds(kern, 4 * kTileBytes);
+    if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
-    hipLaunchKernelGGL(kern, grid, dim3(256), kTileBytes, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
   } else {
     auto kern = mha_fwd_kernel<D, 4, true>;
     int st = set_lds(kern, 4 * kTileBytes);
@@ -607,7 +620,9 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);
   if (p.l >= 1024) {
     auto kern = mha_bwd_dq_kernel<D, 4, false>;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), kTileBytes, s, p);
+    int st = set_lds(kern, 4 * kTileBytes);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else {
     auto kern = mha_bwd_dq_kernel<D, 4, true>;
     int st = set_lds(kern, 4 * kTileBytes);

@@ -1,0 +1,56 @@
+"""``linear(x, w, b)``: ``F.linear`` whose weight gradient is a split-K GEMM.
+
+Forward and input gradient are the plain library GEMMs.  The weight gradient
+``dW = dY^T X`` of the token-wise layers of the path reduces over 16 384 tokens (encoder, the
+decoder's memory projections) or 10^6 grouped rows (set-abstraction MLP) into a 256x256-ish
+matrix; rocBLAS runs that as a handful of output tiles with one long K loop (11 TFLOP/s
+measured).  Splitting the reduction into row chunks turns it into a batched GEMM that fills
+the chip plus a small sum (3.5x - 4x faster, tools/bench_tn.py); the result differs from the
+single GEMM only in fp32 summation order.
+"""
+import torch
+import torch.nn.functional as F
+
+_MIN_ROWS = 4096
+_CHUNK = 2048
+
+
+def tn_gemm(dy, x):
+    """dy (P, Co), x (P, Ci) -> dy^T x (Co, Ci), reduction over P split into chunks."""
+    p = dy.shape[0]
+    if p >= _MIN_ROWS:
+        rows = _CHUNK if p % _CHUNK == 0 else 0
+        if p >= (1 << 18) and p % 16384 == 0:
+            rows = 16384
+        if rows and dy.is_contiguous() and x.is_contiguous():
+            nc = p // rows
+            return torch.bmm(dy.view(nc, rows, -1).transpose(1, 2), x.view(nc, rows, -1)).sum(0)
+    return torch.mm(dy.t(), x)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, w).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = tn_gemm(dy2.contiguous(), x.reshape(-1, x.shape[-1]).contiguous())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    rows = x.numel() // x.shape[-1]
+    if rows < _MIN_ROWS or not (x.requires_grad or w.requires_grad) or not torch.is_grad_enabled():
+        return F.linear(x, w, b)
+    return _Linear.apply(x, w, b)

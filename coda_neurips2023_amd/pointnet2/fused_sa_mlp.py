@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib
+from ..linear_fn import tn_gemm
 
 
 def _p(t):
@@ -164,7 +165,7 @@ class _FusedMlpPool(torch.autograd.Function):
         # ---- hidden layers, top down
         while True:
             a_in = acts[i - 1]                                    # input of layer i
-            grads[3 * i] = torch.mm(dy.t(), a_in).reshape(ctx.wshape[i])   # dW_i = dY^T A_{i-1}
+            grads[3 * i] = tn_gemm(dy, a_in).reshape(ctx.wshape[i])        # dW_i = dY^T A_{i-1} (split-K)
             da = torch.mm(dy, ws[i])                              # dA_{i-1} = dY W_i
             del dy
             i -= 1

@@ -21,6 +21,13 @@ from torch import Tensor, nn
 
 from .attention import MultiheadAttention
 from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, get_clones
+from .linear_fn import linear as _linear
+
+
+def _ffn(layer, x):
+    """linear2(dropout(activation(linear1(x)))) with split-K weight gradients (linear_fn.py)."""
+    h = layer.activation(_linear(x, layer.linear1.weight, layer.linear1.bias))
+    return _linear(layer.dropout(h), layer.linear2.weight, layer.linear2.bias)
 
 
 def _tile_mask_per_head(mask, nhead):
@@ -212,7 +219,7 @@ class TransformerEncoderLayer(nn.Module):
         if getattr(self, "use_norm_fn_on_input", False):  # attribute never set by the reference (:455)
             src = self.norm1(src)
         if self.use_ffn:
-            src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+            src2 = _ffn(self, src)
             src = src + self.dropout2(src2)
             src = self.norm2(src)
         return src
@@ -229,7 +236,7 @@ class TransformerEncoderLayer(nn.Module):
         src = src + self.dropout1(src2)
         if self.use_ffn:
             src2 = self.norm2(src)
-            src2 = self.linear2(self.dropout(self.activation(self.linear1(src2))))
+            src2 = _ffn(self, src2)
             src = src + self.dropout2(src2)
         if return_attn_weights:
             return src, attn_weights
@@ -291,7 +298,7 @@ class TransformerDecoderLayer(nn.Module):
                                          need_weights=bool(return_attn_weights))
         tgt = tgt + self.dropout2(tgt2)
         tgt = self.norm2(tgt)
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        tgt2 = _ffn(self, tgt)
         tgt = tgt + self.dropout3(tgt2)
         tgt = self.norm3(tgt)
         if return_attn_weights:
@@ -317,7 +324,7 @@ class TransformerDecoderLayer(nn.Module):
                                          need_weights=bool(return_attn_weights))
         tgt = tgt + self.dropout2(tgt2)
         tgt2 = self.norm3(tgt)
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt2))))
+        tgt2 = _ffn(self, tgt2)
         tgt = tgt + self.dropout3(tgt2)
         if return_attn_weights:
             return tgt, attn
