@@ -202,36 +202,59 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         angle_residual_normalized = split(angle_residual_normalized)
         angle_residual = angle_residual_normalized * (np.pi / angle_residual_normalized.shape[-1])
 
+        # Box decoding (models/model_3detr.py:1683-1731).  The reference decodes the num_layers
+        # decoder outputs one after the other (~70 tiny kernels per layer, forward and again in
+        # backward); the same elementwise arithmetic is applied here to all layers at once
+        # (leading dim num_layers*batch, layer-major) and sliced per layer afterwards.
+        nlb = num_layers * batch
+
+        def flat(t):
+            return t.reshape(nlb, num_queries, -1)
+
+        dims_rep = [d.repeat(num_layers, 1) for d in point_cloud_dims]
+        query_rep = query_xyz.repeat(num_layers, 1, 1)
+        center_normalized, center_unnormalized = self.box_processor.compute_predicted_center(
+            flat(center_offset), query_rep, dims_rep)
+        angle_continuous = self.box_processor.compute_predicted_angle(flat(angle_logits),
+                                                                      flat(angle_residual))
+        size_unnormalized = self.box_processor.compute_predicted_size(flat(size_normalized), dims_rep)
+        box_corners = self.box_processor.box_parametrization_to_corners(
+            center_unnormalized, size_unnormalized, angle_continuous)
+        box_corners_xyz = self.box_processor.box_parametrization_to_corners_xyz(
+            center_unnormalized, size_unnormalized, angle_continuous)
+        with torch.no_grad():  # matching / mAP only
+            semcls_prob, objectness_prob = self.box_processor.compute_objectness_and_cls_prob(
+                flat(cls_logits))
+
+        def per_layer(t):
+            return t.reshape(num_layers, batch, *t.shape[1:])
+
+        center_normalized = per_layer(center_normalized.contiguous())
+        center_unnormalized = per_layer(center_unnormalized)
+        angle_continuous = per_layer(angle_continuous)
+        size_unnormalized = per_layer(size_unnormalized)
+        box_corners = per_layer(box_corners)
+        box_corners_xyz = per_layer(box_corners_xyz)
+        semcls_prob = per_layer(semcls_prob)
+        objectness_prob = per_layer(objectness_prob)
+
         outputs = []
         for l in range(num_layers):
-            center_normalized, center_unnormalized = self.box_processor.compute_predicted_center(
-                center_offset[l], query_xyz, point_cloud_dims)
-            angle_continuous = self.box_processor.compute_predicted_angle(angle_logits[l],
-                                                                          angle_residual[l])
-            size_unnormalized = self.box_processor.compute_predicted_size(size_normalized[l],
-                                                                          point_cloud_dims)
-            box_corners = self.box_processor.box_parametrization_to_corners(
-                center_unnormalized, size_unnormalized, angle_continuous)
-            box_corners_xyz = self.box_processor.box_parametrization_to_corners_xyz(
-                center_unnormalized, size_unnormalized, angle_continuous)
-            with torch.no_grad():  # matching / mAP only
-                semcls_prob, objectness_prob = self.box_processor.compute_objectness_and_cls_prob(
-                    cls_logits[l])
             outputs.append({
                 "sem_cls_logits": cls_logits[l],
                 "text_correlation_embedding": text_correlation_embedding[l],
-                "center_normalized": center_normalized.contiguous(),
-                "center_unnormalized": center_unnormalized,
+                "center_normalized": center_normalized[l],
+                "center_unnormalized": center_unnormalized[l],
                 "size_normalized": size_normalized[l],
-                "size_unnormalized": size_unnormalized,
+                "size_unnormalized": size_unnormalized[l],
                 "angle_logits": angle_logits[l],
                 "angle_residual": angle_residual[l],
                 "angle_residual_normalized": angle_residual_normalized[l],
-                "angle_continuous": angle_continuous,
-                "objectness_prob": objectness_prob,
-                "sem_cls_prob": semcls_prob,
-                "box_corners": box_corners,
-                "box_corners_xyz": box_corners_xyz,
+                "angle_continuous": angle_continuous[l],
+                "objectness_prob": objectness_prob[l],
+                "sem_cls_prob": semcls_prob[l],
+                "box_corners": box_corners[l],
+                "box_corners_xyz": box_corners_xyz[l],
                 "point_clouds": point_clouds,
             })
         return {"outputs": outputs[-1], "aux_outputs": outputs[:-1]}
