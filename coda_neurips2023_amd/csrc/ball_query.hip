@@ -34,13 +34,14 @@ template <int C>
 __global__ __launch_bounds__(kBqWaves * kWave) void ball_query_scan_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int32_t *__restrict__ idx,
     float *__restrict__ grouped, int n, int m, float r2, float inv_radius, int nsample,
-    int normalize) {
+    int normalize, int nscenes) {
   extern __shared__ __attribute__((aligned(16))) int32_t s_rows[];  // [waves][C][nsample]
 
   const int w = wave_id();
   const int lane = lane_id();
-  const int bi = blockIdx.y;
-  const int j0 = (blockIdx.x * kBqWaves + w) * C;
+  // scene = workgroup id % B keeps a scene on one XCD's L2 (see ball_query_grid.hip)
+  const int bi = blockIdx.x % nscenes;
+  const int j0 = ((blockIdx.x / nscenes) * kBqWaves + w) * C;
   if (j0 >= m) return;  // wave-uniform; no workgroup barrier below
 
   const float *__restrict__ pts = xyz + static_cast<size_t>(bi) * n * 3;
@@ -137,10 +138,10 @@ int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *gro
   }
   const float r2 = radius * radius;  // ball_query_gpu.cu:25 (fp32 product)
   const float inv_radius = 1.0f / radius;
-  dim3 grid(ceil_div(m, kBqWaves * C), b);
+  dim3 grid(ceil_div(m, kBqWaves * C) * b);
   clear_sticky_error();
   hipLaunchKernelGGL(kern, grid, dim3(kBqWaves * kWave), lds, s, new_xyz, xyz, idx, grouped, n, m,
-                     r2, inv_radius, nsample, normalize);
+                     r2, inv_radius, nsample, normalize, b);
   return launch_status();
 }
 

@@ -259,13 +259,18 @@ __device__ __forceinline__ int rank_and_keep(float4 *buf, int h, int keep, int l
 __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int n,
     const unsigned char *__restrict__ ws, size_t scene_stride, int32_t *__restrict__ idx,
-    float *__restrict__ grouped, int m, float r2, float inv_radius, int nsample, int normalize) {
+    float *__restrict__ grouped, int m, float r2, float inv_radius, int nsample, int normalize,
+    int nscenes) {
   __shared__ float4 s_hits[kQueryWaves][kHitCap];
 
   const int w = wave_id();
   const int lane = lane_id();
-  const int bi = blockIdx.y;
-  const int j = blockIdx.x * kQueryWaves + w;
+  // XCD-aware mapping: workgroup id g runs on XCD g % 8 (observed dispatch order), so with
+  // scene = g % B all workgroups of a scene share ONE XCD's L2 (for B = 8: scene s <-> XCD s)
+  // and a scene's records are fetched from HBM once instead of once per XCD.  Only speed
+  // depends on the placement.
+  const int bi = blockIdx.x % nscenes;
+  const int j = (blockIdx.x / nscenes) * kQueryWaves + w;
   if (j >= m) return;  // wave-uniform, no workgroup barrier in this kernel
 
   const unsigned char *base = ws + static_cast<size_t>(bi) * scene_stride;
@@ -381,8 +386,8 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
   const int st = launch_build(grid_build_kernel);
   if (st != CODA_OK) return st;
   const float r2 = radius * radius;
-  hipLaunchKernelGGL(grid_query_kernel, dim3(ceil_div(m, kQueryWaves), b), dim3(kQueryWaves * kWave), 0, s,
-                     new_xyz, xyz, n, ws, stride, idx, grouped, m, r2, 1.0f / radius, nsample, normalize);
+  hipLaunchKernelGGL(grid_query_kernel, dim3(ceil_div(m, kQueryWaves) * b), dim3(kQueryWaves * kWave), 0, s,
+                     new_xyz, xyz, n, ws, stride, idx, grouped, m, r2, 1.0f / radius, nsample, normalize, b);
   return launch_status();
 }
 
