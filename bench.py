@@ -350,7 +350,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                "traffic": None,
+                # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate
+                # rocprofv3 --pmc passes: profiles/r01_pmc_ball_query.md
+                "traffic": 25234432,
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
             },
