@@ -122,28 +122,36 @@ def build_model_workload(dev):
     ang_tgt = torch.randint(0, 12, (B_PER_GPU, nq), generator=gen).to(dev)
     cls_tgt = torch.randint(0, 2, (B_PER_GPU, nq), generator=gen).to(dev)
 
-    def layer_loss(o, targets):
-        loss = crit.loss_predicted_region_embed_l1(o, targets, assign)["loss_predicted_region_embed_l1"]
-        loss = loss + crit.loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(o, targets, assign)[
-            "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi"]
-        loss = loss + F.cross_entropy(o["sem_cls_logits"].transpose(2, 1), cls_tgt)
-        loss = loss + F.l1_loss(o["center_normalized"], box_tgt["center_normalized"])
-        loss = loss + F.l1_loss(o["size_normalized"], box_tgt["size_normalized"])
-        loss = loss + F.cross_entropy(o["angle_logits"].transpose(2, 1), ang_tgt)
-        loss = loss + o["angle_residual_normalized"].abs().mean()
-        return loss
+    nl = default_args().dec_nlayers
+
+    def rep(t):  # per-layer targets: every decoder layer is supervised with the same targets
+        return t.unsqueeze(0).expand(nl, *t.shape)
+
+    assign_st = {k: rep(v) for k, v in assign.items()}
+    cls_tgt_st, ang_tgt_st = rep(cls_tgt).reshape(-1), rep(ang_tgt).reshape(-1)
 
     def step(m, batch):
         pred = m(batch, curr_epoch=0)
         o = pred["outputs"]
+        st = pred["stacked_outputs"]  # (num_layers, B, nq, ...): all decoder layers, evaluated in one pass
         targets = dict(tgt_fixed, text_features_clip=o["text_features_clip"], logit_scale=o["logit_scale"],
                        gt_text_correlation_embedding=o["gt_text_correlation_embedding"],
                        gt_text_correlation_embedding_mask=o["gt_text_correlation_embedding_mask"],
                        weak_box_cate_label=o["weak_box_cate_label"],
                        weak_confidence_weight=o["weak_confidence_weight"])
-        loss = layer_loss(o, targets)
-        for aux in pred["aux_outputs"]:  # every decoder layer is supervised (criterion.py:1205-1215)
-            loss = loss + layer_loss(aux, targets)
+        # every decoder layer is supervised (criterion.py:1205-1215): per-layer terms, summed over layers
+        loss = crit.stacked_loss_predicted_region_embed_l1(st, targets, assign_st)[
+            "loss_predicted_region_embed_l1"].sum()
+        loss = loss + crit.stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(st, targets, assign_st)[
+            "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi"].sum()
+        # plain CE / L1 on the box heads (per-layer means summed over layers = nl * overall mean)
+        k = st["sem_cls_logits"].shape[-1]
+        loss = loss + nl * F.cross_entropy(st["sem_cls_logits"].reshape(-1, k), cls_tgt_st)
+        loss = loss + nl * (st["center_normalized"] - box_tgt["center_normalized"]).abs().mean()
+        loss = loss + nl * (st["size_normalized"] - box_tgt["size_normalized"]).abs().mean()
+        k = st["angle_logits"].shape[-1]
+        loss = loss + nl * F.cross_entropy(st["angle_logits"].reshape(-1, k), ang_tgt_st)
+        loss = loss + nl * st["angle_residual_normalized"].abs().mean()
         return loss
 
     desc = ("configs[2]: full model_3detr (SA 20000->2048 r=0.2 ns=64, enc 3L d=256 h=4, dec 8L d=256 h=4, "

@@ -100,6 +100,7 @@ class SetCriterion(nn.Module):
         self.register_buffer("seen_semcls_percls_weights", seen)
         self.loss_weight_dict = loss_weight_dict
         self.confidence_type = getattr(args, "confidence_type", confidence_type) if args else confidence_type
+        self.layer_batched = True  # evaluate all decoder layers in one pass when the model hands them stacked
         assert self.confidence_type in ["non-confidence", "objectness", "clip+objectness", "clip-max-prob"]
         self.loss_functions = {
             "loss_sem_cls_softmax_skip_none_gt_sample": self.loss_sem_cls_softmax_skip_none_gt_sample,
@@ -112,109 +113,156 @@ class SetCriterion(nn.Module):
                 self.loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi,
         }
 
-    # ---- box terms -----------------------------------------------------------------
+    # ---- loss terms ----------------------------------------------------------------
+    # Every term is written once for tensors with a leading decoder-layer axis,
+    # outputs (L,B,nq,...) / assignments (L,B,nq) / targets (B,...), and returns one value per
+    # layer, shape (L,).  The reference evaluates the terms layer by layer
+    # (criterion.py:1205-1215, ~60 small kernels per layer and term group); the public
+    # single-layer methods below keep its signatures and call the same code with L = 1.
+    @staticmethod
+    def _lift(d, keys):
+        return {k: (v.unsqueeze(0) if torch.is_tensor(v) and k in keys else v) for k, v in d.items()}
+
+    _OUT_KEYS = ("sem_cls_logits", "angle_logits", "angle_residual_normalized", "center_dist", "size_normalized",
+                 "text_correlation_embedding")
+    _ASSIGN_KEYS = ("per_prop_gt_inds", "proposal_matched_mask")
+
+    def _single(self, fn, outputs, targets, assignments):
+        res = fn(self._lift(outputs, self._OUT_KEYS), targets, self._lift(assignments, self._ASSIGN_KEYS))
+        return {k: v[0] for k, v in res.items()}
+
+    @staticmethod
+    def _gather_gt(gt, inds):
+        """gt (B,ngt[,k]) indexed by inds (L,B,nq) -> (L,B,nq[,k])."""
+        nl = inds.shape[0]
+        gt = gt.unsqueeze(0).expand(nl, *gt.shape)
+        if gt.dim() == 4:
+            return torch.gather(gt, 2, inds.unsqueeze(-1).expand(-1, -1, -1, gt.shape[-1]))
+        return torch.gather(gt, 2, inds)
+
+    @staticmethod
+    def _ce(logits, labels, weight=None):
+        """Per-element cross entropy over the last axis: logits (L,B,nq,K), labels (L,B,nq)."""
+        k = logits.shape[-1]
+        return F.cross_entropy(logits.reshape(-1, k), labels.reshape(-1), weight, reduction="none").view(labels.shape)
+
     @torch.no_grad()
-    def loss_cardinality(self, outputs, targets, assignments):
+    def stacked_loss_cardinality(self, outputs, targets, assignments):
         pred_logits = outputs["sem_cls_logits"]
-        pred_objects = (pred_logits.argmax(-1) != pred_logits.shape[-1] - 1).sum(1)
-        card_err = F.l1_loss(pred_objects.float(), targets["nactual_gt"])
+        pred_objects = (pred_logits.argmax(-1) != pred_logits.shape[-1] - 1).sum(-1)
+        card_err = (pred_objects.float() - targets["nactual_gt"]).abs().mean(-1)
         return {"loss_cardinality": card_err}
 
-    def loss_sem_cls_softmax_skip_none_gt_sample(self, outputs, targets, assignments):
+    def stacked_loss_sem_cls_softmax_skip_none_gt_sample(self, outputs, targets, assignments):
         pred_logits = outputs["sem_cls_logits"]
-        gt_box_label = torch.gather(targets["gt_box_sem_cls_label"], 1, assignments["per_prop_gt_inds"])
-        gt_box_label[assignments["proposal_matched_mask"].int() == 0] = pred_logits.shape[-1] - 1
-        loss = F.cross_entropy(pred_logits.transpose(2, 1), gt_box_label, self.semcls_percls_weights,
-                               reduction="none")
+        gt_box_label = self._gather_gt(targets["gt_box_sem_cls_label"], assignments["per_prop_gt_inds"])
+        gt_box_label = torch.where(assignments["proposal_matched_mask"].int() == 0,
+                                   torch.full_like(gt_box_label, pred_logits.shape[-1] - 1), gt_box_label)
+        loss = self._ce(pred_logits, gt_box_label, self.semcls_percls_weights)
         # scenes without any GT box contribute 0 and are not counted (:236-244)
         has_object = (targets["gt_box_present"].sum(dim=1) != 0).to(loss.dtype)
-        final_loss = (loss.sum(dim=1) * has_object).sum()
-        final_loss = final_loss / (has_object.sum() * loss.shape[1] + 1e-32)
+        final_loss = (loss.sum(dim=2) * has_object).sum(dim=1)
+        final_loss = final_loss / (has_object.sum() * loss.shape[2] + 1e-32)
         return {"loss_sem_cls_softmax_skip_none_gt_sample": final_loss}
 
-    def loss_angle(self, outputs, targets, assignments):
+    def stacked_loss_angle(self, outputs, targets, assignments):
         angle_logits = outputs["angle_logits"]
         angle_residual = outputs["angle_residual_normalized"]
         if targets["num_boxes_replica"] > 0:
-            gt_angle_label = targets["gt_angle_class_label"]
-            gt_angle_residual = targets["gt_angle_residual_label"]
-            gt_angle_residual_normalized = gt_angle_residual / (np.pi / self.dataset_config.num_angle_bin)
-            gt_angle_label = torch.gather(gt_angle_label, 1, assignments["per_prop_gt_inds"])
-            angle_cls_loss = F.cross_entropy(angle_logits.transpose(2, 1), gt_angle_label,
-                                             reduction="none")
-            angle_cls_loss = (angle_cls_loss * assignments["proposal_matched_mask"]).sum()
-            gt_angle_residual_normalized = torch.gather(gt_angle_residual_normalized, 1,
-                                                        assignments["per_prop_gt_inds"])
-            one_hot = torch.zeros_like(angle_residual, dtype=torch.float32)
-            one_hot.scatter_(2, gt_angle_label.unsqueeze(-1), 1)
-            angle_residual_for_gt_class = torch.sum(angle_residual * one_hot, -1)
-            angle_reg_loss = huber_loss(angle_residual_for_gt_class - gt_angle_residual_normalized,
-                                        delta=1.0)
-            angle_reg_loss = (angle_reg_loss * assignments["proposal_matched_mask"]).sum()
-            angle_cls_loss /= targets["num_boxes"]
-            angle_reg_loss /= targets["num_boxes"]
+            inds, matched = assignments["per_prop_gt_inds"], assignments["proposal_matched_mask"]
+            gt_angle_residual_normalized = targets["gt_angle_residual_label"] / (
+                np.pi / self.dataset_config.num_angle_bin)
+            gt_angle_label = self._gather_gt(targets["gt_angle_class_label"], inds)
+            angle_cls_loss = (self._ce(angle_logits, gt_angle_label) * matched).sum(dim=(1, 2))
+            gt_angle_residual_normalized = self._gather_gt(gt_angle_residual_normalized, inds)
+            # residual of the GT angle bin (the reference multiplies by a one-hot and sums, :869-876)
+            angle_residual_for_gt_class = torch.gather(angle_residual, 3, gt_angle_label.unsqueeze(-1)).squeeze(-1)
+            angle_reg_loss = huber_loss(angle_residual_for_gt_class - gt_angle_residual_normalized, delta=1.0)
+            angle_reg_loss = (angle_reg_loss * matched).sum(dim=(1, 2))
+            angle_cls_loss = angle_cls_loss / targets["num_boxes"]
+            angle_reg_loss = angle_reg_loss / targets["num_boxes"]
         else:
-            angle_cls_loss = torch.sum(angle_logits) * 0
-            angle_reg_loss = torch.sum(angle_residual) * 0
+            angle_cls_loss = angle_logits.sum(dim=(1, 2, 3)) * 0
+            angle_reg_loss = angle_residual.sum(dim=(1, 2, 3)) * 0
         return {"loss_angle_cls": angle_cls_loss, "loss_angle_reg": angle_reg_loss}
 
-    def loss_center(self, outputs, targets, assignments):
+    def stacked_loss_center(self, outputs, targets, assignments):
         center_dist = outputs["center_dist"]
         if targets["num_boxes_replica"] > 0:
-            center_loss = torch.gather(center_dist, 2,
-                                       assignments["per_prop_gt_inds"].unsqueeze(-1)).squeeze(-1)
-            center_loss = center_loss * assignments["proposal_matched_mask"]
-            center_loss = center_loss.sum()
+            center_loss = torch.gather(center_dist, 3, assignments["per_prop_gt_inds"].unsqueeze(-1)).squeeze(-1)
+            center_loss = (center_loss * assignments["proposal_matched_mask"]).sum(dim=(1, 2))
             if targets["num_boxes"] > 0:
-                center_loss /= targets["num_boxes"]
+                center_loss = center_loss / targets["num_boxes"]
         else:
-            center_loss = torch.sum(center_dist) * 0
+            center_loss = center_dist.sum(dim=(1, 2, 3)) * 0
         return {"loss_center": center_loss}
 
-    def loss_size(self, outputs, targets, assignments):
-        gt_box_sizes = targets["gt_box_sizes_normalized"]
+    def stacked_loss_size(self, outputs, targets, assignments):
         pred_box_sizes = outputs["size_normalized"]
         if targets["num_boxes_replica"] > 0:
-            inds = assignments["per_prop_gt_inds"].unsqueeze(-1).expand(-1, -1, gt_box_sizes.shape[-1])
-            gt_box_sizes = torch.gather(gt_box_sizes, 1, inds)
-            size_loss = F.l1_loss(pred_box_sizes, gt_box_sizes, reduction="none").sum(dim=-1)
-            size_loss = size_loss * assignments["proposal_matched_mask"]
-            size_loss = size_loss.sum()
-            size_loss /= targets["num_boxes"]
+            gt_box_sizes = self._gather_gt(targets["gt_box_sizes_normalized"], assignments["per_prop_gt_inds"])
+            size_loss = (pred_box_sizes - gt_box_sizes).abs().sum(dim=-1)
+            size_loss = (size_loss * assignments["proposal_matched_mask"]).sum(dim=(1, 2))
+            size_loss = size_loss / targets["num_boxes"]
         else:
-            size_loss = torch.sum(pred_box_sizes) * 0
+            size_loss = pred_box_sizes.sum(dim=(1, 2, 3)) * 0
         return {"loss_size": size_loss}
 
-    # ---- CLIP-space alignment terms (hot path) -----------------
-    def loss_predicted_region_embed_l1(self, outputs, targets, assignments):
+    # CLIP-space alignment terms (hot path, SURVEY.md 8a row a13)
+    def stacked_loss_predicted_region_embed_l1(self, outputs, targets, assignments):
         """Masked L1 between the predicted region embedding and the CLIP image
         embedding of the cropped box, / (sum(mask) * 512)."""
         gt = targets["gt_text_correlation_embedding"]
         pred = outputs["text_correlation_embedding"]
         weight_maps = targets["gt_text_correlation_embedding_mask"]
-        ave_weight = torch.sum(weight_maps) * pred.shape[2]
-        l1_loss = F.l1_loss(pred * weight_maps, gt * weight_maps, reduction="sum") / ave_weight
+        ave_weight = torch.sum(weight_maps) * pred.shape[-1]
+        l1_loss = (pred * weight_maps - gt * weight_maps).abs().sum(dim=(1, 2, 3)) / ave_weight
         return {"loss_predicted_region_embed_l1": l1_loss}
 
-    def loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(self, outputs, targets, assignments):
+    def stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(self, outputs, targets, assignments):
         """CE(normalised embedding @ text^T * scale, label) * confidence, where matched
         proposals take the GT label/confidence and the others the CLIP weak label."""
         emb = outputs["text_correlation_embedding"]
         emb = emb / (emb.norm(dim=-1, keepdim=True) + 1e-32)
         text_features_clip = targets["text_features_clip"].to(torch.float32)
         temperature_param = targets["logit_scale"]
-        correlation_map = torch.bmm(emb, text_features_clip.permute(0, 2, 1)) * temperature_param
+        correlation_map = torch.matmul(emb, text_features_clip.permute(0, 2, 1)) * temperature_param
+        inds = assignments["per_prop_gt_inds"]
         matched = assignments["proposal_matched_mask"].int() > 0
-        seen_label = torch.gather(targets["gt_box_seen_sem_cls_label"], 1, assignments["per_prop_gt_inds"])
-        seen_confi = torch.gather(targets["gt_box_seen_sem_cls_confi"], 1, assignments["per_prop_gt_inds"])
+        seen_label = self._gather_gt(targets["gt_box_seen_sem_cls_label"], inds)
+        seen_confi = self._gather_gt(targets["gt_box_seen_sem_cls_confi"], inds)
         gt_box_label = torch.where(matched, seen_label, targets["weak_box_cate_label"])
         gt_box_confidence = torch.where(matched, seen_confi, targets["weak_confidence_weight"])
         if self.confidence_type == "non-confidence":
-            gt_box_confidence[gt_box_confidence > 1e-16] = 1
-        loss = F.cross_entropy(correlation_map.transpose(2, 1), gt_box_label, reduction="none")
-        all_num = torch.sum(gt_box_confidence > 1e-32) + 1e-32
-        final_loss = torch.sum(loss * gt_box_confidence) / all_num
+            gt_box_confidence = torch.where(gt_box_confidence > 1e-16, torch.ones_like(gt_box_confidence),
+                                            gt_box_confidence)
+        loss = self._ce(correlation_map, gt_box_label)
+        all_num = torch.sum(gt_box_confidence > 1e-32, dim=(1, 2)) + 1e-32
+        final_loss = torch.sum(loss * gt_box_confidence, dim=(1, 2)) / all_num
         return {"loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi": final_loss}
+
+    # single-layer entry points with the reference's names and signatures
+    def loss_cardinality(self, outputs, targets, assignments):                       # :169-179
+        return self._single(self.stacked_loss_cardinality, outputs, targets, assignments)
+
+    def loss_sem_cls_softmax_skip_none_gt_sample(self, outputs, targets, assignments):  # :219-246
+        return self._single(self.stacked_loss_sem_cls_softmax_skip_none_gt_sample, outputs, targets, assignments)
+
+    def loss_angle(self, outputs, targets, assignments):                             # :834-900
+        return self._single(self.stacked_loss_angle, outputs, targets, assignments)
+
+    def loss_center(self, outputs, targets, assignments):                            # :1015-1039
+        return self._single(self.stacked_loss_center, outputs, targets, assignments)
+
+    def loss_size(self, outputs, targets, assignments):                              # :1065-1104
+        return self._single(self.stacked_loss_size, outputs, targets, assignments)
+
+    def loss_predicted_region_embed_l1(self, outputs, targets, assignments):         # :924-943
+        return self._single(self.stacked_loss_predicted_region_embed_l1, outputs, targets, assignments)
+
+    def loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(self, outputs, targets, assignments):  # :598-644
+        return self._single(self.stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi, outputs, targets,
+                            assignments)
 
     # ---- drivers -------------------------------------------------------------------
     def single_output_forward(self, outputs, targets, if_region_embed=False, if_aux=False,
@@ -247,6 +295,52 @@ class SetCriterion(nn.Module):
                 final_loss += losses[name]
         return final_loss, losses
 
+    def stacked_forward(self, stacked, targets):
+        """Matching + every live loss term for all decoder layers at once.  ``stacked[k]`` is
+        (L,B,nq,...) with the last decoder layer at index L-1 (what ``outputs`` /
+        ``aux_outputs`` hold layer by layer).  Layers are extra, independent scenes for the
+        matcher (one cost matrix, one host round trip instead of L)."""
+        center = stacked["center_normalized"]
+        nl, bsz, nq = center.shape[:3]
+        ngt = targets["gt_box_centers_normalized"].shape[1]
+        if self.giou_fn is not None:
+            rotated = torch.any(targets["gt_box_angles"] > 0).item()
+            gious = torch.stack([self.giou_fn(stacked["box_corners"][l], targets["gt_box_corners"],
+                                              targets["nactual_gt"], rotated_boxes=rotated, needs_grad=False)
+                                 for l in range(nl)])
+        else:  # gIoU is SURVEY.md 8f "next": zero cost term
+            gious = torch.zeros(nl, bsz, nq, ngt, device=center.device)
+        gt_centers = targets["gt_box_centers_normalized"]
+        center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)
+        flat_out = {"sem_cls_prob": stacked["sem_cls_prob"].flatten(0, 1),
+                    "objectness_prob": stacked["objectness_prob"].flatten(0, 1),
+                    "center_dist": center_dist, "gious": gious.flatten(0, 1)}
+        flat_tgt = {"gt_box_sem_cls_label": targets["gt_box_sem_cls_label"].repeat(nl, 1),
+                    "nactual_gt": targets["nactual_gt"].repeat(nl)}
+        flat_assign = self.matcher(flat_out, flat_tgt)
+        assignments = {"per_prop_gt_inds": flat_assign["per_prop_gt_inds"].view(nl, bsz, nq),
+                       "proposal_matched_mask": flat_assign["proposal_matched_mask"].view(nl, bsz, nq)}
+        outs = dict(stacked, center_dist=center_dist.view(nl, bsz, nq, ngt), gious=gious)
+
+        losses = {}
+        for k in self.loss_functions:
+            loss_wt_key = k + "_weight"
+            if (loss_wt_key in self.loss_weight_dict and self.loss_weight_dict[loss_wt_key] > 1e-32) \
+                    or loss_wt_key not in self.loss_weight_dict:
+                losses.update(getattr(self, "stacked_" + k)(outs, targets, assignments))
+        final = 0
+        for k, w in self.loss_weight_dict.items():
+            if w > 1e-32:
+                name = k.replace("_weight", "")
+                losses[name] = losses[name] * w
+                final = final + losses[name]
+        loss_dict = {}
+        for name, per_layer in losses.items():
+            loss_dict[name] = per_layer[nl - 1]
+            for l in range(nl - 1):
+                loss_dict[f"{name}_{l}"] = per_layer[l]
+        return final.sum(), loss_dict
+
     def forward(self, outputs, targets):
         nactual_gt = targets["gt_box_present"].sum(axis=1).long()
         num_boxes = torch.clamp(all_reduce_average(nactual_gt.sum()), min=1).item()
@@ -258,6 +352,9 @@ class SetCriterion(nn.Module):
             if key in outputs["outputs"]:
                 targets[key] = outputs["outputs"][key]
 
+        if self.layer_batched and "stacked_outputs" in outputs:
+            # this package's model also returns its per-layer tensors stacked: same terms, one pass
+            return self.stacked_forward(outputs["stacked_outputs"], targets)
         loss, loss_dict = self.single_output_forward(outputs["outputs"], targets, if_last_head=True)
         if "aux_outputs" in outputs:
             for k in range(len(outputs["aux_outputs"])):

@@ -1,0 +1,251 @@
+"""GenericMLP stacks on channels-last tokens: (batched) library GEMMs + the streaming
+batch-norm kernels of ``csrc/token_bn.hip`` (``include/coda_token_ops.h``).
+
+The reference evaluates its six prediction heads one after the other as
+Conv1d(k=1) -> BatchNorm1d -> ReLU -> Dropout stacks on ``(layers*batch, C, queries)``
+(models/model_3detr.py:1617-1660, models/helpers.py:45-112), and the encoder->decoder
+projection the same way on ``(batch, C, points)`` (:1866-1868).  A 1x1 convolution over
+tokens is a GEMM on the ``(tokens, C)`` matrix the transformer already holds, and G heads
+over the same input are one batched GEMM, so ``hidden_stack`` computes all heads at once on
+``(G, tokens, C)`` activations with one statistics pass and one normalise/activate/dropout
+pass between two GEMMs.  Parameters stay in the reference-shaped modules
+(``layers.{i}.weight`` ...); train-mode batch statistics, running-statistics updates and
+SyncBatchNorm reductions are those of ``torch.nn.BatchNorm1d`` / ``SyncBatchNorm``.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib
+from . import attention_core as _core
+
+_SPLIT_ROWS = 2048
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _call(name, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args, torch.cuda.current_stream().cuda_stream), name)
+
+
+def _is_sync(bn):
+    return isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
+        and dist.get_world_size(bn.process_group) > 1
+
+
+def parse(mlp):
+    """GenericMLP -> ([(dense, bn, relu, dropout_p), ...], tail dense or None), or None when
+    the stack has a shape the fused path does not cover."""
+    mods = list(mlp.layers.children())
+    blocks, i = [], 0
+    tail = None
+    while i < len(mods):
+        dense = mods[i]
+        if isinstance(dense, nn.Conv1d):
+            if dense.kernel_size != (1,) or dense.stride != (1,) or dense.groups != 1 or dense.padding != (0,):
+                return None
+        elif not isinstance(dense, nn.Linear):
+            return None
+        i += 1
+        if i == len(mods):
+            tail = dense
+            break
+        bn = mods[i]
+        if not isinstance(bn, (nn.BatchNorm1d, nn.SyncBatchNorm)) or dense.bias is not None:
+            return None
+        if not bn.affine or not bn.track_running_stats or bn.momentum is None:
+            return None
+        i += 1
+        relu = i < len(mods) and isinstance(mods[i], nn.ReLU)
+        i += int(relu)
+        p = 0.0
+        if i < len(mods) and isinstance(mods[i], nn.Dropout):
+            p = float(mods[i].p)
+            i += 1
+        cout = dense.weight.shape[0]
+        if cout % 4 or cout > 1024 or 256 % (cout // 4) or not 0.0 <= p < 1.0:
+            return None
+        blocks.append((dense, bn, relu, p))
+    if not blocks:
+        return None
+    return blocks, tail
+
+
+def eligible(mlps, x):
+    """All stacks have the same block structure, are in training mode, fp32 on the GPU."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        return None
+    parsed = [parse(m) for m in mlps]
+    if any(p is None for p in parsed):
+        return None
+    first = parsed[0][0]
+    for blocks, _ in parsed:
+        if len(blocks) != len(first):
+            return None
+        for (d, bn, relu, p), (d0, bn0, relu0, p0) in zip(blocks, first):
+            if d.weight.shape[:2] != d0.weight.shape[:2] or relu != relu0 or p != p0 or bn.eps != bn0.eps \
+                    or bn.momentum != bn0.momentum or not bn.training or type(bn) is not type(bn0):
+                return None
+            if _is_sync(bn) and bn.process_group is not bn0.process_group:
+                return None
+    return parsed
+
+
+def _split_k_tn(dz, a):
+    """dz (G,T,Co), a (G,T,Ci) contiguous -> dz^T a (G,Co,Ci) with the T reduction split."""
+    g, t, co = dz.shape
+    ci = a.shape[-1]
+    if t >= 2 * _SPLIT_ROWS and t % _SPLIT_ROWS == 0:
+        nc = t // _SPLIT_ROWS
+        part = torch.bmm(dz.view(g * nc, _SPLIT_ROWS, co).transpose(1, 2), a.view(g * nc, _SPLIT_ROWS, ci))
+        return part.view(g, nc, co, ci).sum(1)
+    return torch.bmm(dz.transpose(1, 2), a)
+
+
+class _HiddenStack(torch.autograd.Function):
+    """x (T, Cin) shared by G stacks -> (G, T, C_last) after every (dense, BN, ReLU, dropout)
+    block.  params: per block, per group: dense weight, bn weight, bn bias."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        groups, blocks = meta  # blocks: list of (bns [G], relu, p)
+        nb = len(blocks)
+        dev = x.device
+        t = x.shape[0]
+        pit = iter(params)
+        ws, gammas, betas = [], [], []
+        for _ in range(nb):
+            w, gm, bt = [], [], []
+            for _ in range(groups):
+                w.append(next(pit).flatten(1))
+                gm.append(next(pit))
+                bt.append(next(pit))
+            ws.append(torch.stack(w) if groups > 1 else w[0].unsqueeze(0))
+            gammas.append(torch.stack(gm) if groups > 1 else gm[0].unsqueeze(0))
+            betas.append(torch.stack(bt) if groups > 1 else bt[0].unsqueeze(0))
+
+        zs, acts, prms, seeds = [], [], [], []
+        cur = None  # (G,T,C) input of the block (None: x)
+        new_stats, run_stats, counters = [], [], []
+        for i, (bns, relu, p) in enumerate(blocks):
+            c = ws[i].shape[1]
+            if cur is None:
+                if groups == 1:
+                    z = torch.mm(x, ws[i][0].t()).unsqueeze(0)
+                else:  # one batched GEMM over the heads; x is broadcast with batch stride 0
+                    z = torch.bmm(x.unsqueeze(0).expand(groups, -1, -1), ws[i].transpose(1, 2))
+            else:
+                z = torch.bmm(cur, ws[i].transpose(1, 2))
+            sums = torch.empty((groups, 2, c), dtype=torch.float64, device=dev)
+            _call("coda_tok_bn_stats_f32", _p(z), groups, t, c, _p(sums))
+            world = 1
+            if _is_sync(bns[0]):
+                world = dist.get_world_size(bns[0].process_group)
+                dist.all_reduce(sums, group=bns[0].process_group)
+            n = float(t * world)
+            prm = torch.empty((groups, 4, c), dtype=torch.float32, device=dev)
+            stat = torch.empty((groups, 2, c), dtype=torch.float32, device=dev)
+            _call("coda_tok_bn_finalize_f32", _p(sums), _p(gammas[i]), _p(betas[i]), groups, c, n,
+                  float(bns[0].eps), _p(prm), _p(stat))
+            for g, bn in enumerate(bns):
+                run_stats += [bn.running_mean, bn.running_var]
+                new_stats += [stat[g, 0], stat[g, 1]]
+                counters.append(bn.num_batches_tracked)
+            seed, seed_dev = _core._next_seed() if p > 0.0 else (0, None)
+            act = torch.empty_like(z)
+            _call("coda_tok_bn_act_f32", _p(z), _p(prm), groups, t, c, int(relu), p, seed, _p(seed_dev), _p(act))
+            zs.append(z)
+            acts.append(act)
+            prms.append(prm)
+            seeds.append((seed, seed_dev, n))
+            cur = act
+        with torch.no_grad():  # running statistics of all BN modules in two multi-tensor launches
+            torch._foreach_lerp_(run_stats, new_stats, float(blocks[0][0][0].momentum))
+            torch._foreach_add_(counters, 1)
+
+        ctx.meta = meta
+        ctx.seeds = seeds
+        ctx.wshapes = [params[3 * groups * i].shape for i in range(nb)]
+        ctx.save_for_backward(x, *zs, *acts[:-1], *prms, *ws, *gammas)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        groups, blocks = ctx.meta
+        nb = len(blocks)
+        saved = ctx.saved_tensors
+        x = saved[0]
+        zs = saved[1:1 + nb]
+        acts = saved[1 + nb:2 * nb]
+        prms = saved[2 * nb:3 * nb]
+        ws = saved[3 * nb:4 * nb]
+        gammas = saved[4 * nb:5 * nb]
+        dev = x.device
+        t = x.shape[0]
+        grads = [None] * (3 * groups * nb)
+        da = dout.contiguous()
+        dx = None
+        for i in range(nb - 1, -1, -1):
+            bns, relu, p = blocks[i]
+            seed, seed_dev, n = ctx.seeds[i]
+            c = ws[i].shape[1]
+            sums = torch.empty((groups, 2, c), dtype=torch.float64, device=dev)
+            _call("coda_tok_bn_act_bwd_stats_f32", _p(da), _p(zs[i]), _p(prms[i]), groups, t, c, int(relu), p, seed,
+                  _p(seed_dev), _p(sums))
+            total = sums
+            if _is_sync(bns[0]):
+                total = sums.clone()
+                dist.all_reduce(total, group=bns[0].process_group)
+            prmb = torch.empty((groups, 3, c), dtype=torch.float32, device=dev)
+            dgamma = torch.empty((groups, c), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((groups, c), dtype=torch.float32, device=dev)
+            _call("coda_tok_bn_bwd_finalize_f32", _p(sums), _p(total), _p(gammas[i]), _p(prms[i]), groups, c, n,
+                  _p(prmb), _p(dgamma), _p(dbeta))
+            dz = da if da.data_ptr() != dout.data_ptr() else torch.empty_like(da)
+            _call("coda_tok_bn_act_bwd_apply_f32", _p(da), _p(zs[i]), _p(prms[i]), _p(prmb), groups, t, c, int(relu),
+                  p, seed, _p(seed_dev), _p(dz))
+            # weight gradients (split-K) and the gradient of the block input
+            if i > 0:
+                dw = _split_k_tn(dz, acts[i - 1])
+                da = torch.bmm(dz, ws[i])
+            else:
+                xs = x.unsqueeze(0)
+                if groups == 1:
+                    dw = _split_k_tn(dz, xs)
+                    dx = torch.mm(dz[0], ws[0][0]) if ctx.needs_input_grad[0] else None
+                else:
+                    dw = torch.stack([_split_k_tn(dz[g:g + 1], xs)[0] for g in range(groups)])
+                    if ctx.needs_input_grad[0]:
+                        dx = torch.mm(dz[0], ws[0][0])
+                        for g in range(1, groups):
+                            dx.addmm_(dz[g], ws[0][g])
+            for g in range(groups):
+                base = 3 * (groups * i + g)
+                grads[base] = dw[g].view(ctx.wshapes[i])
+                grads[base + 1] = dgamma[g]
+                grads[base + 2] = dbeta[g]
+        return (dx, None, *grads)
+
+
+def hidden_stack(x, parsed):
+    """x (T, Cin) float32 cuda, parsed = eligible(mlps, x) -> (G, T, C_last)."""
+    groups = len(parsed)
+    nb = len(parsed[0][0])
+    blocks = []
+    params = []
+    for i in range(nb):
+        bns = [parsed[g][0][i][1] for g in range(groups)]
+        blocks.append((bns, parsed[0][0][i][2], parsed[0][0][i][3]))
+        for g in range(groups):
+            dense, bn, _, _ = parsed[g][0][i]
+            params += [dense.weight, bn.weight, bn.bias]
+    return _HiddenStack.apply(x.contiguous(), (groups, blocks), *params)
+
+
+def tail_linear(a, dense):
+    """The last, plain dense layer of a stack on (T, C) tokens."""
+    w = dense.weight.flatten(1)
+    return torch.nn.functional.linear(a, w, dense.bias)

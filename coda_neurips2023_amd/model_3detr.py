@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import fused_bn_mlp
 from .helpers import GenericMLP
 from .pointnet2.pointnet2_modules import PointnetSAModuleVotes
 from .pointnet2.pointnet2_utils import furthest_point_sample
@@ -176,30 +177,42 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             enc_inds = torch.gather(pre_enc_inds, 1, enc_inds.long())
         return enc_xyz, enc_features, enc_inds
 
+    def _project_encoder_features(self, enc_features):
+        """(npoints, B, C) -> (npoints, B, dec_dim) through encoder_to_decoder_projection
+        (models/model_3detr.py:1866-1868)."""
+        parsed = fused_bn_mlp.eligible([self.encoder_to_decoder_projection], enc_features)
+        if parsed is not None and parsed[0][1] is None:
+            npoints, batch, channel = enc_features.shape
+            out = fused_bn_mlp.hidden_stack(enc_features.reshape(-1, channel), parsed)
+            return out.view(npoints, batch, -1)
+        return self.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+
     def get_box_predictions(self, query_xyz, point_cloud_dims, box_features, point_clouds=None,
                             inputs=None):
         """box_features: (num_layers, num_queries, batch, channel) -> output dicts."""
-        box_features = box_features.permute(0, 2, 3, 1)
-        num_layers, batch, channel, num_queries = box_features.shape
-        box_features = box_features.reshape(num_layers * batch, channel, num_queries)
-
+        num_layers, num_queries, batch, channel = box_features.shape
         heads = self.mlp_heads
-        cls_logits = heads["sem_cls_head"](box_features).transpose(1, 2)
-        text_correlation_embedding = heads["text_correlation_head"](box_features).transpose(1, 2)
-        center_offset = heads["center_head"](box_features).sigmoid().transpose(1, 2) - 0.5
-        size_normalized = heads["size_head"](box_features).sigmoid().transpose(1, 2)
-        angle_logits = heads["angle_cls_head"](box_features).transpose(1, 2)
-        angle_residual_normalized = heads["angle_residual_head"](box_features).transpose(1, 2)
+        names = ["sem_cls_head", "text_correlation_head", "center_head", "size_head", "angle_cls_head",
+                 "angle_residual_head"]
+        parsed = fused_bn_mlp.eligible([heads[n] for n in names], box_features)
+        if parsed is not None and all(tail is not None for _, tail in parsed):
+            # all six heads at once on the decoder's own (layer, query, scene) token order:
+            # batched GEMMs + fused batch-norm/ReLU/dropout passes (fused_bn_mlp.py)
+            hidden = fused_bn_mlp.hidden_stack(box_features.reshape(-1, channel), parsed)
+            raw = {}
+            for g, n in enumerate(names):
+                out = fused_bn_mlp.tail_linear(hidden[g], parsed[g][1])
+                raw[n] = out.view(num_layers, num_queries, batch, -1).permute(0, 2, 1, 3)
+        else:
+            feats = box_features.permute(0, 2, 3, 1).reshape(num_layers * batch, channel, num_queries)
+            raw = {n: heads[n](feats).transpose(1, 2).reshape(num_layers, batch, num_queries, -1) for n in names}
 
-        def split(t):
-            return t.reshape(num_layers, batch, num_queries, -1)
-
-        cls_logits = split(cls_logits)
-        text_correlation_embedding = split(text_correlation_embedding)
-        center_offset = split(center_offset)
-        size_normalized = split(size_normalized)
-        angle_logits = split(angle_logits)
-        angle_residual_normalized = split(angle_residual_normalized)
+        cls_logits = raw["sem_cls_head"]
+        text_correlation_embedding = raw["text_correlation_head"]
+        center_offset = raw["center_head"].sigmoid() - 0.5
+        size_normalized = raw["size_head"].sigmoid()
+        angle_logits = raw["angle_cls_head"]
+        angle_residual_normalized = raw["angle_residual_head"]
         angle_residual = angle_residual_normalized * (np.pi / angle_residual_normalized.shape[-1])
 
         # Box decoding (models/model_3detr.py:1683-1731).  The reference decodes the num_layers
@@ -238,26 +251,28 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         semcls_prob = per_layer(semcls_prob)
         objectness_prob = per_layer(objectness_prob)
 
-        outputs = []
-        for l in range(num_layers):
-            outputs.append({
-                "sem_cls_logits": cls_logits[l],
-                "text_correlation_embedding": text_correlation_embedding[l],
-                "center_normalized": center_normalized[l],
-                "center_unnormalized": center_unnormalized[l],
-                "size_normalized": size_normalized[l],
-                "size_unnormalized": size_unnormalized[l],
-                "angle_logits": angle_logits[l],
-                "angle_residual": angle_residual[l],
-                "angle_residual_normalized": angle_residual_normalized[l],
-                "angle_continuous": angle_continuous[l],
-                "objectness_prob": objectness_prob[l],
-                "sem_cls_prob": semcls_prob[l],
-                "box_corners": box_corners[l],
-                "box_corners_xyz": box_corners_xyz[l],
-                "point_clouds": point_clouds,
-            })
-        return {"outputs": outputs[-1], "aux_outputs": outputs[:-1]}
+        stacked = {
+            "sem_cls_logits": cls_logits,
+            "text_correlation_embedding": text_correlation_embedding,
+            "center_normalized": center_normalized,
+            "center_unnormalized": center_unnormalized,
+            "size_normalized": size_normalized,
+            "size_unnormalized": size_unnormalized,
+            "angle_logits": angle_logits,
+            "angle_residual": angle_residual,
+            "angle_residual_normalized": angle_residual_normalized,
+            "angle_continuous": angle_continuous,
+            "objectness_prob": objectness_prob,
+            "sem_cls_prob": semcls_prob,
+            "box_corners": box_corners,
+            "box_corners_xyz": box_corners_xyz,
+        }
+        outputs = [dict({k: v[l] for k, v in stacked.items()}, point_clouds=point_clouds)
+                   for l in range(num_layers)]
+        # `stacked_outputs` ((num_layers, batch, ...) per key, last decoder layer at index -1) is this
+        # package's addition to the reference's return value: criterion.SetCriterion evaluates all
+        # layers from it in one pass instead of looping over outputs / aux_outputs.
+        return {"outputs": outputs[-1], "aux_outputs": outputs[:-1], "stacked_outputs": stacked}
 
     def get_class_scores(self, box_predictions):
         """Open-vocabulary class scores: softmax(normalised embedding @ text^T * scale)
@@ -279,7 +294,7 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
                 if_cmp_class=False):
         point_clouds = inputs["point_clouds"]
         enc_xyz, enc_features, enc_inds = self.run_encoder(point_clouds)
-        enc_features = self.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+        enc_features = self._project_encoder_features(enc_features)
         if encoder_only:
             return enc_xyz, enc_features.transpose(0, 1)
         point_cloud_dims = [inputs["point_cloud_dims_min"], inputs["point_cloud_dims_max"]]

@@ -1,0 +1,77 @@
+/*
+ * coda_token_ops.h -- C ABI of the token-wise streaming kernels around the library GEMMs of
+ * the model's MLP stacks and transformer layers.
+ *
+ * Part 1, batch-norm MLP blocks.  The reference builds its prediction heads, the
+ * encoder->decoder projection and the query projection from GenericMLP
+ * (models/helpers.py:45-112): Conv1d(k=1, no bias) -> BatchNorm1d -> ReLU [-> Dropout] on
+ * (batch, C, tokens) tensors, six heads over the same decoder output
+ * (models/model_3detr.py:1566-1601, 1617-1660).  Here the activations are kept
+ * CHANNELS-LAST as z (G, R, C): G independent stacks ("groups": the heads), R tokens,
+ * C channels; the 1x1 convolutions are (batched) library GEMMs on that layout and these
+ * kernels do everything between two GEMMs in one pass each:
+ *
+ *   forward    stats -> finalize -> act        a = dropout(relu(z * scale + shift))
+ *   backward   act_bwd_stats -> bwd_finalize -> act_bwd_apply
+ *
+ * Batch statistics are summed in fp64.  With SyncBatchNorm the caller all-reduces the
+ * `sums` buffers between the stats and the finalize call.  Dropout masks come from a
+ * counter hash of (seed, element index) and are regenerated, not stored, in the backward.
+ *
+ * C must be a multiple of 4 with C/4 dividing 256 (4 ... 1024).  Conventions as in
+ * coda_pointnet2.h: raw device pointers, `stream` is a hipStream_t, 0 / CODA_EINVAL /
+ * hipError_t status.
+ */
+#ifndef CODA_TOKEN_OPS_H
+#define CODA_TOKEN_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sums (G,2,C) doubles, zeroed by the call: [g][0][c] = sum_r z, [g][1][c] = sum_r z^2 */
+int coda_tok_bn_stats_f32(const float *z, int groups, long long rows, int c, double *sums,
+                          void *stream);
+
+/* Batch-norm parameters of this step from the (all-reduced) sums over `count` tokens:
+ * prm (G,4,C) = scale (gamma*invstd), shift (beta - mean*scale), mean, invstd;
+ * stat (G,2,C) = mean, unbiased variance (what the running statistics take; may be NULL).
+ * gamma / beta (G,C). */
+int coda_tok_bn_finalize_f32(const double *sums, const float *gamma, const float *beta,
+                             int groups, int c, double count, float eps, float *prm,
+                             float *stat, void *stream);
+
+/* a = dropout_p(relu(z * scale + shift)); `relu` 0/1; a may alias z.  seed_dev: optional
+ * device-resident 64-bit word folded into the seed (hipGraph replays), may be NULL. */
+int coda_tok_bn_act_f32(const float *z, const float *prm, int groups, long long rows, int c,
+                        int relu, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                        float *a, void *stream);
+
+/* d = da * keep/(1-p) where the activation is positive (relu) else da * keep/(1-p);
+ * sums (G,2,C) doubles, zeroed by the call: sum_r d, sum_r d * xhat */
+int coda_tok_bn_act_bwd_stats_f32(const float *da, const float *z, const float *prm,
+                                  int groups, long long rows, int c, int relu,
+                                  float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                                  double *sums, void *stream);
+
+/* From the local sums (-> dgamma = sum d*xhat, dbeta = sum d, both (G,C) fp32) and the
+ * all-reduced sums over `count` tokens (== local sums single-process):
+ * prmb (G,3,C) = gamma*invstd, sum d / count, sum d*xhat / count. */
+int coda_tok_bn_bwd_finalize_f32(const double *sums_local, const double *sums_total,
+                                 const float *gamma, const float *prm, int groups, int c,
+                                 double count, float *prmb, float *dgamma, float *dbeta,
+                                 void *stream);
+
+/* dz = prmb[0] * (d - prmb[1] - xhat * prmb[2]); dz may alias da */
+int coda_tok_bn_act_bwd_apply_f32(const float *da, const float *z, const float *prm,
+                                  const float *prmb, int groups, long long rows, int c,
+                                  int relu, float dropout_p, uint64_t seed,
+                                  const uint64_t *seed_dev, float *dz, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODA_TOKEN_OPS_H */
