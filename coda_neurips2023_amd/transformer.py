@@ -19,9 +19,76 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
+import os
+
+from . import attention_core as _core
+from . import fused_layers as _fl
 from .attention import MultiheadAttention
 from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, get_clones
 from .linear_fn import linear as _linear
+
+
+# ---- fused pre-norm layers -----------------------------------------------------------------
+# The layer classes below keep the reference's module structure and run it op by op
+# (``forward_pre`` / ``forward_post``) for every configuration.  For the configuration the CoDA
+# models build -- pre-norm, LayerNorm, ReLU, fp32 on the GPU, head_dim 64/128 -- the containers
+# run the same arithmetic through ``fused_layers``: every bias / Dropout / residual /
+# LayerNorm / ``with_pos_embed`` chain between two GEMMs is one kernel each way, and the
+# residual stream is carried between layers as a PENDING sum ``res + dropout_p(x + bias)``
+# that the next LayerNorm kernel resolves.
+class _Pending:
+    __slots__ = ("res", "x", "bias", "p")
+
+    def __init__(self, res, x=None, bias=None, p=0.0):
+        self.res, self.x, self.bias, self.p = res, x, bias, p
+
+
+def _resolve(pend, norm=None, pos=None):
+    """-> (s, y, yp) with s the materialised residual stream."""
+    if pend.x is None:
+        if norm is None:
+            return pend.res, None, None
+        return _fl.add_ln(pend.res, norm=norm, pos=pos)
+    return _fl.add_ln(pend.x, norm=norm, bias=pend.bias, res=pend.res, pos=pos, p=pend.p)
+
+
+def _drop_p(mod):
+    return float(mod.p) if mod.training else 0.0
+
+
+def _attn_ok(attn):
+    e = attn.embed_dim
+    return isinstance(attn, MultiheadAttention) and attn.head_dim in (64, 128) and attn.in_proj_bias is not None \
+        and e % 4 == 0 and e <= 1024
+
+
+def _ffn_ok(layer):
+    f = layer.linear1.out_features
+    return isinstance(layer.activation, nn.ReLU) and f % 4 == 0 and f <= 1024 and 256 % (f // 4) == 0
+
+
+def _fusable(layers, x, norms_of):
+    if os.environ.get("CODA_LAYERS", "fused") == "modules":  # A/B switch: module-by-module path
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32):
+        return False
+    for layer in layers:
+        if not layer.normalize_before or not all(isinstance(n, nn.LayerNorm) and n.elementwise_affine
+                                                 for n in norms_of(layer)):
+            return False
+    return True
+
+
+def _mask_u8(attn_mask, key_padding_mask, bsz, nhead, tgt_len, src_len):
+    mask = _core.merge_masks(attn_mask, key_padding_mask, bsz, nhead, tgt_len, src_len)
+    return None if mask is None else mask.contiguous().to(torch.uint8)
+
+
+def _ffn_fused(layer, y):
+    """linear2's product WITHOUT its bias (it joins the pending residual)."""
+    h = _linear(y, layer.linear1.weight, None)
+    h = _fl.ffn_act(h, layer.linear1.bias, _drop_p(layer.dropout))
+    return _linear(h, layer.linear2.weight, None)
 
 
 def _ffn(layer, x):
@@ -65,13 +132,22 @@ class TransformerEncoder(nn.Module):
         elif orig_mask is not None:
             orig_mask = [mask for _ in range(len(self.layers))]
 
-        for idx, layer in enumerate(self.layers):
-            if orig_mask is not None:
-                mask = _tile_mask_per_head(orig_mask[idx], layer.nhead)
-            output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
-
-        if self.norm is not None:
-            output = self.norm(output)
+        if TransformerEncoderLayer.fusable(self.layers, output) and (self.norm is None
+                                                                     or isinstance(self.norm, nn.LayerNorm)):
+            pend = _Pending(output)
+            for idx, layer in enumerate(self.layers):
+                if orig_mask is not None:
+                    mask = _tile_mask_per_head(orig_mask[idx], layer.nhead)
+                pend = layer.forward_fused(pend, mask, src_key_padding_mask, pos)
+            s, y, _ = _resolve(pend, self.norm)
+            output = s if self.norm is None else y
+        else:
+            for idx, layer in enumerate(self.layers):
+                if orig_mask is not None:
+                    mask = _tile_mask_per_head(orig_mask[idx], layer.nhead)
+                output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
+            if self.norm is not None:
+                output = self.norm(output)
         if transpose_swap:
             output = output.permute(1, 2, 0).view(bs, c, h, w).contiguous()
         xyz_inds = None
@@ -107,6 +183,10 @@ class TransformerDecoder(nn.Module):
             memory = memory.flatten(2).permute(2, 0, 1)  # (bs, c, t) -> (t, bs, c)
             if pos is not None:
                 pos = pos.flatten(2).permute(2, 0, 1)
+        if not return_attn_weights and self.norm is not None and isinstance(self.norm, nn.LayerNorm) \
+                and TransformerDecoderLayer.fusable(self.layers, tgt):
+            return self._forward_fused(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
+                                       memory_key_padding_mask, pos, query_pos), []
         output = tgt
         intermediate = []
         attns = []
@@ -130,6 +210,30 @@ class TransformerDecoder(nn.Module):
         if self.return_intermediate:
             return torch.stack(intermediate), attns
         return output, attns
+
+
+    def _forward_fused(self, tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
+                       memory_key_padding_mask, pos, query_pos):
+        """Same values as the loop in ``forward``; ``memory + pos`` (recomputed by every layer of
+        the reference, transformer.py:566-569) is formed once."""
+        nq, bsz, _ = tgt.shape
+        nmem = memory.shape[0]
+        nhead = self.layers[0].self_attn.num_heads
+        memory = memory.contiguous()
+        memory_pos = memory if pos is None else memory + pos
+        self_mask = _mask_u8(tgt_mask, tgt_key_padding_mask, bsz, nhead, nq, nq)
+        cross_mask = _mask_u8(memory_mask, memory_key_padding_mask, bsz, nhead, nq, nmem)
+        pend = _Pending(tgt)
+        intermediate = []
+        for layer in self.layers:
+            pend = layer.forward_fused(pend, memory, memory_pos, query_pos, self_mask, cross_mask)
+            # materialise the layer output and apply the decoder norm to it in the same pass
+            s, y, _ = _resolve(pend, self.norm)
+            pend = _Pending(s)
+            intermediate.append(y)
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return intermediate[-1]
 
 
 class MaskedTransformerEncoder(TransformerEncoder):
@@ -164,12 +268,16 @@ class MaskedTransformerEncoder(TransformerEncoder):
         output = src
         xyz_dist = None
         xyz_inds = None
+        fused = TransformerEncoderLayer.fusable(self.layers, output)
         for idx, layer in enumerate(self.layers):
             mask = None
             if self.masking_radius[idx] > 0:
                 mask, xyz_dist = self.compute_mask(xyz, self.masking_radius[idx], xyz_dist)
                 mask = _tile_mask_per_head(mask, layer.nhead)
-            output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
+            if fused:
+                output = _resolve(layer.forward_fused(_Pending(output), mask, src_key_padding_mask, pos))[0]
+            else:
+                output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
             if idx == 0 and self.interim_downsampling:
                 # (npoints, batch, channel) -> (batch, channel, npoints) for the SA module
                 output = output.permute(1, 2, 0)
@@ -241,6 +349,24 @@ class TransformerEncoderLayer(nn.Module):
         if return_attn_weights:
             return src, attn_weights
         return src
+
+    @staticmethod
+    def fusable(layers, x):
+        return _fusable(layers, x, lambda l: [l.norm1] + ([l.norm2] if l.use_ffn else [])) and all(
+            _attn_ok(l.self_attn) and (not l.use_ffn or _ffn_ok(l)) for l in layers)
+
+    def forward_fused(self, pend, src_mask, src_key_padding_mask, pos):
+        """``forward_pre`` on a pending residual stream; returns the new pending stream."""
+        s, y, yp = _resolve(pend, self.norm1, pos)
+        tgt_len, bsz, _ = s.shape
+        qk = y if pos is None else yp
+        mask = _mask_u8(src_mask, src_key_padding_mask, bsz, self.nhead, tgt_len, tgt_len)
+        a = _fl.mha(self.self_attn, qk, qk, y, mask)
+        pend = _Pending(s, a, self.self_attn.out_proj.bias, _drop_p(self.dropout1))
+        if not self.use_ffn:
+            return pend
+        s, y, _ = _resolve(pend, self.norm2)
+        return _Pending(s, _ffn_fused(self, y), self.linear2.bias, _drop_p(self.dropout2))
 
     def forward(self, src, src_mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
@@ -329,6 +455,23 @@ class TransformerDecoderLayer(nn.Module):
         if return_attn_weights:
             return tgt, attn
         return tgt, None
+
+    @staticmethod
+    def fusable(layers, x):
+        return _fusable(layers, x, lambda l: [l.norm1, l.norm2, l.norm3]) and all(
+            _attn_ok(l.self_attn) and _attn_ok(l.multihead_attn) and _ffn_ok(l) for l in layers)
+
+    def forward_fused(self, pend, memory, memory_pos, query_pos, self_mask, cross_mask):
+        """``forward_pre`` on a pending residual stream; returns the new pending stream."""
+        s, y, yp = _resolve(pend, self.norm1, query_pos)
+        qk = y if query_pos is None else yp
+        a = _fl.mha(self.self_attn, qk, qk, y, self_mask)
+        s, y, yp = _fl.add_ln(a, norm=self.norm2, bias=self.self_attn.out_proj.bias, res=s, pos=query_pos,
+                              p=_drop_p(self.dropout1))
+        a = _fl.mha(self.multihead_attn, y if query_pos is None else yp, memory_pos, memory, cross_mask)
+        s, y, _ = _fl.add_ln(a, norm=self.norm3, bias=self.multihead_attn.out_proj.bias, res=s,
+                             p=_drop_p(self.dropout2))
+        return _Pending(s, _ffn_fused(self, y), self.linear2.bias, _drop_p(self.dropout3))
 
     def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
                 memory_mask: Optional[Tensor] = None,

@@ -71,6 +71,52 @@ int coda_tok_bn_act_bwd_apply_f32(const float *da, const float *z, const float *
                                   int relu, float dropout_p, uint64_t seed,
                                   const uint64_t *seed_dev, float *dz, void *stream);
 
+/*
+ * Part 2, the glue of the pre-norm transformer layers (models/transformer.py:457-494,
+ * 558-594): between two GEMMs the reference runs bias add, Dropout, residual add, LayerNorm
+ * and the positional-embedding add as separate passes over the (tokens, C) activations,
+ * forward and backward.  One kernel each way here:
+ *
+ *   v = dropout_p(x + bias)        bias, dropout optional
+ *   s = res + v                    res optional (s == v without it)
+ *   y = LayerNorm(s) * gamma + beta            gamma == NULL: no norm, only s is produced
+ *   yp = y + pos                   pos optional
+ *
+ * x, res, pos, s, y, yp are (rows, C) row-major; C a multiple of 4, C <= 1024; mean / rstd
+ * (rows).  s_out may be NULL when s == x (no bias, no dropout, no residual).
+ */
+int coda_tok_add_ln_fwd_f32(const float *x, const float *bias, const float *res, const float *pos,
+                            const float *gamma, const float *beta, long long rows, int c, float eps,
+                            float dropout_p, uint64_t seed, const uint64_t *seed_dev, float *s_out,
+                            float *y_out, float *yp_out, float *mean, float *rstd, void *stream);
+
+/* number of (3,C) partial-sum slots the backward needs in `partials` */
+int coda_tok_add_ln_bwd_blocks(long long rows, int c);
+
+/* Backward of the above.  dy / dyp / ds are the gradients of y / yp / s (each may be NULL);
+ *   dres = ds + LayerNorm_backward(dy + dyp)      (written to dres_out; the gradient of res)
+ *   dx   = dropout-masked dres                    (written to dx_out; may be NULL when there is
+ *                                                  no dropout: dx == dres)
+ * partials (blocks,3,C): per-block column sums of [(dy+dyp)*xhat, (dy+dyp), dx]; reduce them
+ * with coda_tok_colsum_finalize_f32 into dgamma, dbeta, dbias. */
+int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, const float *s,
+                            const float *mean, const float *rstd, const float *gamma, long long rows,
+                            int c, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                            float *dres_out, float *dx_out, float *partials, void *stream);
+
+/* out[j] = sum_b partials[b][j], j < n (n = 3*C above) */
+int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int n, float *out, void *stream);
+
+/* Feed-forward activation: a = dropout_p(relu(h + bias)) on (rows, C); a may alias h; C/4 must
+ * divide 256.  Backward: dz = da / (1-p) where a > 0, else 0 (a dropped or clamped element has
+ * a == 0 either way); partials (blocks,1,C) column sums of dz -> dbias. */
+int coda_tok_bias_relu_dropout_fwd_f32(const float *h, const float *bias, long long rows, int c,
+                                       float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                                       float *a, void *stream);
+int coda_tok_bias_relu_dropout_bwd_blocks(long long rows, int c);
+int coda_tok_bias_relu_dropout_bwd_f32(const float *da, const float *a, long long rows, int c,
+                                       float dropout_p, float *dz, float *partials, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,185 @@
+"""Token-wise glue kernels of the fused transformer layers (csrc/token_ln.hip through
+fused_layers.py) against plain torch in float64, and the fused encoder / decoder containers
+against the module-by-module path of the same classes (CODA_LAYERS=modules), which is the
+reference's op sequence (models/transformer.py:457-494, 558-594).  Tolerance 1e-3 relative
+(north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from coda_neurips2023_amd import fused_layers as fl
+from coda_neurips2023_amd.transformer import (TransformerDecoder, TransformerDecoderLayer, TransformerEncoder,
+                                              TransformerEncoderLayer)
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3
+
+
+def _close(got, ref, what, rtol=RTOL):
+    got, ref = got.detach().double().cpu().numpy(), ref.detach().double().cpu().numpy()
+    err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+    assert err < rtol, f"{what}: max err / max|ref| = {err:.3e}"
+
+
+@pytest.mark.parametrize("rows,c", [((128, 8), 256), ((37, 3), 512), ((5, 2), 100), ((2048, 8), 256), ((3, 1), 1024)])
+@pytest.mark.parametrize("variant", ["ln", "ln_pos", "bias_res_ln_pos", "res_only", "bias_res_ln"])
+def test_add_ln_matches_torch(dev, rows, c, variant):
+    torch.manual_seed(0)
+    shape = (*rows, c)
+    x = torch.randn(shape, device=dev, requires_grad=True)
+    norm = torch.nn.LayerNorm(c).to(dev) if variant != "res_only" else None
+    if norm is not None:
+        torch.nn.init.uniform_(norm.weight, 0.5, 1.5)
+        torch.nn.init.uniform_(norm.bias, -0.5, 0.5)
+    bias = torch.randn(c, device=dev, requires_grad=True) if "bias" in variant or variant == "res_only" else None
+    res = (3 * torch.randn(shape, device=dev)).requires_grad_(True) if "res" in variant else None
+    pos = torch.randn(shape, device=dev, requires_grad=True) if "pos" in variant else None
+    s, y, yp = fl.add_ln(x, norm=norm, bias=bias, res=res, pos=pos)
+
+    d = lambda t: None if t is None else t.detach().double().requires_grad_(True)  # noqa: E731
+    x64, b64, r64, p64 = d(x), d(bias), d(res), d(pos)
+    s64 = x64 if b64 is None else x64 + b64
+    s64 = s64 if r64 is None else r64 + s64
+    y64 = yp64 = None
+    if norm is not None:
+        g64, be64 = d(norm.weight), d(norm.bias)
+        y64 = F.layer_norm(s64, (c,), g64, be64, norm.eps)
+        yp64 = y64 + p64 if p64 is not None else None
+    loss = loss64 = 0
+    for got, ref, name in [(s, s64, "s"), (y, y64, "y"), (yp, yp64, "yp")]:
+        assert (got is None) == (ref is None), name
+        if got is not None:
+            _close(got, ref, name)
+            w = torch.randn_like(got)
+            loss = loss + (got * w).sum()
+            loss64 = loss64 + (ref * w.double()).sum()
+    loss.backward()
+    loss64.backward()
+    pairs = [(x, x64, "dx"), (bias, b64, "dbias"), (res, r64, "dres"), (pos, p64, "dpos")]
+    if norm is not None:
+        pairs += [(norm.weight, g64, "dgamma"), (norm.bias, be64, "dbeta")]
+    for t, t64, name in pairs:
+        if t is not None:
+            _close(t.grad, t64.grad, name)
+
+
+def test_add_ln_partial_use_of_outputs(dev):
+    """Only y, only the stream, or neither normalised output used downstream."""
+    torch.manual_seed(1)
+    c = 256
+    norm = torch.nn.LayerNorm(c).to(dev)
+    x = torch.randn(64, 4, c, device=dev, requires_grad=True)
+    res = torch.randn(64, 4, c, device=dev, requires_grad=True)
+    pos = torch.randn(64, 4, c, device=dev)
+    s, y, yp = fl.add_ln(x, norm=norm, res=res, pos=pos)
+    (s * 2.0).sum().backward()
+    assert torch.allclose(x.grad, torch.full_like(x, 2.0)) and torch.allclose(res.grad, torch.full_like(x, 2.0))
+    assert norm.weight.grad is None or float(norm.weight.grad.abs().max()) == 0.0
+    x.grad = res.grad = None
+    s, y, yp = fl.add_ln(x, norm=norm, res=res, pos=pos)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    x64 = (x + res).detach().double().requires_grad_(True)
+    (F.layer_norm(x64, (c,), norm.weight.detach().double(), norm.bias.detach().double(), norm.eps)
+     * w.double()).sum().backward()
+    _close(x.grad, x64.grad, "dx through y only", rtol=2e-3)
+
+
+def test_add_ln_dropout(dev):
+    torch.manual_seed(2)
+    c, p = 256, 0.1
+    norm = torch.nn.LayerNorm(c).to(dev)
+    x = (torch.rand(4096, 2, c, device=dev) + 1.0).requires_grad_(True)
+    res = torch.randn(4096, 2, c, device=dev, requires_grad=True)
+    s, y, _ = fl.add_ln(x, norm=norm, res=res, p=p)
+    v = (s - res).detach()
+    dropped = v.abs() < 1e-6
+    assert abs(float(dropped.float().mean()) - p) < 3e-3
+    assert torch.allclose(v[~dropped], x.detach()[~dropped] / (1 - p), rtol=1e-5, atol=1e-5)
+    _close(y, F.layer_norm(s.detach(), (c,), norm.weight, norm.bias, norm.eps), "y of the dropped-out stream")
+    w = torch.randn_like(s)
+    (s * w).sum().backward()
+    assert torch.equal(x.grad == 0, dropped)
+    assert torch.allclose(x.grad[~dropped], (w / (1 - p))[~dropped], rtol=1e-5)
+    assert torch.allclose(res.grad, w)
+    s2, _, _ = fl.add_ln(x, norm=norm, res=res, p=p)  # a fresh mask per call
+    assert 0.1 < float((((s2 - res).abs() < 1e-6) != dropped).float().mean()) < 0.25  # 2p(1-p) = 0.18
+
+
+@pytest.mark.parametrize("rows,c,p", [(2048, 256, 0.0), (16384, 128, 0.0), (77, 512, 0.0), (4096, 256, 0.1)])
+def test_ffn_act(dev, rows, c, p):
+    torch.manual_seed(3)
+    h = torch.randn(rows, c, device=dev, requires_grad=True)
+    b = torch.randn(c, device=dev, requires_grad=True)
+    a = fl.ffn_act(h, b, p)
+    ref = torch.relu(h.detach() + b.detach())
+    w = torch.randn_like(a)
+    (a * w).sum().backward()
+    if p == 0.0:
+        assert torch.allclose(a, ref, rtol=1e-6, atol=1e-6)
+        g = w * (ref > 0)
+        assert torch.allclose(h.grad, g, rtol=1e-6, atol=1e-6)
+        _close(b.grad, g.double().sum(0), "dbias", rtol=1e-5)
+    else:
+        alive = ref > 0
+        dropped = alive & (a == 0)
+        assert abs(float(dropped.sum()) / float(alive.sum()) - p) < 5e-3
+        kept = alive & ~dropped
+        assert torch.allclose(a[kept], ref[kept] / (1 - p), rtol=1e-5)
+        assert torch.allclose(h.grad[kept], w[kept] / (1 - p), rtol=1e-5)
+        assert float(h.grad[~kept].abs().max()) == 0.0
+        _close(b.grad, h.grad.double().sum(0), "dbias", rtol=1e-5)
+
+
+def _run_encoder(dev, env, monkeypatch, src, norm):
+    monkeypatch.setenv("CODA_LAYERS", env)
+    torch.manual_seed(7)
+    layer = TransformerEncoderLayer(d_model=256, nhead=4, dim_feedforward=128, dropout=0.0)
+    enc = TransformerEncoder(layer, 3, norm=torch.nn.LayerNorm(256) if norm else None).to(dev).train()
+    x = src.clone().requires_grad_(True)
+    out = enc(x)[1]
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    (out * w).sum().backward()
+    return out, x.grad, {k: p.grad for k, p in enc.named_parameters()}
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_fused_encoder_equals_module_path(dev, monkeypatch, norm):
+    src = torch.randn(320, 3, 256, generator=torch.Generator().manual_seed(0)).to(dev)
+    out_f, gx_f, gp_f = _run_encoder(dev, "fused", monkeypatch, src, norm)
+    out_m, gx_m, gp_m = _run_encoder(dev, "modules", monkeypatch, src, norm)
+    _close(out_f, out_m, "encoder output")
+    _close(gx_f, gx_m, "encoder input gradient")
+    for k in gp_m:
+        _close(gp_f[k], gp_m[k], f"grad {k}")
+
+
+def _run_decoder(dev, env, monkeypatch, tgt, memory, pos, query_pos):
+    monkeypatch.setenv("CODA_LAYERS", env)
+    torch.manual_seed(9)
+    layer = TransformerDecoderLayer(d_model=256, nhead=4, dim_feedforward=256, dropout=0.0)
+    dec = TransformerDecoder(layer, 3, return_intermediate=True).to(dev).train()
+    m = memory.clone().requires_grad_(True)
+    qp = query_pos.clone().requires_grad_(True)
+    out = dec(tgt, m, pos=pos, query_pos=qp)[0]
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    (out * w).sum().backward()
+    return out, m.grad, qp.grad, {k: p.grad for k, p in dec.named_parameters()}
+
+
+def test_fused_decoder_equals_module_path(dev, monkeypatch):
+    gen = torch.Generator().manual_seed(4)
+    nq, nmem, b = 64, 300, 3
+    tgt = torch.zeros(nq, b, 256, device=dev)
+    memory = torch.randn(nmem, b, 256, generator=gen).to(dev)
+    pos = torch.randn(nmem, b, 256, generator=gen).to(dev)
+    query_pos = torch.randn(nq, b, 256, generator=gen).to(dev)
+    out_f, gm_f, gq_f, gp_f = _run_decoder(dev, "fused", monkeypatch, tgt, memory, pos, query_pos)
+    out_m, gm_m, gq_m, gp_m = _run_decoder(dev, "modules", monkeypatch, tgt, memory, pos, query_pos)
+    assert out_f.shape == out_m.shape == (3, nq, b, 256)
+    _close(out_f, out_m, "decoder outputs")
+    _close(gm_f, gm_m, "memory gradient")
+    _close(gq_f, gq_m, "query_pos gradient")
+    for k in gp_m:
+        _close(gp_f[k], gp_m[k], f"grad {k}")
