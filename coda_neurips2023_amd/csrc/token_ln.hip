@@ -195,18 +195,47 @@ __global__ __launch_bounds__(kThreads) void add_ln_bwd_kernel(LnBwd p) {
   }
 }
 
-__global__ void colsum_finalize_kernel(const float *__restrict__ partials, int blocks, int n,
-                                       float *__restrict__ out) {
-  // 64 columns x 4 row-slices per block; fixed summation order
-  __shared__ float s_part[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+// out[g][j] = sum_b partials[g][b][j]: 64 columns x 16 block-slices per workgroup, fixed order
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float *__restrict__ partials, int blocks,
+                                                               int n, float *__restrict__ out) {
+  __shared__ float s_part[16][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const float *pg = partials + static_cast<size_t>(blockIdx.y) * blocks * n;
   float t = 0.f;
   if (col < n)
-    for (int b = slice; b < blocks; b += 4) t += partials[static_cast<size_t>(b) * n + col];
-  s_part[slice][threadIdx.x & 63] = t;
+    for (int b = slice; b < blocks; b += 16) t += pg[static_cast<size_t>(b) * n + col];
+  s_part[slice][lane] = t;
   __syncthreads();
-  if (slice == 0 && col < n)
-    out[col] = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+  if (slice == 0 && col < n) {
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r += s_part[q][lane];
+    out[static_cast<size_t>(blockIdx.y) * n + col] = r;
+  }
+}
+
+// per-block column sums of x (G, rows, C): partials (G, blocks, C)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long long rows, int c,
+                                                             float *__restrict__ partials) {
+  __shared__ float4 s_part[256];
+  const int tpr = c >> 2, rpb = 256 / tpr, cq = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+  const float *xg = x + static_cast<size_t>(blockIdx.y) * rows * c;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  long long r = static_cast<long long>(blockIdx.x) * rpb + rsub;
+  const long long step = static_cast<long long>(gridDim.x) * rpb;
+  for (; r + step < rows; r += 2 * step) {  // two independent loads in flight
+    a0 = add4(a0, ld4(xg + static_cast<size_t>(r) * c + 4 * cq));
+    a1 = add4(a1, ld4(xg + static_cast<size_t>(r + step) * c + 4 * cq));
+  }
+  if (r < rows) a0 = add4(a0, ld4(xg + static_cast<size_t>(r) * c + 4 * cq));
+  s_part[threadIdx.x] = add4(a0, a1);
+  __syncthreads();
+  if (rsub == 0) {
+    float4 t = s_part[cq];
+    for (int q = 1; q < rpb; ++q) t = add4(t, s_part[q * tpr + cq]);
+    st4(partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * c + 4 * cq, t);
+  }
 }
 
 // ---- feed-forward activation ------------------------------------------------------------
@@ -263,9 +292,9 @@ Drop make_drop(float p, uint64_t seed, const uint64_t *seed_dev) {
   return d;
 }
 bool bad_ln_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0; }
-int ln_blocks(long long rows) {
+int ln_blocks(long long rows, int cap = 512) {  // backward: one (3,C) partial per block
   const long long want = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
-  return static_cast<int>(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  return static_cast<int>(want < 1 ? 1 : (want > cap ? cap : want));
 }
 bool bad_row_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0 || (kT % (c / 4)) != 0; }
 int row_blocks(long long rows, int c) {
@@ -294,7 +323,7 @@ CODA_API int coda_tok_add_ln_fwd_f32(const float *x, const float *bias, const fl
   LnFwd p{x, bias, res, pos, gamma, beta, s_out, y_out, yp_out, mean, rstd, rows, c, eps,
           make_drop(dropout_p, seed, seed_dev)};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(ln_blocks(rows));
+  const dim3 grid(ln_blocks(rows, 4096));
   clear_sticky_error();
   if (c <= 256) hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, dim3(kThreads), 0, s, p);
   else if (c <= 512) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, dim3(kThreads), 0, s, p);
@@ -334,8 +363,29 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
 CODA_API int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int n, float *out, void *stream) {
   if (blocks <= 0 || n <= 0 || !partials || !out) return CODA_EINVAL;
   clear_sticky_error();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     partials, blocks, n, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((n + 63) / 64, 1), dim3(1024), 0,
+                     static_cast<hipStream_t>(stream), partials, blocks, n, out);
+  return launch_status();
+}
+
+CODA_API int coda_tok_colsum_blocks(long long rows, int c) {
+  if (rows < 0 || bad_row_c(c)) return CODA_EINVAL;
+  return row_blocks(rows, c);
+}
+
+CODA_API int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials, float *out,
+                                 void *stream) {
+  if (groups <= 0 || rows < 0 || bad_row_c(c) || !out) return CODA_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * groups * c, s);
+    return e == hipSuccess ? CODA_OK : static_cast<int>(e);
+  }
+  if (!x || !partials) return CODA_EINVAL;
+  const int blocks = row_blocks(rows, c);
+  clear_sticky_error();
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks, groups), dim3(256), 0, s, x, rows, c, partials);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64, groups), dim3(1024), 0, s, partials, blocks, c, out);
   return launch_status();
 }
 

@@ -6,7 +6,7 @@ Conv1d(k=1) -> BatchNorm1d -> ReLU -> Dropout stacks on ``(layers*batch, C, quer
 (models/model_3detr.py:1617-1660, models/helpers.py:45-112), and the encoder->decoder
 projection the same way on ``(batch, C, points)`` (:1866-1868).  A 1x1 convolution over
 tokens is a GEMM on the ``(tokens, C)`` matrix the transformer already holds, and G heads
-over the same input are one batched GEMM, so ``hidden_stack`` computes all heads at once on
+over the same input are one batched GEMM, so ``run_stacks`` computes all heads at once on
 ``(G, tokens, C)`` activations with one statistics pass and one normalise/activate/dropout
 pass between two GEMMs.  Parameters stay in the reference-shaped modules
 (``layers.{i}.weight`` ...); train-mode batch statistics, running-statistics updates and
@@ -107,11 +107,13 @@ def _split_k_tn(dz, a):
 
 class _HiddenStack(torch.autograd.Function):
     """x (T, Cin) shared by G stacks -> (G, T, C_last) after every (dense, BN, ReLU, dropout)
-    block.  params: per block, per group: dense weight, bn weight, bn bias."""
+    block, or, with tail layers, the G outputs (T, out_g) of the final plain dense layers.
+    params: per block, per group: dense weight, bn weight, bn bias; then per group the tail
+    weight and bias (bias may be None)."""
 
     @staticmethod
     def forward(ctx, x, meta, *params):
-        groups, blocks = meta  # blocks: list of (bns [G], relu, p)
+        groups, blocks, has_tail = meta  # blocks: list of (bns [G], relu, p)
         nb = len(blocks)
         dev = x.device
         t = x.shape[0]
@@ -169,24 +171,44 @@ class _HiddenStack(torch.autograd.Function):
         ctx.meta = meta
         ctx.seeds = seeds
         ctx.wshapes = [params[3 * groups * i].shape for i in range(nb)]
-        ctx.save_for_backward(x, *zs, *acts[:-1], *prms, *ws, *gammas)
-        return acts[-1]
+        tails = [next(pit) for _ in range(2 * groups)] if has_tail else []
+        ctx.tail_shapes = [w.shape for w in tails[0::2]]
+        ctx.tail_bias = [b is not None for b in tails[1::2]]
+        tail_ws = [w.flatten(1) for w in tails[0::2]]
+        ctx.save_for_backward(x, *zs, *acts, *prms, *ws, *gammas, *tail_ws)
+        if not has_tail:
+            return acts[-1]
+        return tuple(torch.addmm(tails[2 * g + 1], acts[-1][g], tail_ws[g].t()) if tails[2 * g + 1] is not None
+                     else torch.mm(acts[-1][g], tail_ws[g].t()) for g in range(groups))
 
     @staticmethod
-    def backward(ctx, dout):
-        groups, blocks = ctx.meta
+    def backward(ctx, *douts):
+        groups, blocks, has_tail = ctx.meta
         nb = len(blocks)
         saved = ctx.saved_tensors
         x = saved[0]
         zs = saved[1:1 + nb]
-        acts = saved[1 + nb:2 * nb]
-        prms = saved[2 * nb:3 * nb]
-        ws = saved[3 * nb:4 * nb]
-        gammas = saved[4 * nb:5 * nb]
+        acts = saved[1 + nb:1 + 2 * nb]
+        prms = saved[1 + 2 * nb:1 + 3 * nb]
+        ws = saved[1 + 3 * nb:1 + 4 * nb]
+        gammas = saved[1 + 4 * nb:1 + 5 * nb]
+        tail_ws = saved[1 + 5 * nb:]
         dev = x.device
         t = x.shape[0]
         grads = [None] * (3 * groups * nb)
-        da = dout.contiguous()
+        tail_grads = []
+        if has_tail:
+            # gradients of the G tail layers; dA is assembled in place, group by group
+            dout = None
+            da = torch.empty_like(acts[-1])
+            for g in range(groups):
+                dg = douts[g].contiguous()
+                torch.mm(dg, tail_ws[g], out=da[g])
+                dw = _split_k_tn(dg.unsqueeze(0), acts[-1][g].unsqueeze(0))[0]
+                tail_grads += [dw.view(ctx.tail_shapes[g]), _colsum(dg) if ctx.tail_bias[g] else None]
+        else:
+            dout = douts[0]
+            da = dout.contiguous()
         dx = None
         for i in range(nb - 1, -1, -1):
             bns, relu, p = blocks[i]
@@ -204,7 +226,7 @@ class _HiddenStack(torch.autograd.Function):
             dbeta = torch.empty((groups, c), dtype=torch.float32, device=dev)
             _call("coda_tok_bn_bwd_finalize_f32", _p(sums), _p(total), _p(gammas[i]), _p(prms[i]), groups, c, n,
                   _p(prmb), _p(dgamma), _p(dbeta))
-            dz = da if da.data_ptr() != dout.data_ptr() else torch.empty_like(da)
+            dz = da if (dout is None or da.data_ptr() != dout.data_ptr()) else torch.empty_like(da)
             _call("coda_tok_bn_act_bwd_apply_f32", _p(da), _p(zs[i]), _p(prms[i]), _p(prmb), groups, t, c, int(relu),
                   p, seed, _p(seed_dev), _p(dz))
             # weight gradients (split-K) and the gradient of the block input
@@ -227,11 +249,37 @@ class _HiddenStack(torch.autograd.Function):
                 grads[base] = dw[g].view(ctx.wshapes[i])
                 grads[base + 1] = dgamma[g]
                 grads[base + 2] = dbeta[g]
-        return (dx, None, *grads)
+        return (dx, None, *grads, *tail_grads)
+
+
+def _colsum(x2):
+    """(rows, C) -> (C,) column sums (bias gradient)."""
+    rows, c = x2.shape
+    if c % 4 or c > 1024 or 256 % (c // 4):
+        return x2.sum(0)
+    blocks = _lib.load().coda_tok_colsum_blocks(rows, c)
+    partials = torch.empty((blocks, c), dtype=torch.float32, device=x2.device)
+    out = torch.empty(c, dtype=torch.float32, device=x2.device)
+    _call("coda_tok_colsum_f32", _p(x2), 1, rows, c, _p(partials), _p(out))
+    return out
+
+
+def run_stacks(x, parsed):
+    """x (T, Cin) float32 cuda, parsed = eligible(mlps, x).  Stacks with a final plain dense
+    layer -> list of G outputs (T, out_g); stacks ending in a block -> (G, T, C_last)."""
+    has_tail = all(tail is not None for _, tail in parsed)
+    if not has_tail and any(tail is not None for _, tail in parsed):
+        raise RuntimeError("stacks with and without a final dense layer cannot be mixed")
+    out = _apply(x, parsed, has_tail)
+    return list(out) if has_tail else out
 
 
 def hidden_stack(x, parsed):
-    """x (T, Cin) float32 cuda, parsed = eligible(mlps, x) -> (G, T, C_last)."""
+    """-> (G, T, C_last): the activations after the last (dense, BN, ReLU, dropout) block."""
+    return _apply(x, parsed, False)
+
+
+def _apply(x, parsed, has_tail):
     groups = len(parsed)
     nb = len(parsed[0][0])
     blocks = []
@@ -242,10 +290,7 @@ def hidden_stack(x, parsed):
         for g in range(groups):
             dense, bn, _, _ = parsed[g][0][i]
             params += [dense.weight, bn.weight, bn.bias]
-    return _HiddenStack.apply(x.contiguous(), (groups, blocks), *params)
-
-
-def tail_linear(a, dense):
-    """The last, plain dense layer of a stack on (T, C) tokens."""
-    w = dense.weight.flatten(1)
-    return torch.nn.functional.linear(a, w, dense.bias)
+    if has_tail:
+        for g in range(groups):
+            params += [parsed[g][1].weight, parsed[g][1].bias]
+    return _HiddenStack.apply(x.contiguous(), (groups, blocks, has_tail), *params)

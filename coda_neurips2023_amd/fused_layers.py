@@ -39,6 +39,17 @@ def _colsums(partials, blocks, n):
     return out
 
 
+def _colsum_into(out, x3):
+    """out (G*C) <- column sums of x3 (G, rows, C)."""
+    g, rows, c = x3.shape
+    if c % 4 or c > 1024 or 256 % (c // 4):
+        torch.sum(x3, 1, out=out.view(g, c))
+        return
+    blocks = _lib.load().coda_tok_colsum_blocks(rows, c)
+    partials = torch.empty((g, blocks, c), dtype=torch.float32, device=x3.device)
+    _call("coda_tok_colsum_f32", _p(x3), g, rows, c, _p(partials), _p(out))
+
+
 def _tn_into(out, dy, x):
     """out (Co,Ci) <- dy^T x with the row reduction split into chunks for long inputs."""
     p = dy.shape[0]
@@ -207,10 +218,10 @@ class _MHA(torch.autograd.Function):
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * e, dtype=torch.float32, device=dev)
         if dqkv is not None:
-            torch.sum(dqkv, 1, out=db_in.view(3, e))
+            _colsum_into(db_in, dqkv)
         else:
-            torch.sum(dq, 0, out=db_in[:e])
-            torch.sum(dkv, 1, out=db_in[e:].view(2, e))
+            _colsum_into(db_in[:e], dq.unsqueeze(0))
+            _colsum_into(db_in[e:], dkv)
         _tn_into(dw_in[:e], dq, xq2)
         _tn_into(dw_in[e:2 * e], dk, xk2)
         _tn_into(dw_in[2 * e:], dv, xv2)

@@ -198,11 +198,8 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         if parsed is not None and all(tail is not None for _, tail in parsed):
             # all six heads at once on the decoder's own (layer, query, scene) token order:
             # batched GEMMs + fused batch-norm/ReLU/dropout passes (fused_bn_mlp.py)
-            hidden = fused_bn_mlp.hidden_stack(box_features.reshape(-1, channel), parsed)
-            raw = {}
-            for g, n in enumerate(names):
-                out = fused_bn_mlp.tail_linear(hidden[g], parsed[g][1])
-                raw[n] = out.view(num_layers, num_queries, batch, -1).permute(0, 2, 1, 3)
+            outs = fused_bn_mlp.run_stacks(box_features.reshape(-1, channel), parsed)
+            raw = {n: out.view(num_layers, num_queries, batch, -1).permute(0, 2, 1, 3) for n, out in zip(names, outs)}
         else:
             feats = box_features.permute(0, 2, 3, 1).reshape(num_layers * batch, channel, num_queries)
             raw = {n: heads[n](feats).transpose(1, 2).reshape(num_layers, batch, num_queries, -1) for n in names}

@@ -107,6 +107,13 @@ int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, 
 /* out[j] = sum_b partials[b][j], j < n (n = 3*C above) */
 int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int n, float *out, void *stream);
 
+/* Column sums of x (G, rows, C) -> out (G, C) (the bias gradients of the projections):
+ * per-block partials (G, blocks, C) with blocks = coda_tok_colsum_blocks(rows, c), then a
+ * fixed-order reduction.  C/4 must divide 256. */
+int coda_tok_colsum_blocks(long long rows, int c);
+int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials,
+                        float *out, void *stream);
+
 /* Feed-forward activation: a = dropout_p(relu(h + bias)) on (rows, C); a may alias h; C/4 must
  * divide 256.  Backward: dz = da / (1-p) where a > 0, else 0 (a dropped or clamped element has
  * a == 0 either way); partials (blocks,1,C) column sums of dz -> dbias. */

@@ -50,9 +50,7 @@ def test_heads_match_module_path(dev, outs, hidden, cin, tokens):
 
     parsed = fused_bn_mlp.eligible(heads, x)
     assert parsed is not None
-    hidden_act = fused_bn_mlp.hidden_stack(x.reshape(-1, cin), parsed)
-    got = [fused_bn_mlp.tail_linear(hidden_act[g], parsed[g][1]).view(nl, nq, b, -1).permute(0, 2, 1, 3)
-           for g in range(len(heads))]
+    got = [o.view(nl, nq, b, -1).permute(0, 2, 1, 3) for o in fused_bn_mlp.run_stacks(x.reshape(-1, cin), parsed)]
     feats = x_ref.permute(0, 2, 3, 1).reshape(nl * b, cin, nq)
     ref = [h(feats).transpose(1, 2).reshape(nl, b, nq, -1) for h in ref_heads]
 
@@ -85,7 +83,7 @@ def test_projection_stack_without_tail(dev):
     x_ref = x.detach().double().requires_grad_(True)
     parsed = fused_bn_mlp.eligible([mlp], x)
     assert parsed is not None and parsed[0][1] is None and len(parsed[0][0]) == 3
-    got = fused_bn_mlp.hidden_stack(x.reshape(-1, 64), parsed).view(300, 4, 64)
+    got = fused_bn_mlp.run_stacks(x.reshape(-1, 64), parsed).view(300, 4, 64)
     ref = ref_mlp(x_ref.permute(1, 2, 0)).permute(2, 0, 1)
     _close(got, ref, "projection output")
     w = torch.randn_like(got)

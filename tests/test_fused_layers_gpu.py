@@ -132,6 +132,15 @@ def test_ffn_act(dev, rows, c, p):
         _close(b.grad, h.grad.double().sum(0), "dbias", rtol=1e-5)
 
 
+@pytest.mark.parametrize("g,rows,c", [(3, 16384, 256), (1, 77, 512), (2, 2048, 128), (1, 5, 16)])
+def test_colsum_kernel(dev, g, rows, c):
+    from coda_neurips2023_amd.fused_layers import _colsum_into
+    x = torch.randn(g, rows, c, device=dev)
+    out = torch.empty(g * c, device=dev)
+    _colsum_into(out, x)
+    _close(out.view(g, c), x.double().sum(1), "column sums", rtol=1e-5)
+
+
 def _run_encoder(dev, env, monkeypatch, src, norm):
     monkeypatch.setenv("CODA_LAYERS", env)
     torch.manual_seed(7)
