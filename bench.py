@@ -58,6 +58,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                    help="replay the whole step (fwd+bwd+optimizer) as one captured hipGraph")
+    p.add_argument("--prefetch", choices=["on", "off"], default="on",
+                   help="model workload: sample (FPS) batch i+1 on a side stream during step i")
     return p.parse_args()
 
 
@@ -240,7 +242,14 @@ def main():
     use_graph = args.graph == "on"  # measured: the step is GPU-bound, replay gives no gain (profiles/README.md)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph)
 
+    raw_model = model.module if hasattr(model, "module") else model
+    prefetch = args.prefetch == "on" and kind == "model" and not use_graph
+
     def one_step_eager(i):
+        if prefetch:
+            # the data pipeline knows the next batch: its furthest point sampling (8 workgroups,
+            # ~3.4 ms of dependent rounds) runs on a side stream while this step computes
+            raw_model.prefetch_sampling(pool[(i + 1) % len(pool)])
         opt.zero_grad(set_to_none=True)
         loss = step_fn(model, pool[i % len(pool)])
         loss.backward()
@@ -346,7 +355,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": N_POINTS,
                        "parallelism": f"dp{world}", "optimizer": "AdamW (in timed region)",
-                       "execution": "hipGraph replay of fwd+bwd+optimizer" if graph is not None else "eager"},
+                       "execution": "hipGraph replay of fwd+bwd+optimizer" if graph is not None else "eager",
+                       "sampling": ("furthest point sampling of batch i+1 runs on a side stream during step i "
+                                    "(one FPS per step, inside the timed region)" if prefetch else "in line")},
             "roofline": {
                 "kernel": "grid_build_kernel + grid_query_kernel (cell-binned ball_query fused with xyz grouping, "
                           "one coda_query_and_group_xyz_f32 call)",

@@ -286,18 +286,26 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 // S = Q K^T is evaluated UN-transposed here (A = Q rows, B = K rows): a lane then owns one
 // key column and 16 queries in registers, which is the A-operand layout of dV = Pd^T dO and
 // dK = dS^T Q (k-dimension = query).
-template <int D, int KW>
-__global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p) {
+// QSPLIT = false: the KW waves of a block own KW different key tiles and walk all queries
+//                 (long key sequences: the encoder, the decoder's memory).
+// QSPLIT = true:  all KW waves own the SAME 32 keys and split the query tiles (KW tiles are
+//                 staged per step, wave w takes tile w); the partial dK / dV are summed
+//                 through LDS at the end.  Short key sequences (the decoder's 256 queries
+//                 attending to themselves) would otherwise leave one wave per CU.
+template <int D, int KW, bool QSPLIT>
+__global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
-  constexpr int QT = 2;  // query tiles staged per barrier pair
-  __shared__ __attribute__((aligned(16))) float s_q[QT * kTile * LS];
-  __shared__ __attribute__((aligned(16))) float s_do[QT * kTile * LS];
-  __shared__ float s_lse[QT * kTile], s_delta[QT * kTile];
+  constexpr int QT = QSPLIT ? KW : 2;  // query tiles staged per barrier pair
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *s_q = s_dyn;
+  float *s_do = s_q + QT * kTile * LS;
+  float *s_lse = s_do + QT * kTile * LS;
+  float *s_delta = s_lse + QT * kTile;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
   const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
-  const int k0 = (blockIdx.x * KW + w) * kTile;
+  const int k0 = QSPLIT ? blockIdx.x * kTile : (blockIdx.x * KW + w) * kTile;
   const int mykey = k0 + l31;
   const bool wave_active = k0 < p.s;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
     }
     __syncthreads();
     if (!wave_active) continue;
-    for (int qt = 0; qt < QT; ++qt) {
+    for (int qt = QSPLIT ? w : 0; qt < (QSPLIT ? w + 1 : QT); ++qt) {
     const int q0 = qbase0 + qt * kTile;
     if (q0 >= p.l) break;
     const float *tq = s_q + qt * kTile * LS, *tdo = s_do + qt * kTile * LS;
@@ -405,6 +413,31 @@ __global__ __launch_bounds__(KW * kWave) void mha_bwd_dkv_kernel(MhaBwdParams p)
     }  // query tile
   }
 
+  if (QSPLIT && KW > 1) {  // sum the per-wave partial dK / dV: [wave-1][2*NT*16][64 lanes]
+    __syncthreads();
+    if (w > 0) {
+      float *slot = s_dyn + static_cast<size_t>(w - 1) * (2 * NT * 16) * kWave;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          slot[(t * 16 + r) * kWave + lane] = dk[t][r];
+          slot[((NT + t) * 16 + r) * kWave + lane] = dv[t][r];
+        }
+    }
+    __syncthreads();
+    if (w > 0) return;
+    for (int ww = 1; ww < KW; ++ww) {
+      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (2 * NT * 16) * kWave;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dk[t][r] += sl[(t * 16 + r) * kWave + lane];
+          dv[t][r] += sl[((NT + t) * 16 + r) * kWave + lane];
+        }
+    }
+  }
   // dk[t][r]: row i = crow(r, half) = key within the tile, column j = l31 <-> component NT*l31 + t
   if (wave_active) {
 #pragma unroll
@@ -591,6 +624,8 @@ template <int D>
 int launch_fwd(const MhaParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
   clear_sticky_error();
+  // split-key variants: 8 waves per block when 8 K/V tile pairs fit the 160 KB LDS (D = 64)
+  constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   if (p.l >= 1024) {
     auto kern = mha_fwd_kernel<D, 4, false>;
     int st = set_lds(kern, 4 * kTileBytes);
@@ -598,11 +633,11 @@ int launch_fwd(const MhaParams &p, hipStream_t s) {
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
     hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
   } else {
-    auto kern = mha_fwd_kernel<D, 4, true>;
-    int st = set_lds(kern, 4 * kTileBytes);
+    auto kern = mha_fwd_kernel<D, SW, true>;
+    int st = set_lds(kern, SW * kTileBytes);
     if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(SW * kWave), SW * kTileBytes, s, p);
   }
   return launch_status();
 }
@@ -612,22 +647,32 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   clear_sticky_error();
   const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
   hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+  constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one Q + one dO (or K + V) tile
+  constexpr size_t kRowBytes = sizeof(float) * 2 * kTile;                // lse + delta of a tile
+  constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   if (p.s >= 1024) {
-    hipLaunchKernelGGL((mha_bwd_dkv_kernel<D, 4>), dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), 0, s, p);
+    auto kern = mha_bwd_dkv_kernel<D, 4, false>;
+    const size_t lds = 2 * (kTileBytes + kRowBytes);
+    int st = set_lds(kern, lds);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
   } else {
-    hipLaunchKernelGGL((mha_bwd_dkv_kernel<D, 1>), dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(64), 0, s, p);
+    auto kern = mha_bwd_dkv_kernel<D, 4, true>;
+    const size_t lds = 4 * (kTileBytes + kRowBytes);
+    int st = set_lds(kern, lds);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
-  constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);
   if (p.l >= 1024) {
     auto kern = mha_bwd_dq_kernel<D, 4, false>;
     int st = set_lds(kern, 4 * kTileBytes);
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else {
-    auto kern = mha_bwd_dq_kernel<D, 4, true>;
-    int st = set_lds(kern, 4 * kTileBytes);
+    auto kern = mha_bwd_dq_kernel<D, SW, true>;
+    int st = set_lds(kern, SW * kTileBytes);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
   }
   return launch_status();
 }

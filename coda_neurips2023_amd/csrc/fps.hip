@@ -109,6 +109,22 @@ __device__ __forceinline__ uint32_t block_argmax(uint32_t hi, uint32_t lo, uint2
   return hi == 0u ? 0u : rank_to_index(~lo, log2T);
 }
 
+// Selected indices are staged in LDS and written out 256 at a time: __syncthreads() waits for
+// ALL outstanding memory operations of a wave (s_waitcnt vmcnt(0)), so a global store per round
+// would put a full HBM write latency (~0.5 us) on the critical path of every round.
+constexpr int kOutRing = 256;
+__device__ __forceinline__ void out_put(int32_t *s_out, int j, int32_t v) {
+  if (threadIdx.x == 0) s_out[j & (kOutRing - 1)] = v;
+}
+// called by ALL threads, after out_put of round j (j, m block-uniform)
+__device__ __forceinline__ void out_flush(const int32_t *s_out, int j, int m, int32_t *__restrict__ out) {
+  if ((j & (kOutRing - 1)) == kOutRing - 1 || j == m - 1) {
+    __syncthreads();
+    const int base = j & ~(kOutRing - 1);
+    if (static_cast<int>(threadIdx.x) <= (j & (kOutRing - 1))) out[base + threadIdx.x] = s_out[threadIdx.x];
+  }
+}
+
 // ---- register-resident kernel: P points per thread, THREADS per scene --------
 template <int P, int THREADS>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restrict__ xyz, int n,
@@ -116,6 +132,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
                                                           int32_t *__restrict__ idx) {
   constexpr int NW = THREADS / kWave;
   __shared__ uint2 s_key[2][NW];
+  __shared__ int32_t s_out[kOutRing];
 
   const int tid = threadIdx.x;
   const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
@@ -139,7 +156,8 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
     }
   }
 
-  if (tid == 0) out[0] = 0;  // :88-89
+  out_put(s_out, 0, 0);  // :88-89
+  out_flush(s_out, 0, m, out);
   float cx = pts[0], cy = pts[1], cz = pts[2];
 
   for (int j = 1; j < m; ++j) {
@@ -163,7 +181,8 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
       lo = ~tie_rank(static_cast<uint32_t>(tid + besti * THREADS), log2T);
     }
     const uint32_t old = block_argmax<NW>(hi, lo, s_key, j & 1, log2T);
-    if (tid == 0) out[j] = static_cast<int32_t>(old);  // :173-174
+    out_put(s_out, j, static_cast<int32_t>(old));  // :173-174
+    out_flush(s_out, j, m, out);
     cx = pts[old * 3 + 0];  // wave-uniform address -> scalar loads
     cy = pts[old * 3 + 1];
     cz = pts[old * 3 + 2];
@@ -236,6 +255,7 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
                                                        int32_t *__restrict__ idx) {
   constexpr int THREADS = 512, H = P / 2;
   __shared__ unsigned long long s_slot[3];
+  __shared__ int32_t s_out[kOutRing];
 
   const int tid = threadIdx.x;
   const int lane = lane_id();
@@ -261,9 +281,10 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
     t[i] = pt;
   }
   if (tid < 3) s_slot[tid] = 0ull;
-  if (tid == 0) out[0] = 0;
+  out_put(s_out, 0, 0);
   float cx = pts[0], cy = pts[1], cz = pts[2];
   __syncthreads();
+  out_flush(s_out, 0, m, out);
 
   for (int j = 1; j < m; ++j) {
     const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
@@ -299,7 +320,8 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
     uint32_t old = ((rk & 0x7fffffu) << 9) | (__brev(rk >> 23) >> 23);
     if ((key >> 32) == 0ull) old = 0u;  // nothing participated: reference besti = 0
     old = __builtin_amdgcn_readfirstlane(old);
-    if (tid == 0) out[j] = static_cast<int32_t>(old);
+    out_put(s_out, j, static_cast<int32_t>(old));
+    out_flush(s_out, j, m, out);
     cx = pts[old * 3 + 0];
     cy = pts[old * 3 + 1];
     cz = pts[old * 3 + 2];
@@ -322,6 +344,300 @@ bool dispatch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStrea
   else if (p <= 32) launch_t512<32>(xyz, b, n, m, idx, s);
   else launch_t512<40>(xyz, b, n, m, idx, s);
   return true;
+}
+
+// ---- v3: spatial buckets + exact bounding-box pruning ---------------------------------
+//
+// A round only changes the running distance of points that are closer to the new sample
+// than to every earlier one -- after the first few rounds a small neighbourhood.  The cloud
+// is therefore sorted (once, in the prologue) along a 16^3 Morton grid and cut into buckets of
+// 64 consecutive points; bucket (slot j, wave w) lives in register slot j of wave w, one point
+// per lane, and lane j of the wave keeps the bucket's bounding box, its current maximum running
+// distance and the tie-break key of the point holding it.  Per round a wave tests all its
+// buckets at once (lane j: squared distance from the new sample to box j); a bucket whose box
+// is no closer than its maximum running distance cannot change and is skipped:
+//     d(k) >= LB(box) >= max_b temp >= temp[k]  =>  min(d(k), temp[k]) == temp[k]
+// LB is evaluated with the same rounded operations as d on the clamped sample, and rounding is
+// monotone, so LB <= d(k) holds bit-exactly for every k in the box: the selected indices are
+// IDENTICAL to the exhaustive scan's, only the work differs (measured: ~3% of the buckets are
+// touched per round on room-like clouds).  The arg-max runs over the cached per-bucket maxima
+// with the composite (distance, bitrev(k mod T), k) order of the kernels above.
+constexpr int kBucketThreads = 512, kBucketWaves = kBucketThreads / kWave;
+constexpr int kMortonCells = 4096;  // 16^3
+
+__device__ __forceinline__ uint32_t spread4(uint32_t v) {  // bits 0..3 -> bits 0,3,6,9
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+__device__ __forceinline__ float wave_reduce_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+struct BucketMeta {  // lane j: bucket in slot j of this wave
+  float lox, loy, loz, hix, hiy, hiz;  // bounding box
+  float maxt;                          // largest running distance in the bucket
+  uint32_t key;                        // tie-break key of the point holding it ...
+  float bx, by, bz;                    // ... and its coordinates
+};
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Update the points of one bucket against the new sample and refresh its cached maximum.
+__device__ __forceinline__ void bucket_update(float px, float py, float pz, float &t, const uint32_t *s_keys,
+                                              int slot, float cx, float cy, float cz, BucketMeta &md) {
+  const uint32_t key = s_keys[slot * kBucketThreads + threadIdx.x];  // issued early, used after the max
+  // opaque copy: keeps the compiler from hoisting the distance arithmetic of ALL buckets out of
+  // the loop over the active ones (it is loop-invariant there, and pruning it is the point)
+  asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+  const float d = sqdist3(__fsub_rn(px, cx), __fsub_rn(py, cy), __fsub_rn(pz, cz));
+  asm volatile("v_min_f32 %0, %1, %0" : "+v"(t) : "v"(d));  // in place; lanes without a point keep -1
+  const float wmax = wave_max_f32(t);
+  const uint32_t cand = (t == wmax) ? key : 0xffffffffu;
+  const uint32_t wkey = wave_min_u32(cand);
+  const int owner = __builtin_ctzll(__ballot(cand == wkey));  // keys are unique; all-empty buckets never get here
+  const float ox = readlane_f(px, owner), oy = readlane_f(py, owner), oz = readlane_f(pz, owner);
+  if (lane_id() == slot) {
+    md.maxt = wmax;
+    md.key = wkey;
+    md.bx = ox; md.by = oy; md.bz = oz;
+  }
+}
+
+template <int SL>  // register slots (buckets) per wave; n <= 64 * kBucketWaves * SL
+__global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float *__restrict__ xyz, int n, int m,
+                                                                    int log2T, float4 *__restrict__ sorted,
+                                                                    int32_t *__restrict__ idx) {
+  __shared__ unsigned int s_hist[kMortonCells];
+  __shared__ float s_red[6][kBucketWaves];
+  __shared__ unsigned int s_wsum[kBucketWaves];
+  __shared__ unsigned long long s_slot[3];
+  __shared__ float4 s_xyz[2][kBucketWaves];  // per-wave candidate coordinates, round parity
+  __shared__ int32_t s_out[kOutRing];
+  extern __shared__ uint32_t s_keys[];  // [SL][512]: tie-break key of the point in (slot, thread)
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
+  float4 *__restrict__ rec = sorted + static_cast<size_t>(blockIdx.x) * n;
+  int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
+
+  // ---- prologue 1: bounding box of the participating points
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = tid; k < n; k += kBucketThreads) {
+    const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+    if (!fps_skipped(x, y, z)) {
+      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_reduce_min(lo[a]);
+    hi[a] = wave_reduce_max(hi[a]);
+  }
+  if (lane == 0)
+    for (int a = 0; a < 3; ++a) {
+      s_red[a][w] = lo[a];
+      s_red[3 + a][w] = hi[a];
+    }
+  for (int c = tid; c < kMortonCells; c += kBucketThreads) s_hist[c] = 0u;
+  if (tid < 3) s_slot[tid] = 0ull;
+  __syncthreads();
+  float inv[3];
+  for (int a = 0; a < 3; ++a) {
+    float l = s_red[a][0], h = s_red[3 + a][0];
+    for (int q = 1; q < kBucketWaves; ++q) {
+      l = fminf(l, s_red[a][q]);
+      h = fmaxf(h, s_red[3 + a][q]);
+    }
+    lo[a] = l;
+    inv[a] = (h > l) ? 16.0f / (h - l) : 0.0f;
+  }
+  auto cell_of = [&](float x, float y, float z) -> uint32_t {
+    const int qx = min(15, max(0, static_cast<int>((x - lo[0]) * inv[0])));
+    const int qy = min(15, max(0, static_cast<int>((y - lo[1]) * inv[1])));
+    const int qz = min(15, max(0, static_cast<int>((z - lo[2]) * inv[2])));
+    return spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
+  };
+
+  // ---- prologue 2: counting sort by Morton cell into `rec` (x, y, z, index)
+  for (int k = tid; k < n; k += kBucketThreads) {
+    const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+    if (!fps_skipped(x, y, z)) atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
+  }
+  __syncthreads();
+  {  // exclusive scan of the 4096 counters: 8 per thread
+    unsigned int v[8], sum = 0u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      v[q] = s_hist[tid * 8 + q];
+      sum += v[q];
+    }
+    unsigned int incl = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int up = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += up;
+    }
+    if (lane == kWave - 1) s_wsum[w] = incl;
+    __syncthreads();
+    unsigned int base = 0u;
+    for (int q = 0; q < w; ++q) base += s_wsum[q];
+    unsigned int run = base + incl - sum;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s_hist[tid * 8 + q] = run;
+      run += v[q];
+    }
+  }
+  __syncthreads();
+  unsigned int nvalid = 0u;
+  for (int q = 0; q < kBucketWaves; ++q) nvalid += s_wsum[q];
+  for (int k = tid; k < n; k += kBucketThreads) {
+    const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+    if (!fps_skipped(x, y, z)) {
+      const unsigned int pos = atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
+      rec[pos] = make_float4(x, y, z, __uint_as_float(static_cast<uint32_t>(k)));
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- prologue 3: buckets into registers; bucket b -> wave b % 8, slot b / 8
+  float px[SL], py[SL], pz[SL], t[SL];
+  BucketMeta md;
+  md.lox = md.loy = md.loz = INFINITY;
+  md.hix = md.hiy = md.hiz = -INFINITY;
+  md.maxt = -1.0f;
+  md.key = 0xffffffffu;
+  md.bx = md.by = md.bz = 0.0f;
+#pragma unroll
+  for (int j = 0; j < SL; ++j) {
+    const unsigned int pos = (static_cast<unsigned int>(j) * kBucketWaves + w) * kWave + lane;
+    float x = 0.f, y = 0.f, z = 0.f, tt = -1.0f;
+    uint32_t kk = 0xffffffffu;
+    if (pos < nvalid) {
+      const float4 r = rec[pos];
+      x = r.x; y = r.y; z = r.z;
+      const uint32_t k = __float_as_uint(r.w);
+      const uint32_t kmod = k & ((1u << log2T) - 1u);
+      kk = (bitrev_low(kmod, log2T) << 15) | k;  // order: bitrev(k mod T), then k  (k < 2^15)
+      tt = 1e10f;  // sampling.cpp:75-77
+    }
+    px[j] = x; py[j] = y; pz[j] = z; t[j] = tt;
+    s_keys[j * kBucketThreads + tid] = kk;
+    const bool has = tt >= 0.0f;
+    const float bl0 = wave_reduce_min(has ? x : INFINITY), bl1 = wave_reduce_min(has ? y : INFINITY),
+                bl2 = wave_reduce_min(has ? z : INFINITY);
+    const float bh0 = wave_reduce_max(has ? x : -INFINITY), bh1 = wave_reduce_max(has ? y : -INFINITY),
+                bh2 = wave_reduce_max(has ? z : -INFINITY);
+    const float bt = wave_reduce_max(tt);
+    if (lane == j) {
+      md.lox = bl0; md.loy = bl1; md.loz = bl2;
+      md.hix = bh0; md.hiy = bh1; md.hiz = bh2;
+      md.maxt = bt;
+    }
+  }
+
+  out_put(s_out, 0, 0);  // :88-89
+  out_flush(s_out, 0, m, out);
+  float cx = pts[0], cy = pts[1], cz = pts[2];
+  float wv = -1.0f;           // this wave's candidate: max running distance ...
+  uint32_t wk = 0xffffffffu;  // ... the key of the point holding it ...
+  float wx = 0.f, wy = 0.f, wz = 0.f;  // ... and its coordinates
+
+  for (int j = 1; j < m; ++j) {
+    // lane s: can bucket s change?  LB = |clamp(c, box) - c|^2 with the rounding of sqdist3
+    const float qx = fminf(fmaxf(cx, md.lox), md.hix), qy = fminf(fmaxf(cy, md.loy), md.hiy),
+                qz = fminf(fmaxf(cz, md.loz), md.hiz);
+    const float lb = sqdist3(__fsub_rn(qx, cx), __fsub_rn(qy, cy), __fsub_rn(qz, cz));
+    unsigned long long mask = __ballot(lane < SL && lb < md.maxt);
+    if (mask != 0ull) {
+      while (mask != 0ull) {
+        const int sl = __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        switch (sl) {
+#define CODA_FPS_CASE(J)                                                                   \
+  case J:                                                                                  \
+    if (J < SL) bucket_update(px[J < SL ? J : 0], py[J < SL ? J : 0], pz[J < SL ? J : 0],  \
+                              t[J < SL ? J : 0], s_keys, J, cx, cy, cz, md);                \
+    break;
+          CODA_FPS_CASE(0) CODA_FPS_CASE(1) CODA_FPS_CASE(2) CODA_FPS_CASE(3) CODA_FPS_CASE(4)
+          CODA_FPS_CASE(5) CODA_FPS_CASE(6) CODA_FPS_CASE(7) CODA_FPS_CASE(8) CODA_FPS_CASE(9)
+          CODA_FPS_CASE(10) CODA_FPS_CASE(11) CODA_FPS_CASE(12) CODA_FPS_CASE(13) CODA_FPS_CASE(14)
+          CODA_FPS_CASE(15) CODA_FPS_CASE(16) CODA_FPS_CASE(17) CODA_FPS_CASE(18) CODA_FPS_CASE(19)
+          CODA_FPS_CASE(20) CODA_FPS_CASE(21) CODA_FPS_CASE(22) CODA_FPS_CASE(23) CODA_FPS_CASE(24)
+          CODA_FPS_CASE(25) CODA_FPS_CASE(26) CODA_FPS_CASE(27) CODA_FPS_CASE(28) CODA_FPS_CASE(29)
+          CODA_FPS_CASE(30) CODA_FPS_CASE(31) CODA_FPS_CASE(32) CODA_FPS_CASE(33) CODA_FPS_CASE(34)
+          CODA_FPS_CASE(35) CODA_FPS_CASE(36) CODA_FPS_CASE(37) CODA_FPS_CASE(38) CODA_FPS_CASE(39)
+#undef CODA_FPS_CASE
+          default: break;
+        }
+      }
+      // the wave's candidate over its bucket maxima (lanes >= SL hold -1)
+      wv = wave_max_f32(md.maxt);
+      const uint32_t cand = (md.maxt == wv) ? md.key : 0xffffffffu;
+      wk = wave_min_u32(cand);
+      const int owner = __builtin_ctzll(__ballot(cand == wk) | (1ull << 63));
+      wx = readlane_f(md.bx, owner);
+      wy = readlane_f(md.by, owner);
+      wz = readlane_f(md.bz, owner);
+    }
+    if (lane == 0 && wv >= 0.0f) {
+      // (distance, ~key) orders the candidates; the wave id in the low byte never decides (keys
+      // are unique) and tells the readers whose coordinates to take
+      const unsigned long long kk = (static_cast<unsigned long long>(__float_as_uint(wv) + 1u) << 32) |
+                                    ((static_cast<uint32_t>(~wk) & 0xffffffu) << 8) | static_cast<uint32_t>(w);
+      s_xyz[j & 1][w] = make_float4(wx, wy, wz, 0.f);
+      atomicMax(&s_slot[j % 3], kk);
+    }
+    __syncthreads();
+    const unsigned long long kk = s_slot[j % 3];
+    if (tid == 0) s_slot[(j + 2) % 3] = 0ull;  // next use is two barriers away
+    if ((kk >> 32) == 0ull) {  // nothing participated: reference besti = 0
+      out_put(s_out, j, 0);
+      cx = pts[0]; cy = pts[1]; cz = pts[2];
+    } else {
+      const uint32_t lo32 = static_cast<uint32_t>(kk);
+      const float4 c = s_xyz[j & 1][lo32 & 0xffu];
+      out_put(s_out, j, static_cast<int32_t>((~(lo32 >> 8)) & 0x7fffu));
+      cx = c.x; cy = c.y; cz = c.z;
+    }
+    out_flush(s_out, j, m, out);
+  }
+}
+
+constexpr int kBucketMinPoints = 4096, kBucketMaxPoints = 64 * kBucketWaves * 40, kBucketMinSamples = 128;
+
+bool bucket_eligible(int n, int m) { return n >= kBucketMinPoints && n <= kBucketMaxPoints && m >= kBucketMinSamples; }
+
+template <int SL>
+int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
+  constexpr size_t lds = sizeof(uint32_t) * SL * kBucketThreads;
+  auto kern = fps_bucket_kernel<SL>;
+  static bool raised = false;  // per SL: static + dynamic LDS exceeds the 64 KB default
+  if (!raised && lds + 20 * 1024 > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+    raised = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx);
+  return CODA_OK;
+}
+
+int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
+  const int sl = ceil_div(n, 64 * kBucketWaves);
+  if (sl <= 8) return launch_bucket<8>(xyz, b, n, m, log2T, ws, idx, s);
+  if (sl <= 16) return launch_bucket<16>(xyz, b, n, m, log2T, ws, idx, s);
+  if (sl <= 24) return launch_bucket<24>(xyz, b, n, m, log2T, ws, idx, s);
+  if (sl <= 32) return launch_bucket<32>(xyz, b, n, m, log2T, ws, idx, s);
+  return launch_bucket<40>(xyz, b, n, m, log2T, ws, idx, s);
 }
 
 // ---- streaming fallback: any n; running distances in LDS or in workspace -------
@@ -421,8 +737,8 @@ constexpr size_t kStreamKeyBytes = sizeof(uint2) * 2 * (kStreamThreads / kWave);
 }  // namespace coda
 
 CODA_API size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
-  (void)m;
   if (b <= 0 || n <= 0) return 0;
+  if (coda::bucket_eligible(n, m)) return sizeof(float4) * static_cast<size_t>(b) * n;  // Morton-sorted records
   const size_t lds_need = coda::kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
   if (n <= 1024 * 24 || lds_need <= coda::kLdsBudget) return 0;
   return sizeof(float) * static_cast<size_t>(b) * n;
@@ -438,9 +754,17 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   const int log2T = reference_block_log2(n);
 
   (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated HIP calls
-  // variant 0 (default): v2 kernel where it applies; 1: force the v1 register kernel (A/B, tests)
+  // variant 0 (default): bucketed kernel (needs the workspace), else v2 where it applies;
+  // 1: force the v1 register kernel, 2: never use the bucketed kernel (A/B, tests)
   static const int variant = [] { const char *e = getenv("CODA_FPS_VARIANT"); return e ? atoi(e) : 0; }();
-  bool done = variant == 0 && dispatch_t512(xyz, b, n, m, idx, s);
+  bool done = false;
+  if (variant == 0 && bucket_eligible(n, m) && workspace &&
+      workspace_bytes >= sizeof(float4) * static_cast<size_t>(b) * n && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+    const int st = dispatch_bucket(xyz, b, n, m, log2T, static_cast<float4 *>(workspace), idx, s);
+    if (st != CODA_OK) return st;
+    done = true;
+  }
+  if (!done) done = variant != 1 && dispatch_t512(xyz, b, n, m, idx, s);
   if (!done) done = dispatch_reg(xyz, b, n, m, log2T, idx, s);
   if (!done) {
     const size_t lds_need = kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);

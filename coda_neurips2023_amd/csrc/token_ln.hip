@@ -203,8 +203,15 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float *__re
   const int col = blockIdx.x * 64 + lane;
   const float *pg = partials + static_cast<size_t>(blockIdx.y) * blocks * n;
   float t = 0.f;
-  if (col < n)
-    for (int b = slice; b < blocks; b += 16) t += pg[static_cast<size_t>(b) * n + col];
+  if (col < n) {
+    int b = slice;
+    for (; b + 48 < blocks; b += 64) {  // four independent loads in flight
+      const float v0 = pg[static_cast<size_t>(b) * n + col], v1 = pg[static_cast<size_t>(b + 16) * n + col];
+      const float v2 = pg[static_cast<size_t>(b + 32) * n + col], v3 = pg[static_cast<size_t>(b + 48) * n + col];
+      t += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < blocks; b += 16) t += pg[static_cast<size_t>(b) * n + col];
+  }
   s_part[slice][lane] = t;
   __syncthreads();
   if (slice == 0 && col < n) {
@@ -292,15 +299,19 @@ Drop make_drop(float p, uint64_t seed, const uint64_t *seed_dev) {
   return d;
 }
 bool bad_ln_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0; }
-int ln_blocks(long long rows, int cap = 512) {  // backward: one (3,C) partial per block
+int ln_blocks(long long rows) {  // forward: a wave per row, 4 rows per block and pass
   const long long want = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
-  return static_cast<int>(want < 1 ? 1 : (want > cap ? cap : want));
+  return static_cast<int>(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+}
+int ln_bwd_blocks(long long rows) {  // backward: >= 4 passes per block, one (3,C) partial per block
+  const long long want = (rows + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+  return static_cast<int>(want < 1 ? 1 : (want > 256 ? 256 : want));
 }
 bool bad_row_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0 || (kT % (c / 4)) != 0; }
 int row_blocks(long long rows, int c) {
   const int rpb = kT / (c / 4);
-  const long long want = (rows + rpb - 1) / rpb;
-  return static_cast<int>(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  const long long want = (rows + 4 * rpb - 1) / (4 * rpb);  // >= 4 passes per block
+  return static_cast<int>(want < 1 ? 1 : (want > 512 ? 512 : want));
 }
 
 }  // namespace
@@ -323,7 +334,7 @@ CODA_API int coda_tok_add_ln_fwd_f32(const float *x, const float *bias, const fl
   LnFwd p{x, bias, res, pos, gamma, beta, s_out, y_out, yp_out, mean, rstd, rows, c, eps,
           make_drop(dropout_p, seed, seed_dev)};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(ln_blocks(rows, 4096));
+  const dim3 grid(ln_blocks(rows));
   clear_sticky_error();
   if (c <= 256) hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, dim3(kThreads), 0, s, p);
   else if (c <= 512) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, dim3(kThreads), 0, s, p);
@@ -333,7 +344,7 @@ CODA_API int coda_tok_add_ln_fwd_f32(const float *x, const float *bias, const fl
 
 CODA_API int coda_tok_add_ln_bwd_blocks(long long rows, int c) {
   if (rows < 0 || bad_ln_c(c)) return CODA_EINVAL;
-  return ln_blocks(rows);
+  return ln_bwd_blocks(rows);
 }
 
 CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, const float *s_in,
@@ -345,7 +356,7 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
   if (!gamma && !ds) return CODA_EINVAL;
   if (!dres_out && !dx_out) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int blocks = ln_blocks(rows);
+  const int blocks = ln_bwd_blocks(rows);
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(partials, 0, sizeof(float) * 3 * c * blocks, s);
     return e == hipSuccess ? CODA_OK : static_cast<int>(e);

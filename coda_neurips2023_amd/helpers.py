@@ -85,6 +85,27 @@ class GenericMLP(nn.Module):
     def forward(self, x):
         return self.layers(x)
 
+    def tokens_supported(self):
+        """True when the stack is token-wise without batch statistics (k=1 convolutions or
+        Linear, activations, dropout): it can then run on channels-last (..., C) tokens."""
+        for m in self.layers:
+            if isinstance(m, nn.Conv1d):
+                if m.kernel_size != (1,) or m.stride != (1,) or m.padding != (0,) or m.groups != 1:
+                    return False
+            elif not isinstance(m, (nn.Linear, nn.ReLU, nn.GELU, nn.LeakyReLU, nn.Dropout, nn.Identity)):
+                return False
+        return True
+
+    def forward_tokens(self, x):
+        """Same function as ``forward`` on (..., C) tokens instead of (N, C, tokens): a k=1
+        Conv1d is a Linear over the channel axis (one library GEMM, no layout transposes)."""
+        for m in self.layers:
+            if isinstance(m, nn.Conv1d):
+                x = nn.functional.linear(x, m.weight.squeeze(-1), m.bias)
+            else:
+                x = m(x)
+        return x
+
 
 def get_clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])

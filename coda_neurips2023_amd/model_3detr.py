@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import fused_bn_mlp
 from .helpers import GenericMLP
 from .pointnet2.pointnet2_modules import PointnetSAModuleVotes
-from .pointnet2.pointnet2_utils import furthest_point_sample
+from .pointnet2.pointnet2_utils import SamplingPrefetcher, furthest_point_sample
 from .position_embedding import PositionEmbeddingCoordsSine, scale_points, shift_scale_points
 from .transformer import (MaskedTransformerEncoder, TransformerDecoder, TransformerDecoderLayer,
                           TransformerEncoder, TransformerEncoderLayer)
@@ -157,7 +157,11 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         query_inds = furthest_point_sample(encoder_xyz, self.num_queries).long()
         query_xyz = torch.gather(encoder_xyz, 1, query_inds.unsqueeze(-1).expand(-1, -1, 3))
         pos_embed = self.pos_embedding(query_xyz, input_range=point_cloud_dims)
-        query_embed = self.query_projection(pos_embed)
+        if self.query_projection.tokens_supported():
+            # (B, C, nq) -> query-major tokens; the caller's permute(2, 0, 1) undoes the view below
+            query_embed = self.query_projection.forward_tokens(pos_embed.permute(2, 0, 1)).permute(1, 2, 0)
+        else:
+            query_embed = self.query_projection(pos_embed)
         return query_xyz, query_embed
 
     def _break_up_pc(self, pc):
@@ -165,9 +169,28 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def prefetch_sampling(self, inputs):
+        """Optional: start the pre-encoder's furthest point sampling of an upcoming batch on a
+        side stream (pointnet2_utils.SamplingPrefetcher); ``forward`` on the same
+        ``inputs["point_clouds"]`` tensor then finds the indices ready.  Purely a scheduling
+        aid: outputs are identical with and without it."""
+        npoint = getattr(self.pre_encoder, "npoint", None)
+        pc = inputs["point_clouds"]
+        if npoint is None or not pc.is_cuda:
+            return
+        if not hasattr(self, "_sampling_prefetcher"):
+            self._sampling_prefetcher = SamplingPrefetcher()
+        self._sampling_prefetcher.submit(pc, npoint)
+
     def run_encoder(self, point_clouds):
         xyz, features = self._break_up_pc(point_clouds)
-        pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features)
+        inds = None
+        if hasattr(self, "_sampling_prefetcher"):
+            inds = self._sampling_prefetcher.take(point_clouds, self.pre_encoder.npoint)
+        if inds is not None:
+            pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features, inds)
+        else:
+            pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features)
         # (B, C, npoints) -> (npoints, B, C) for the seq-first transformer
         pre_enc_features = pre_enc_features.permute(2, 0, 1)
         enc_xyz, enc_features, enc_inds = self.encoder(pre_enc_features, xyz=pre_enc_xyz)

@@ -29,6 +29,50 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+class SamplingPrefetcher:
+    """Furthest point sampling of an UPCOMING batch on a side HIP stream.
+
+    FPS is ``npoint`` strictly dependent rounds on one workgroup per scene: for a batch of 8
+    scenes it keeps 8 of the 256 CUs busy for milliseconds, and everything else in the model
+    waits for its indices.  A training loop knows its next batch while the current step runs,
+    so ``submit(point_clouds, npoint)`` starts the sampling of that batch on a side stream
+    (the other 248 CUs keep working on the current step) and the model's forward picks the
+    indices up with ``take`` -- same kernel, same indices, no host synchronisation.  Entries
+    are matched by tensor identity + version, so a batch that was modified or never submitted
+    simply samples in line.
+    """
+
+    def __init__(self, max_pending=4):
+        self._stream = None
+        self._pending = []
+        self._max = max_pending
+
+    def submit(self, point_clouds, npoint):
+        dev = point_clouds.device
+        cur = torch.cuda.current_stream(dev)
+        if self._stream is None or self._stream.device != dev:
+            self._stream = torch.cuda.Stream(device=dev)
+        self._stream.wait_stream(cur)  # the batch is produced on the caller's stream
+        with torch.cuda.stream(self._stream):
+            xyz = point_clouds[..., 0:3].contiguous()
+            inds = furthest_point_sample(xyz, npoint)
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        self._pending.append((point_clouds, point_clouds._version, int(npoint), inds, xyz, done))
+        del self._pending[:-self._max]
+
+    def take(self, point_clouds, npoint):
+        """The prefetched (B, npoint) indices of this very tensor, or None."""
+        for k, (pc, version, n, inds, _xyz, done) in enumerate(self._pending):
+            if pc is point_clouds and version == point_clouds._version and n == int(npoint):
+                del self._pending[k]
+                cur = torch.cuda.current_stream(point_clouds.device)
+                cur.wait_event(done)
+                inds.record_stream(cur)
+                return inds
+        return None
+
+
 class GatherOperation(Function):
     """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (pointnet2_utils.py:80-111)."""
 

@@ -45,6 +45,7 @@ def test_python_signatures_cover_the_header():
 
 def test_workspace_queries_run_without_gpu():
     lib = _lib.load()
-    assert lib.coda_furthest_point_sampling_workspace_bytes(8, 20000, 2048) == 0
+    assert lib.coda_furthest_point_sampling_workspace_bytes(8, 2048, 256) == 0
+    assert lib.coda_furthest_point_sampling_workspace_bytes(8, 20000, 2048) == 8 * 20000 * 16  # sorted records
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 100000, 2048) == 8 * 100000 * 4
     assert lib.coda_ball_query_workspace_bytes(8, 20000, 2048, 64) >= 0

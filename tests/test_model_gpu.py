@@ -104,3 +104,29 @@ def test_open_vocabulary_class_scores(dev):
         pred = model(_inputs(dev), if_real_test=True)
     close(pred["outputs"]["sem_cls_prob"], G["class_scores"], "get_class_scores", rtol=2e-3)
     assert pred["outputs"]["text_features_clip"].shape == (2, 10, 512)
+
+
+def test_prefetched_sampling_gives_identical_outputs(dev):
+    """model.prefetch_sampling(batch) (FPS on a side stream) followed by forward on the same
+    tensor: identical outputs to the in-line path; a modified or unknown tensor samples in line."""
+    import numpy as np
+    from coda_neurips2023_amd.synthetic_scenes import make_batch
+    model, _ = build_model(tiny_args(), HotPathDatasetConfig())
+    fill_deterministic(model, seed=5)
+    model.to(dev).eval()
+    pc, mn, mx = make_batch(2, 5000, seed=3)
+    inputs = {"point_clouds": torch.from_numpy(pc).to(dev), "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
+              "point_cloud_dims_max": torch.from_numpy(mx).to(dev)}
+    with torch.no_grad():
+        ref = model(inputs)["outputs"]
+        model.prefetch_sampling(inputs)
+        assert len(model._sampling_prefetcher._pending) == 1
+        got = model(inputs)["outputs"]
+        assert len(model._sampling_prefetcher._pending) == 0  # consumed
+        for k in ["center_normalized", "sem_cls_logits", "box_corners"]:
+            assert torch.equal(got[k], ref[k]), k
+        model.prefetch_sampling(inputs)
+        inputs["point_clouds"].mul_(1.0)  # version bump: the stale entry must not be used
+        other = model(inputs)["outputs"]
+        assert len(model._sampling_prefetcher._pending) == 1
+        assert torch.equal(other["center_normalized"], ref["center_normalized"])

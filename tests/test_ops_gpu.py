@@ -45,6 +45,35 @@ def test_fps_tie_rule_with_duplicates(dev, oracle, n):
     assert np.array_equal(got, oracle.furthest_point_sampling(x, 80))
 
 
+@pytest.mark.parametrize("n,m,kind", [(4096, 128, "normal"), (4097, 300, "dup"), (9000, 256, "plane"),
+                                      (20000, 512, "dup"), (20480, 200, "normal"), (20000, 300, "skip"),
+                                      (6000, 150, "same"), (20000, 2048, "line")])
+def test_fps_bucketed_kernel_bit_exact(dev, oracle, n, m, kind):
+    """n in [4096, 20480], m >= 128: the Morton-bucketed kernel with bounding-box pruning must
+    select exactly the exhaustive scan's indices, including ties between duplicated points,
+    degenerate extents and points inside the skip radius."""
+    rng = np.random.default_rng(n + m)
+    if kind == "normal":
+        x = (rng.standard_normal((2, n, 3)) * 1.5).astype(np.float32)
+    elif kind == "dup":  # 300 distinct locations -> massive ties
+        base = (rng.random((300, 3), dtype=np.float32) * 4 - 2).astype(np.float32)
+        x = base[rng.integers(0, 300, (2, n))]
+    elif kind == "plane":  # zero extent along z, and along y for scene 1
+        x = (rng.random((2, n, 3), dtype=np.float32) * 5).astype(np.float32)
+        x[..., 2] = 1.25
+        x[1, :, 1] = -0.5
+    elif kind == "skip":  # a third of the points inside the skip radius, incl. point 0
+        x = (rng.standard_normal((2, n, 3)) * 1.0).astype(np.float32)
+        x[:, ::3] *= 0.01
+    elif kind == "same":  # one location only
+        x = np.tile(np.array([0.7, -1.1, 2.0], np.float32), (2, n, 1))
+    else:  # points on a line, many exactly equal distances
+        tline = np.round(rng.random((2, n, 1), dtype=np.float32) * 64) / 64
+        x = (tline * np.array([1.0, 2.0, -0.5], np.float32)).astype(np.float32)
+    got = _ext.furthest_point_sampling(cu(x, dev), m).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(x, m))
+
+
 def test_fps_skip_rule(dev, oracle):
     x = np.zeros((2, 10, 3), np.float32)
     x[0, 3] = (0.03, 0, 0)
