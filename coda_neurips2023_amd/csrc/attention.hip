@@ -33,13 +33,20 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// Counter-based dropout decision, identical in forward and backward.
-__device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t bh, uint32_t q, uint32_t key,
-                                             uint32_t s_len, uint32_t thresh24) {
-  uint32_t x = (q * s_len + key) ^ (bh * 0x9E3779B9u) ^ seed;
+// Counter-based dropout, identical in forward and backward: one 32-bit hash (lowbias32) of
+// (seed, b*h, query, key >> 1) serves the two keys of an aligned pair, 16 bits each, so the
+// kernels whose lanes hold a query and whose registers hold consecutive keys (forward, dQ) pay
+// one hash per two probabilities.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t c, uint32_t q, uint32_t s_len, uint32_t key) {
+  uint32_t x = (q * s_len + (key & ~1u)) ^ c;
   x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  x += bh; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
-  return (x >> 8) >= thresh24;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_const(uint32_t seed, uint32_t bh) { return (bh * 0x9E3779B9u) ^ seed ^ (bh << 27); }
+__device__ __forceinline__ bool drop_keep_lo(uint32_t h, uint32_t thresh16) { return (h & 0xffffu) >= thresh16; }
+__device__ __forceinline__ bool drop_keep_hi(uint32_t h, uint32_t thresh16) { return (h >> 16) >= thresh16; }
+__device__ __forceinline__ bool drop_keep(uint32_t h, uint32_t key, uint32_t thresh16) {
+  return ((key & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -51,7 +58,7 @@ struct MhaParams {
   int b, h, l, s;
   int ldq, ldk, ldv;  // floats between consecutive batch rows of q / k / v (H*D when dense)
   float scale, inv_keep;
-  uint32_t thresh24, seed;
+  uint32_t thresh16, seed;
   const uint64_t *seed_dev;  // optional device-resident seed (graph replays draw fresh masks)
 };
 
@@ -81,7 +88,7 @@ __device__ __forceinline__ void load_tile(float *lds, const float *g, size_t gst
 //                 staged per step, wave w takes tile w); the partial (m, l, O) are merged
 //                 through LDS at the end.  This is what fills the chip for the decoder, whose
 //                 256 queries give only 8 query blocks per (scene, head).
-template <int D, int QW, bool SPLIT>
+template <int D, int QW, bool SPLIT, bool GEN>
 __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
   constexpr int TILES = QW;  // K/V tiles staged per barrier pair (SPLIT: one per wave; else all waves walk all)
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
-  const bool use_drop = p.thresh24 != 0u;
-  const uint32_t seed = use_drop ? effective_seed(p.seed, p.seed_dev) : 0u;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
 
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
     __syncthreads();
@@ -146,36 +153,54 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     // sacc[r] = scale * <q[myq], k[s0 + crow(r, half)]>
     float pr[16];
     float tmax = -INFINITY;
+    // GEN = false (host-checked): no mask, L and S multiples of the tile -> nothing to mask out
+    constexpr bool plain = !GEN;
+    if (plain) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = s0 + crow(r, half);
-      bool dead = key >= p.s;
-      if (p.mask && !dead && myq < p.l)
-        dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
-      pr[r] = dead ? -INFINITY : sacc[r];
-      tmax = fmaxf(tmax, pr[r]);
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = sacc[r];
+        tmax = fmaxf(tmax, pr[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + crow(r, half);
+        bool dead = key >= p.s;
+        if (p.mask && !dead && myq < p.l)
+          dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
+        pr[r] = dead ? -INFINITY : sacc[r];
+        tmax = fmaxf(tmax, pr[r]);
+      }
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m, tmax);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = fast_exp2((m - m_safe) * kLog2e);
+    // lazy rescale: once the running row maxima have settled no lane changes its maximum and the
+    // accumulators (AGPRs: a rescale costs a read-modify-write of all of them) are left alone
+    if (__ballot(m_new != m) != 0ull) {
+      const float alpha = fast_exp2((m - m_safe) * kLog2e);
+      lsum *= alpha;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m = m_new;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float e = fast_exp2((pr[r] - m_safe) * kLog2e);
-      rs += e;
-      if (use_drop) {
-        const int key = s0 + crow(r, half);
-        e = dropout_keep(seed, bh, myq, key, p.s, p.thresh24) ? e * p.inv_keep : 0.f;
-      }
-      pr[r] = e;
+      pr[r] = fast_exp2((pr[r] - m_safe) * kLog2e);
+      rs += pr[r];
     }
-    lsum = lsum * alpha + rs;
-    m = m_new;
+    lsum += rs;
+    if (use_drop) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      for (int r = 0; r < 16; r += 2) {  // keys crow(r), crow(r)+1: one aligned pair
+        const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
+        pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] * p.inv_keep : 0.f;
+        pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] * p.inv_keep : 0.f;
+      }
+    }
 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -260,7 +285,7 @@ struct MhaBwdParams {
   int b, h, l, s;
   int ldq, ldk, ldv;
   float scale, inv_keep;
-  uint32_t thresh24, seed;
+  uint32_t thresh16, seed;
   const uint64_t *seed_dev;
 };
 
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 //                 staged per step, wave w takes tile w); the partial dK / dV are summed
 //                 through LDS at the end.  Short key sequences (the decoder's 256 queries
 //                 attending to themselves) would otherwise leave one wave per CU.
-template <int D, int KW, bool QSPLIT>
+template <int D, int KW, bool QSPLIT, bool GEN>
 __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
   constexpr int QT = QSPLIT ? KW : 2;  // query tiles staged per barrier pair
@@ -310,8 +335,8 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   const bool wave_active = k0 < p.s;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
   const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
-  const bool use_drop = p.thresh24 != 0u;
-  const uint32_t seed = use_drop ? effective_seed(p.seed, p.seed_dev) : 0u;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
 
   const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
                vstride = static_cast<size_t>(p.b) * p.ldv;
@@ -372,17 +397,31 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     }
     // lane: key = mykey, register r: query q0 + crow(r, half)
     float pd[16], ds[16];
+    constexpr bool plain = !GEN;  // no mask, L and S multiples of the tile
+    if (plain) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = crow(r, half), qq = q0 + qi;
-      bool dead = qq >= p.l || mykey >= p.s;
-      if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
-      const float lse = t_lse[qi];
-      float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
-      float keep = 1.f;
-      if (use_drop) keep = dropout_keep(seed, bh, qq, mykey, p.s, p.thresh24) ? p.inv_keep : 0.f;
-      pd[r] = prob * keep;
-      ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
+      for (int r = 0; r < 16; ++r) {
+        const int qi = crow(r, half);
+        const float prob = fast_exp2((sacc[r] * p.scale - t_lse[qi]) * kLog2e);  // lse = -inf cannot occur here
+        float keep = 1.f;
+        if (use_drop)
+          keep = drop_keep(drop_hash(dconst, q0 + qi, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
+        pd[r] = prob * keep;
+        ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = crow(r, half), qq = q0 + qi;
+        bool dead = qq >= p.l || mykey >= p.s;
+        if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
+        const float lse = t_lse[qi];
+        float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
+        float keep = 1.f;
+        if (use_drop) keep = drop_keep(drop_hash(dconst, qq, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
+        pd[r] = prob * keep;
+        ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
+      }
     }
     // dV^T? no: dV[key][dv] += sum_q Pd[q][key] dO[q][dv]  (A = Pd^T: lane = key, k = query)
 #pragma unroll
@@ -460,7 +499,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 
 // dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
 // the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
-template <int D, int QW, bool SPLIT>
+template <int D, int QW, bool SPLIT, bool GEN>
 __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
   constexpr int TILES = QW;
@@ -477,8 +516,8 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
   const bool wave_active = q0 < p.l;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
   const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
-  const bool use_drop = p.thresh24 != 0u;
-  const uint32_t seed = use_drop ? effective_seed(p.seed, p.seed_dev) : 0u;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
 
   const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
                vstride = static_cast<size_t>(p.b) * p.ldv;
@@ -502,6 +541,8 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
     lse = p.lse[static_cast<size_t>(bh) * p.l + myq];
     delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
   }
+  // rows past the end or without any admissible key: exp2(x - inf) = 0 without a per-element test
+  const float lse_eff = (myq < p.l && lse != -INFINITY) ? lse : INFINITY;
   f32x16 dq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -535,15 +576,32 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
       pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, gf[c + 3], pacc, 0, 0, 0);
     }
     float ds[16];
+    constexpr bool plain = !GEN;  // no mask, L and S multiples of the tile; lse_eff = +inf kills empty rows
+    if (plain) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = s0 + crow(r, half);
-      bool dead = key >= p.s || myq >= p.l;
-      if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
-      const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] - lse) * kLog2e);
-      float keep = 1.f;
-      if (use_drop) keep = dropout_keep(seed, bh, myq, key, p.s, p.thresh24) ? p.inv_keep : 0.f;
-      ds[r] = prob * (pacc[r] * keep - delta) * p.scale;
+      for (int r = 0; r < 16; r += 2) {
+        float keep0 = 1.f, keep1 = 1.f;
+        if (use_drop) {
+          const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
+          keep0 = drop_keep_lo(hsh, p.thresh16) ? p.inv_keep : 0.f;
+          keep1 = drop_keep_hi(hsh, p.thresh16) ? p.inv_keep : 0.f;
+        }
+        const float prob0 = fast_exp2((sacc[r] - lse_eff) * kLog2e);
+        const float prob1 = fast_exp2((sacc[r + 1] - lse_eff) * kLog2e);
+        ds[r] = prob0 * (pacc[r] * keep0 - delta) * p.scale;
+        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta) * p.scale;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + crow(r, half);
+        bool dead = key >= p.s || myq >= p.l;
+        if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
+        const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] - lse) * kLog2e);
+        float keep = 1.f;
+        if (use_drop) keep = drop_keep(drop_hash(dconst, myq, p.s, key), key, p.thresh16) ? p.inv_keep : 0.f;
+        ds[r] = prob * (pacc[r] * keep - delta) * p.scale;
+      }
     }
     // dQ[q][d] += sum_key dS[q][key] K[key][d]   (A = dS: lane = query, k = key)
 #pragma unroll
@@ -598,11 +656,11 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
   }
 }
 
-uint32_t drop_threshold(float p) {
+uint32_t drop_threshold(float p) {  // 16-bit: keep iff hash16 >= threshold; 0 = dropout off
   if (!(p > 0.f)) return 0u;
-  double t = static_cast<double>(p) * 16777216.0;
+  double t = static_cast<double>(p) * 65536.0 + 0.5;
   if (t < 1.0) t = 1.0;
-  if (t > 16777215.0) t = 16777215.0;
+  if (t > 65535.0) t = 65535.0;
   return static_cast<uint32_t>(t);
 }
 
@@ -620,20 +678,19 @@ int set_lds(K kern, size_t bytes) {
   return CODA_OK;
 }
 
-template <int D>
-int launch_fwd(const MhaParams &p, hipStream_t s) {
+template <int D, bool GEN>
+int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
-  clear_sticky_error();
   // split-key variants: 8 waves per block when 8 K/V tile pairs fit the 160 KB LDS (D = 64)
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   if (p.l >= 1024) {
-    auto kern = mha_fwd_kernel<D, 4, false>;
+    auto kern = mha_fwd_kernel<D, 4, false, GEN>;
     int st = set_lds(kern, 4 * kTileBytes);
     if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
     hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
   } else {
-    auto kern = mha_fwd_kernel<D, SW, true>;
+    auto kern = mha_fwd_kernel<D, SW, true, GEN>;
     int st = set_lds(kern, SW * kTileBytes);
     if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
@@ -643,38 +700,51 @@ int launch_fwd(const MhaParams &p, hipStream_t s) {
 }
 
 template <int D>
-int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
+int launch_fwd(const MhaParams &p, hipStream_t s) {
   clear_sticky_error();
-  const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
-  hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+  const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
+  return gen ? launch_fwd_g<D, true>(p, s) : launch_fwd_g<D, false>(p, s);
+}
+
+template <int D, bool GEN>
+int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one Q + one dO (or K + V) tile
   constexpr size_t kRowBytes = sizeof(float) * 2 * kTile;                // lse + delta of a tile
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   if (p.s >= 1024) {
-    auto kern = mha_bwd_dkv_kernel<D, 4, false>;
+    auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
   } else {
-    auto kern = mha_bwd_dkv_kernel<D, 4, true>;
+    auto kern = mha_bwd_dkv_kernel<D, 4, true, GEN>;
     const size_t lds = 4 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
   if (p.l >= 1024) {
-    auto kern = mha_bwd_dq_kernel<D, 4, false>;
+    auto kern = mha_bwd_dq_kernel<D, 4, false, GEN>;
     int st = set_lds(kern, 4 * kTileBytes);
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else {
-    auto kern = mha_bwd_dq_kernel<D, SW, true>;
+    auto kern = mha_bwd_dq_kernel<D, SW, true, GEN>;
     int st = set_lds(kern, SW * kTileBytes);
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
   }
   return launch_status();
+}
+
+template <int D>
+int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
+  clear_sticky_error();
+  const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
+  hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+  const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
+  return gen ? launch_bwd_g<D, true>(p, s) : launch_bwd_g<D, false>(p, s);
 }
 
 }  // namespace
@@ -695,7 +765,7 @@ CODA_API int coda_mha_fwd_f32(const float *q, const float *k, const float *v, co
   p.b = b; p.h = h; p.l = l; p.s = s;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
   p.scale = scale;
-  p.thresh24 = drop_threshold(dropout_p);
+  p.thresh16 = drop_threshold(dropout_p);
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
   p.seed_dev = seed_dev;
@@ -721,7 +791,7 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
   p.b = b; p.h = h; p.l = l; p.s = s;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
   p.scale = scale;
-  p.thresh24 = drop_threshold(dropout_p);
+  p.thresh16 = drop_threshold(dropout_p);
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
   p.seed_dev = seed_dev;
