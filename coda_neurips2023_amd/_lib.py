@@ -36,12 +36,12 @@ SIGNATURES = {
     "coda_three_interpolate_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_grad_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     # include/coda_sa_mlp.h
-    "coda_sa_col_stats_f32": (_c_int, [_P, _P, ctypes.c_longlong, _c_int, _P, _P]),
+    "coda_sa_col_stats_f32": (_c_int, [_P, _P, ctypes.c_longlong, _c_int, _P, _P, _P]),
     "coda_sa_bn_relu_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
-    "coda_sa_col_stats_pool_f32": (_c_int, [_P, ctypes.c_longlong, _c_int, _c_int, _P, _P, _P, _P, _P, _P]),
-    "coda_sa_bn_bwd_sparse_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_int, _P, _P]),
+    "coda_sa_col_stats_pool_f32": (_c_int, [_P, ctypes.c_longlong, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "coda_sa_bn_bwd_sparse_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_int, _P, _P, _P, _P]),
     "coda_sa_relu_bn_bwd_stats_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
-    "coda_sa_relu_bn_bwd_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P, _P]),
+    "coda_sa_relu_bn_bwd_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P, _P, _P]),
     # include/coda_token_ops.h
     "coda_tok_bn_stats_f32": (_c_int, [_P, _c_int, ctypes.c_longlong, _c_int, _P, _P]),
     "coda_tok_bn_finalize_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, ctypes.c_double, _c_float, _P, _P, _P]),
@@ -108,6 +108,12 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def current_stream_handle():
+    """Raw hipStream_t of torch's current stream on the current device (cheap: no Stream object)."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def check(status, what):

@@ -92,7 +92,7 @@ class _FusedAttention(torch.autograd.Function):
         with torch.cuda.device(q.device):
             st = lib.coda_mha_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
                                       b, h, l, s, d, ldq, ldk, ldv, float(scale), float(dropout_p), seed,
-                                      _ptr(seed_dev), torch.cuda.current_stream().cuda_stream)
+                                      _ptr(seed_dev), _lib.current_stream_handle())
         _lib.check(st, "mha_fwd")
         ctx.save_for_backward(q, k, v, mask_u8, out, lse)
         ctx.meta = (ldq, ldk, ldv, float(scale), float(dropout_p), seed, seed_dev)
@@ -114,7 +114,7 @@ class _FusedAttention(torch.autograd.Function):
             st = lib.coda_mha_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
                                       _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
                                       ldq, ldk, ldv, scale, dropout_p, seed, _ptr(seed_dev),
-                                      torch.cuda.current_stream().cuda_stream)
+                                      _lib.current_stream_handle())
         _lib.check(st, "mha_bwd")
         return dq, dk, dv, None, None, None
 

@@ -25,7 +25,7 @@ namespace coda {
 namespace {
 
 constexpr int kT = 256;
-constexpr int kRowsPerBlock = 2048;  // rows streamed by one block before it reduces
+constexpr int kMaxBlocks = 512;  // streaming kernels: ~2 workgroups per CU, each ends in 2*C fp64 atomics
 
 struct RowMap {
   int tpr, rpb, cq, rsub;  // threads per row, rows per pass, channel quad, row sub-index
@@ -37,6 +37,12 @@ __device__ __forceinline__ RowMap row_map(int c) {
   m.cq = threadIdx.x % m.tpr;
   m.rsub = threadIdx.x / m.tpr;
   return m;
+}
+
+// rows streamed by one block: the grid (<= kMaxBlocks) splits the p rows evenly, in whole passes
+__device__ __forceinline__ long long block_rows(long long p, int rpb) {
+  const long long per = (p + gridDim.x - 1) / gridDim.x;
+  return (per + rpb - 1) / rpb * rpb;
 }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -90,21 +96,30 @@ __device__ __forceinline__ void acc_stats(float4 (&acc)[2], float4 y) {
   acc[0].x += y.x; acc[0].y += y.y; acc[0].z += y.z; acc[0].w += y.w;
   acc[1].x += y.x * y.x; acc[1].y += y.y * y.y; acc[1].z += y.z * y.z; acc[1].w += y.w * y.w;
 }
+// row counted `w` times (de-duplicated groups: the first row of a group stands for its copies)
+__device__ __forceinline__ void acc_stats_w(float4 (&acc)[2], float4 y, float w) {
+  const float4 wy = make_float4(w * y.x, w * y.y, w * y.z, w * y.w);
+  acc[0].x += wy.x; acc[0].y += wy.y; acc[0].z += wy.z; acc[0].w += wy.w;
+  acc[1].x += wy.x * y.x; acc[1].y += wy.y * y.y; acc[1].z += wy.z * y.z; acc[1].w += wy.w * y.w;
+}
 
 // ---- forward ---------------------------------------------------------------------------
 template <bool FROM_X>
 __global__ __launch_bounds__(kT) void col_stats_kernel(const float *__restrict__ src,
                                                        const float *__restrict__ w1, long long p, int c,
+                                                       const float *__restrict__ roww,
                                                        double *__restrict__ sums) {
   const RowMap m = row_map(c);
   W4 w;
   if (FROM_X) w = load_w1(w1, m.cq);
   float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-  const long long r0 = static_cast<long long>(blockIdx.x) * kRowsPerBlock;
-  const long long r1 = min(r0 + kRowsPerBlock, p);
+  const long long rows_pb = block_rows(p, m.rpb);
+  const long long r0 = static_cast<long long>(blockIdx.x) * rows_pb;
+  const long long r1 = min(r0 + rows_pb, p);
   for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
     const float4 y = FROM_X ? conv3(src + r * 3, w) : ld4(src + r * c + 4 * m.cq);
-    acc_stats(acc, y);
+    if (roww) acc_stats_w(acc, y, roww[r]);
+    else acc_stats(acc, y);
   }
   block_reduce_to_global<2>(acc, m, c, sums);
 }
@@ -119,8 +134,9 @@ __global__ __launch_bounds__(kT) void bn_relu_apply_kernel(const float *__restri
   W4 w;
   if (FROM_X) w = load_w1(w1, m.cq);
   const float4 a = ld4(scale + 4 * m.cq), b = ld4(shift + 4 * m.cq);
-  const long long r0 = static_cast<long long>(blockIdx.x) * kRowsPerBlock;
-  const long long r1 = min(r0 + kRowsPerBlock, p);
+  const long long rows_pb = block_rows(p, m.rpb);
+  const long long r0 = static_cast<long long>(blockIdx.x) * rows_pb;
+  const long long r1 = min(r0 + rows_pb, p);
   for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
     const float4 y = FROM_X ? conv3(src + r * 3, w) : ld4(src + r * c + 4 * m.cq);
     st4(dst + r * c + 4 * m.cq, relu4(affine(y, a, b)));
@@ -129,7 +145,9 @@ __global__ __launch_bounds__(kT) void bn_relu_apply_kernel(const float *__restri
 
 // Last layer: statistics + max / min / arg over the S rows of each group (centre).
 __global__ __launch_bounds__(kT) void col_stats_pool_kernel(const float *__restrict__ y, long long groups,
-                                                            int s, int c, double *__restrict__ sums,
+                                                            int s_fixed, int c, const float *__restrict__ roww,
+                                                            const int *__restrict__ goff,
+                                                            double *__restrict__ sums,
                                                             float *__restrict__ ymax, float *__restrict__ ymin,
                                                             int *__restrict__ amax, int *__restrict__ amin) {
   __shared__ float4 s_mx[kT], s_mn[kT];
@@ -137,13 +155,16 @@ __global__ __launch_bounds__(kT) void col_stats_pool_kernel(const float *__restr
   const RowMap m = row_map(c);
   float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
   for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
-    const float *base = y + g * s * c + 4 * m.cq;
+    const long long row0 = goff ? goff[g] : g * s_fixed;
+    const int s = goff ? goff[g + 1] - goff[g] : s_fixed;
+    const float *base = y + row0 * c + 4 * m.cq;
     float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     int4 ax = make_int4(0, 0, 0, 0), an = make_int4(0, 0, 0, 0);
     for (int r = m.rsub; r < s; r += m.rpb) {
       const float4 v = ld4(base + static_cast<long long>(r) * c);
-      acc_stats(acc, v);
+      if (roww) acc_stats_w(acc, v, roww[row0 + r]);
+      else acc_stats(acc, v);
       if (v.x > mx.x) { mx.x = v.x; ax.x = r; }
       if (v.y > mx.y) { mx.y = v.y; ax.y = r; }
       if (v.z > mx.z) { mx.z = v.z; ax.z = r; }
@@ -187,7 +208,9 @@ __global__ __launch_bounds__(kT) void bn_bwd_sparse_kernel(const float *__restri
                                                            const float *__restrict__ d,
                                                            const int *__restrict__ sel,
                                                            const float *__restrict__ coef,  // [5][C]
-                                                           long long groups, int s, int c,
+                                                           long long groups, int s_fixed, int c,
+                                                           const float *__restrict__ roww,
+                                                           const int *__restrict__ goff,
                                                            float *__restrict__ dy) {
   const RowMap m = row_map(c);
   const float4 a = ld4(coef + 4 * m.cq), m1 = ld4(coef + c + 4 * m.cq), m2 = ld4(coef + 2 * c + 4 * m.cq),
@@ -196,14 +219,17 @@ __global__ __launch_bounds__(kT) void bn_bwd_sparse_kernel(const float *__restri
     const long long o = g * c + 4 * m.cq;
     const float4 dg = ld4(d + o);
     const int4 sg = *reinterpret_cast<const int4 *>(sel + o);
+    const long long row0 = goff ? goff[g] : g * s_fixed;
+    const int s = goff ? goff[g + 1] - goff[g] : s_fixed;
     for (int r = m.rsub; r < s; r += m.rpb) {
-      const long long off = (g * s + r) * c + 4 * m.cq;
+      const long long off = (row0 + r) * c + 4 * m.cq;
       const float4 v = ld4(y + off);
+      const float w = roww ? roww[row0 + r] : 1.0f;  // the row's gradient stands for w identical rows
       float4 out;
-      out.x = a.x * ((r == sg.x ? dg.x : 0.f) - m1.x - (v.x - mu.x) * is.x * m2.x);
-      out.y = a.y * ((r == sg.y ? dg.y : 0.f) - m1.y - (v.y - mu.y) * is.y * m2.y);
-      out.z = a.z * ((r == sg.z ? dg.z : 0.f) - m1.z - (v.z - mu.z) * is.z * m2.z);
-      out.w = a.w * ((r == sg.w ? dg.w : 0.f) - m1.w - (v.w - mu.w) * is.w * m2.w);
+      out.x = a.x * ((r == sg.x ? dg.x : 0.f) - w * (m1.x + (v.x - mu.x) * is.x * m2.x));
+      out.y = a.y * ((r == sg.y ? dg.y : 0.f) - w * (m1.y + (v.y - mu.y) * is.y * m2.y));
+      out.z = a.z * ((r == sg.z ? dg.z : 0.f) - w * (m1.z + (v.z - mu.z) * is.z * m2.z));
+      out.w = a.w * ((r == sg.w ? dg.w : 0.f) - w * (m1.w + (v.w - mu.w) * is.w * m2.w));
       st4(dy + off, out);
     }
   }
@@ -222,8 +248,9 @@ __global__ __launch_bounds__(kT) void relu_bn_bwd_stats_kernel(const float *__re
   const float4 a = ld4(prm + 4 * m.cq), b = ld4(prm + c + 4 * m.cq), mu = ld4(prm + 2 * c + 4 * m.cq),
                is = ld4(prm + 3 * c + 4 * m.cq);
   float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-  const long long r0 = static_cast<long long>(blockIdx.x) * kRowsPerBlock;
-  const long long r1 = min(r0 + kRowsPerBlock, p);
+  const long long rows_pb = block_rows(p, m.rpb);
+  const long long r0 = static_cast<long long>(blockIdx.x) * rows_pb;
+  const long long r1 = min(r0 + rows_pb, p);
   for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
     const float4 y = FROM_X ? conv3(src + r * 3, w) : ld4(src + r * c + 4 * m.cq);
     const float4 g = ld4(da + r * c + 4 * m.cq);
@@ -244,7 +271,8 @@ __global__ __launch_bounds__(kT) void relu_bn_bwd_apply_kernel(const float *__re
                                                                const float *__restrict__ src,
                                                                const float *__restrict__ w1,
                                                                const float *__restrict__ prm, long long p,
-                                                               int c, float *__restrict__ dy,
+                                                               int c, const float *__restrict__ roww,
+                                                               float *__restrict__ dy,
                                                                double *__restrict__ dw1) {
   const RowMap m = row_map(c);
   W4 w;
@@ -253,17 +281,19 @@ __global__ __launch_bounds__(kT) void relu_bn_bwd_apply_kernel(const float *__re
                is = ld4(prm + 3 * c + 4 * m.cq), ca = ld4(prm + 4 * c + 4 * m.cq),
                m1 = ld4(prm + 5 * c + 4 * m.cq), m2 = ld4(prm + 6 * c + 4 * m.cq);
   float4 acc[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-  const long long r0 = static_cast<long long>(blockIdx.x) * kRowsPerBlock;
-  const long long r1 = min(r0 + kRowsPerBlock, p);
+  const long long rows_pb = block_rows(p, m.rpb);
+  const long long r0 = static_cast<long long>(blockIdx.x) * rows_pb;
+  const long long r1 = min(r0 + rows_pb, p);
   for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
     const float4 y = FROM_X ? conv3(src + r * 3, w) : ld4(src + r * c + 4 * m.cq);
     const float4 g = ld4(da + r * c + 4 * m.cq);
     const float4 act = affine(y, a, b);
+    const float wr = roww ? roww[r] : 1.0f;
     float4 out;
-    out.x = ca.x * ((act.x > 0.f ? g.x : 0.f) - m1.x - (y.x - mu.x) * is.x * m2.x);
-    out.y = ca.y * ((act.y > 0.f ? g.y : 0.f) - m1.y - (y.y - mu.y) * is.y * m2.y);
-    out.z = ca.z * ((act.z > 0.f ? g.z : 0.f) - m1.z - (y.z - mu.z) * is.z * m2.z);
-    out.w = ca.w * ((act.w > 0.f ? g.w : 0.f) - m1.w - (y.w - mu.w) * is.w * m2.w);
+    out.x = ca.x * ((act.x > 0.f ? g.x : 0.f) - wr * (m1.x + (y.x - mu.x) * is.x * m2.x));
+    out.y = ca.y * ((act.y > 0.f ? g.y : 0.f) - wr * (m1.y + (y.y - mu.y) * is.y * m2.y));
+    out.z = ca.z * ((act.z > 0.f ? g.z : 0.f) - wr * (m1.z + (y.z - mu.z) * is.z * m2.z));
+    out.w = ca.w * ((act.w > 0.f ? g.w : 0.f) - wr * (m1.w + (y.w - mu.w) * is.w * m2.w));
     if (FROM_X) {
       const float x0 = src[r * 3], x1 = src[r * 3 + 1], x2 = src[r * 3 + 2];
       acc[0].x += out.x * x0; acc[0].y += out.y * x0; acc[0].z += out.z * x0; acc[0].w += out.w * x0;
@@ -277,15 +307,18 @@ __global__ __launch_bounds__(kT) void relu_bn_bwd_apply_kernel(const float *__re
 }
 
 bool bad_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0 || (kT % (c / 4)) != 0; }
-int nblocks(long long p) { return static_cast<int>((p + kRowsPerBlock - 1) / kRowsPerBlock); }
+int nblocks(long long p) {
+  const long long want = (p + 255) / 256;  // at least 256 rows per block
+  return static_cast<int>(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+}
 
 }  // namespace
 }  // namespace coda
 
 using namespace coda;
 
-CODA_API int coda_sa_col_stats_f32(const float *src, const float *w1, long long p, int c, double *sums,
-                                   void *stream) {
+CODA_API int coda_sa_col_stats_f32(const float *src, const float *w1, long long p, int c, const float *row_weight,
+                                   double *sums, void *stream) {
   if (p < 0 || bad_c(c) || !sums) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s);
@@ -293,8 +326,8 @@ CODA_API int coda_sa_col_stats_f32(const float *src, const float *w1, long long 
   if (p == 0) return CODA_OK;
   if (!src) return CODA_EINVAL;
   clear_sticky_error();
-  if (w1) hipLaunchKernelGGL(col_stats_kernel<true>, dim3(nblocks(p)), dim3(kT), 0, s, src, w1, p, c, sums);
-  else hipLaunchKernelGGL(col_stats_kernel<false>, dim3(nblocks(p)), dim3(kT), 0, s, src, w1, p, c, sums);
+  if (w1) hipLaunchKernelGGL(col_stats_kernel<true>, dim3(nblocks(p)), dim3(kT), 0, s, src, w1, p, c, row_weight, sums);
+  else hipLaunchKernelGGL(col_stats_kernel<false>, dim3(nblocks(p)), dim3(kT), 0, s, src, w1, p, c, row_weight, sums);
   return launch_status();
 }
 
@@ -310,10 +343,11 @@ CODA_API int coda_sa_bn_relu_apply_f32(const float *src, const float *w1, const 
   return launch_status();
 }
 
-CODA_API int coda_sa_col_stats_pool_f32(const float *y, long long groups, int s_len, int c, double *sums,
+CODA_API int coda_sa_col_stats_pool_f32(const float *y, long long groups, int s_len, int c,
+                                        const float *row_weight, const int32_t *group_offsets, double *sums,
                                         float *ymax, float *ymin, int32_t *amax, int32_t *amin,
                                         void *stream) {
-  if (groups < 0 || s_len <= 0 || bad_c(c) || !sums) return CODA_EINVAL;
+  if (groups < 0 || (s_len <= 0 && !group_offsets) || bad_c(c) || !sums) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s);
   if (e != hipSuccess) return static_cast<int>(e);
@@ -321,20 +355,21 @@ CODA_API int coda_sa_col_stats_pool_f32(const float *y, long long groups, int s_
   if (!y || !ymax || !ymin || !amax || !amin) return CODA_EINVAL;
   const int grid = static_cast<int>(groups < 4096 ? groups : 4096);
   clear_sticky_error();
-  hipLaunchKernelGGL(col_stats_pool_kernel, dim3(grid), dim3(kT), 0, s, y, groups, s_len, c, sums, ymax, ymin,
-                     amax, amin);
+  hipLaunchKernelGGL(col_stats_pool_kernel, dim3(grid), dim3(kT), 0, s, y, groups, s_len, c, row_weight,
+                     group_offsets, sums, ymax, ymin, amax, amin);
   return launch_status();
 }
 
 CODA_API int coda_sa_bn_bwd_sparse_f32(const float *y, const float *d, const int32_t *sel, const float *coef,
-                                       long long groups, int s_len, int c, float *dy, void *stream) {
-  if (groups < 0 || s_len <= 0 || bad_c(c)) return CODA_EINVAL;
+                                       long long groups, int s_len, int c, const float *row_weight,
+                                       const int32_t *group_offsets, float *dy, void *stream) {
+  if (groups < 0 || (s_len <= 0 && !group_offsets) || bad_c(c)) return CODA_EINVAL;
   if (groups == 0) return CODA_OK;
   if (!y || !d || !sel || !coef || !dy) return CODA_EINVAL;
   const int grid = static_cast<int>(groups < 8192 ? groups : 8192);
   clear_sticky_error();
   hipLaunchKernelGGL(bn_bwd_sparse_kernel, dim3(grid), dim3(kT), 0, static_cast<hipStream_t>(stream), y, d, sel,
-                     coef, groups, s_len, c, dy);
+                     coef, groups, s_len, c, row_weight, group_offsets, dy);
   return launch_status();
 }
 
@@ -354,8 +389,8 @@ CODA_API int coda_sa_relu_bn_bwd_stats_f32(const float *da, const float *src, co
 }
 
 CODA_API int coda_sa_relu_bn_bwd_apply_f32(const float *da, const float *src, const float *w1,
-                                           const float *prm, long long p, int c, float *dy, double *dw1,
-                                           void *stream) {
+                                           const float *prm, long long p, int c, const float *row_weight,
+                                           float *dy, double *dw1, void *stream) {
   if (p < 0 || bad_c(c)) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (w1) {
@@ -368,7 +403,7 @@ CODA_API int coda_sa_relu_bn_bwd_apply_f32(const float *da, const float *src, co
   if (p == 0) return CODA_OK;
   if (!da || !src || !prm) return CODA_EINVAL;
   clear_sticky_error();
-  if (w1) hipLaunchKernelGGL(relu_bn_bwd_apply_kernel<true>, dim3(nblocks(p)), dim3(kT), 0, s, da, src, w1, prm, p, c, dy, dw1);
-  else hipLaunchKernelGGL(relu_bn_bwd_apply_kernel<false>, dim3(nblocks(p)), dim3(kT), 0, s, da, src, w1, prm, p, c, dy, dw1);
+  if (w1) hipLaunchKernelGGL(relu_bn_bwd_apply_kernel<true>, dim3(nblocks(p)), dim3(kT), 0, s, da, src, w1, prm, p, c, row_weight, dy, dw1);
+  else hipLaunchKernelGGL(relu_bn_bwd_apply_kernel<false>, dim3(nblocks(p)), dim3(kT), 0, s, da, src, w1, prm, p, c, row_weight, dy, dw1);
   return launch_status();
 }

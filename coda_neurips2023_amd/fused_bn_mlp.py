@@ -28,7 +28,7 @@ def _p(t):
 
 def _call(name, *args):
     lib = _lib.load()
-    _lib.check(getattr(lib, name)(*args, torch.cuda.current_stream().cuda_stream), name)
+    _lib.check(getattr(lib, name)(*args, _lib.current_stream_handle()), name)
 
 
 def _is_sync(bn):

@@ -25,7 +25,7 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def _call(name, *args):

@@ -169,26 +169,26 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def prefetch_sampling(self, inputs):
-        """Optional: start the pre-encoder's furthest point sampling of an upcoming batch on a
-        side stream (pointnet2_utils.SamplingPrefetcher); ``forward`` on the same
-        ``inputs["point_clouds"]`` tensor then finds the indices ready.  Purely a scheduling
-        aid: outputs are identical with and without it."""
-        npoint = getattr(self.pre_encoder, "npoint", None)
+    def prefetch_sampling(self, inputs, wait_for="current"):
+        """Optional: run the pre-encoder's sampling / grouping of an upcoming batch on a side
+        stream (pointnet2_utils.SamplingPrefetcher); ``forward`` on the same
+        ``inputs["point_clouds"]`` tensor then finds it ready.  Purely a scheduling aid: outputs
+        are identical with and without it (up to fp32 summation order in the batch statistics)."""
         pc = inputs["point_clouds"]
-        if npoint is None or not pc.is_cuda:
+        if not pc.is_cuda or pc.size(-1) > 3 or not hasattr(self.pre_encoder, "prepare"):
             return
         if not hasattr(self, "_sampling_prefetcher"):
             self._sampling_prefetcher = SamplingPrefetcher()
-        self._sampling_prefetcher.submit(pc, npoint)
+        self._sampling_prefetcher.submit(pc, self.pre_encoder, wait_for)
 
     def run_encoder(self, point_clouds):
         xyz, features = self._break_up_pc(point_clouds)
-        inds = None
+        prepared = None
         if hasattr(self, "_sampling_prefetcher"):
-            inds = self._sampling_prefetcher.take(point_clouds, self.pre_encoder.npoint)
-        if inds is not None:
-            pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features, inds)
+            prepared = self._sampling_prefetcher.take(point_clouds)
+        if prepared is not None:
+            pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(prepared["xyz"], features,
+                                                                           prepared=prepared)
         else:
             pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features)
         # (B, C, npoints) -> (npoints, B, C) for the seq-first transformer

@@ -74,7 +74,7 @@ def _check_device(ref, *others):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def _ptr(t):

@@ -23,7 +23,7 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def _call(name, *args):
@@ -42,15 +42,61 @@ def _all_reduce(t, bn):
     return t
 
 
+def count_distinct_rows(idx):
+    """idx (B,M,S) int32 ball-query indices -> (cnt (G,), goff (G+1,) int64, total (1,) int64):
+    distinct rows per group, their exclusive prefix sum and the overall count.  ball_query fills
+    the slots a group has no point for with copies of its FIRST hit (ball_query_gpu.cu:35-48;
+    real hits are distinct ascending indices)."""
+    b, m, s = idx.shape
+    idx2 = idx.view(b * m, s)
+    cnt = (idx2[:, 1:] != idx2[:, :1]).sum(1) + 1
+    goff = torch.zeros(b * m + 1, dtype=torch.int64, device=idx.device)
+    torch.cumsum(cnt, 0, out=goff[1:])
+    return cnt, goff, goff[-1:]
+
+
+def compact_groups(idx, grouped_cl, counts=None, total=None, min_saving=0.25):
+    """De-duplicate the padded groups of a ball query.
+
+    idx (B,M,S) int32, grouped_cl (B,M,S,3).  Identical rows stay identical through the whole
+    shared MLP, so only the distinct rows of a group need to be computed.  Returns
+    ``(x (Pp,3), row_weight (Pp,), group_offsets (G+1,) int32)`` with Pp the number of distinct
+    rows rounded up to a multiple of 2048 (zero rows of weight 0), or None when fewer than
+    ``min_saving`` of the rows are copies.  The row count sizes the GEMMs, so it must be known
+    on the host: pass ``counts`` / ``total`` from an earlier ``count_distinct_rows`` whose
+    result has already been copied back (the sampling prefetcher does), otherwise this call
+    synchronises."""
+    b, m, s = idx.shape
+    g = b * m
+    dev = idx.device
+    cnt, goff, tot = counts if counts is not None else count_distinct_rows(idx)
+    if total is None:
+        total = int(tot.item())
+    if total > (1.0 - min_saving) * g * s:
+        return None
+    pp = -(-total // 2048) * 2048
+    grp = torch.repeat_interleave(torch.arange(g, device=dev), cnt, output_size=total)
+    src = grp * s + (torch.arange(total, device=dev) - goff[grp])
+    x = torch.zeros((pp, 3), dtype=torch.float32, device=dev)
+    x[:total] = grouped_cl.reshape(-1, 3)[src]
+    roww = torch.zeros(pp, dtype=torch.float32, device=dev)
+    roww[:total] = 1.0
+    roww[goff[:-1]] = (s - cnt + 1).to(torch.float32)
+    return x, roww, goff.to(torch.int32)
+
+
 class _FusedMlpPool(torch.autograd.Function):
-    """x (P,3) grouped xyz channels-last, P = groups * nsample.  Returns (groups, C_last)."""
+    """x (P,3) grouped xyz channels-last, P = groups * nsample (or the distinct rows of
+    ``compact_groups`` with ``dedup = (row_weight, group_offsets)``).  Returns (groups, C_last)."""
 
     @staticmethod
-    def forward(ctx, x, groups, nsample, bns, training, *params):
+    def forward(ctx, x, groups, nsample, bns, training, dedup, *params):
         # params: for each layer: conv weight (Cout, Cin[,1,1]), bn weight, bn bias
         nl = len(bns)
         dev = x.device
         p = x.shape[0]
+        roww, goff = dedup if dedup is not None else (None, None)
+        n_rows = groups * nsample  # rows the statistics are taken over (copies included)
         ws = [params[3 * i].reshape(params[3 * i].shape[0], -1) for i in range(nl)]
         gammas = [params[3 * i + 1] for i in range(nl)]
         betas = [params[3 * i + 2] for i in range(nl)]
@@ -78,15 +124,15 @@ class _FusedMlpPool(torch.autograd.Function):
                 amin = torch.empty_like(amax)
                 if i == 0:
                     raise RuntimeError("fused SA MLP needs at least two layers")
-                _call("coda_sa_col_stats_pool_f32", _p(src), groups, nsample, c, _p(s), _p(ymax), _p(ymin),
-                      _p(amax), _p(amin))
+                _call("coda_sa_col_stats_pool_f32", _p(src), groups, nsample, c, _p(roww), _p(goff), _p(s), _p(ymax),
+                      _p(ymin), _p(amax), _p(amin))
                 pool = (ymax, ymin, amax, amin)
             elif training:
-                _call("coda_sa_col_stats_f32", _p(src), _p(w1), p, c, _p(s))
+                _call("coda_sa_col_stats_f32", _p(src), _p(w1), p, c, _p(roww), _p(s))
             bn = bns[i]
             if training:
                 tot = _all_reduce(s.clone(), bn)
-                n = float(p * world[i])
+                n = float(n_rows * world[i])
                 mean = tot[:c] / n
                 var = (tot[c:] / n - mean * mean).clamp_(min=0.0)
                 invstd = torch.rsqrt(var + bn.eps)
@@ -119,7 +165,8 @@ class _FusedMlpPool(torch.autograd.Function):
         sel = torch.where(pos, amax, amin)
         out = torch.relu(ysel * scale + shift)   # (groups, C)
 
-        ctx.meta = (groups, nsample, bns, training, nl, world)
+        ctx.meta = (groups, nsample, bns, training, nl, world, n_rows)
+        ctx.dedup = dedup
         ctx.wshape = [params[3 * i].shape for i in range(nl)]
         ctx.stats = stats
         ctx.save_for_backward(x, ysel, sel, out, *[t for t in saved_pre if t is not None], *saved_act, *ws, *gammas)
@@ -128,7 +175,8 @@ class _FusedMlpPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        groups, nsample, bns, training, nl, world = ctx.meta
+        groups, nsample, bns, training, nl, world, n_rows = ctx.meta
+        roww, goff = ctx.dedup if ctx.dedup is not None else (None, None)
         saved = ctx.saved_tensors
         x, ysel, sel, out = saved[:4]
         pres = [None] + list(saved[4:4 + ctx.n_pre])              # pre-BN activations of layers 1..nl-1
@@ -151,16 +199,17 @@ class _FusedMlpPool(torch.autograd.Function):
         grads[3 * i + 1] = sum_dx.to(torch.float32)              # d gamma
         if training:
             tot = _all_reduce(torch.cat([sum_d, sum_dx]), bns[i])
-            n = float(p * world[i])
+            n = float(n_rows * world[i])
             m1 = (tot[:c] / n).to(torch.float32)
             m2 = (tot[c:] / n).to(torch.float32)
         else:
             m1 = torch.zeros(c, device=dev)
             m2 = torch.zeros(c, device=dev)
         coef = torch.stack([gammas[i] * invstd, m1, m2, mean, invstd]).contiguous()
-        dy = torch.empty((p, c), dtype=torch.float32, device=dev)
+        # de-duplicated rows: the padding rows past the last group belong to no group and stay zero
+        dy = (torch.zeros if roww is not None else torch.empty)((p, c), dtype=torch.float32, device=dev)
         _call("coda_sa_bn_bwd_sparse_f32", _p(pres[i]), _p(d), _p(sel.contiguous()), _p(coef), groups, nsample, c,
-              _p(dy))
+              _p(roww), _p(goff), _p(dy))
 
         # ---- hidden layers, top down
         while True:
@@ -181,7 +230,7 @@ class _FusedMlpPool(torch.autograd.Function):
             grads[3 * i + 1] = sums[c:].to(torch.float32)
             if training:
                 tot = _all_reduce(sums.clone(), bns[i])
-                n = float(p * world[i])
+                n = float(n_rows * world[i])
                 m1 = (tot[:c] / n).to(torch.float32)
                 m2 = (tot[c:] / n).to(torch.float32)
             else:
@@ -190,23 +239,35 @@ class _FusedMlpPool(torch.autograd.Function):
             prm7 = torch.stack([scale, shift, mean, invstd, gammas[i] * invstd, m1, m2]).contiguous()
             if first:
                 dw1 = torch.empty(3 * c, dtype=torch.float64, device=dev)
-                _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), _p(w1), _p(prm7), p, c, None, _p(dw1))
+                _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), _p(w1), _p(prm7), p, c, _p(roww), None, _p(dw1))
                 grads[0] = dw1.view(3, c).t().to(torch.float32).reshape(ctx.wshape[0])
                 break
-            _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), None, _p(prm7), p, c, _p(da), None)
+            _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), None, _p(prm7), p, c, _p(roww), _p(da), None)
             dy = da
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
-def fused_mlp_pool(x_cl, groups, nsample, mlp_module):
-    """x_cl (P,3) float32 cuda; mlp_module: the reference-shaped SharedMLP.  -> (groups, C_last)."""
+def fused_mlp_pool(x_cl, groups, nsample, mlp_module, idx=None, counts=None, total=None):
+    """x_cl (P,3) float32 cuda grouped xyz (P = groups*nsample rows); mlp_module: the
+    reference-shaped SharedMLP; idx: the ball-query indices (B,M,S) the rows came from.
+    Padded copies inside a group are computed once (``compact_groups``) when the distinct-row
+    count is already on the host (``counts`` / ``total`` from a prefetched preparation) or when
+    ``CODA_SA_DEDUP=1`` accepts a synchronisation for it; ``CODA_SA_DEDUP=0`` never de-duplicates.
+    -> (groups, C_last)."""
     layers = list(mlp_module.children())
     bns = [layer.bn.bn for layer in layers]
     params = []
     for layer in layers:
         params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
     training = bns[0].training
-    return _FusedMlpPool.apply(x_cl, groups, nsample, bns, training, *params)
+    dedup = None
+    mode = os.environ.get("CODA_SA_DEDUP", "auto")
+    if idx is not None and mode != "0" and (total is not None or mode == "1"):
+        compact = compact_groups(idx, x_cl, counts, total)
+        if compact is not None:
+            x_cl, roww, goff = compact
+            dedup = (roww, goff)
+    return _FusedMlpPool.apply(x_cl, groups, nsample, bns, training, dedup, *params)
 
 
 def eligible(mlp_module, features, use_xyz, pooling, xyz):

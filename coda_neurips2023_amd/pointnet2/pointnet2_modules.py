@@ -51,11 +51,41 @@ class PointnetSAModuleVotes(nn.Module):
             mlp_spec[0] += 3  # in place, like the reference (:201-203)
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
+    def _fused(self, xyz, features):
+        return (self.npoint is not None and not self.ret_unique_cnt and not self.grouper.sample_uniformly
+                and not xyz.requires_grad
+                and fused_sa_mlp.eligible(self.mlp_module, features, self.use_xyz, self.pooling, xyz))
+
+    def prepare(self, xyz: torch.Tensor):
+        """The parameter-free front of ``forward`` for an xyz-only module -- sampling, gathering
+        the centres, ball query + grouping, distinct-row counts -- on the CURRENT stream, with the
+        row count on its way to pinned host memory.  ``pointnet2_utils.SamplingPrefetcher`` runs
+        this for an upcoming batch on a side stream; ``forward(..., prepared=...)`` continues from
+        it.  Returns None when the module's configuration is not the fused xyz-only one."""
+        if not self._fused(xyz, None):
+            return None
+        inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        idx, grouped_cl = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample,
+                                                   self.normalize_xyz, channels_last=True)
+        cnt, goff, tot = fused_sa_mlp.count_distinct_rows(idx)
+        total_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        total_host.copy_(tot, non_blocking=True)
+        return {"xyz": xyz, "inds": inds, "new_xyz": new_xyz, "idx": idx, "grouped_cl": grouped_cl,
+                "counts": (cnt, goff, tot), "total_host": total_host}
+
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None,
-                inds: torch.Tensor = None):
+                inds: torch.Tensor = None, prepared: dict = None):
         """xyz (B,N,3), features (B,C,N) or None, inds (B,npoint) or None ->
         new_xyz (B,npoint,3), new_features (B,mlp[-1],npoint), inds (B,npoint)
-        [, unique_cnt]."""
+        [, unique_cnt].  ``prepared``: the result of ``prepare`` on this very xyz (its host-side
+        row count must have arrived, i.e. the stream it ran on has been waited for)."""
+        if prepared is not None and features is None and self._fused(xyz, None):
+            b, npoint = prepared["new_xyz"].shape[0], prepared["new_xyz"].shape[1]
+            pooled = fused_sa_mlp.fused_mlp_pool(prepared["grouped_cl"].view(-1, 3), b * npoint, self.nsample,
+                                                 self.mlp_module, idx=prepared["idx"], counts=prepared["counts"],
+                                                 total=int(prepared["total_host"][0]))
+            return prepared["new_xyz"], pooled.view(b, npoint, -1).permute(0, 2, 1), prepared["inds"]
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
@@ -67,16 +97,14 @@ class PointnetSAModuleVotes(nn.Module):
         else:
             new_xyz = None
 
-        if (self.npoint is not None and not self.ret_unique_cnt and not self.grouper.sample_uniformly
-                and not xyz.requires_grad
-                and fused_sa_mlp.eligible(self.mlp_module, features, self.use_xyz, self.pooling, xyz)):
+        if self._fused(xyz, features):
             # xyz-only set abstraction (the model's pre-encoder): fused ball query + grouping into
             # channels-last, then the fused shared MLP + batch norm + ReLU + max-pool
-            _, grouped_cl = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample,
-                                                     self.normalize_xyz, channels_last=True)
+            idx, grouped_cl = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample,
+                                                       self.normalize_xyz, channels_last=True)
             b, npoint = new_xyz.shape[0], new_xyz.shape[1]
             pooled = fused_sa_mlp.fused_mlp_pool(grouped_cl.view(-1, 3), b * npoint, self.nsample,
-                                                 self.mlp_module)
+                                                 self.mlp_module, idx=idx)
             new_features = pooled.view(b, npoint, -1).permute(0, 2, 1)  # (B, mlp[-1], npoint)
             return new_xyz, new_features, inds
 

@@ -30,16 +30,23 @@ furthest_point_sample = FurthestPointSampling.apply
 
 
 class SamplingPrefetcher:
-    """Furthest point sampling of an UPCOMING batch on a side HIP stream.
+    """Sampling / grouping of an UPCOMING batch on a side HIP stream.
 
     FPS is ``npoint`` strictly dependent rounds on one workgroup per scene: for a batch of 8
     scenes it keeps 8 of the 256 CUs busy for milliseconds, and everything else in the model
     waits for its indices.  A training loop knows its next batch while the current step runs,
-    so ``submit(point_clouds, npoint)`` starts the sampling of that batch on a side stream
-    (the other 248 CUs keep working on the current step) and the model's forward picks the
-    indices up with ``take`` -- same kernel, same indices, no host synchronisation.  Entries
-    are matched by tensor identity + version, so a batch that was modified or never submitted
-    simply samples in line.
+    so ``submit(point_clouds, module)`` runs the parameter-free front of the set-abstraction
+    module (``PointnetSAModuleVotes.prepare``: FPS, centre gather, ball query + grouping,
+    distinct-row counts) for that batch on a side stream -- the other 248 CUs keep working on
+    the current step -- and the model's forward picks the result up with ``take``: same
+    kernels, same values, no host synchronisation on the compute stream.  Because the
+    distinct-row count has reached the host by then, the shared MLP can run on de-duplicated
+    groups without stalling.  Entries are matched by tensor identity + version, so a batch
+    that was modified or never submitted is simply processed in line.
+
+    ``wait_for``: what the side stream has to wait for before it reads the batch -- "current"
+    (default: everything enqueued on the caller's stream so far), a ``torch.cuda.Event`` (e.g.
+    the batch's host-to-device copy), or None when the batch is known to be resident.
     """
 
     def __init__(self, max_pending=4):
@@ -47,29 +54,38 @@ class SamplingPrefetcher:
         self._pending = []
         self._max = max_pending
 
-    def submit(self, point_clouds, npoint):
+    def submit(self, point_clouds, module, wait_for="current"):
         dev = point_clouds.device
-        cur = torch.cuda.current_stream(dev)
         if self._stream is None or self._stream.device != dev:
             self._stream = torch.cuda.Stream(device=dev)
-        self._stream.wait_stream(cur)  # the batch is produced on the caller's stream
-        with torch.cuda.stream(self._stream):
+        if isinstance(wait_for, torch.cuda.Event):
+            self._stream.wait_event(wait_for)
+        elif wait_for == "current":
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._stream), torch.no_grad():
             xyz = point_clouds[..., 0:3].contiguous()
-            inds = furthest_point_sample(xyz, npoint)
+            prepared = module.prepare(xyz)
+            if prepared is None:
+                return False
             done = torch.cuda.Event()
             done.record(self._stream)
-        self._pending.append((point_clouds, point_clouds._version, int(npoint), inds, xyz, done))
+        self._pending.append((point_clouds, point_clouds._version, prepared, done))
         del self._pending[:-self._max]
+        return True
 
-    def take(self, point_clouds, npoint):
-        """The prefetched (B, npoint) indices of this very tensor, or None."""
-        for k, (pc, version, n, inds, _xyz, done) in enumerate(self._pending):
-            if pc is point_clouds and version == point_clouds._version and n == int(npoint):
+    def take(self, point_clouds):
+        """The prepared front of this very tensor (see ``PointnetSAModuleVotes.prepare``), or None."""
+        for k, (pc, version, prepared, done) in enumerate(self._pending):
+            if pc is point_clouds and version == point_clouds._version:
                 del self._pending[k]
+                done.synchronize()  # host: the row count has landed (normally long ago)
                 cur = torch.cuda.current_stream(point_clouds.device)
                 cur.wait_event(done)
-                inds.record_stream(cur)
-                return inds
+                for v in prepared.values():
+                    for t in (v if isinstance(v, tuple) else (v,)):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
+                return prepared
         return None
 
 

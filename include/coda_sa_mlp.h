@@ -13,6 +13,14 @@
  * when NULL, `src` is the stored pre-BN activation (P,C).
  * Statistics (`sums`, 2*C doubles: per-channel sum, then sum of squares / or sum d,
  * then sum d*xhat in the backward) are zeroed by the call.
+ *
+ * De-duplicated groups.  ball_query pads a group that has fewer than nsample points in its
+ * radius with copies of its first hit (ball_query_gpu.cu:35-48), and every layer of the MLP
+ * maps identical rows to identical rows, so the caller may store each group as its DISTINCT
+ * rows only (variable length, `group_offsets` (G+1) row offsets) with a per-row multiplicity
+ * `row_weight` (1, or 1 + number of copies for the first row of a group): statistics count a
+ * row `row_weight` times, pooling is unaffected, and in the backward a row carries the SUM of
+ * the gradients of the rows it stands for.  Both pointers NULL = dense groups of s_len rows.
  */
 #ifndef CODA_SA_MLP_H
 #define CODA_SA_MLP_H
@@ -26,7 +34,7 @@ extern "C" {
 
 /* sums[0:C] = sum_p y, sums[C:2C] = sum_p y^2 */
 int coda_sa_col_stats_f32(const float *src, const float *w1, long long p, int c,
-                          double *sums, void *stream);
+                          const float *row_weight, double *sums, void *stream);
 /* dst = relu(y * scale + shift) */
 int coda_sa_bn_relu_apply_f32(const float *src, const float *w1, const float *scale,
                               const float *shift, long long p, int c, float *dst,
@@ -34,24 +42,27 @@ int coda_sa_bn_relu_apply_f32(const float *src, const float *w1, const float *sc
 /* last layer: statistics + per-(group, channel) max / min over the s_len rows of a group
  * and the row index (0..s_len-1) where they occur (lowest on ties) */
 int coda_sa_col_stats_pool_f32(const float *y, long long groups, int s_len, int c,
+                               const float *row_weight, const int32_t *group_offsets,
                                double *sums, float *ymax, float *ymin,
                                int32_t *amax, int32_t *amin, void *stream);
 /* backward of max-pool + ReLU + BN of the last layer; coef = [a, m1, m2, mean, invstd][C]:
- * dy[p][c] = a * ((row == sel ? d : 0) - m1 - (y - mean) * invstd * m2) */
+ * dy[p][c] = a * ((row == sel ? d : 0) - w_p * (m1 + (y - mean) * invstd * m2)) */
 int coda_sa_bn_bwd_sparse_f32(const float *y, const float *d, const int32_t *sel,
                               const float *coef, long long groups, int s_len, int c,
+                              const float *row_weight, const int32_t *group_offsets,
                               float *dy, void *stream);
 /* hidden layers, prm = [scale, shift, mean, invstd][C]; d = da where scale*y+shift > 0:
  * sums[0:C] = sum d, sums[C:2C] = sum d * (y - mean) * invstd */
 int coda_sa_relu_bn_bwd_stats_f32(const float *da, const float *src, const float *w1,
                                   const float *prm, long long p, int c, double *sums,
                                   void *stream);
-/* prm = [scale, shift, mean, invstd, a, m1, m2][C]; dy = a * (d - m1 - xhat * m2).
+/* prm = [scale, shift, mean, invstd, a, m1, m2][C]; dy = a * (d - w_p * (m1 + xhat * m2)).
  * w1 == NULL: dy (P,C) is written (may alias da).  w1 != NULL (first layer): dy is not
  * stored, dw1[k*C + c] = sum_p dy[p][c] * x[p][k] (3*C doubles, zeroed by the call). */
 int coda_sa_relu_bn_bwd_apply_f32(const float *da, const float *src, const float *w1,
-                                  const float *prm, long long p, int c, float *dy,
-                                  double *dw1, void *stream);
+                                  const float *prm, long long p, int c,
+                                  const float *row_weight, float *dy, double *dw1,
+                                  void *stream);
 
 #ifdef __cplusplus
 }

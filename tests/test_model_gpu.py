@@ -124,9 +124,10 @@ def test_prefetched_sampling_gives_identical_outputs(dev):
         got = model(inputs)["outputs"]
         assert len(model._sampling_prefetcher._pending) == 0  # consumed
         for k in ["center_normalized", "sem_cls_logits", "box_corners"]:
-            assert torch.equal(got[k], ref[k]), k
+            # same indices and groups; the shared MLP may run on de-duplicated rows (summation order)
+            assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-5), k
         model.prefetch_sampling(inputs)
         inputs["point_clouds"].mul_(1.0)  # version bump: the stale entry must not be used
         other = model(inputs)["outputs"]
         assert len(model._sampling_prefetcher._pending) == 1
-        assert torch.equal(other["center_normalized"], ref["center_normalized"])
+        assert torch.allclose(other["center_normalized"], ref["center_normalized"], rtol=1e-4, atol=1e-5)

@@ -53,8 +53,9 @@ def test_sa_module_matches_reference(dev, golden_sa, tag, c_in):
     _close(new_feat_eval, g[f"{tag}_new_feat_eval"], "eval-mode features")
 
 
+@pytest.mark.parametrize("dedup", ["1", "0"])
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train):
+def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train, dedup):
     """The fused channels-last shared MLP + BN + ReLU + max-pool (csrc/sa_mlp.hip + library GEMMs)
     against the per-layer Conv2d/BatchNorm2d/ReLU/max_pool2d path of the same module, same weights,
     at the pre-encoder's widths [3,64,128,256]: outputs, every parameter gradient and the
@@ -67,6 +68,7 @@ def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train):
 
     def run(kind):
         monkeypatch.setenv("CODA_SA_MLP", kind)
+        monkeypatch.setenv("CODA_SA_DEDUP", dedup)  # padded copies of a group computed once / every row
         torch.manual_seed(3)
         mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=512, radius=0.2,
                                                       nsample=64, normalize_xyz=True).to(dev)
@@ -95,3 +97,34 @@ def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train):
         assert err < 1e-3, f"{k}: {err:.3e}"
     for k in s1:
         assert torch.allclose(s1[k].float(), s2[k].float(), rtol=1e-5, atol=1e-6), k
+
+
+def test_group_compaction(dev):
+    """compact_groups: distinct rows per group, multiplicities summing to nsample, offsets; dense
+    groups (no copies) are left alone."""
+    from coda_neurips2023_amd.pointnet2 import _ext, fused_sa_mlp
+    from coda_neurips2023_amd.synthetic_scenes import make_batch
+    pc, _, _ = make_batch(2, 6000, seed=5)
+    xyz = torch.from_numpy(pc).to(dev)
+    inds = _ext.furthest_point_sampling(xyz, 256)
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx, grouped = _ext.query_and_group_xyz(new_xyz, xyz, 0.2, 64, True, channels_last=True)
+    out = fused_sa_mlp.compact_groups(idx, grouped)
+    assert out is not None
+    x, w, goff = out
+    g = 2 * 256
+    assert x.shape[0] % 2048 == 0 and goff.shape == (g + 1,) and goff.dtype == torch.int32
+    total = int(goff[-1])
+    idx2 = idx.view(g, 64).cpu()
+    grouped2 = grouped.view(g, 64, 3).cpu()
+    goff_c, x_c, w_c = goff.cpu(), x.cpu(), w.cpu()
+    for gi in [0, 1, 17, 255, 256, g - 1]:
+        cnt = len(set(idx2[gi].tolist()))
+        a, b = int(goff_c[gi]), int(goff_c[gi + 1])
+        assert b - a == cnt
+        assert torch.equal(x_c[a:b], grouped2[gi, :cnt])
+        assert float(w_c[a:b].sum()) == 64.0 and float(w_c[a]) == 64 - cnt + 1
+    assert float(w_c[total:].abs().sum()) == 0.0 and float(x_c[total:].abs().sum()) == 0.0
+    # radius large enough that every group is full: nothing to de-duplicate
+    idx_full, grouped_full = _ext.query_and_group_xyz(new_xyz, xyz, 5.0, 16, True, channels_last=True)
+    assert fused_sa_mlp.compact_groups(idx_full, grouped_full) is None

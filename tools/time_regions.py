@@ -13,7 +13,7 @@ from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
 model, step_fn, _, _ = bench.build_workload("model", dev)
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
 pc, mn, mx = make_batch(bench.B_PER_GPU, bench.N_POINTS, seed=1)
 batch = {"point_clouds": torch.from_numpy(pc).to(dev), "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
          "point_cloud_dims_max": torch.from_numpy(mx).to(dev)}
