@@ -22,6 +22,7 @@ from torch import Tensor, nn
 import os
 
 from . import attention_core as _core
+from . import fused_blocks as _fb
 from . import fused_layers as _fl
 from .attention import MultiheadAttention
 from .helpers import ACTIVATION_DICT, NORM_DICT, WEIGHT_INIT_DICT, get_clones
@@ -50,6 +51,11 @@ def _resolve(pend, norm=None, pos=None):
             return pend.res, None, None
         return _fl.add_ln(pend.res, norm=norm, pos=pos)
     return _fl.add_ln(pend.x, norm=norm, bias=pend.bias, res=pend.res, pos=pos, p=pend.p)
+
+
+def _layer_nodes():
+    # A/B switch: "ops" chains the fused_layers blocks through autograd (one node per block)
+    return os.environ.get("CODA_LAYER_NODES", "layer") != "ops"
 
 
 def _drop_p(mod):
@@ -357,10 +363,15 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward_fused(self, pend, src_mask, src_key_padding_mask, pos):
         """``forward_pre`` on a pending residual stream; returns the new pending stream."""
-        s, y, yp = _resolve(pend, self.norm1, pos)
-        tgt_len, bsz, _ = s.shape
-        qk = y if pos is None else yp
+        tgt_len, bsz, _ = pend.res.shape
         mask = _mask_u8(src_mask, src_key_padding_mask, bsz, self.nhead, tgt_len, tgt_len)
+        if _layer_nodes():
+            s, o = _fb.encoder_layer(self, pend, pos, mask)
+            if not self.use_ffn:
+                return _Pending(s, o, self.self_attn.out_proj.bias, _drop_p(self.dropout1))
+            return _Pending(s, o, self.linear2.bias, _drop_p(self.dropout2))
+        s, y, yp = _resolve(pend, self.norm1, pos)
+        qk = y if pos is None else yp
         a = _fl.mha(self.self_attn, qk, qk, y, mask)
         pend = _Pending(s, a, self.self_attn.out_proj.bias, _drop_p(self.dropout1))
         if not self.use_ffn:
@@ -463,6 +474,9 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward_fused(self, pend, memory, memory_pos, query_pos, self_mask, cross_mask):
         """``forward_pre`` on a pending residual stream; returns the new pending stream."""
+        if _layer_nodes():
+            s, o = _fb.decoder_layer(self, pend, memory, memory_pos, query_pos, self_mask, cross_mask)
+            return _Pending(s, o, self.linear2.bias, _drop_p(self.dropout3))
         s, y, yp = _resolve(pend, self.norm1, query_pos)
         qk = y if query_pos is None else yp
         a = _fl.mha(self.self_attn, qk, qk, y, self_mask)

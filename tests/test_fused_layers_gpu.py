@@ -153,8 +153,10 @@ def _run_encoder(dev, env, monkeypatch, src, norm):
     return out, x.grad, {k: p.grad for k, p in enc.named_parameters()}
 
 
+@pytest.mark.parametrize("nodes", ["layer", "ops"])
 @pytest.mark.parametrize("norm", [False, True])
-def test_fused_encoder_equals_module_path(dev, monkeypatch, norm):
+def test_fused_encoder_equals_module_path(dev, monkeypatch, norm, nodes):
+    monkeypatch.setenv("CODA_LAYER_NODES", nodes)  # one autograd node per layer / per block
     src = torch.randn(320, 3, 256, generator=torch.Generator().manual_seed(0)).to(dev)
     out_f, gx_f, gp_f = _run_encoder(dev, "fused", monkeypatch, src, norm)
     out_m, gx_m, gp_m = _run_encoder(dev, "modules", monkeypatch, src, norm)
@@ -177,7 +179,9 @@ def _run_decoder(dev, env, monkeypatch, tgt, memory, pos, query_pos):
     return out, m.grad, qp.grad, {k: p.grad for k, p in dec.named_parameters()}
 
 
-def test_fused_decoder_equals_module_path(dev, monkeypatch):
+@pytest.mark.parametrize("nodes", ["layer", "ops"])
+def test_fused_decoder_equals_module_path(dev, monkeypatch, nodes):
+    monkeypatch.setenv("CODA_LAYER_NODES", nodes)
     gen = torch.Generator().manual_seed(4)
     nq, nmem, b = 64, 300, 3
     tgt = torch.zeros(nq, b, 256, device=dev)
