@@ -200,6 +200,64 @@ __global__ __launch_bounds__(kT) void col_stats_pool_kernel(const float *__restr
   block_reduce_to_global<2>(acc, m, c, sums);
 }
 
+// C == 256: a row is exactly one wave wide, so each of the 4 waves of a block walks its own group
+// (4 row loads in flight) with no LDS exchange or barrier per group -- with de-duplicated groups
+// of ~16 rows the per-group synchronisation of the kernel above costs more than the data.
+__device__ __forceinline__ void pool_step(float4 v, int r, float4 &mx, float4 &mn, int4 &ax, int4 &an) {
+  if (v.x > mx.x) { mx.x = v.x; ax.x = r; }
+  if (v.y > mx.y) { mx.y = v.y; ax.y = r; }
+  if (v.z > mx.z) { mx.z = v.z; ax.z = r; }
+  if (v.w > mx.w) { mx.w = v.w; ax.w = r; }
+  if (v.x < mn.x) { mn.x = v.x; an.x = r; }
+  if (v.y < mn.y) { mn.y = v.y; an.y = r; }
+  if (v.z < mn.z) { mn.z = v.z; an.z = r; }
+  if (v.w < mn.w) { mn.w = v.w; an.w = r; }
+}
+__global__ __launch_bounds__(kT) void col_stats_pool_wave_kernel(const float *__restrict__ y, long long groups,
+                                                                 int s_fixed, const float *__restrict__ roww,
+                                                                 const int *__restrict__ goff,
+                                                                 double *__restrict__ sums,
+                                                                 float *__restrict__ ymax, float *__restrict__ ymin,
+                                                                 int *__restrict__ amax, int *__restrict__ amin) {
+  constexpr int c = 256;
+  const RowMap m = row_map(c);  // tpr = 64: cq = lane, rsub = wave
+  float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+  for (long long g = static_cast<long long>(blockIdx.x) * 4 + m.rsub; g < groups;
+       g += static_cast<long long>(gridDim.x) * 4) {
+    const long long row0 = goff ? goff[g] : g * s_fixed;
+    const int s = goff ? goff[g + 1] - goff[g] : s_fixed;
+    const float *base = y + row0 * c + 4 * m.cq;
+    float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    int4 ax = make_int4(0, 0, 0, 0), an = make_int4(0, 0, 0, 0);
+    int r = 0;
+    for (; r + 4 <= s; r += 4) {
+      const float4 v0 = ld4(base + static_cast<long long>(r) * c), v1 = ld4(base + static_cast<long long>(r + 1) * c),
+                   v2 = ld4(base + static_cast<long long>(r + 2) * c), v3 = ld4(base + static_cast<long long>(r + 3) * c);
+      if (roww) {
+        acc_stats_w(acc, v0, roww[row0 + r]); acc_stats_w(acc, v1, roww[row0 + r + 1]);
+        acc_stats_w(acc, v2, roww[row0 + r + 2]); acc_stats_w(acc, v3, roww[row0 + r + 3]);
+      } else {
+        acc_stats(acc, v0); acc_stats(acc, v1); acc_stats(acc, v2); acc_stats(acc, v3);
+      }
+      pool_step(v0, r, mx, mn, ax, an); pool_step(v1, r + 1, mx, mn, ax, an);
+      pool_step(v2, r + 2, mx, mn, ax, an); pool_step(v3, r + 3, mx, mn, ax, an);
+    }
+    for (; r < s; ++r) {
+      const float4 v = ld4(base + static_cast<long long>(r) * c);
+      if (roww) acc_stats_w(acc, v, roww[row0 + r]);
+      else acc_stats(acc, v);
+      pool_step(v, r, mx, mn, ax, an);
+    }
+    const long long o = g * c + 4 * m.cq;
+    st4(ymax + o, mx);
+    st4(ymin + o, mn);
+    *reinterpret_cast<int4 *>(amax + o) = ax;
+    *reinterpret_cast<int4 *>(amin + o) = an;
+  }
+  block_reduce_to_global<2>(acc, m, c, sums);
+}
+
 // ---- backward --------------------------------------------------------------------------
 // Last layer.  d (G,C) is the gradient that survived max-pool + ReLU, living at sample
 // sel[g][c] of its group; BN backward makes it dense:
@@ -355,8 +413,14 @@ CODA_API int coda_sa_col_stats_pool_f32(const float *y, long long groups, int s_
   if (!y || !ymax || !ymin || !amax || !amin) return CODA_EINVAL;
   const int grid = static_cast<int>(groups < 4096 ? groups : 4096);
   clear_sticky_error();
-  hipLaunchKernelGGL(col_stats_pool_kernel, dim3(grid), dim3(kT), 0, s, y, groups, s_len, c, row_weight,
-                     group_offsets, sums, ymax, ymin, amax, amin);
+  if (c == 256) {
+    const long long want = (groups + 3) / 4;
+    hipLaunchKernelGGL(col_stats_pool_wave_kernel, dim3(static_cast<int>(want < 2048 ? want : 2048)), dim3(kT), 0, s,
+                       y, groups, s_len, row_weight, group_offsets, sums, ymax, ymin, amax, amin);
+  } else {
+    hipLaunchKernelGGL(col_stats_pool_kernel, dim3(grid), dim3(kT), 0, s, y, groups, s_len, c, row_weight,
+                       group_offsets, sums, ymax, ymin, amax, amin);
+  }
   return launch_status();
 }
 

@@ -350,7 +350,8 @@ CODA_API int coda_tok_add_ln_bwd_blocks(long long rows, int c) {
 CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, const float *s_in,
                                      const float *mean, const float *rstd, const float *gamma, long long rows,
                                      int c, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
-                                     float *dres_out, float *dx_out, float *partials, void *stream) {
+                                     float *dres_out, float *dx_out, float *partials, float *sums_out,
+                                     void *stream) {
   if (rows < 0 || bad_ln_c(c) || bad_p(dropout_p) || !partials) return CODA_EINVAL;
   if (gamma && (!s_in || !mean || !rstd || (!dy && !dyp))) return CODA_EINVAL;
   if (!gamma && !ds) return CODA_EINVAL;
@@ -359,6 +360,7 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
   const int blocks = ln_bwd_blocks(rows);
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(partials, 0, sizeof(float) * 3 * c * blocks, s);
+    if (e == hipSuccess && sums_out) e = hipMemsetAsync(sums_out, 0, sizeof(float) * 3 * c, s);
     return e == hipSuccess ? CODA_OK : static_cast<int>(e);
   }
   LnBwd p{dy, dyp, ds, s_in, mean, rstd, gamma, dres_out, dx_out, partials, rows, c,
@@ -368,6 +370,9 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
   if (c <= 256) hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, dim3(kThreads), 0, s, p);
   else if (c <= 512) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, dim3(kThreads), 0, s, p);
   else hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, dim3(kThreads), 0, s, p);
+  if (sums_out)  // second launch of the same call: fixed-order reduction of the per-block partials
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((3 * c + 63) / 64, 1), dim3(1024), 0, s, partials, blocks, 3 * c,
+                       sums_out);
   return launch_status();
 }
 
@@ -418,17 +423,21 @@ CODA_API int coda_tok_bias_relu_dropout_bwd_blocks(long long rows, int c) {
 }
 
 CODA_API int coda_tok_bias_relu_dropout_bwd_f32(const float *da, const float *a, long long rows, int c,
-                                                float dropout_p, float *dz, float *partials, void *stream) {
+                                                float dropout_p, float *dz, float *partials, float *dbias,
+                                                void *stream) {
   if (rows < 0 || bad_row_c(c) || bad_p(dropout_p) || !partials) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int blocks = row_blocks(rows, c);
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(partials, 0, sizeof(float) * c * blocks, s);
+    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, sizeof(float) * c, s);
     return e == hipSuccess ? CODA_OK : static_cast<int>(e);
   }
   if (!da || !a || !dz) return CODA_EINVAL;
   clear_sticky_error();
   hipLaunchKernelGGL(bias_relu_dropout_bwd_kernel, dim3(blocks), dim3(kT), 0, s, da, a, rows, c,
                      1.0f / (1.0f - dropout_p), dz, partials);
+  if (dbias)
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64, 1), dim3(1024), 0, s, partials, blocks, c, dbias);
   return launch_status();
 }

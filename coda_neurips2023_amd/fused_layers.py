@@ -33,12 +33,6 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args, _stream()), name)
 
 
-def _colsums(partials, blocks, n):
-    out = torch.empty(n, dtype=torch.float32, device=partials.device)
-    _call("coda_tok_colsum_finalize_f32", _p(partials), blocks, n, _p(out))
-    return out
-
-
 def _colsum_into(out, x3):
     """out (G*C) <- column sums of x3 (G, rows, C)."""
     g, rows, c = x3.shape
@@ -99,9 +93,9 @@ class _AddLN(torch.autograd.Function):
         partials = torch.empty((blocks, 3, c), dtype=torch.float32, device=s.device)
         dres = torch.empty_like(s) if (has_res or p == 0.0) else None
         dx = torch.empty_like(s) if p > 0.0 else None
+        sums = torch.empty(3 * c, dtype=torch.float32, device=s.device)
         _call("coda_tok_add_ln_bwd_f32", _p(dy), _p(dyp), _p(ds), _p(s), _p(mean), _p(rstd), _p(gamma), rows, c, p,
-              seed, _p(seed_dev), _p(dres), _p(dx), _p(partials))
-        sums = _colsums(partials, blocks, 3 * c)
+              seed, _p(seed_dev), _p(dres), _p(dx), _p(partials), _p(sums))
         if dx is None:
             dx = dres
         has_ln = gamma is not None
@@ -140,8 +134,8 @@ class _FfnAct(torch.autograd.Function):
         blocks = _lib.load().coda_tok_bias_relu_dropout_bwd_blocks(rows, c)
         partials = torch.empty((blocks, c), dtype=torch.float32, device=a.device)
         dz = torch.empty_like(a)
-        _call("coda_tok_bias_relu_dropout_bwd_f32", _p(da), _p(a), rows, c, p, _p(dz), _p(partials))
-        db = _colsums(partials, blocks, c) if has_bias else None
+        db = torch.empty(c, dtype=torch.float32, device=a.device) if has_bias else None
+        _call("coda_tok_bias_relu_dropout_bwd_f32", _p(da), _p(a), rows, c, p, _p(dz), _p(partials), _p(db))
         return dz, db, None
 
 

@@ -97,32 +97,37 @@ int coda_tok_add_ln_bwd_blocks(long long rows, int c);
  *   dres = ds + LayerNorm_backward(dy + dyp)      (written to dres_out; the gradient of res)
  *   dx   = dropout-masked dres                    (written to dx_out; may be NULL when there is
  *                                                  no dropout: dx == dres)
- * partials (blocks,3,C): per-block column sums of [(dy+dyp)*xhat, (dy+dyp), dx]; reduce them
- * with coda_tok_colsum_finalize_f32 into dgamma, dbeta, dbias. */
+ * partials (blocks,3,C): per-block column sums of [(dy+dyp)*xhat, (dy+dyp), dx] = the
+ * contributions to dgamma, dbeta, dbias.  With sums_out (3,C) != NULL the call also reduces
+ * them (fixed order: deterministic) with a second launch; with sums_out == NULL the caller does,
+ * e.g. with coda_tok_colsum_finalize_f32. */
 int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, const float *s,
                             const float *mean, const float *rstd, const float *gamma, long long rows,
                             int c, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
-                            float *dres_out, float *dx_out, float *partials, void *stream);
+                            float *dres_out, float *dx_out, float *partials, float *sums_out,
+                            void *stream);
 
 /* out[j] = sum_b partials[b][j], j < n (n = 3*C above) */
 int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int n, float *out, void *stream);
 
 /* Column sums of x (G, rows, C) -> out (G, C) (the bias gradients of the projections):
  * per-block partials (G, blocks, C) with blocks = coda_tok_colsum_blocks(rows, c), then a
- * fixed-order reduction.  C/4 must divide 256. */
+ * fixed-order reduction (two launches of one call).  C/4 must divide 256. */
 int coda_tok_colsum_blocks(long long rows, int c);
 int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials,
                         float *out, void *stream);
 
 /* Feed-forward activation: a = dropout_p(relu(h + bias)) on (rows, C); a may alias h; C/4 must
  * divide 256.  Backward: dz = da / (1-p) where a > 0, else 0 (a dropped or clamped element has
- * a == 0 either way); partials (blocks,1,C) column sums of dz -> dbias. */
+ * a == 0 either way); partials (blocks,1,C) column sums of dz, reduced into dbias (C) by the
+ * same call when dbias != NULL. */
 int coda_tok_bias_relu_dropout_fwd_f32(const float *h, const float *bias, long long rows, int c,
                                        float dropout_p, uint64_t seed, const uint64_t *seed_dev,
                                        float *a, void *stream);
 int coda_tok_bias_relu_dropout_bwd_blocks(long long rows, int c);
 int coda_tok_bias_relu_dropout_bwd_f32(const float *da, const float *a, long long rows, int c,
-                                       float dropout_p, float *dz, float *partials, void *stream);
+                                       float dropout_p, float *dz, float *partials, float *dbias,
+                                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -49,3 +49,16 @@ def test_workspace_queries_run_without_gpu():
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 20000, 2048) == 8 * 20000 * 16  # sorted records
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 100000, 2048) == 8 * 100000 * 4
     assert lib.coda_ball_query_workspace_bytes(8, 20000, 2048, 64) >= 0
+
+
+def test_python_signatures_have_the_arity_of_the_header():
+    """Every ctypes signature lists exactly as many arguments as the C declaration (a missing
+    entry silently passes the trailing stream handle as a 32-bit int)."""
+    decl = {}
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for name, args in re.findall(r"\b(coda_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+            args = args.strip()
+            decl[name] = 0 if args in ("", "void") else len(args.split(","))
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        assert decl[name] == len(argtypes), f"{name}: header has {decl[name]} parameters, ctypes lists {len(argtypes)}"
