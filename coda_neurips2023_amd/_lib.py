@@ -68,8 +68,8 @@ SIGNATURES = {
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _P]),
     "coda_mha_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
-                                  _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P,
-                                  _P]),
+                                  _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                  ctypes.c_uint64, _P, _P]),
 }
 
 _lib = None

@@ -113,7 +113,7 @@ class _FusedAttention(torch.autograd.Function):
         with torch.cuda.device(q.device):
             st = lib.coda_mha_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
                                       _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
-                                      ldq, ldk, ldv, scale, dropout_p, seed, _ptr(seed_dev),
+                                      ldq, ldk, ldv, 0, 0, 0, scale, dropout_p, seed, _ptr(seed_dev),
                                       _lib.current_stream_handle())
         _lib.check(st, "mha_bwd")
         return dq, dk, dv, None, None, None

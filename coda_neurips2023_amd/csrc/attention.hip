@@ -284,6 +284,7 @@ struct MhaBwdParams {
   float *dq, *dk, *dv, *delta;
   int b, h, l, s;
   int ldq, ldk, ldv;
+  int lddq, lddk, lddv;  // floats between consecutive batch rows of dq / dk / dv (H*D when dense)
   float scale, inv_keep;
   uint32_t thresh16, seed;
   const uint64_t *seed_dev;
@@ -483,8 +484,8 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + crow(r, half);
       if (key < p.s) {
-        float *dkrow = p.dk + static_cast<size_t>(key) * rstride + head_off + NT * l31;
-        float *dvrow = p.dv + static_cast<size_t>(key) * rstride + head_off + NT * l31;
+        float *dkrow = p.dk + (static_cast<size_t>(key) * p.b + bi) * p.lddk + hi * D + NT * l31;
+        float *dvrow = p.dv + (static_cast<size_t>(key) * p.b + bi) * p.lddv + hi * D + NT * l31;
         if (NT == 2) {
           *reinterpret_cast<float2 *>(dkrow) = make_float2(dk[0][r], dk[1][r]);
           *reinterpret_cast<float2 *>(dvrow) = make_float2(dv[0][r], dv[1][r]);
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
     for (int r = 0; r < 16; ++r) {
       const int qq = q0 + crow(r, half);
       if (qq < p.l) {
-        float *row = p.dq + static_cast<size_t>(qq) * rstride + head_off + NT * l31;
+        float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + NT * l31;
         if (NT == 2) {
           *reinterpret_cast<float2 *>(row) = make_float2(dq[0][r], dq[1][r]);
         } else {
@@ -776,11 +777,15 @@ CODA_API int coda_mha_fwd_f32(const float *q, const float *k, const float *v, co
 CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, const uint8_t *mask,
                               const float *out, const float *lse, const float *dout, float *dq,
                               float *dk, float *dv, float *delta, int b, int h, int l, int s, int d,
-                              int ldq, int ldk, int ldv, float scale, float dropout_p, uint64_t seed,
-                              const uint64_t *seed_dev, void *stream) {
+                              int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                              float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *stream) {
   using namespace coda;
+  if (lddq == 0) lddq = h * d;
+  if (lddk == 0) lddk = h * d;
+  if (lddv == 0) lddv = h * d;
   if (b < 0 || h <= 0 || l < 0 || s < 0 || (d != 64 && d != 128) || dropout_p < 0.f || dropout_p >= 1.f ||
-      ldq < h * d || ldk < h * d || ldv < h * d || (ldq | ldk | ldv) % 4 != 0)
+      ldq < h * d || ldk < h * d || ldv < h * d || (ldq | ldk | ldv) % 4 != 0 || lddq < h * d || lddk < h * d ||
+      lddv < h * d || (lddq | lddk | lddv) % 4 != 0)
     return CODA_EINVAL;
   if (b == 0 || (l == 0 && s == 0)) return CODA_OK;
   if (l == 0 || s == 0) return CODA_EINVAL;
@@ -790,6 +795,7 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
   p.dq = dq; p.dk = dk; p.dv = dv; p.delta = delta;
   p.b = b; p.h = h; p.l = l; p.s = s;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale;
   p.thresh16 = drop_threshold(dropout_p);
   p.inv_keep = 1.0f / (1.0f - dropout_p);

@@ -199,3 +199,183 @@ def encoder_layer(layer, pend, pos, mask):
                                layer.norm2.weight if use_ffn else none, layer.norm2.bias if use_ffn else none,
                                layer.linear1.weight if use_ffn else none, layer.linear1.bias if use_ffn else none,
                                layer.linear2.weight if use_ffn else none)
+
+
+# ---- the whole decoder as one node ------------------------------------------------------------
+#
+# Every decoder layer projects the SAME encoder memory to its cross-attention keys and values
+# (models/transformer.py:566-573).  With the decoder as a single autograd node these 2 x 8
+# projections of the 16 384 memory tokens are two GEMMs over the concatenated weights before the
+# layer loop, the attention kernels read layer l's keys / values as column slices of the packed
+# (tokens, 8*E) results and write their gradients back into the same slices, and the memory /
+# weight gradients of all layers are again two GEMMs each after the loop -- instead of 8 x
+# (2 forward GEMMs, 2 input-gradient GEMMs, 2 split-K weight-gradient GEMMs, bias column sums
+# and 2 gradient accumulations over the 16 MB memory tensor).  The per-layer bodies are the
+# blocks of fused_layers.py; the decoder norm of every layer output (return_intermediate) is the
+# LayerNorm of the kernel that materialises the layer's residual stream.
+_NP = 18  # parameters per decoder layer, in the order built by `decoder_stack` below
+
+
+def _colsum_vec(x2):
+    from .fused_layers import _colsum_into
+    out = torch.empty(x2.shape[1], dtype=torch.float32, device=x2.device)
+    _colsum_into(out, x2.unsqueeze(0))
+    return out
+
+
+class _DecoderStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tgt, memory, pos, query_pos, self_mask, cross_mask, cfg, norm_g, norm_b, *params):
+        from . import _lib
+        from . import attention_core as _core
+        eps, nheads, p_attn, p1, p2, p_ffn, p3 = cfg
+        nl = len(params) // _NP
+        nq, bsz, e = tgt.shape
+        ns = memory.shape[0]
+        d = e // nheads
+        dev = tgt.device
+        lib = _lib.load()
+        layers = [params[_NP * l:_NP * (l + 1)] for l in range(nl)]
+        mem2 = memory.reshape(-1, e)
+        mp2 = mem2 if pos is None else (memory + pos).reshape(-1, e)
+        wk_all = torch.cat([lp[8][e:2 * e] for lp in layers])          # in_proj rows of the keys   (nl*E, E)
+        wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
+        bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
+        bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
+        k_all = torch.addmm(bk_all, mp2, wk_all.t())                   # (S*B, nl*E)
+        v_all = torch.addmm(bv_all, mem2, wv_all.t())
+        ld_kv = nl * e
+        scale = 1.0 / (d ** 0.5)
+        mask_ptr = cross_mask.data_ptr() if cross_mask is not None else None
+
+        blocks, outs = [], []
+        res = tgt
+        for l, lp in enumerate(layers):
+            g1, b1n, in1, ib1, ow1, ob1, g2, b2n, in2, ib2, ow2, ob2, g3, b3n, w1, fb1, w2, fb2 = lp
+            c1 = _Ctx()
+            _, y1, y1p = _AddLN.forward(c1, res, None, None, query_pos, g1, b1n, eps, 0.0)
+            qk = y1 if query_pos is None else y1p
+            c2 = _Ctx()
+            a1 = _MHA.forward(c2, qk, qk, y1, in1, ib1, ow1, self_mask, nheads, p_attn)
+            c3 = _Ctx()
+            s2, y2, y2p = _AddLN.forward(c3, a1, ob1, res, query_pos, g2, b2n, eps, p1)
+            # cross attention on the pre-projected memory
+            xq2 = (y2 if query_pos is None else y2p).reshape(-1, e)
+            q = torch.addmm(ib2[:e], xq2, in2[:e].t())
+            attn = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
+            lse = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
+            seed, seed_dev = _core._next_seed() if p_attn > 0.0 else (0, None)
+            _lib.check(lib.coda_mha_fwd_f32(q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e,
+                                            mask_ptr, attn.data_ptr(), lse.data_ptr(), bsz, nheads, nq, ns, d, e, ld_kv,
+                                            ld_kv, scale, float(p_attn), seed,
+                                            seed_dev.data_ptr() if seed_dev is not None else None,
+                                            _lib.current_stream_handle()), "mha_fwd")
+            a2 = torch.mm(attn, ow2.t()).view(nq, bsz, e)
+            c5 = _Ctx()
+            s3, y3, _ = _AddLN.forward(c5, a2, ob2, s2, None, g3, b3n, eps, p2)
+            o, ffn_saved = _ffn_forward(y3, w1, fb1, w2, p_ffn)
+            cn = _Ctx()  # materialise the layer output and apply the decoder norm to it in the same pass
+            s4, yn, _ = _AddLN.forward(cn, o, fb2, s3, None, norm_g, norm_b, eps, p3)
+            blocks.append((c1, c2, c3, (xq2, q, attn, lse, seed, seed_dev), c5, ffn_saved, cn))
+            outs.append(yn)
+            res = s4
+        ctx.blocks = blocks
+        ctx.dims = (nl, nq, bsz, e, ns, nheads, scale, float(p_attn), query_pos is not None, pos is not None)
+        ctx.cross_mask = cross_mask
+        ctx.save_for_backward(mem2, mp2, k_all, v_all, wk_all, wv_all, *params)
+        return torch.stack(outs)
+
+    @staticmethod
+    def backward(ctx, dstack):
+        from . import _lib
+        nl, nq, bsz, e, ns, nheads, scale, p_attn, has_qpos, has_pos = ctx.dims
+        saved = ctx.saved_tensors
+        mem2, mp2, k_all, v_all, wk_all, wv_all = saved[:6]
+        params = saved[6:]
+        layers = [params[_NP * l:_NP * (l + 1)] for l in range(nl)]
+        dev = dstack.device
+        lib = _lib.load()
+        d = e // nheads
+        ld_kv = nl * e
+        mask_ptr = ctx.cross_mask.data_ptr() if ctx.cross_mask is not None else None
+        dstack = dstack.contiguous()
+        dk_all = torch.empty_like(k_all)
+        dv_all = torch.empty_like(v_all)
+        din2_all = torch.empty((nl, 3 * e, e), dtype=torch.float32, device=dev)   # cross in_proj weight grads
+        dib2_all = torch.empty((nl, 3 * e), dtype=torch.float32, device=dev)
+        dnorm = torch.empty((nl, 2, e), dtype=torch.float32, device=dev)          # decoder norm: per-layer parts
+        grads = [None] * (nl * _NP)
+        ds_next = None
+        dqpos = None
+        for l in range(nl - 1, -1, -1):
+            g1, b1n, in1, ib1, ow1, ob1, g2, b2n, in2, ib2, ow2, ob2, g3, b3n, w1, fb1, w2, fb2 = layers[l]
+            c1, c2, c3, (xq2, q, attn, lse, seed, seed_dev), c5, ffn_saved, cn = ctx.blocks[l]
+            do, dfb2, ds3, _, dgn, dbn, _, _ = _AddLN.backward(cn, ds_next, dstack[l], None)
+            dnorm[l, 0].copy_(dgn)
+            dnorm[l, 1].copy_(dbn)
+            dy3, dw1, dfb1, dw2 = _ffn_backward(ffn_saved, do, w1, w2)
+            da2, dob2, ds2, _, dg3, db3n, _, _ = _AddLN.backward(c5, ds3, dy3, None)
+            # cross attention backward; dK / dV go straight into layer l's column slices
+            da2_2 = da2.reshape(-1, e)
+            dow2 = tn_gemm(da2_2.contiguous(), attn)
+            dattn = torch.mm(da2_2, ow2)
+            dq = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
+            delta = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
+            _lib.check(lib.coda_mha_bwd_f32(q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e,
+                                            mask_ptr, attn.data_ptr(), lse.data_ptr(), dattn.data_ptr(), dq.data_ptr(),
+                                            dk_all.data_ptr() + 4 * l * e, dv_all.data_ptr() + 4 * l * e, delta.data_ptr(),
+                                            bsz, nheads, nq, ns, d, e, ld_kv, ld_kv, 0, ld_kv, ld_kv, scale, p_attn, seed,
+                                            seed_dev.data_ptr() if seed_dev is not None else None,
+                                            _lib.current_stream_handle()), "mha_bwd")
+            torch.mm(dq.t(), xq2, out=din2_all[l, :e])
+            dib2_all[l, :e].copy_(_colsum_vec(dq))
+            dxq = torch.mm(dq, in2[:e]).view(nq, bsz, e)
+            da1, dob1, ds1, dpos2, dg2, db2n, _, _ = _AddLN.backward(c3, ds2, None if has_qpos else dxq,
+                                                                     dxq if has_qpos else None)
+            dqk, _, dv1, din1, dib1, dow1, _, _, _ = _MHA.backward(c2, da1)
+            if has_qpos:
+                g = _AddLN.backward(c1, ds1, dv1, dqk)
+                dqpos = _add(dqpos, g[3] + dpos2)
+            else:
+                g = _AddLN.backward(c1, ds1, _add(dv1, dqk), None)
+            ds_next = g[0]  # the block's input WAS the stream: d(stream) + d(LayerNorm path)
+            grads[_NP * l:_NP * (l + 1)] = [g[4], g[5], din1, dib1, dow1, dob1, dg2, db2n, din2_all[l], dib2_all[l],
+                                            dow2, dob2, dg3, db3n, dw1, dfb1, dw2, dfb2]
+        # memory side of all layers at once
+        dmp2 = torch.mm(dk_all, wk_all)
+        dmem2 = torch.mm(dv_all, wv_all)
+        dwk = tn_gemm(dk_all, mp2)   # (nl*E, E)
+        dwv = tn_gemm(dv_all, mem2)
+        din2_all[:, e:2 * e].copy_(dwk.view(nl, e, e))
+        din2_all[:, 2 * e:].copy_(dwv.view(nl, e, e))
+        dib2_all[:, e:2 * e].copy_(_colsum_vec(dk_all).view(nl, e))
+        dib2_all[:, 2 * e:].copy_(_colsum_vec(dv_all).view(nl, e))
+        dnorm_sum = dnorm.sum(0)
+        if has_pos:
+            dmemory = (dmp2 + dmem2).view(ns, bsz, e)
+            dpos = dmp2.view(ns, bsz, e)
+        else:
+            dmemory = (dmp2 + dmem2).view(ns, bsz, e)
+            dpos = None
+        return (ds_next, dmemory, dpos, dqpos, None, None, None, dnorm_sum[0], dnorm_sum[1], *grads)
+
+
+def decoder_stack(decoder, tgt, memory, pos, query_pos, self_mask, cross_mask):
+    """All layers of a TransformerDecoder (pre-norm, return_intermediate) -> (num_layers, nq, B, E):
+    the decoder-normed output of every layer."""
+    def p(m):
+        return float(m.p) if m.training else 0.0
+
+    first = decoder.layers[0]
+    sa = first.self_attn
+    cfg = (float(first.norm1.eps), sa.num_heads, float(sa.dropout) if sa.training else 0.0,
+           p(first.dropout1), p(first.dropout2), p(first.dropout), p(first.dropout3))
+    params = []
+    for layer in decoder.layers:
+        s, c = layer.self_attn, layer.multihead_attn
+        params += [layer.norm1.weight, layer.norm1.bias, s.in_proj_weight, s.in_proj_bias, s.out_proj.weight,
+                   s.out_proj.bias, layer.norm2.weight, layer.norm2.bias, c.in_proj_weight, c.in_proj_bias,
+                   c.out_proj.weight, c.out_proj.bias, layer.norm3.weight, layer.norm3.bias, layer.linear1.weight,
+                   layer.linear1.bias, layer.linear2.weight, layer.linear2.bias]
+    return _DecoderStack.apply(tgt, memory.contiguous(), pos, query_pos, self_mask, cross_mask, cfg,
+                               decoder.norm.weight, decoder.norm.bias, *params)

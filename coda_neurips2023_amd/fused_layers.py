@@ -207,7 +207,7 @@ class _MHA(torch.autograd.Function):
             dk, dv = dkv[0], dkv[1]
         delta = torch.empty((bsz, nheads, tgt_len), dtype=torch.float32, device=dev)
         _lib.check(lib.coda_mha_bwd_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), _p(dattn), _p(dq), _p(dk),
-                                        _p(dv), _p(delta), bsz, nheads, tgt_len, src_len, d, ldq, ldk, ldv, scale, p,
+                                        _p(dv), _p(delta), bsz, nheads, tgt_len, src_len, d, ldq, ldk, ldv, 0, 0, 0, scale, p,
                                         seed, _p(seed_dev), _stream()), "mha_bwd")
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * e, dtype=torch.float32, device=dev)

@@ -218,6 +218,16 @@ class TransformerDecoder(nn.Module):
         return output, attns
 
 
+    def _uniform_layers(self):
+        """All layers share dropout rates / head count / eps and have biases (the stack node reads
+        them from the first layer)."""
+        f = self.layers[0]
+        key = lambda l: (l.dropout.p, l.dropout1.p, l.dropout2.p, l.dropout3.p, l.self_attn.num_heads,  # noqa: E731
+                         l.self_attn.dropout, l.multihead_attn.dropout, l.norm1.eps, l.training)
+        return all(key(l) == key(f) and l.linear1.bias is not None and l.linear2.bias is not None
+                   and l.multihead_attn.num_heads == l.self_attn.num_heads for l in self.layers) \
+            and f.self_attn.dropout == f.multihead_attn.dropout and self.norm.eps == f.norm1.eps
+
     def _forward_fused(self, tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
                        memory_key_padding_mask, pos, query_pos):
         """Same values as the loop in ``forward``; ``memory + pos`` (recomputed by every layer of
@@ -226,9 +236,13 @@ class TransformerDecoder(nn.Module):
         nmem = memory.shape[0]
         nhead = self.layers[0].self_attn.num_heads
         memory = memory.contiguous()
-        memory_pos = memory if pos is None else memory + pos
         self_mask = _mask_u8(tgt_mask, tgt_key_padding_mask, bsz, nhead, nq, nq)
         cross_mask = _mask_u8(memory_mask, memory_key_padding_mask, bsz, nhead, nq, nmem)
+        if _layer_nodes() and os.environ.get("CODA_DECODER_NODE", "stack") == "stack" and self._uniform_layers():
+            # the whole decoder as one node, memory projections of all layers batched
+            stacked = _fb.decoder_stack(self, tgt, memory, pos, query_pos, self_mask, cross_mask)
+            return stacked if self.return_intermediate else stacked[-1]
+        memory_pos = memory if pos is None else memory + pos
         pend = _Pending(tgt)
         intermediate = []
         for layer in self.layers:

@@ -47,14 +47,16 @@ int coda_mha_fwd_f32(const float *q, const float *k, const float *v,
                      float dropout_p, uint64_t seed, const uint64_t *seed_dev,
                      void *stream);
 
-/* dq (L,B,H,D), dk / dv (S,B,H,D) are fully written.  `delta` is a (B,H,L) float
- * scratch provided by the caller (rowsum(dout * out)). */
+/* dq (L,B,H,D), dk / dv (S,B,H,D) are fully written.  lddq / lddk / lddv: floats between
+ * consecutive batch rows of the gradient outputs (0 = dense, H*D), so that they can be
+ * written straight into column slices of a packed buffer, like ldq / ldk / ldv for the
+ * inputs.  `delta` is a (B,H,L) float scratch provided by the caller (rowsum(dout * out)). */
 int coda_mha_bwd_f32(const float *q, const float *k, const float *v,
                      const uint8_t *mask, const float *out, const float *lse,
                      const float *dout, float *dq, float *dk, float *dv,
                      float *delta, int b, int h, int l, int s, int d, int ldq,
-                     int ldk, int ldv, float scale, float dropout_p, uint64_t seed,
-                     const uint64_t *seed_dev, void *stream);
+                     int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                     float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -179,9 +179,11 @@ def _run_decoder(dev, env, monkeypatch, tgt, memory, pos, query_pos):
     return out, m.grad, qp.grad, {k: p.grad for k, p in dec.named_parameters()}
 
 
-@pytest.mark.parametrize("nodes", ["layer", "ops"])
+@pytest.mark.parametrize("nodes", ["stack", "layer", "ops"])
 def test_fused_decoder_equals_module_path(dev, monkeypatch, nodes):
-    monkeypatch.setenv("CODA_LAYER_NODES", nodes)
+    # one autograd node for the whole decoder / per layer / per block
+    monkeypatch.setenv("CODA_LAYER_NODES", "ops" if nodes == "ops" else "layer")
+    monkeypatch.setenv("CODA_DECODER_NODE", "stack" if nodes == "stack" else "layers")
     gen = torch.Generator().manual_seed(4)
     nq, nmem, b = 64, 300, 3
     tgt = torch.zeros(nq, b, 256, device=dev)
