@@ -20,6 +20,7 @@ from . import _lib
 from . import attention_core as _core
 
 _SPLIT_ROWS = 2048
+_NARROW = 16  # tails with at most this many outputs are batched (zero-padded) into one GEMM
 
 
 def _p(t):
@@ -34,6 +35,20 @@ def _call(name, *args):
 def _is_sync(bn):
     return isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
         and dist.get_world_size(bn.process_group) > 1
+
+
+_PAD_ROWS = {}
+
+
+def _pad_rows(outs, width, device):
+    """Index of row r of head g in the zero-padded (len(outs)*width) stack, cached per shape."""
+    key = (outs, width, str(device))
+    idx = _PAD_ROWS.get(key)
+    if idx is None:
+        idx = torch.tensor([g * width + r for g, o in enumerate(outs) for r in range(o)], dtype=torch.int64,
+                           device=device)
+        _PAD_ROWS[key] = idx
+    return idx
 
 
 def parse(mlp):
@@ -175,11 +190,36 @@ class _HiddenStack(torch.autograd.Function):
         ctx.tail_shapes = [w.shape for w in tails[0::2]]
         ctx.tail_bias = [b is not None for b in tails[1::2]]
         tail_ws = [w.flatten(1) for w in tails[0::2]]
-        ctx.save_for_backward(x, *zs, *acts, *prms, *ws, *gammas, *tail_ws)
+        # Narrow tails (box heads: 2..12 outputs) are GEMMs with a tiny N (forward) / K (backward)
+        # that the library runs at a few % of its rate: the leading run of narrow heads is
+        # evaluated as ONE batched GEMM on weights zero-padded to a common width.
+        ns = 0
+        while has_tail and ns < groups and tail_ws[ns].shape[0] <= _NARROW and tails[2 * ns + 1] is not None:
+            ns += 1
+        ns = ns if ns >= 2 else 0
+        wpad = None
+        if ns:
+            outs_n = tuple(int(tail_ws[g].shape[0]) for g in range(ns))
+            width = -(-max(outs_n) // 4) * 4
+            rows = _pad_rows(outs_n, width, dev)                      # row of the padded stack for every real row
+            c_last = tail_ws[0].shape[1]
+            wpad = torch.zeros((ns * width, c_last), dtype=torch.float32, device=dev)
+            wpad.index_copy_(0, rows, torch.cat([tail_ws[g] for g in range(ns)]))
+            wpad = wpad.view(ns, width, c_last)
+            bpad = torch.zeros(ns * width, dtype=torch.float32, device=dev)
+            bpad.index_copy_(0, rows, torch.cat([tails[2 * g + 1] for g in range(ns)]))
+            bpad = bpad.view(ns, width)
+        ctx.narrow = ns
+        ctx.save_for_backward(x, *zs, *acts, *prms, *ws, *gammas, *tail_ws, *([wpad] if ns else []))
         if not has_tail:
             return acts[-1]
-        return tuple(torch.addmm(tails[2 * g + 1], acts[-1][g], tail_ws[g].t()) if tails[2 * g + 1] is not None
-                     else torch.mm(acts[-1][g], tail_ws[g].t()) for g in range(groups))
+        outs = []
+        if ns:
+            small = torch.baddbmm(bpad.unsqueeze(1), acts[-1][:ns], wpad.transpose(1, 2))  # (ns, T, width)
+            outs = [small[g, :, :tail_ws[g].shape[0]] for g in range(ns)]
+        outs += [torch.addmm(tails[2 * g + 1], acts[-1][g], tail_ws[g].t()) if tails[2 * g + 1] is not None
+                 else torch.mm(acts[-1][g], tail_ws[g].t()) for g in range(ns, groups)]
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
@@ -192,7 +232,8 @@ class _HiddenStack(torch.autograd.Function):
         prms = saved[1 + 2 * nb:1 + 3 * nb]
         ws = saved[1 + 3 * nb:1 + 4 * nb]
         gammas = saved[1 + 4 * nb:1 + 5 * nb]
-        tail_ws = saved[1 + 5 * nb:]
+        ns = ctx.narrow
+        tail_ws = saved[1 + 5 * nb:1 + 5 * nb + groups] if has_tail else ()
         dev = x.device
         t = x.shape[0]
         grads = [None] * (3 * groups * nb)
@@ -201,7 +242,19 @@ class _HiddenStack(torch.autograd.Function):
             # gradients of the G tail layers; dA is assembled in place, group by group
             dout = None
             da = torch.empty_like(acts[-1])
-            for g in range(groups):
+            if ns:  # the narrow heads as one batched problem on zero-padded gradients
+                wpad = saved[-1]
+                width = wpad.shape[1]
+                dpad = torch.zeros((ns, t, width), dtype=torch.float32, device=dev)
+                for g in range(ns):
+                    dpad[g, :, :tail_ws[g].shape[0]].copy_(douts[g])
+                torch.bmm(dpad, wpad, out=da[:ns])
+                dwp = _split_k_tn(dpad, acts[-1][:ns])                                     # (ns, width, C)
+                dbp = dpad.sum(1)
+                for g in range(ns):
+                    og = tail_ws[g].shape[0]
+                    tail_grads += [dwp[g, :og].reshape(ctx.tail_shapes[g]), dbp[g, :og]]
+            for g in range(ns, groups):
                 dg = douts[g].contiguous()
                 torch.mm(dg, tail_ws[g], out=da[g])
                 dw = _split_k_tn(dg.unsqueeze(0), acts[-1][g].unsqueeze(0))[0]

@@ -215,8 +215,9 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         """box_features: (num_layers, num_queries, batch, channel) -> output dicts."""
         num_layers, num_queries, batch, channel = box_features.shape
         heads = self.mlp_heads
-        names = ["sem_cls_head", "text_correlation_head", "center_head", "size_head", "angle_cls_head",
-                 "angle_residual_head"]
+        # the narrow box heads first (their final layers run as one batched GEMM), the 512-d head last
+        names = ["sem_cls_head", "center_head", "size_head", "angle_cls_head", "angle_residual_head",
+                 "text_correlation_head"]
         parsed = fused_bn_mlp.eligible([heads[n] for n in names], box_features)
         if parsed is not None and all(tail is not None for _, tail in parsed):
             # all six heads at once on the decoder's own (layer, query, scene) token order:
