@@ -338,12 +338,28 @@ def main():
         torch.cuda.synchronize()
         _ext.disable_kernel_timing()
 
-    def avg_ms(name):
-        ev = timing.get(name, [])
+    def avg_ms(name, store=None):
+        ev = (timing if store is None else store).get(name, [])
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
+
+    alone = {}
+    if rank == 0 and graph is None and prefetch:
+        # with the sampling prefetch the operator ran on a side stream, competing with the step's own
+        # kernels for CUs: also time it with the GPU to itself, `steps` launches on the same inputs
+        alone = _ext.enable_kernel_timing(["query_and_group_xyz"])
+        with torch.no_grad():
+            for i in range(args.steps):
+                xyz = pool[i % len(pool)]["point_clouds"][..., :3].contiguous()
+                inds = _ext.furthest_point_sampling(xyz, M_CENTRES)
+                new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+                torch.cuda.synchronize()
+                _ext.query_and_group_xyz(new_xyz, xyz, RADIUS, NSAMPLE, True, channels_last=True)
+        torch.cuda.synchronize()
+        _ext.disable_kernel_timing()
 
     if rank == 0:
         bq_ms = avg_ms("query_and_group_xyz") or avg_ms("ball_query")
+        bq_alone_ms = avg_ms("query_and_group_xyz", alone)
         fps_ev = timing.get("furthest_point_sampling", [])
         # two FPS calls per step in the model workload (20000->2048, 2048->nq): report the large one
         fps_ms = max((s.elapsed_time(e) for s, e in fps_ev), default=None)
@@ -371,7 +387,9 @@ def main():
             "roofline": {
                 "kernel": "grid_build_kernel + grid_query_kernel (cell-binned ball_query fused with xyz grouping, "
                           "one coda_query_and_group_xyz_f32 call)",
-                "timing": ("HIP events around each call inside the timed region" if graph is None else
+                "timing": (("HIP events around each call inside the timed region"
+                            + (" (side stream, concurrent with the step's kernels)" if prefetch else ""))
+                           if graph is None else
                            "timed region replays a hipGraph; HIP events around `steps` eager calls of the same "
                            "operator on the bench inputs right after it"),
                 "bound": "hbm",
@@ -384,6 +402,11 @@ def main():
                 "traffic": 25234432,
                 "bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
+                # same operator, same inputs, GPU otherwise idle (only reported when the timed region ran it
+                # concurrently with the step on a side stream)
+                "avg_launch_ms_alone": round(bq_alone_ms, 5) if bq_alone_ms else None,
+                "frac_alone": round(bytes_per_launch / (bq_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                if bq_alone_ms else None,
             },
             "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
         }

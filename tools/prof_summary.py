@@ -11,7 +11,12 @@ def cat(nm):
     if "fps_" in nm: return "FPS (hip)"
     if "ball_query" in nm or "grid_" in nm: return "ball_query+group (hip)"
     if "mha_" in nm: return "attention (hip)"
-    if "coda" in nm and any(k in nm for k in ("col_stats", "bn_", "relu_bn")): return "SA shared-MLP streaming (hip)"
+    if "coda" in nm and any(k in nm for k in ("col_stats", "bn_relu_apply", "bn_bwd_sparse", "relu_bn")):
+        return "SA shared-MLP streaming (hip)"
+    if "coda" in nm and any(k in nm for k in ("bn_stats", "bn_finalize", "bn_act", "bn_bwd_finalize")):
+        return "GenericMLP batch-norm kernels (hip)"
+    if "coda" in nm and any(k in nm for k in ("add_ln", "colsum", "bias_relu_dropout")):
+        return "transformer token kernels (hip)"
     if "coda" in nm: return "gather/group/interp (hip)"
     if "max_pool" in nm: return "max-pool (torch)"
     if "BatchNorm" in nm or "batch_norm" in nm: return "batch-norm (MIOpen)"
@@ -22,7 +27,7 @@ def cat(nm):
     if "elementwise" in nm or "copy" in nm.lower() or "fill" in nm.lower(): return "elementwise / copy / fill (torch)"
     if "reduce" in nm: return "reductions (torch)"
     if "layer_norm" in nm.lower() or "LayerNorm" in nm or "GammaBeta" in nm: return "layer-norm (torch)"
-    if "multi_tensor" in nm: return "optimizer (torch)"
+    if "multi_tensor" in nm or "FusedAdam" in nm: return "optimizer (torch)"
     return "other"
 
 
