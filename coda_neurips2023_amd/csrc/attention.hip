@@ -23,6 +23,8 @@
 #include "coda_attention.h"
 #include "common.hip.h"
 
+#include <cstdlib>
+
 namespace coda {
 namespace {
 
@@ -82,16 +84,47 @@ __device__ __forceinline__ void load_tile(float *lds, const float *g, size_t gst
   }
 }
 
+// The same copy in two halves, for double buffering: global -> registers (issued before the
+// compute on the current LDS buffer), registers -> the other LDS buffer (after it).
+template <int D, int THREADS, int ROWS>
+__device__ __forceinline__ void fetch_tile(float4 (&regs)[ROWS * D / 4 / THREADS], const float *g, size_t gstride,
+                                           int row0, int nrows_total, int tid) {
+#pragma unroll
+  for (int j = 0; j < ROWS * D / 4 / THREADS; ++j) {
+    const int i = tid + j * THREADS;
+    const int row = i / (D / 4), c4 = i % (D / 4);
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + row < nrows_total)
+      val = *reinterpret_cast<const float4 *>(g + static_cast<size_t>(row0 + row) * gstride + c4 * 4);
+    regs[j] = val;
+  }
+}
+template <int D, int THREADS, int ROWS>
+__device__ __forceinline__ void store_tile(float *lds, const float4 (&regs)[ROWS * D / 4 / THREADS], int tid) {
+  constexpr int LS = D + 4;
+#pragma unroll
+  for (int j = 0; j < ROWS * D / 4 / THREADS; ++j) {
+    const int i = tid + j * THREADS;
+    const int row = i / (D / 4), c4 = i % (D / 4);
+    *reinterpret_cast<float4 *>(lds + row * LS + c4 * 4) = regs[j];
+  }
+}
+
 // SPLIT = false: every wave owns its own block of 32 queries and all waves share one K/V tile
 //                 per step (long query sequences: the encoder).
 // SPLIT = true:  all QW waves work on the SAME 32 queries and split the keys (QW tiles are
 //                 staged per step, wave w takes tile w); the partial (m, l, O) are merged
 //                 through LDS at the end.  This is what fills the chip for the decoder, whose
 //                 256 queries give only 8 query blocks per (scene, head).
-template <int D, int QW, bool SPLIT, bool GEN>
+// DB (non-SPLIT only): the same LDS holds two half-size stages; the global loads of stage i+1 are
+//                 in flight while stage i is computed and land in the other buffer afterwards --
+//                 one barrier per stage and no wave parked on an HBM round trip.
+template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
 __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  constexpr int TILES = QW;  // K/V tiles staged per barrier pair (SPLIT: one per wave; else all waves walk all)
+  // K/V tiles staged per step (SPLIT: one per wave; else all waves walk all of them)
+  constexpr int TILES = DB ? QW / 2 : QW;
+  static_assert(!(DB && SPLIT), "double buffering is implemented for the long-sequence kernel");
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
@@ -129,11 +162,33 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   const bool use_drop = p.thresh16 != 0u;
   const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
 
-  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
+  constexpr int kStageFloats = 2 * TILES * kTile * LS;  // one K + V stage
+  constexpr int NLD = DB ? TILES * kTile * D / 4 / THREADS : 1;
+  constexpr int FROWS = DB ? TILES * kTile : THREADS * 4 / D;
+  float4 rk[NLD], rv[NLD];
+  if (DB) {  // prologue: stage 0 straight into buffer 0
+    fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, 0, p.s, tid);
+    fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, 0, p.s, tid);
+    store_tile<D, THREADS, FROWS>(s_k, rk, tid);
+    store_tile<D, THREADS, FROWS>(s_v, rv, tid);
     __syncthreads();
-    load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
-    load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
-    __syncthreads();
+  }
+  int stage = 0;
+  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES, ++stage) {
+    const bool more = DB && sbase + kTile * TILES < p.s;
+    if (!DB) {
+      __syncthreads();
+      load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
+      load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
+      __syncthreads();
+    } else {
+      s_k = s_dyn + (stage & 1) * kStageFloats;
+      s_v = s_k + TILES * kTile * LS;
+      if (more) {  // next stage: loads in flight during this stage's MFMAs
+        fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, sbase + kTile * TILES, p.s, tid);
+        fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, sbase + kTile * TILES, p.s, tid);
+      }
+    }
     for (int tile = SPLIT ? my_tile : 0; tile < (SPLIT ? my_tile + 1 : TILES); ++tile) {
     const int s0 = sbase + tile * kTile;
     if (!wave_active || s0 >= p.s) break;
@@ -218,6 +273,14 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       }
     }
     }  // tile
+    if (DB) {
+      if (more) {
+        float *nk = s_dyn + ((stage + 1) & 1) * kStageFloats;
+        store_tile<D, THREADS, FROWS>(nk, rk, tid);
+        store_tile<D, THREADS, FROWS>(nk + TILES * kTile * LS, rv, tid);
+      }
+      __syncthreads();
+    }
   }
 
   lsum += __shfl_xor(lsum, 32);
@@ -500,10 +563,11 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 
 // dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
 // the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
-template <int D, int QW, bool SPLIT, bool GEN>
-__global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) {
+template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
+__global__ __launch_bounds__(QW * kWave, ((DB && D == 64) ? 2 : 1)) void mha_bwd_dq_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  constexpr int TILES = QW;
+  constexpr int TILES = DB ? QW / 2 : QW;  // DB: two half-size stages, double buffered (see mha_fwd_kernel)
+  static_assert(!(DB && SPLIT), "double buffering is implemented for the long-sequence kernel");
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
@@ -550,11 +614,33 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
 
-  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
+  constexpr int kStageFloats = 2 * TILES * kTile * LS;  // one K + V stage
+  constexpr int NLD = DB ? TILES * kTile * D / 4 / THREADS : 1;
+  constexpr int FROWS = DB ? TILES * kTile : THREADS * 4 / D;
+  float4 rk[NLD], rv[NLD];
+  if (DB) {  // prologue: stage 0 straight into buffer 0
+    fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, 0, p.s, tid);
+    fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, 0, p.s, tid);
+    store_tile<D, THREADS, FROWS>(s_k, rk, tid);
+    store_tile<D, THREADS, FROWS>(s_v, rv, tid);
     __syncthreads();
-    load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
-    load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
-    __syncthreads();
+  }
+  int stage = 0;
+  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES, ++stage) {
+    const bool more = DB && sbase + kTile * TILES < p.s;
+    if (!DB) {
+      __syncthreads();
+      load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
+      load_tile<D, THREADS, kTile * TILES>(s_v, vbase, vstride, sbase, p.s, tid);
+      __syncthreads();
+    } else {
+      s_k = s_dyn + (stage & 1) * kStageFloats;
+      s_v = s_k + TILES * kTile * LS;
+      if (more) {  // next stage: loads in flight during this stage's MFMAs
+        fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, sbase + kTile * TILES, p.s, tid);
+        fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, sbase + kTile * TILES, p.s, tid);
+      }
+    }
     for (int tile = SPLIT ? my_tile : 0; tile < (SPLIT ? my_tile + 1 : TILES); ++tile) {
     const int s0 = sbase + tile * kTile;
     if (!wave_active || s0 >= p.s) break;
@@ -621,6 +707,14 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_kernel(MhaBwdParams p) 
       }
     }
     }  // tile
+    if (DB) {
+      if (more) {
+        float *nk = s_dyn + ((stage + 1) & 1) * kStageFloats;
+        store_tile<D, THREADS, FROWS>(nk, rk, tid);
+        store_tile<D, THREADS, FROWS>(nk + TILES * kTile * LS, rv, tid);
+      }
+      __syncthreads();
+    }
   }
   if (SPLIT && QW > 1) {  // sum the per-wave partial dQ through LDS: [wave-1][NT*16][64 lanes]
     __syncthreads();
@@ -679,17 +773,30 @@ int set_lds(K kern, size_t bytes) {
   return CODA_OK;
 }
 
+// double-buffered K/V staging of the long-sequence kernels (CODA_ATTN_DB=0: single buffer, A/B)
+bool double_buffered() {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_DB"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 template <int D, bool GEN>
 int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
   // split-key variants: 8 waves per block when 8 K/V tile pairs fit the 160 KB LDS (D = 64)
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   if (p.l >= 1024) {
-    auto kern = mha_fwd_kernel<D, 4, false, GEN>;
-    int st = set_lds(kern, 4 * kTileBytes);
-    if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+    if (double_buffered()) {
+      auto kern = mha_fwd_kernel<D, 4, false, GEN, true>;
+      int st = set_lds(kern, 4 * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+    } else {
+      auto kern = mha_fwd_kernel<D, 4, false, GEN>;
+      int st = set_lds(kern, 4 * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+    }
   } else {
     auto kern = mha_fwd_kernel<D, SW, true, GEN>;
     int st = set_lds(kern, SW * kTileBytes);
@@ -725,7 +832,12 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
-  if (p.l >= 1024) {
+  if (p.l >= 1024 && double_buffered()) {
+    auto kern = mha_bwd_dq_kernel<D, 4, false, GEN, true>;
+    int st = set_lds(kern, 4 * kTileBytes);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
+  } else if (p.l >= 1024) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN>;
     int st = set_lds(kern, 4 * kTileBytes);
     if (st != CODA_OK) return st;
