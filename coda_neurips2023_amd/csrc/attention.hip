@@ -123,8 +123,9 @@ template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
 __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
   // K/V tiles staged per step (SPLIT: one per wave; else all waves walk all of them)
-  constexpr int TILES = DB ? QW / 2 : QW;
-  static_assert(!(DB && SPLIT), "double buffering is implemented for the long-sequence kernel");
+  // (DB: two stages in LDS -- half-size ones in the same footprint for the long-sequence kernel,
+  //  full-size ones, i.e. twice the LDS, for the split-key kernel where every wave needs its tile)
+  constexpr int TILES = (DB && !SPLIT) ? QW / 2 : QW;
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
@@ -564,10 +565,9 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 // dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
 // the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
 template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
-__global__ __launch_bounds__(QW * kWave, ((DB && D == 64) ? 2 : 1)) void mha_bwd_dq_kernel(MhaBwdParams p) {
+__global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) void mha_bwd_dq_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
-  constexpr int TILES = DB ? QW / 2 : QW;  // DB: two half-size stages, double buffered (see mha_fwd_kernel)
-  static_assert(!(DB && SPLIT), "double buffering is implemented for the long-sequence kernel");
+  constexpr int TILES = (DB && !SPLIT) ? QW / 2 : QW;  // DB: two stages, double buffered (see mha_fwd_kernel)
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
@@ -774,6 +774,12 @@ int set_lds(K kern, size_t bytes) {
 }
 
 // double-buffered K/V staging of the long-sequence kernels (CODA_ATTN_DB=0: single buffer, A/B)
+// split-key kernels: 4 waves with two full stages in LDS (default) or 8 waves, single stage
+// (CODA_ATTN_SPLIT_DB=0, A/B): measured 53 -> 40 us forward, 65 -> 50 us dQ on the decoder shapes
+bool split_double_buffered() {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_SPLIT_DB"); return !e || atoi(e) != 0; }();
+  return on;
+}
 bool double_buffered() {
   static const bool on = [] { const char *e = getenv("CODA_ATTN_DB"); return !e || atoi(e) != 0; }();
   return on;
@@ -798,11 +804,18 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
       hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
     }
   } else {
-    auto kern = mha_fwd_kernel<D, SW, true, GEN>;
-    int st = set_lds(kern, SW * kTileBytes);
-    if (st != CODA_OK) return st;
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
-    hipLaunchKernelGGL(kern, grid, dim3(SW * kWave), SW * kTileBytes, s, p);
+    if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
+      auto kern = mha_fwd_kernel<D, 4, true, GEN, true>;  // 4 waves, 2 x 4 tile pairs
+      int st = set_lds(kern, 8 * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, grid, dim3(4 * kWave), 8 * kTileBytes, s, p);
+    } else {
+      auto kern = mha_fwd_kernel<D, SW, true, GEN>;
+      int st = set_lds(kern, SW * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, grid, dim3(SW * kWave), SW * kTileBytes, s, p);
+    }
   }
   return launch_status();
 }
@@ -843,10 +856,17 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else {
-    auto kern = mha_bwd_dq_kernel<D, SW, true, GEN>;
-    int st = set_lds(kern, SW * kTileBytes);
-    if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
+    if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
+      auto kern = mha_bwd_dq_kernel<D, 4, true, GEN, true>;
+      int st = set_lds(kern, 8 * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(4 * kWave), 8 * kTileBytes, s, p);
+    } else {
+      auto kern = mha_bwd_dq_kernel<D, SW, true, GEN>;
+      int st = set_lds(kern, SW * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
+    }
   }
   return launch_status();
 }
