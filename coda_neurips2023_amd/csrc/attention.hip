@@ -382,10 +382,14 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 //                 staged per step, wave w takes tile w); the partial dK / dV are summed
 //                 through LDS at the end.  Short key sequences (the decoder's 256 queries
 //                 attending to themselves) would otherwise leave one wave per CU.
-template <int D, int KW, bool QSPLIT, bool GEN>
+// DB (non-QSPLIT): two single-tile stages of Q / dO in the same LDS, double buffered like the
+//                 forward kernel's K / V staging.
+template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false>
 __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
-  constexpr int QT = QSPLIT ? KW : 2;  // query tiles staged per barrier pair
+  constexpr int QT = QSPLIT ? KW : (DB ? 1 : 2);  // query tiles staged per step
+  static_assert(!(DB && QSPLIT), "double buffering is implemented for the long-key-sequence kernel");
+  constexpr int kStageFloats = 2 * QT * kTile * LS + 2 * QT * kTile;  // Q, dO tiles + lse, delta rows
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_q = s_dyn;
   float *s_do = s_q + QT * kTile * LS;
@@ -426,17 +430,51 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
 
-  for (int qbase0 = 0; qbase0 < p.l; qbase0 += kTile * QT) {
-    __syncthreads();
-    load_tile<D, THREADS, kTile * QT>(s_q, qbase, qstride, qbase0, p.l, tid);
-    load_tile<D, THREADS, kTile * QT>(s_do, p.dout + head_off, rstride, qbase0, p.l, tid);
+  constexpr int NLD = DB ? QT * kTile * D / 4 / THREADS : 1;
+  constexpr int FROWS = DB ? QT * kTile : THREADS * 4 / D;
+  float4 rq[NLD], rg[NLD];
+  float r_lse = 0.f, r_delta = 0.f;
+  auto fetch_rows = [&](int qb) {  // lse / delta of the stage's queries: one value per thread
     if (tid < kTile * QT) {
-      const int qq = qbase0 + tid;
-      s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
-      s_delta[tid] = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+      const int qq = qb + tid;
+      r_lse = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+      r_delta = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
     }
+  };
+  if (DB) {  // prologue: stage 0 straight into buffer 0
+    fetch_tile<D, THREADS, FROWS>(rq, qbase, qstride, 0, p.l, tid);
+    fetch_tile<D, THREADS, FROWS>(rg, p.dout + head_off, rstride, 0, p.l, tid);
+    fetch_rows(0);
+    store_tile<D, THREADS, FROWS>(s_q, rq, tid);
+    store_tile<D, THREADS, FROWS>(s_do, rg, tid);
+    if (tid < kTile * QT) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
     __syncthreads();
-    if (!wave_active) continue;
+  }
+  int stage = 0;
+  for (int qbase0 = 0; qbase0 < p.l; qbase0 += kTile * QT, ++stage) {
+    const bool more = DB && qbase0 + kTile * QT < p.l;
+    if (!DB) {
+      __syncthreads();
+      load_tile<D, THREADS, kTile * QT>(s_q, qbase, qstride, qbase0, p.l, tid);
+      load_tile<D, THREADS, kTile * QT>(s_do, p.dout + head_off, rstride, qbase0, p.l, tid);
+      if (tid < kTile * QT) {
+        const int qq = qbase0 + tid;
+        s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+        s_delta[tid] = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+      }
+      __syncthreads();
+    } else {
+      s_q = s_dyn + (stage & 1) * kStageFloats;
+      s_do = s_q + QT * kTile * LS;
+      s_lse = s_do + QT * kTile * LS;
+      s_delta = s_lse + QT * kTile;
+      if (more) {  // next stage: loads in flight during this stage's MFMAs
+        fetch_tile<D, THREADS, FROWS>(rq, qbase, qstride, qbase0 + kTile * QT, p.l, tid);
+        fetch_tile<D, THREADS, FROWS>(rg, p.dout + head_off, rstride, qbase0 + kTile * QT, p.l, tid);
+        fetch_rows(qbase0 + kTile * QT);
+      }
+    }
+    if (wave_active) {
     for (int qt = QSPLIT ? w : 0; qt < (QSPLIT ? w + 1 : QT); ++qt) {
     const int q0 = qbase0 + qt * kTile;
     if (q0 >= p.l) break;
@@ -515,6 +553,19 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
       }
     }
     }  // query tile
+    }  // wave_active
+    if (DB) {
+      if (more) {
+        float *nq = s_dyn + ((stage + 1) & 1) * kStageFloats;
+        store_tile<D, THREADS, FROWS>(nq, rq, tid);
+        store_tile<D, THREADS, FROWS>(nq + QT * kTile * LS, rg, tid);
+        if (tid < kTile * QT) {
+          nq[2 * QT * kTile * LS + tid] = r_lse;
+          nq[2 * QT * kTile * LS + QT * kTile + tid] = r_delta;
+        }
+      }
+      __syncthreads();
+    }
   }
 
   if (QSPLIT && KW > 1) {  // sum the per-wave partial dK / dV: [wave-1][2*NT*16][64 lanes]
@@ -832,7 +883,15 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one Q + one dO (or K + V) tile
   constexpr size_t kRowBytes = sizeof(float) * 2 * kTile;                // lse + delta of a tile
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
-  if (p.s >= 1024) {
+  // double-buffered Q / dO staging pays on long query sequences (encoder: -5 %); with 256 queries
+  // (decoder memory) there are only 8 stages and the prologue eats the gain
+  if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
+    auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
+    const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
+    int st = set_lds(kern, lds);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+  } else if (p.s >= 1024) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
