@@ -11,7 +11,7 @@ the chained blocks (the parity tests run both, ``CODA_LAYER_NODES=ops`` selects 
 """
 import torch
 
-from .fused_layers import _AddLN, _FfnAct, _MHA
+from .fused_layers import _AddLN, _FfnAct, _MHA, _colsum_into
 from .linear_fn import tn_gemm
 
 
@@ -217,7 +217,6 @@ _NP = 18  # parameters per decoder layer, in the order built by `decoder_stack` 
 
 
 def _colsum_vec(x2):
-    from .fused_layers import _colsum_into
     out = torch.empty(x2.shape[1], dtype=torch.float32, device=x2.device)
     _colsum_into(out, x2.unsqueeze(0))
     return out
@@ -303,7 +302,7 @@ class _DecoderStack(torch.autograd.Function):
         dv_all = torch.empty_like(v_all)
         din2_all = torch.empty((nl, 3 * e, e), dtype=torch.float32, device=dev)   # cross in_proj weight grads
         dib2_all = torch.empty((nl, 3 * e), dtype=torch.float32, device=dev)
-        dnorm = torch.empty((nl, 2, e), dtype=torch.float32, device=dev)          # decoder norm: per-layer parts
+        dnorm_g, dnorm_b = [], []                                                  # decoder norm: per-layer parts
         grads = [None] * (nl * _NP)
         ds_next = None
         dqpos = None
@@ -311,8 +310,8 @@ class _DecoderStack(torch.autograd.Function):
             g1, b1n, in1, ib1, ow1, ob1, g2, b2n, in2, ib2, ow2, ob2, g3, b3n, w1, fb1, w2, fb2 = layers[l]
             c1, c2, c3, (xq2, q, attn, lse, seed, seed_dev), c5, ffn_saved, cn = ctx.blocks[l]
             do, dfb2, ds3, _, dgn, dbn, _, _ = _AddLN.backward(cn, ds_next, dstack[l], None)
-            dnorm[l, 0].copy_(dgn)
-            dnorm[l, 1].copy_(dbn)
+            dnorm_g.append(dgn)
+            dnorm_b.append(dbn)
             dy3, dw1, dfb1, dw2 = _ffn_backward(ffn_saved, do, w1, w2)
             da2, dob2, ds2, _, dg3, db3n, _, _ = _AddLN.backward(c5, ds3, dy3, None)
             # cross attention backward; dK / dV go straight into layer l's column slices
@@ -328,7 +327,7 @@ class _DecoderStack(torch.autograd.Function):
                                             seed_dev.data_ptr() if seed_dev is not None else None,
                                             _lib.current_stream_handle()), "mha_bwd")
             torch.mm(dq.t(), xq2, out=din2_all[l, :e])
-            dib2_all[l, :e].copy_(_colsum_vec(dq))
+            _colsum_into(dib2_all[l, :e], dq.unsqueeze(0))
             dxq = torch.mm(dq, in2[:e]).view(nq, bsz, e)
             da1, dob1, ds1, dpos2, dg2, db2n, _, _ = _AddLN.backward(c3, ds2, None if has_qpos else dxq,
                                                                      dxq if has_qpos else None)
@@ -350,7 +349,7 @@ class _DecoderStack(torch.autograd.Function):
         din2_all[:, 2 * e:].copy_(dwv.view(nl, e, e))
         dib2_all[:, e:2 * e].copy_(_colsum_vec(dk_all).view(nl, e))
         dib2_all[:, 2 * e:].copy_(_colsum_vec(dv_all).view(nl, e))
-        dnorm_sum = dnorm.sum(0)
+        dnorm_sum = (torch.stack(dnorm_g).sum(0), torch.stack(dnorm_b).sum(0))
         if has_pos:
             dmemory = (dmp2 + dmem2).view(ns, bsz, e)
             dpos = dmp2.view(ns, bsz, e)
