@@ -84,7 +84,8 @@ class PointnetSAModuleVotes(nn.Module):
             b, npoint = prepared["new_xyz"].shape[0], prepared["new_xyz"].shape[1]
             pooled = fused_sa_mlp.fused_mlp_pool(prepared["grouped_cl"].view(-1, 3), b * npoint, self.nsample,
                                                  self.mlp_module, idx=prepared["idx"], counts=prepared["counts"],
-                                                 total=int(prepared["total_host"][0]))
+                                                 total=None if prepared["total_host"] is None
+                                                 else int(prepared["total_host"][0]))
             return prepared["new_xyz"], pooled.view(b, npoint, -1).permute(0, 2, 1), prepared["inds"]
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)

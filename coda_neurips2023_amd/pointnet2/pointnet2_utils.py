@@ -78,7 +78,11 @@ class SamplingPrefetcher:
         for k, (pc, version, prepared, done) in enumerate(self._pending):
             if pc is point_clouds and version == point_clouds._version:
                 del self._pending[k]
-                done.synchronize()  # host: the row count has landed (normally long ago)
+                if not done.query():
+                    # the side stream is still busy (its workgroups need whole CUs and may have been
+                    # starved): do not stall the host for the row count -- drop it (the shared MLP then
+                    # runs on all rows) and let the compute stream wait on the device side
+                    prepared = dict(prepared, total_host=None)
                 cur = torch.cuda.current_stream(point_clouds.device)
                 cur.wait_event(done)
                 for v in prepared.values():
