@@ -64,6 +64,11 @@ SIGNATURES = {
                                                     _P, _P]),
     "coda_tok_bias_relu_dropout_bwd_blocks": (_c_int, [ctypes.c_longlong, _c_int]),
     "coda_tok_bias_relu_dropout_bwd_f32": (_c_int, [_P, _P, ctypes.c_longlong, _c_int, _c_float, _P, _P, _P, _P]),
+    # include/coda_align_loss.h
+    "coda_align_loss_fwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P, _P,
+                                         _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
+    "coda_align_loss_bwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P, _P,
+                                         _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
     # include/coda_attention.h
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _P]),

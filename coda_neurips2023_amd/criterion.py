@@ -101,6 +101,8 @@ class SetCriterion(nn.Module):
         self.loss_weight_dict = loss_weight_dict
         self.confidence_type = getattr(args, "confidence_type", confidence_type) if args else confidence_type
         self.layer_batched = True  # evaluate all decoder layers in one pass when the model hands them stacked
+        self.fused_alignment = True  # GPU fp32: both alignment terms from one HIP pass (align_loss.py)
+        self._align_cache = None
         assert self.confidence_type in ["non-confidence", "objectness", "clip+objectness", "clip-max-prob"]
         self.loss_functions = {
             "loss_sem_cls_softmax_skip_none_gt_sample": self.loss_sem_cls_softmax_skip_none_gt_sample,
@@ -209,9 +211,48 @@ class SetCriterion(nn.Module):
         return {"loss_size": size_loss}
 
     # CLIP-space alignment terms (hot path)
+    def _alignment_labels(self, targets, assignments):
+        """Label / confidence of every proposal for the CE alignment term: matched proposals take
+        the GT box's, the others the CLIP weak label (criterion.py:618-631)."""
+        inds = assignments["per_prop_gt_inds"]
+        matched = assignments["proposal_matched_mask"].int() > 0
+        seen_label = self._gather_gt(targets["gt_box_seen_sem_cls_label"], inds)
+        seen_confi = self._gather_gt(targets["gt_box_seen_sem_cls_confi"], inds)
+        gt_box_label = torch.where(matched, seen_label, targets["weak_box_cate_label"])
+        gt_box_confidence = torch.where(matched, seen_confi, targets["weak_confidence_weight"])
+        if self.confidence_type == "non-confidence":
+            gt_box_confidence = torch.where(gt_box_confidence > 1e-16, torch.ones_like(gt_box_confidence),
+                                            gt_box_confidence)
+        return gt_box_label, gt_box_confidence
+
+    def _fused_alignment(self, outputs, targets, assignments):
+        """Both alignment terms of all layers from the fused HIP pass (align_loss.py), or None when
+        the tensors are not the GPU fp32 case it covers.  Cached for the second term's call."""
+        from . import align_loss
+        emb = outputs["text_correlation_embedding"]
+        gt = targets["gt_text_correlation_embedding"]
+        text = targets["text_features_clip"]
+        if not self.fused_alignment or not align_loss.eligible(emb, gt, text, targets["logit_scale"]):
+            return None
+        key = (id(emb), emb._version, id(assignments["per_prop_gt_inds"]))
+        if self._align_cache is not None and self._align_cache[0] == key:
+            result, self._align_cache = self._align_cache[1], None  # second term: served, not kept alive
+            return result
+        label, conf = self._alignment_labels(targets, assignments)
+        weight_maps = targets["gt_text_correlation_embedding_mask"]
+        l1_sum, ce_sum = align_loss.align_loss_sums(emb, gt, weight_maps, text, targets["logit_scale"], label, conf)
+        ave_weight = torch.sum(weight_maps) * emb.shape[-1]
+        all_num = torch.sum(conf > 1e-32, dim=(1, 2)) + 1e-32
+        result = (l1_sum / ave_weight, ce_sum / all_num)
+        self._align_cache = (key, result)
+        return result
+
     def stacked_loss_predicted_region_embed_l1(self, outputs, targets, assignments):
         """Masked L1 between the predicted region embedding and the CLIP image
         embedding of the cropped box, / (sum(mask) * 512)."""
+        fused = self._fused_alignment(outputs, targets, assignments)
+        if fused is not None:
+            return {"loss_predicted_region_embed_l1": fused[0]}
         gt = targets["gt_text_correlation_embedding"]
         pred = outputs["text_correlation_embedding"]
         weight_maps = targets["gt_text_correlation_embedding_mask"]
@@ -222,20 +263,15 @@ class SetCriterion(nn.Module):
     def stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(self, outputs, targets, assignments):
         """CE(normalised embedding @ text^T * scale, label) * confidence, where matched
         proposals take the GT label/confidence and the others the CLIP weak label."""
+        fused = self._fused_alignment(outputs, targets, assignments)
+        if fused is not None:
+            return {"loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi": fused[1]}
         emb = outputs["text_correlation_embedding"]
         emb = emb / (emb.norm(dim=-1, keepdim=True) + 1e-32)
         text_features_clip = targets["text_features_clip"].to(torch.float32)
         temperature_param = targets["logit_scale"]
         correlation_map = torch.matmul(emb, text_features_clip.permute(0, 2, 1)) * temperature_param
-        inds = assignments["per_prop_gt_inds"]
-        matched = assignments["proposal_matched_mask"].int() > 0
-        seen_label = self._gather_gt(targets["gt_box_seen_sem_cls_label"], inds)
-        seen_confi = self._gather_gt(targets["gt_box_seen_sem_cls_confi"], inds)
-        gt_box_label = torch.where(matched, seen_label, targets["weak_box_cate_label"])
-        gt_box_confidence = torch.where(matched, seen_confi, targets["weak_confidence_weight"])
-        if self.confidence_type == "non-confidence":
-            gt_box_confidence = torch.where(gt_box_confidence > 1e-16, torch.ones_like(gt_box_confidence),
-                                            gt_box_confidence)
+        gt_box_label, gt_box_confidence = self._alignment_labels(targets, assignments)
         loss = self._ce(correlation_map, gt_box_label)
         all_num = torch.sum(gt_box_confidence > 1e-32, dim=(1, 2)) + 1e-32
         final_loss = torch.sum(loss * gt_box_confidence, dim=(1, 2)) / all_num
