@@ -8,11 +8,15 @@ synthetic SUN-RGBD-shaped scenes (20 000 points) per GPU, inputs resident in HBM
 before the timed region.  Prints ONE JSON line on rank 0 (see the task contract):
 scenes/s over all ranks, plus
 
-* ``roofline``     for the ball_query(+group) kernel: algorithmic bytes
-                   (3 126 016 B/scene) / its average launch duration,
-                   measured live with HIP events on the launch stream inside the
-                   timed region; ``traffic`` comes from a separate rocprofv3 --pmc
-                   pass and is null here.
+* ``roofline``     model workload: the dominant kernel of the step's critical path, the
+                   encoder self-attention dK/dV kernel (fp32 MFMA bound): its flops per
+                   launch (SURVEY.md 8d attention-core counts) / its average launch
+                   duration, measured live with HIP events on the launch stream inside
+                   the timed region (coda_mha_timing_*).  sa workload: the
+                   ball_query(+group) operator against HBM (3 126 016 B/scene).
+* ``roofline_others`` the other attention kernels (timed in extra steps right after the
+                   timed region) and the ball_query(+group) operator (BASELINE.json's
+                   "ball_query HBM GB/s"), same definitions.
 * ``cpu_baseline`` the CPU oracle port (C ops + torch-CPU layers) on the host
                    cores, bounded sample, rank 0 at N=1 only.
 
@@ -47,6 +51,15 @@ RADIUS = 0.2
 BQ_GROUP_BYTES_PER_SCENE = (12 * N_POINTS + 12 * M_CENTRES + 4 * M_CENTRES * NSAMPLE) + \
                            (4 * M_CENTRES * NSAMPLE + 12 * N_POINTS + 12 * M_CENTRES * NSAMPLE)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+# MFMA flops of one attention kernel per (query, key, model-channel) triple: forward QK^T + PV;
+# dK/dV kernel S = QK^T (recomputed), dP = dO V^T, dV = P^T dO, dK = dS^T Q; dQ kernel S, dP, dQ = dS K.
+# SURVEY.md 8d counts the whole backward as 8 (+4 "if recomputed") = the dV, dK, dP, dQ products plus
+# one recomputation; the two-kernel split executes 14.
+ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6}
+# HBM bytes per launch of the 2048x2048 dK/dV kernel from PMC: FETCH_SIZE 55 374 KB x 2 (gfx950 correction) +
+# WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
+ATTN_DKV_TRAFFIC = (55374 * 2 + 49272) * 1024
 
 
 def parse():
@@ -233,6 +246,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if os.environ.get("CODA_BLAS"):  # dev A/B: "cublas" (= rocBLAS) | "cublaslt" (= hipBLASLt, torch's default here)
+        torch.backends.cuda.preferred_blas_library(os.environ["CODA_BLAS"])
     mod, step_fn, desc, kind = build_workload(args.workload, dev)
     model = mod
     if world > 1:
@@ -309,6 +324,11 @@ def main():
 
     timing = _ext.enable_kernel_timing(["query_and_group_xyz", "ball_query", "furthest_point_sampling"]) \
         if graph is None else {}
+    attn_timed = kind == "model" and graph is None and rank == 0
+    if attn_timed:
+        from coda_neurips2023_amd import attention_core
+        # long-sequence launches only (encoder self-attention: 12 kernels per step) inside the timed region
+        attention_core.enable_kernel_timing(1024)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -321,6 +341,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _ext.disable_kernel_timing()
+    attn_ms, attn_ms_all = {}, {}
+    if attn_timed:
+        attn_ms = attention_core.collect_kernel_timing()
+        # every attention kernel (decoder shapes too), `steps` more steps outside the timed region
+        attention_core.enable_kernel_timing(0)
+        for i in range(args.steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        attn_ms_all = attention_core.collect_kernel_timing()
+        attention_core.disable_kernel_timing()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -365,6 +395,62 @@ def main():
         fps_ms = max((s.elapsed_time(e) for s, e in fps_ev), default=None)
         bytes_per_launch = BQ_GROUP_BYTES_PER_SCENE * B_PER_GPU
         achieved = bytes_per_launch / (bq_ms * 1e-3) / 1e9 if bq_ms else None
+        bq_roofline = {
+            "kernel": "grid_build_kernel + grid_query_kernel (cell-binned ball_query fused with xyz grouping, "
+                      "one coda_query_and_group_xyz_f32 call)",
+            "timing": (("HIP events around each call inside the timed region"
+                        + (" (side stream, concurrent with the step's kernels)" if prefetch else ""))
+                       if graph is None else
+                       "timed region replays a hipGraph; HIP events around `steps` eager calls of the same "
+                       "operator on the bench inputs right after it"),
+            "bound": "hbm",
+            "achieved": round(achieved, 3) if achieved else None,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+            # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate
+            # rocprofv3 --pmc passes: profiles/r01_pmc_ball_query.md
+            "traffic": 25234432,
+            "bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
+            # same operator, same inputs, GPU otherwise idle (only reported when the timed region ran it
+            # concurrently with the step on a side stream)
+            "avg_launch_ms_alone": round(bq_alone_ms, 5) if bq_alone_ms else None,
+            "frac_alone": round(bytes_per_launch / (bq_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            if bq_alone_ms else None,
+        }
+
+        def attn_entry(key, samples, timing_note):
+            k, l, s_len = key
+            ms = sum(samples) / len(samples)
+            flops = ATTN_FLOPS[k] * l * s_len * 256 * B_PER_GPU  # 4 heads x 64 = 256 model channels
+            tf = flops / (ms * 1e-3) / 1e12
+            names = {"fwd": "mha_fwd_kernel", "dkv": "mha_bwd_dkv_kernel", "dq": "mha_bwd_dq_kernel"}
+            return {"kernel": f"{names[k]} (queries {l} x keys {s_len}, {B_PER_GPU} scenes x 4 heads x 64, "
+                              f"dropout 0.1)",
+                    "timing": timing_note, "bound": "mfma", "achieved": round(tf, 2),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": None, "flops_per_launch": flops,
+                    "flops_formula": f"{ATTN_FLOPS[k]} * Lq * Lk * 256 * scenes (SURVEY 8d attention core)",
+                    "avg_launch_ms": round(ms, 5), "launches": len(samples)}
+
+        roofline, others = bq_roofline, []
+        dom = ("dkv", 2048, 2048)
+        if dom in attn_ms:
+            roofline = attn_entry(dom, attn_ms[dom], "HIP events around each launch inside the timed region "
+                                                     "(coda_mha_timing_*, launch stream)")
+            # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes): profiles/README.md
+            roofline["traffic"] = ATTN_DKV_TRAFFIC
+            t_bwd = sum(sum(attn_ms[(k, 2048, 2048)]) / len(attn_ms[(k, 2048, 2048)])
+                        for k in ("delta", "dkv", "dq") if (k, 2048, 2048) in attn_ms)
+            # SURVEY 8d's count for the whole backward with recomputation: 12 * Lq * Lk * d over delta + dK/dV + dQ
+            roofline["frac_whole_backward_8d"] = round(
+                12 * 2048 * 2048 * 256 * B_PER_GPU / (t_bwd * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+            note = "HIP events around each launch, `steps` extra steps right after the timed region"
+            for key in sorted(attn_ms_all, key=lambda k: (-k[1] * k[2], k[0])):
+                if key[0] != "delta" and key != dom:
+                    others.append(attn_entry(key, attn_ms_all[key], note))
+            others.append(bq_roofline)
         out = {
             "metric": "scenes/sec fwd+bwd (20k pts, 256 queries)",
             "value": round(world * B_PER_GPU * args.steps / dt, 3),
@@ -384,32 +470,11 @@ def main():
                        "sampling": ("FPS + ball query of batch i+1 run on a side stream during step i (once per "
                                     "step, inside the timed region); padded group copies are computed once"
                                     if prefetch else "in line")},
-            "roofline": {
-                "kernel": "grid_build_kernel + grid_query_kernel (cell-binned ball_query fused with xyz grouping, "
-                          "one coda_query_and_group_xyz_f32 call)",
-                "timing": (("HIP events around each call inside the timed region"
-                            + (" (side stream, concurrent with the step's kernels)" if prefetch else ""))
-                           if graph is None else
-                           "timed region replays a hipGraph; HIP events around `steps` eager calls of the same "
-                           "operator on the bench inputs right after it"),
-                "bound": "hbm",
-                "achieved": round(achieved, 3) if achieved else None,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate
-                # rocprofv3 --pmc passes: profiles/r01_pmc_ball_query.md
-                "traffic": 25234432,
-                "bytes_per_launch": bytes_per_launch,
-                "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
-                # same operator, same inputs, GPU otherwise idle (only reported when the timed region ran it
-                # concurrently with the step on a side stream)
-                "avg_launch_ms_alone": round(bq_alone_ms, 5) if bq_alone_ms else None,
-                "frac_alone": round(bytes_per_launch / (bq_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                if bq_alone_ms else None,
-            },
+            "roofline": roofline,
             "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
         }
+        if others:
+            out["roofline_others"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind)
         print(json.dumps(out), flush=True)

@@ -75,6 +75,8 @@ SIGNATURES = {
     "coda_mha_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                   ctypes.c_uint64, _P, _P]),
+    "coda_mha_timing_enable": (_c_int, [_c_int]),
+    "coda_mha_timing_collect": (_c_int, [_P, _P, _P, _P, _c_int]),
 }
 
 _lib = None

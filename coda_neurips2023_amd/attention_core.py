@@ -142,3 +142,31 @@ def attention(q, k, v, mask, scale, dropout_p, need_weights):
                 scores = scores.masked_fill(mask, float("-inf"))
             probs = torch.softmax(scores, dim=-1)
     return out, probs
+
+
+# ---- measurement aid (bench.py): per-kernel HIP-event timing inside the C library ----------------
+TIMING_KINDS = ("fwd", "delta", "dkv", "dq")
+
+
+def enable_kernel_timing(min_len=0):
+    """Bracket every attention kernel of problems with l, s >= min_len with HIP events on its launch
+    stream (coda_mha_timing_enable); drops earlier records."""
+    _lib.check(_lib.load().coda_mha_timing_enable(int(min_len)), "coda_mha_timing_enable")
+
+
+def disable_kernel_timing():
+    _lib.check(_lib.load().coda_mha_timing_enable(-1), "coda_mha_timing_enable")
+
+
+def collect_kernel_timing(cap=16384):
+    """{(kind, l, s): [ms, ...]} of the launches recorded since enable_kernel_timing()."""
+    import ctypes
+    kind, l, s = ((ctypes.c_int * cap)() for _ in range(3))
+    ms = (ctypes.c_float * cap)()
+    n = _lib.load().coda_mha_timing_collect(kind, l, s, ms, cap)
+    if n < 0:
+        raise RuntimeError(f"coda_mha_timing_collect failed ({n})")
+    out = {}
+    for i in range(n):
+        out.setdefault((TIMING_KINDS[kind[i]], l[i], s[i]), []).append(ms[i])
+    return out

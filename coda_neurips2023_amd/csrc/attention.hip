@@ -24,6 +24,7 @@
 #include "common.hip.h"
 
 #include <cstdlib>
+#include <vector>
 
 namespace coda {
 namespace {
@@ -62,7 +63,23 @@ struct MhaParams {
   float scale, inv_keep;
   uint32_t thresh16, seed;
   const uint64_t *seed_dev;  // optional device-resident seed (graph replays draw fresh masks)
+  int xcd_map;               // XCD-aware workgroup -> (tile, head) mapping (tile_head())
 };
+
+// XCD-aware workgroup -> (tile, batch*head) mapping.  Workgroups are dispatched round-robin over the 8
+// XCDs in linear-id order (x fastest), so with the plain grid (x = tile, y = head) the tiles of one head
+// are spread over all 8 XCDs and every private L2 pulls every head's K/V (or Q/dO) from the fabric:
+// FETCH_SIZE showed 2.8-5x the algorithmic bytes.  Here the workgroups that share a head share an XCD.
+struct TileHead {
+  int tile, bh;
+};
+__device__ __forceinline__ TileHead tile_head(int xcd_map) {
+  const int T = gridDim.x, BH = gridDim.y;
+  if (!xcd_map || (BH & 7) != 0) return {static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y)};
+  const int i = blockIdx.x + T * blockIdx.y;
+  const int j = i >> 3;
+  return {j % T, (j / T) * 8 + (i & 7)};
+}
 
 __device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint64_t *seed_dev) {
   if (!seed_dev) return seed;
@@ -132,8 +149,9 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = SPLIT ? blockIdx.x * kTile : (blockIdx.x * QW + w) * kTile;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = SPLIT ? th.tile * kTile : (th.tile * QW + w) * kTile;
   const int my_tile = SPLIT ? w : 0;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;  // wave-uniform
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m = -INFINITY, lsum = 0.f;
   const bool use_drop = p.thresh16 != 0u;
-  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
 
   constexpr int kStageFloats = 2 * TILES * kTile * LS;  // one K + V stage
   constexpr int NLD = DB ? TILES * kTile * D / 4 / THREADS : 1;
@@ -349,6 +367,7 @@ struct MhaBwdParams {
   int b, h, l, s;
   int ldq, ldk, ldv;
   int lddq, lddk, lddv;  // floats between consecutive batch rows of dq / dk / dv (H*D when dense)
+  int xcd_map;
   float scale, inv_keep;
   uint32_t thresh16, seed;
   const uint64_t *seed_dev;
@@ -398,14 +417,15 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
-  const int k0 = QSPLIT ? blockIdx.x * kTile : (blockIdx.x * KW + w) * kTile;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int k0 = QSPLIT ? th.tile * kTile : (th.tile * KW + w) * kTile;
   const int mykey = k0 + l31;
   const bool wave_active = k0 < p.s;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
   const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
   const bool use_drop = p.thresh16 != 0u;
-  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
 
   const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
                vstride = static_cast<size_t>(p.b) * p.ldv;
@@ -625,15 +645,16 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = SPLIT ? blockIdx.x * kTile : (blockIdx.x * QW + w) * kTile;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = SPLIT ? th.tile * kTile : (th.tile * QW + w) * kTile;
   const int my_tile = SPLIT ? w : 0;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
   const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
   const bool use_drop = p.thresh16 != 0u;
-  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(blockIdx.y)) : 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
 
   const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
                vstride = static_cast<size_t>(p.b) * p.ldv;
@@ -831,6 +852,46 @@ bool split_double_buffered() {
   static const bool on = [] { const char *e = getenv("CODA_ATTN_SPLIT_DB"); return !e || atoi(e) != 0; }();
   return on;
 }
+// ---- optional per-kernel HIP-event timing (coda_mha_timing_*) -----------------------------------
+struct TimingRecord {
+  int kind, l, s;
+  hipEvent_t e0, e1;
+};
+int g_timing_min_len = -1;  // < 0: off
+std::vector<TimingRecord> g_timing;
+constexpr size_t kTimingCap = 16384;
+
+void timing_clear() {
+  for (auto &r : g_timing) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_timing.clear();
+}
+
+// brackets the launches issued during its lifetime
+struct KernelTimer {
+  hipStream_t stream;
+  hipEvent_t e1 = nullptr;
+  KernelTimer(int kind, int l, int s, hipStream_t st) : stream(st) {
+    if (g_timing_min_len < 0 || l < g_timing_min_len || s < g_timing_min_len || g_timing.size() >= kTimingCap)
+      return;
+    TimingRecord r{kind, l, s, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, stream);
+    e1 = r.e1;
+    g_timing.push_back(r);
+  }
+  ~KernelTimer() {
+    if (e1) (void)hipEventRecord(e1, stream);
+  }
+};
+
+// CODA_ATTN_XCD=0: plain (tile, head) grid (A/B)
+bool xcd_mapped() {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_XCD"); return !e || atoi(e) != 0; }();
+  return on;
+}
 bool double_buffered() {
   static const bool on = [] { const char *e = getenv("CODA_ATTN_DB"); return !e || atoi(e) != 0; }();
   return on;
@@ -841,6 +902,7 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
   // split-key variants: 8 waves per block when 8 K/V tile pairs fit the 160 KB LDS (D = 64)
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
+  KernelTimer timer(0, p.l, p.s, s);
   if (p.l >= 1024) {
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
     if (double_buffered()) {
@@ -885,6 +947,8 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   // double-buffered Q / dO staging pays on long query sequences (encoder: -5 %); with 256 queries
   // (decoder memory) there are only 8 stages and the prologue eats the gain
+  {
+  KernelTimer timer(2, p.l, p.s, s);
   if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
@@ -904,6 +968,8 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
+  }
+  KernelTimer timer(3, p.l, p.s, s);
   if (p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN, true>;
     int st = set_lds(kern, 4 * kTileBytes);
@@ -934,7 +1000,10 @@ template <int D>
 int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   clear_sticky_error();
   const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
-  hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+  {
+    KernelTimer timer(1, p.l, p.s, s);
+    hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+  }
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
   return gen ? launch_bwd_g<D, true>(p, s) : launch_bwd_g<D, false>(p, s);
 }
@@ -961,6 +1030,7 @@ CODA_API int coda_mha_fwd_f32(const float *q, const float *k, const float *v, co
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
   p.seed_dev = seed_dev;
+  p.xcd_map = xcd_mapped();
   hipStream_t st = static_cast<hipStream_t>(stream);
   return d == 64 ? launch_fwd<64>(p, st) : launch_fwd<128>(p, st);
 }
@@ -992,6 +1062,31 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
   p.inv_keep = 1.0f / (1.0f - dropout_p);
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
   p.seed_dev = seed_dev;
+  p.xcd_map = xcd_mapped();
   hipStream_t st = static_cast<hipStream_t>(stream);
   return d == 64 ? launch_bwd<64>(p, st) : launch_bwd<128>(p, st);
+}
+
+CODA_API int coda_mha_timing_enable(int min_len) {
+  using namespace coda;
+  timing_clear();
+  g_timing_min_len = min_len;
+  return CODA_OK;
+}
+
+CODA_API int coda_mha_timing_collect(int *kind, int *l, int *s, float *ms, int cap) {
+  using namespace coda;
+  if (cap < 0 || (cap > 0 && (!kind || !l || !s || !ms))) return CODA_EINVAL;
+  int n = 0;
+  for (const auto &r : g_timing) {
+    if (n >= cap) break;
+    hipError_t e = hipEventSynchronize(r.e1);
+    if (e != hipSuccess) return -(1000 + static_cast<int>(e));
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.e0, r.e1);
+    if (e != hipSuccess) return -(1000 + static_cast<int>(e));
+    kind[n] = r.kind; l[n] = r.l; s[n] = r.s; ms[n] = t;
+    ++n;
+  }
+  return n;
 }

@@ -58,6 +58,16 @@ int coda_mha_bwd_f32(const float *q, const float *k, const float *v,
                      int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
                      float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *stream);
 
+/* Measurement aid (bench.py's live roofline figures; no reference counterpart).  While
+ * enabled, each kernel launched by coda_mha_fwd_f32 / coda_mha_bwd_f32 for a problem with
+ * l >= min_len and s >= min_len is bracketed by two HIP events on the launch stream.
+ * coda_mha_timing_enable(min_len < 0) disables; every call drops the records taken so far.
+ * coda_mha_timing_collect synchronises the recorded events and writes up to `cap` records
+ * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ; the call's l and s; milliseconds); returns the
+ * number written, CODA_EINVAL, or -(1000 + hipError_t) if an event query failed. */
+int coda_mha_timing_enable(int min_len);
+int coda_mha_timing_collect(int *kind, int *l, int *s, float *ms, int cap);
+
 #ifdef __cplusplus
 }
 #endif

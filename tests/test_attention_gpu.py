@@ -39,6 +39,9 @@ def make_qkv(dev, l, s, b, h, d, packed, seed):
     (1024, 1024, 1, 4, 64, True, True),     # masked encoder after interim down-sampling
     (40, 160, 2, 4, 128, False, False),     # dec_dim 512
     (128, 128, 2, 4, 128, True, True),
+    (256, 2048, 8, 4, 64, False, False),    # 32 batch*heads: four head groups per XCD in tile_head()
+    (300, 200, 4, 4, 64, False, True),      # 16 batch*heads, ragged tiles, mask
+    (96, 64, 3, 4, 64, False, False),       # 12 batch*heads: not a multiple of 8, plain grid
 ])
 def test_forward_backward_match_torch_reference(dev, l, s, b, h, d, packed, masked):
     leaves, q, k, v = make_qkv(dev, l, s, b, h, d, packed, seed=l + s)
@@ -113,6 +116,26 @@ def test_dropout_mask_statistics_and_backward_consistency(dev):
     grads_ref = torch.autograd.grad((ref * gw).sum(), (q, k, v))
     for a, r in zip(grads, grads_ref):
         assert rel(a, r) < 1e-3
+
+
+def test_kernel_timing_records_every_launch(dev):
+    """coda_mha_timing_*: one record per kernel of the calls at or above the length filter."""
+    _, q, k, v = make_qkv(dev, 256, 256, 2, 4, 64, False, seed=5)
+    _, q2, k2, v2 = make_qkv(dev, 64, 64, 2, 4, 64, False, seed=6)
+    attention_core.enable_kernel_timing(128)
+    try:
+        for _ in range(3):
+            out, _ = attention_core.attention(q, k, v, None, 0.125, 0.0, False)
+            out.sum().backward()
+            small, _ = attention_core.attention(q2, k2, v2, None, 0.125, 0.0, False)  # below the filter
+            small.sum().backward()
+        rec = attention_core.collect_kernel_timing()
+    finally:
+        attention_core.disable_kernel_timing()
+    assert sorted(rec) == [(kind, 256, 256) for kind in sorted(attention_core.TIMING_KINDS)]
+    for samples in rec.values():
+        assert len(samples) == 3 and all(0.0 < ms < 50.0 for ms in samples)
+    assert attention_core.collect_kernel_timing() == {}  # disabling dropped the records
 
 
 def test_cpu_tensors_rejected():
