@@ -69,8 +69,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="auto", choices=["auto", "sa", "model"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="replay the whole step (fwd+bwd+optimizer) as one captured hipGraph")
+    p.add_argument("--graph", default="off", choices=["on", "off"],
+                   help="EXPERIMENTAL (model workload, one process): replay everything behind the set-abstraction "
+                        "stage (encoder, decoder, heads, loss; forward + backward) as one captured hipGraph")
     p.add_argument("--prefetch", choices=["on", "off"], default="on",
                    help="model workload: sample (FPS) batch i+1 on a side stream during step i")
     return p.parse_args()
@@ -145,8 +146,8 @@ def build_model_workload(dev):
     assign_st = {k: rep(v) for k, v in assign.items()}
     cls_tgt_st, ang_tgt_st = rep(cls_tgt).reshape(-1), rep(ang_tgt).reshape(-1)
 
-    def step(m, batch):
-        pred = m(batch, curr_epoch=0)
+    def step(m, batch, pre_encoded=None):
+        pred = m(batch, curr_epoch=0, pre_encoded=pre_encoded) if pre_encoded is not None else m(batch, curr_epoch=0)
         o = pred["outputs"]
         st = pred["stacked_outputs"]  # (num_layers, B, nq, ...): all decoder layers, evaluated in one pass
         targets = dict(tgt_fixed, text_features_clip=o["text_features_clip"], logit_scale=o["logit_scale"],
@@ -262,12 +263,16 @@ def main():
         pool.append({"point_clouds": torch.from_numpy(pc).to(dev),
                      "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
-    use_graph = args.graph == "on"  # measured: the step is GPU-bound, replay gives no gain (profiles/README.md)
-    # fused=True: one multi-tensor kernel per parameter group instead of ~10 foreach launches
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph, fused=not use_graph)
-
     raw_model = model.module if hasattr(model, "module") else model
-    prefetch = args.prefetch == "on" and kind == "model" and not use_graph
+    # EXPERIMENTAL, opt-in (--graph on): hipGraph replay of everything behind the set-abstraction stage
+    # (step_graph.GraphedTail, see its docstring for the status).  The default is the eager step.
+    use_graph = kind == "model" and world == 1 and args.graph == "on"
+    if args.graph == "on" and not use_graph:
+        print("[bench] --graph on applies to the single-process model workload only; running eagerly",
+              file=sys.stderr)
+    # fused=True: one multi-tensor kernel per parameter group instead of ~10 foreach launches
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    prefetch = args.prefetch == "on" and kind == "model"
 
     def one_step_eager(i):
         if prefetch:
@@ -280,53 +285,49 @@ def main():
         opt.step()
 
     graph = None
-    static = {k: v.clone() for k, v in pool[0].items()}
     if use_graph:
-        # Launch-bound loop (~3000 small kernels per step): capture forward + backward + optimizer
-        # once and replay it as a hipGraph.  Dropout masks of the fused attention come from a
-        # device-resident seed that the graph itself advances, so every replay draws new masks.
-        try:
-            from coda_neurips2023_amd import attention_core
-            seed_t = torch.zeros(1, dtype=torch.int64, device=dev)
-            attention_core.use_device_seed(seed_t)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for i in range(3):
-                    opt.zero_grad(set_to_none=True)
-                    step_fn(model, static).backward()
-                    opt.step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                seed_t += 1
-                step_fn(model, static).backward()
-                opt.step()
-        except Exception as e:  # noqa: BLE001 -- capture is an optimisation; the eager loop is the fallback
-            import traceback
-            traceback.print_exc(limit=12)
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
-            graph = None
-            from coda_neurips2023_amd import attention_core
-            attention_core.use_device_seed(None)
-            opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+        from coda_neurips2023_amd.step_graph import GraphedTail
 
-    def one_step(i):
-        if graph is None:
-            return one_step_eager(i)
-        for k, v in pool[i % len(pool)].items():
-            static[k].copy_(v)
-        graph.replay()
+        def tail_fn(xyz, feat, inds, pc, dims_min, dims_max):
+            batch = {"point_clouds": pc, "point_cloud_dims_min": dims_min, "point_cloud_dims_max": dims_max}
+            return step_fn(raw_model, batch, pre_encoded=(xyz, feat, inds))
+
+        b0 = pool[0]
+        with torch.no_grad():
+            xyz0, feat0, inds0 = raw_model.run_pre_encoder(b0["point_clouds"])
+        sa_params = list(raw_model.pre_encoder.parameters())
+        sa_ids = {id(p) for p in sa_params}
+        graph = GraphedTail(tail_fn, [xyz0, feat0.requires_grad_(True), inds0, b0["point_clouds"],
+                                      b0["point_cloud_dims_min"], b0["point_cloud_dims_max"]],
+                            [p for p in raw_model.parameters() if id(p) not in sa_ids])
+        if prefetch:
+            # the host has time to spare now: wait for the side stream's row counts instead of dropping them
+            raw_model.prefetch_sampling(pool[0], wait_for=None)
+            raw_model._sampling_prefetcher.wait_for_counts = True
+
+    def one_step_graph(i):
+        if prefetch:
+            raw_model.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)
+        b = pool[i % len(pool)]
+        for p in sa_params:
+            p.grad = None
+        xyz, feat, inds = raw_model.run_pre_encoder(b["point_clouds"])  # eager: data-dependent row counts
+        _, grads = graph.replay(xyz, feat.detach(), inds, b["point_clouds"], b["point_cloud_dims_min"],
+                                b["point_cloud_dims_max"])
+        feat.backward(grads[1])
+        opt.step()
+
+    one_step = one_step_graph if graph is not None else one_step_eager
 
     for i in range(args.warmup):
         one_step(i)
 
-    timing = _ext.enable_kernel_timing(["query_and_group_xyz", "ball_query", "furthest_point_sampling"]) \
-        if graph is None else {}
-    attn_timed = kind == "model" and graph is None and rank == 0
+    # the set-abstraction stage (and its side-stream sampling) is enqueued eagerly in both modes
+    timing = _ext.enable_kernel_timing(["query_and_group_xyz", "ball_query", "furthest_point_sampling"])
+    attn_timed = kind == "model" and rank == 0
     if attn_timed:
         from coda_neurips2023_amd import attention_core
+    if attn_timed and graph is None:
         # long-sequence launches only (encoder self-attention: 12 kernels per step) inside the timed region
         attention_core.enable_kernel_timing(1024)
     if world > 1:
@@ -343,37 +344,31 @@ def main():
     _ext.disable_kernel_timing()
     attn_ms, attn_ms_all = {}, {}
     if attn_timed:
-        attn_ms = attention_core.collect_kernel_timing()
-        # every attention kernel (decoder shapes too), `steps` more steps outside the timed region
+        if graph is None:
+            attn_ms = attention_core.collect_kernel_timing()
+        # every attention kernel (decoder shapes too), `steps` more EAGER steps outside the timed region.  When
+        # the timed region replayed a hipGraph these also stand in for the dominant kernel: HIP events cannot
+        # be read back from inside a graph replay (the rocprofv3 trace of the same command under profiles/
+        # does see the replayed kernels and is the cross-check)
         attention_core.enable_kernel_timing(0)
         for i in range(args.steps):
-            one_step(i)
+            one_step_eager(i)
         torch.cuda.synchronize()
         attn_ms_all = attention_core.collect_kernel_timing()
         attention_core.disable_kernel_timing()
+        if graph is not None:
+            attn_ms = attn_ms_all
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if graph is not None and rank == 0:
-        # the timed region replayed a graph (no per-launch events possible): time the same operator
-        # launches on the same inputs with HIP events right after it, `steps` launches each
-        timing = _ext.enable_kernel_timing(["query_and_group_xyz", "furthest_point_sampling"])
-        with torch.no_grad():
-            for i in range(args.steps):
-                xyz = pool[i % len(pool)]["point_clouds"][..., :3].contiguous()
-                inds = _ext.furthest_point_sampling(xyz, M_CENTRES)
-                new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-                _ext.query_and_group_xyz(new_xyz, xyz, RADIUS, NSAMPLE, True, channels_last=True)
-        torch.cuda.synchronize()
-        _ext.disable_kernel_timing()
 
     def avg_ms(name, store=None):
         ev = (timing if store is None else store).get(name, [])
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
 
     alone = {}
-    if rank == 0 and graph is None and prefetch:
+    if rank == 0 and prefetch:
         # with the sampling prefetch the operator ran on a side stream, competing with the step's own
         # kernels for CUs: also time it with the GPU to itself, `steps` launches on the same inputs
         alone = _ext.enable_kernel_timing(["query_and_group_xyz"])
@@ -398,11 +393,8 @@ def main():
         bq_roofline = {
             "kernel": "grid_build_kernel + grid_query_kernel (cell-binned ball_query fused with xyz grouping, "
                       "one coda_query_and_group_xyz_f32 call)",
-            "timing": (("HIP events around each call inside the timed region"
-                        + (" (side stream, concurrent with the step's kernels)" if prefetch else ""))
-                       if graph is None else
-                       "timed region replays a hipGraph; HIP events around `steps` eager calls of the same "
-                       "operator on the bench inputs right after it"),
+            "timing": ("HIP events around each call inside the timed region"
+                       + (" (side stream, concurrent with the step's kernels)" if prefetch else "")),
             "bound": "hbm",
             "achieved": round(achieved, 3) if achieved else None,
             "peak": HBM_PEAK_GBS,
@@ -437,8 +429,12 @@ def main():
         roofline, others = bq_roofline, []
         dom = ("dkv", 2048, 2048)
         if dom in attn_ms:
-            roofline = attn_entry(dom, attn_ms[dom], "HIP events around each launch inside the timed region "
-                                                     "(coda_mha_timing_*, launch stream)")
+            roofline = attn_entry(dom, attn_ms[dom],
+                                  "HIP events around each launch inside the timed region (coda_mha_timing_*, launch "
+                                  "stream)" if graph is None else
+                                  "the timed region replays this kernel inside a hipGraph (no per-launch events can "
+                                  "be read back): HIP events around each launch (coda_mha_timing_*, launch stream) in "
+                                  "`steps` eagerly enqueued steps of the same workload right after it")
             # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes): profiles/README.md
             roofline["traffic"] = ATTN_DKV_TRAFFIC
             t_bwd = sum(sum(attn_ms[(k, 2048, 2048)]) / len(attn_ms[(k, 2048, 2048)])
@@ -466,7 +462,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": N_POINTS,
                        "parallelism": f"dp{world}", "optimizer": "AdamW (fused, in timed region)",
-                       "execution": "hipGraph replay of fwd+bwd+optimizer" if graph is not None else "eager",
+                       "execution": ("set-abstraction stage eager; encoder + decoder + heads + loss, forward and "
+                                     "backward, replayed as one hipGraph; optimizer eager"
+                                     if graph is not None else "eager"),
                        "sampling": ("FPS + ball query of batch i+1 run on a side stream during step i (once per "
                                     "step, inside the timed region); padded group copies are computed once"
                                     if prefetch else "in line")},

@@ -181,16 +181,23 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             self._sampling_prefetcher = SamplingPrefetcher()
         self._sampling_prefetcher.submit(pc, self.pre_encoder, wait_for)
 
-    def run_encoder(self, point_clouds):
+    def run_pre_encoder(self, point_clouds):
+        """The set-abstraction stage alone: -> (xyz (B,M,3), features (B,C,M), inds (B,M)).  Its result
+        can be handed back to ``forward(..., pre_encoded=...)``: the stage has data-dependent shapes
+        (de-duplicated groups) while everything behind it is static and can replay as a hipGraph
+        (step_graph.GraphedTail)."""
         xyz, features = self._break_up_pc(point_clouds)
         prepared = None
         if hasattr(self, "_sampling_prefetcher"):
             prepared = self._sampling_prefetcher.take(point_clouds)
         if prepared is not None:
-            pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(prepared["xyz"], features,
-                                                                           prepared=prepared)
-        else:
-            pre_enc_xyz, pre_enc_features, pre_enc_inds = self.pre_encoder(xyz, features)
+            return self.pre_encoder(prepared["xyz"], features, prepared=prepared)
+        return self.pre_encoder(xyz, features)
+
+    def run_encoder(self, point_clouds, pre_encoded=None):
+        if pre_encoded is None:
+            pre_encoded = self.run_pre_encoder(point_clouds)
+        pre_enc_xyz, pre_enc_features, pre_enc_inds = pre_encoded
         # (B, C, npoints) -> (npoints, B, C) for the seq-first transformer
         pre_enc_features = pre_enc_features.permute(2, 0, 1)
         enc_xyz, enc_features, enc_inds = self.encoder(pre_enc_features, xyz=pre_enc_xyz)
@@ -312,9 +319,11 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         return box_predictions, outputs["sem_cls_prob"], outputs["objectness_prob"]
 
     def forward(self, inputs, encoder_only=False, if_test=False, if_real_test=False, curr_epoch=-1,
-                if_cmp_class=False):
+                if_cmp_class=False, pre_encoded=None):
+        """models/model_3detr.py:1767-1817.  ``pre_encoded`` (this package's addition): the result of
+        ``run_pre_encoder`` on ``inputs["point_clouds"]``, when the caller ran that stage itself."""
         point_clouds = inputs["point_clouds"]
-        enc_xyz, enc_features, enc_inds = self.run_encoder(point_clouds)
+        enc_xyz, enc_features, enc_inds = self.run_encoder(point_clouds, pre_encoded)
         enc_features = self._project_encoder_features(enc_features)
         if encoder_only:
             return enc_xyz, enc_features.transpose(0, 1)

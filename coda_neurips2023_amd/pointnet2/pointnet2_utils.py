@@ -47,12 +47,19 @@ class SamplingPrefetcher:
     ``wait_for``: what the side stream has to wait for before it reads the batch -- "current"
     (default: everything enqueued on the caller's stream so far), a ``torch.cuda.Event`` (e.g.
     the batch's host-to-device copy), or None when the batch is known to be resident.
+
+    ``wait_for_counts``: what ``take`` does when the side stream has not finished yet.  False
+    (default, right for an eagerly enqueued step whose host thread is the bottleneck): never
+    stall the host -- the row counts are dropped and the shared MLP runs on all rows.  True
+    (right when the rest of the step is a hipGraph replay and the host has time to spare):
+    wait for the side stream's event, at most one sampling time.
     """
 
-    def __init__(self, max_pending=4):
+    def __init__(self, max_pending=4, wait_for_counts=False):
         self._stream = None
         self._pending = []
         self._max = max_pending
+        self.wait_for_counts = wait_for_counts
 
     def submit(self, point_clouds, module, wait_for="current"):
         dev = point_clouds.device
@@ -78,7 +85,9 @@ class SamplingPrefetcher:
         for k, (pc, version, prepared, done) in enumerate(self._pending):
             if pc is point_clouds and version == point_clouds._version:
                 del self._pending[k]
-                if not done.query():
+                if self.wait_for_counts:
+                    done.synchronize()
+                elif not done.query():
                     # the side stream is still busy (its workgroups need whole CUs and may have been
                     # starved): do not stall the host for the row count -- drop it (the shared MLP then
                     # runs on all rows) and let the compute stream wait on the device side

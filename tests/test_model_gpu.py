@@ -131,3 +131,20 @@ def test_prefetched_sampling_gives_identical_outputs(dev):
         other = model(inputs)["outputs"]
         assert len(model._sampling_prefetcher._pending) == 1
         assert torch.allclose(other["center_normalized"], ref["center_normalized"], rtol=1e-4, atol=1e-5)
+
+
+def test_pre_encoded_entry_point_gives_the_same_outputs(dev):
+    """forward(inputs, pre_encoded=run_pre_encoder(pc)) is forward(inputs): the set-abstraction stage can
+    be run by the caller (model_3detr.run_pre_encoder) and handed back."""
+    model, _ = build_model(tiny_args(), HotPathDatasetConfig())
+    fill_deterministic(model, seed=9)
+    model.to(dev).eval()  # eval: no running-statistics update between the two calls
+    inputs = _inputs(dev)
+    with torch.no_grad():
+        ref = model(inputs)["outputs"]
+        xyz, feat, inds = model.run_pre_encoder(inputs["point_clouds"])
+        assert xyz.shape[1:] == (128, 3) and feat.shape[1:] == (256, 128) and inds.dtype == torch.int32
+        got = model(inputs, pre_encoded=(xyz, feat, inds))["outputs"]
+    for k in ["sem_cls_logits", "center_normalized", "size_normalized", "angle_logits", "box_corners",
+              "text_correlation_embedding"]:
+        assert torch.equal(got[k], ref[k]), k

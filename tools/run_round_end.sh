@@ -1,28 +1,27 @@
 #!/bin/bash
 # dev: one GPU-box call that refreshes the round's measured artifacts under gpurun_out/
+#   (copied by hand into profiles/ afterwards).  Usage: gpurun -- 'bash tools/run_round_end.sh [tests]'
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-python -m pytest tests/test_attention_gpu.py tests/test_abi.py -x -q -m gpu 2>&1 | tail -3
+if [ "$1" = "tests" ]; then
+  python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+fi
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
-tail -c 3000 gpurun_out/final_bench.json
+python bench.py --prefetch off --no-cpu-baseline > gpurun_out/final_bench_noprefetch.json 2>> gpurun_out/final_bench.err
+python bench.py --workload sa --no-cpu-baseline > gpurun_out/final_bench_sa.json 2>> gpurun_out/final_bench.err
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $R/gpurun_out/pmc_attn_$c
-  timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_attn_$c -o run -- python $R/tools/bench_attn.py > /dev/null 2>&1
-done
+rm -rf $R/gpurun_out/final_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
+  python $R/bench.py --no-cpu-baseline > $R/gpurun_out/final_prof_bench.json 2>/dev/null
+rm -f $R/gpurun_out/final_prof/run_kernel_trace.csv   # tens of MB; the stats file is what gets committed
 cd $R
 python - <<'PY'
-import csv, glob, collections
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(f"gpurun_out/pmc_attn_{c}/**/*counter_collection.csv", recursive=True):
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == c:
-                acc[(r["Kernel_Name"][:60], r["Grid_Size"])].append(float(r["Counter_Value"]))
-        for k, v in sorted(acc.items()):
-            if "mha" in k[0]:
-                v.sort()
-                print(c, k, "n", len(v), "median", v[len(v) // 2], "min", v[0], "max", v[-1])
+import json
+for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_prof_bench"):
+    d = json.load(open(f"gpurun_out/{f}.json"))
+    r = d["roofline"]
+    print(f, d["value"], d["ms_per_step"], r["kernel"][:40], r["achieved"], r["frac"], r.get("avg_launch_ms"),
+          d.get("cpu_baseline", {}).get("value"))
 PY
