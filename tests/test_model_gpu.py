@@ -147,4 +147,5 @@ def test_pre_encoded_entry_point_gives_the_same_outputs(dev):
         got = model(inputs, pre_encoded=(xyz, feat, inds))["outputs"]
     for k in ["sem_cls_logits", "center_normalized", "size_normalized", "angle_logits", "box_corners",
               "text_correlation_embedding"]:
-        assert torch.equal(got[k], ref[k]), k
+        err = float((got[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-12))
+        assert err < 1e-5, (k, err)
