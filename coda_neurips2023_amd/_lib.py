@@ -75,6 +75,9 @@ SIGNATURES = {
     "coda_mha_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                   ctypes.c_uint64, _P, _P]),
+    # include/coda_gemm.h
+    "coda_gemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
+                               _P, ctypes.c_longlong, _P, _c_int, _P]),
     "coda_mha_timing_enable": (_c_int, [_c_int]),
     "coda_mha_timing_collect": (_c_int, [_P, _P, _P, _P, _c_int]),
 }
@@ -102,9 +105,11 @@ def load():
     # torch puts a second runtime in the process and every launch fails with
     # hipErrorNoDevice.
     import torch  # noqa: F401
-    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
-    if os.path.exists(bundled):
-        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+    # (same for hipBLASLt, which coda_gemm_f32 calls: one copy per process, PyTorch's)
+    for name in ("libamdhip64.so", "libhipblaslt.so"):
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", name)
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:

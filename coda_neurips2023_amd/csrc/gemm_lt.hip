@@ -1,0 +1,122 @@
+// gemm_lt.hip -- coda_gemm_f32: fp32 hipBLASLt GEMM with per-shape cached plans (host code only).
+//
+// hipBLASLt is column-major.  A row-major X (r x c, row stride ld) is the column-major matrix X^T
+// (c x r, leading dimension ld), so  C = op(A) op(B)  is computed as  C^T = op(B)^T op(A)^T :
+// the library's first operand is B (transposed in its view iff transb), the second is A.
+#include "coda_gemm.h"
+#include "common.hip.h"
+
+#include <hipblaslt/hipblaslt.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <unordered_map>
+
+namespace coda {
+namespace {
+
+constexpr size_t kWorkspaceBytes = 32u << 20;
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t workspace = 0;
+};
+
+using Key = std::tuple<int, int, int, int, int, long long, long long, long long, int>;
+
+struct State {
+  std::mutex mu;
+  hipblasLtHandle_t handle = nullptr;
+  hipblasLtMatmulPreference_t pref = nullptr;
+  std::map<Key, Plan> plans;
+  std::unordered_map<hipStream_t, void *> workspaces;
+};
+
+State &state() {
+  static State s;
+  return s;
+}
+
+int lt_error(hipblasStatus_t st) { return -(2000 + static_cast<int>(st)); }
+
+#define LT_CHECK(expr)                                   \
+  do {                                                   \
+    hipblasStatus_t st_ = (expr);                        \
+    if (st_ != HIPBLAS_STATUS_SUCCESS) return lt_error(st_); \
+  } while (0)
+
+int make_plan(State &s, const Key &key, Plan &p) {
+  const auto [transa, transb, m, n, k, lda, ldb, ldc, has_bias] = key;
+  LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  // library operand 1 = B, operand 2 = A (see the header comment)
+  const hipblasOperation_t op1 = transb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  const hipblasOperation_t op2 = transa ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op1, sizeof(op1)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op2, sizeof(op2)));
+  if (has_bias) {
+    const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+  }
+  // column-major shapes as stored: B row-major (k x n) -> (n x k); transb: stored (n x k) -> (k x n)
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_32F, transb ? k : n, transb ? n : k, ldb));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_32F, transa ? m : k, transa ? k : m, lda));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, n, m, ldc));
+  hipblasLtMatmulHeuristicResult_t res;
+  int found = 0;
+  LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.la, p.lb, p.lc, p.lc, s.pref, 1, &res, &found));
+  if (found < 1) return lt_error(HIPBLAS_STATUS_NOT_SUPPORTED);
+  p.algo = res.algo;
+  p.workspace = res.workspaceSize;
+  return CODA_OK;
+}
+
+}  // namespace
+}  // namespace coda
+
+CODA_API int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a, long long lda,
+                           const float *b, long long ldb, float *c, long long ldc, const float *bias,
+                           int accumulate, void *stream) {
+  using namespace coda;
+  if (m < 0 || n < 0 || k < 0) return CODA_EINVAL;
+  if (m == 0 || n == 0) return CODA_OK;
+  if (k == 0 || !a || !b || !c) return CODA_EINVAL;
+  if (lda < (transa ? m : k) || ldb < (transb ? k : n) || ldc < n) return CODA_EINVAL;
+  State &s = state();
+  std::lock_guard<std::mutex> lock(s.mu);
+  if (!s.handle) {
+    LT_CHECK(hipblasLtCreate(&s.handle));
+    LT_CHECK(hipblasLtMatmulPreferenceCreate(&s.pref));
+    const uint64_t ws = kWorkspaceBytes;
+    LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(s.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws,
+                                                   sizeof(ws)));
+  }
+  const Key key{transa != 0, transb != 0, m, n, k, lda, ldb, ldc, bias != nullptr};
+  auto it = s.plans.find(key);
+  if (it == s.plans.end()) {
+    Plan p;
+    const int st = make_plan(s, key, p);
+    if (st != CODA_OK) return st;
+    it = s.plans.emplace(key, p).first;
+  }
+  Plan &p = it->second;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  void *ws = nullptr;
+  if (p.workspace) {
+    auto w = s.workspaces.find(hs);
+    if (w == s.workspaces.end()) {
+      void *buf = nullptr;
+      const hipError_t e = hipMalloc(&buf, kWorkspaceBytes);
+      if (e != hipSuccess) return static_cast<int>(e);
+      w = s.workspaces.emplace(hs, buf).first;
+    }
+    ws = w->second;
+  }
+  if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
+  LT_CHECK(hipblasLtMatmul(s.handle, p.desc, &alpha, b, p.la, a, p.lb, &beta, c, p.lc, c, p.lc, &p.algo, ws,
+                           p.workspace, hs));
+  return CODA_OK;
+}

@@ -11,6 +11,7 @@ the chained blocks (the parity tests run both, ``CODA_LAYER_NODES=ops`` selects 
 """
 import torch
 
+from . import gemm
 from .fused_layers import _AddLN, _FfnAct, _MHA, _colsum_into
 from .linear_fn import tn_gemm
 
@@ -43,10 +44,10 @@ def _add(a, b):
 def _ffn_forward(y, w1, b1, w2, p):
     e = y.shape[-1]
     y2 = y.reshape(-1, e)
-    h0 = torch.mm(y2, w1.t())
+    h0 = gemm.linear(y2, w1)
     cf = _Ctx()
     h = _FfnAct.forward(cf, h0, b1, p)
-    o = torch.mm(h, w2.t()).view(y.shape[:-1] + (w2.shape[0],))
+    o = gemm.linear(h, w2).view(y.shape[:-1] + (w2.shape[0],))
     return o, (cf, y2, h)
 
 
@@ -54,10 +55,10 @@ def _ffn_backward(saved, do, w1, w2):
     cf, y2, h = saved
     do2 = do.reshape(-1, do.shape[-1]).contiguous()
     dw2 = tn_gemm(do2, h)
-    dh = torch.mm(do2, w2)
+    dh = gemm.mm(do2, w2)
     dh0, db1, _ = _FfnAct.backward(cf, dh)
     dw1 = tn_gemm(dh0, y2)
-    dy = torch.mm(dh0, w1)
+    dy = gemm.mm(dh0, w1)
     return dy, dw1, db1, dw2
 
 
@@ -241,8 +242,8 @@ class _DecoderStack(torch.autograd.Function):
         wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
         bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
         bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
-        k_all = torch.addmm(bk_all, mp2, wk_all.t())                   # (S*B, nl*E)
-        v_all = torch.addmm(bv_all, mem2, wv_all.t())
+        k_all = gemm.linear(mp2, wk_all, bk_all)                   # (S*B, nl*E)
+        v_all = gemm.linear(mem2, wv_all, bv_all)
         ld_kv = nl * e
         scale = 1.0 / (d ** 0.5)
         mask_ptr = cross_mask.data_ptr() if cross_mask is not None else None
@@ -260,7 +261,7 @@ class _DecoderStack(torch.autograd.Function):
             s2, y2, y2p = _AddLN.forward(c3, a1, ob1, res, query_pos, g2, b2n, eps, p1)
             # cross attention on the pre-projected memory
             xq2 = (y2 if query_pos is None else y2p).reshape(-1, e)
-            q = torch.addmm(ib2[:e], xq2, in2[:e].t())
+            q = gemm.linear(xq2, in2[:e], ib2[:e])
             attn = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
             lse = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
             seed, seed_dev = _core._next_seed() if p_attn > 0.0 else (0, None)
@@ -269,7 +270,7 @@ class _DecoderStack(torch.autograd.Function):
                                             ld_kv, scale, float(p_attn), seed,
                                             seed_dev.data_ptr() if seed_dev is not None else None,
                                             _lib.current_stream_handle()), "mha_fwd")
-            a2 = torch.mm(attn, ow2.t()).view(nq, bsz, e)
+            a2 = gemm.linear(attn, ow2).view(nq, bsz, e)
             c5 = _Ctx()
             s3, y3, _ = _AddLN.forward(c5, a2, ob2, s2, None, g3, b3n, eps, p2)
             o, ffn_saved = _ffn_forward(y3, w1, fb1, w2, p_ffn)
@@ -317,7 +318,7 @@ class _DecoderStack(torch.autograd.Function):
             # cross attention backward; dK / dV go straight into layer l's column slices
             da2_2 = da2.reshape(-1, e)
             dow2 = tn_gemm(da2_2.contiguous(), attn)
-            dattn = torch.mm(da2_2, ow2)
+            dattn = gemm.mm(da2_2, ow2)
             dq = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
             delta = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
             _lib.check(lib.coda_mha_bwd_f32(q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e,
@@ -326,9 +327,9 @@ class _DecoderStack(torch.autograd.Function):
                                             bsz, nheads, nq, ns, d, e, ld_kv, ld_kv, 0, ld_kv, ld_kv, scale, p_attn, seed,
                                             seed_dev.data_ptr() if seed_dev is not None else None,
                                             _lib.current_stream_handle()), "mha_bwd")
-            torch.mm(dq.t(), xq2, out=din2_all[l, :e])
+            gemm.mm_tn(dq, xq2, out=din2_all[l, :e])
             _colsum_into(dib2_all[l, :e], dq.unsqueeze(0))
-            dxq = torch.mm(dq, in2[:e]).view(nq, bsz, e)
+            dxq = gemm.mm(dq, in2[:e]).view(nq, bsz, e)
             da1, dob1, ds1, dpos2, dg2, db2n, _, _ = _AddLN.backward(c3, ds2, None if has_qpos else dxq,
                                                                      dxq if has_qpos else None)
             dqk, _, dv1, din1, dib1, dow1, _, _, _ = _MHA.backward(c2, da1)
@@ -341,8 +342,8 @@ class _DecoderStack(torch.autograd.Function):
             grads[_NP * l:_NP * (l + 1)] = [g[4], g[5], din1, dib1, dow1, dob1, dg2, db2n, din2_all[l], dib2_all[l],
                                             dow2, dob2, dg3, db3n, dw1, dfb1, dw2, dfb2]
         # memory side of all layers at once
-        dmp2 = torch.mm(dk_all, wk_all)
-        dmem2 = torch.mm(dv_all, wv_all)
+        dmp2 = gemm.mm(dk_all, wk_all)
+        dmem2 = gemm.mm(dv_all, wv_all)
         dwk = tn_gemm(dk_all, mp2)   # (nl*E, E)
         dwv = tn_gemm(dv_all, mem2)
         din2_all[:, e:2 * e].copy_(dwk.view(nl, e, e))

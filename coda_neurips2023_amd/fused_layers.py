@@ -15,7 +15,7 @@ neither their names nor their values:
 """
 import torch
 
-from . import _lib
+from . import _lib, gemm
 from . import attention_core as _core
 from .linear_fn import _CHUNK, _MIN_ROWS
 
@@ -52,7 +52,7 @@ def _tn_into(out, dy, x):
         part = torch.bmm(dy.view(nc, _CHUNK, -1).transpose(1, 2), x.view(nc, _CHUNK, -1))
         torch.sum(part, 0, out=out)
     else:
-        torch.mm(dy.t(), x, out=out)
+        gemm.mm_tn(dy, x, out=out)
 
 
 class _AddLN(torch.autograd.Function):
@@ -159,19 +159,19 @@ class _MHA(torch.autograd.Function):
         xk2 = xq2 if same_qk else xk.reshape(-1, e)
         xv2 = xk2 if same_kv else xv.reshape(-1, e)
         if same_qk and same_kv:
-            qkv = torch.addmm(b_in, xq2, w_in.t())
+            qkv = gemm.linear(xq2, w_in, b_in)
             q, k, v = qkv[:, :e], qkv[:, e:2 * e], qkv[:, 2 * e:]
             ldq = ldk = ldv = 3 * e
         elif same_qk:
-            qk = torch.addmm(b_in[:2 * e], xq2, w_in[:2 * e].t())
+            qk = gemm.linear(xq2, w_in[:2 * e], b_in[:2 * e])
             q, k = qk[:, :e], qk[:, e:]
-            v = torch.addmm(b_in[2 * e:], xv2, w_in[2 * e:].t())
+            v = gemm.linear(xv2, w_in[2 * e:], b_in[2 * e:])
             ldq = ldk = 2 * e
             ldv = e
         else:
-            q = torch.addmm(b_in[:e], xq2, w_in[:e].t())
-            k = torch.addmm(b_in[e:2 * e], xk2, w_in[e:2 * e].t())
-            v = torch.addmm(b_in[2 * e:], xv2, w_in[2 * e:].t())
+            q = gemm.linear(xq2, w_in[:e], b_in[:e])
+            k = gemm.linear(xk2, w_in[e:2 * e], b_in[e:2 * e])
+            v = gemm.linear(xv2, w_in[2 * e:], b_in[2 * e:])
             ldq = ldk = ldv = e
         attn = torch.empty((tgt_len * bsz, e), dtype=torch.float32, device=xq.device)
         lse = torch.empty((bsz, nheads, tgt_len), dtype=torch.float32, device=xq.device)
@@ -180,7 +180,7 @@ class _MHA(torch.autograd.Function):
         _lib.check(lib.coda_mha_fwd_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), bsz, nheads, tgt_len,
                                         src_len, d, ldq, ldk, ldv, scale, float(p), seed, _p(seed_dev), _stream()),
                    "mha_fwd")
-        out = torch.mm(attn, w_out.t()).view(tgt_len, bsz, e)
+        out = gemm.linear(attn, w_out).view(tgt_len, bsz, e)
         ctx.meta = (tgt_len, src_len, bsz, e, nheads, ldq, ldk, ldv, scale, float(p), seed, seed_dev, same_qk, same_kv)
         ctx.save_for_backward(xq2, xk2, xv2, q, k, v, attn, lse, w_in, w_out, mask_u8)
         return out
@@ -195,7 +195,7 @@ class _MHA(torch.autograd.Function):
         dout2 = dout.reshape(-1, e)
         dw_out = torch.empty_like(w_out)
         _tn_into(dw_out, dout2.contiguous(), attn)
-        dattn = torch.mm(dout2, w_out)
+        dattn = gemm.mm(dout2, w_out)
         rq, rk = tgt_len * bsz, src_len * bsz
         if rq == rk:
             dqkv = torch.empty((3, rq, e), dtype=torch.float32, device=dev)
@@ -223,25 +223,25 @@ class _MHA(torch.autograd.Function):
         dxq = dxk = dxv = None
         if same_qk and same_kv:
             if need_q:
-                dxq = torch.mm(dq, w_in[:e])
-                dxq.addmm_(dk, w_in[e:2 * e])
-                dxq.addmm_(dv, w_in[2 * e:])
+                dxq = gemm.mm(dq, w_in[:e])
+                gemm.mm(dk, w_in[e:2 * e], out=dxq, accumulate=True)
+                gemm.mm(dv, w_in[2 * e:], out=dxq, accumulate=True)
         elif same_qk:
             if need_q:
-                dxq = torch.mm(dq, w_in[:e])
-                dxq.addmm_(dk, w_in[e:2 * e])
+                dxq = gemm.mm(dq, w_in[:e])
+                gemm.mm(dk, w_in[e:2 * e], out=dxq, accumulate=True)
             if need_v:
-                dxv = torch.mm(dv, w_in[2 * e:])
+                dxv = gemm.mm(dv, w_in[2 * e:])
         else:
             if need_q:
-                dxq = torch.mm(dq, w_in[:e])
+                dxq = gemm.mm(dq, w_in[:e])
             if need_k:
-                dxk = torch.mm(dk, w_in[e:2 * e])
+                dxk = gemm.mm(dk, w_in[e:2 * e])
             if need_v:
                 if same_kv:
-                    dxk = torch.mm(dv, w_in[2 * e:]) if dxk is None else dxk.addmm_(dv, w_in[2 * e:])
+                    dxk = gemm.mm(dv, w_in[2 * e:]) if dxk is None else gemm.mm(dv, w_in[2 * e:], out=dxk, accumulate=True)
                 else:
-                    dxv = torch.mm(dv, w_in[2 * e:])
+                    dxv = gemm.mm(dv, w_in[2 * e:])
 
         def shaped(t, n):
             return t.view(n, bsz, e) if t is not None else None

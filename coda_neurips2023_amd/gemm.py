@@ -1,0 +1,75 @@
+"""Plain fp32 GEMMs of the host-side mirrors through the C ABI (include/coda_gemm.h).
+
+`linear`, `mm`, `mm_tn` are `F.linear` / `torch.mm` on 2-D CUDA tensors, computed by the same
+vendor library (hipBLASLt) PyTorch-ROCm calls, but through `coda_gemm_f32`, whose matmul plans
+are cached per shape: ~3x less host time per launch-sized GEMM than `torch.mm` / `torch.addmm`
+(which rebuild descriptors and re-query the heuristic on every call).  Row strides are passed
+through, so row / column slices of packed buffers (in_proj weights, q|k|v activations) need no
+copy.  These helpers are used inside hand-written autograd nodes only: they do not record
+autograd history themselves.
+"""
+import os
+
+import torch
+
+from . import _lib
+
+_USE_TORCH = os.environ.get("CODA_GEMM", "") == "torch"  # dev A/B switch
+
+
+def _rows(t):
+    """2-D fp32 CUDA tensor with unit inner stride (copied only if it is not)."""
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    st = _lib.load().coda_gemm_f32(transa, transb, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                   out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
+                                   1 if accumulate else 0, _lib.current_stream_handle())
+    if st <= -2000:
+        # hipBLASLt has no kernel for this problem (odd leading dimensions): PyTorch's own GEMM path
+        a2 = a.t() if transa else a
+        b2 = b.t() if transb else b
+        ref = torch.mm(a2, b2) if bias is None else torch.addmm(bias, a2, b2)
+        return out.add_(ref) if accumulate else out.copy_(ref)
+    if st != 0:
+        raise RuntimeError(f"coda_gemm_f32 failed ({st}) for transa={transa} transb={transb} m={m} n={n} k={k}")
+    return out
+
+
+def linear(x, w, bias=None, out=None):
+    """x (M,K), w (N,K), bias (N,) or None -> x @ w.T + bias, (M,N)."""
+    if _USE_TORCH or x.shape[0] == 0:
+        r = torch.mm(x, w.t()) if bias is None else torch.addmm(bias, x, w.t())
+        return r if out is None else out.copy_(r)
+    x, w = _rows(x), _rows(w)
+    if bias is not None and bias.stride(0) != 1:
+        bias = bias.contiguous()
+    return _run(0, 1, x.shape[0], w.shape[0], x.shape[1], x, w, out, bias, False)
+
+
+def mm(a, b, out=None, accumulate=False):
+    """a (M,K), b (K,N) -> a @ b; ``accumulate`` adds to ``out`` instead of overwriting it."""
+    assert out is not None or not accumulate
+    if _USE_TORCH or a.shape[0] == 0:
+        if accumulate:
+            return out.addmm_(a, b)
+        return torch.mm(a, b) if out is None else torch.mm(a, b, out=out)
+    a, b = _rows(a), _rows(b)
+    return _run(0, 0, a.shape[0], b.shape[1], a.shape[1], a, b, out, None, accumulate)
+
+
+def mm_tn(a, b, out=None, accumulate=False):
+    """a (K,M), b (K,N) -> a.T @ b, (M,N); ``accumulate`` adds to ``out`` instead of overwriting it."""
+    assert out is not None or not accumulate
+    if _USE_TORCH or a.shape[0] == 0:
+        r = torch.mm(a.t(), b)
+        if out is None:
+            return r
+        return out.add_(r) if accumulate else out.copy_(r)
+    a, b = _rows(a), _rows(b)
+    return _run(1, 0, a.shape[1], b.shape[1], a.shape[0], a, b, out, None, accumulate)

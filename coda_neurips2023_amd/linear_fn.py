@@ -11,6 +11,8 @@ single GEMM only in fp32 summation order.
 import torch
 import torch.nn.functional as F
 
+from . import gemm
+
 _MIN_ROWS = 4096
 _CHUNK = 2048
 
@@ -25,6 +27,8 @@ def tn_gemm(dy, x):
         if rows and dy.is_contiguous() and x.is_contiguous():
             nc = p // rows
             return torch.bmm(dy.view(nc, rows, -1).transpose(1, 2), x.view(nc, rows, -1)).sum(0)
+    if dy.is_cuda and dy.dim() == 2 and dy.dtype == torch.float32:
+        return gemm.mm_tn(dy, x)
     return torch.mm(dy.t(), x)
 
 

@@ -1,0 +1,72 @@
+"""coda_gemm_f32 (include/coda_gemm.h) through gemm.py against torch.mm: plain, biased, accumulating,
+and on row / column slices of packed buffers (the strides the attention blocks pass)."""
+import pytest
+import torch
+
+from coda_neurips2023_amd import gemm
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 256, 256), (16384, 768, 256), (2048, 128, 256), (33, 7, 19), (1, 512, 256),
+                                   (256, 256, 2048)])
+def test_linear_mm_mm_tn_match_torch(dev, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g).to(dev)
+    w = torch.randn(n, k, generator=g).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    assert rel(gemm.linear(x, w), x @ w.t()) < 1e-5
+    assert rel(gemm.linear(x, w, b), torch.addmm(b, x, w.t())) < 1e-5
+    dy = torch.randn(m, n, generator=g).to(dev)
+    assert rel(gemm.mm(dy, w), dy @ w) < 1e-5                    # input gradient
+    assert rel(gemm.mm_tn(dy, x), dy.t() @ x) < 1e-5             # weight gradient
+    # twice the same shape: the cached plan is reused
+    assert rel(gemm.mm_tn(dy, x), dy.t() @ x) < 1e-5
+
+
+def test_strided_operands_and_accumulation(dev):
+    g = torch.Generator().manual_seed(0)
+    e, rows = 256, 2048
+    w_in = torch.randn(3 * e, e, generator=g).to(dev)            # packed in_proj weight
+    b_in = torch.randn(3 * e, generator=g).to(dev)
+    x = torch.randn(rows, e, generator=g).to(dev)
+    qkv = gemm.linear(x, w_in, b_in)                             # (rows, 3e)
+    k = qkv[:, e:2 * e]                                          # column slice: row stride 3e
+    ref_k = torch.addmm(b_in[e:2 * e], x, w_in[e:2 * e].t())
+    assert rel(k, ref_k) < 1e-5
+    assert rel(gemm.linear(x, w_in[e:2 * e], b_in[e:2 * e]), ref_k) < 1e-5      # row slice of the weight
+    assert rel(gemm.mm(k, w_in[e:2 * e]), ref_k @ w_in[e:2 * e]) < 1e-5        # strided A
+    out = torch.zeros(3 * e, e, device=dev)
+    gemm.mm_tn(k, x, out=out[e:2 * e])                            # into a row block of a packed gradient
+    assert rel(out[e:2 * e], ref_k.t() @ x) < 1e-5 and float(out[:e].abs().max()) == 0.0
+    acc = gemm.mm(k, w_in[e:2 * e])
+    gemm.mm(qkv[:, :e], w_in[:e], out=acc, accumulate=True)
+    assert rel(acc, ref_k @ w_in[e:2 * e] + qkv[:, :e] @ w_in[:e]) < 1e-5
+    tn = gemm.mm_tn(k, x)
+    gemm.mm_tn(qkv[:, :e], x, out=tn, accumulate=True)
+    assert rel(tn, ref_k.t() @ x + qkv[:, :e].t() @ x) < 1e-5
+
+
+def test_side_stream_gets_its_own_workspace(dev):
+    x = torch.randn(4096, 256, device=dev)
+    w = torch.randn(256, 256, device=dev)
+    ref = x @ w.t()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = gemm.linear(x, w)
+    torch.cuda.current_stream().wait_stream(s)
+    assert rel(out, ref) < 1e-5
+
+
+def test_invalid_arguments_are_reported(dev):
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(8, 8, device=dev)
+    st = lib.coda_gemm_f32(0, 0, 8, 8, 8, x.data_ptr(), 4, x.data_ptr(), 8, x.data_ptr(), 8, None, 0,
+                           _lib.current_stream_handle())
+    assert st == _lib.CODA_EINVAL  # lda < k
