@@ -17,6 +17,12 @@ from . import _lib
 _USE_TORCH = os.environ.get("CODA_GEMM", "") == "torch"  # dev A/B switch
 
 
+def _plain(*ts):
+    """True when every operand is a 2-D fp32 CUDA tensor (what coda_gemm_f32 takes); anything else
+    (fp64 reference runs of the same modules, CPU tensors of the oracle port) goes to torch's own GEMM."""
+    return not _USE_TORCH and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 for t in ts)
+
+
 def _rows(t):
     """2-D fp32 CUDA tensor with unit inner stride (copied only if it is not)."""
     if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
@@ -43,7 +49,7 @@ def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
 
 def linear(x, w, bias=None, out=None):
     """x (M,K), w (N,K), bias (N,) or None -> x @ w.T + bias, (M,N)."""
-    if _USE_TORCH or x.shape[0] == 0:
+    if not _plain(x, w) or x.shape[0] == 0:
         r = torch.mm(x, w.t()) if bias is None else torch.addmm(bias, x, w.t())
         return r if out is None else out.copy_(r)
     x, w = _rows(x), _rows(w)
@@ -55,7 +61,7 @@ def linear(x, w, bias=None, out=None):
 def mm(a, b, out=None, accumulate=False):
     """a (M,K), b (K,N) -> a @ b; ``accumulate`` adds to ``out`` instead of overwriting it."""
     assert out is not None or not accumulate
-    if _USE_TORCH or a.shape[0] == 0:
+    if not _plain(a, b) or a.shape[0] == 0:
         if accumulate:
             return out.addmm_(a, b)
         return torch.mm(a, b) if out is None else torch.mm(a, b, out=out)
@@ -66,7 +72,7 @@ def mm(a, b, out=None, accumulate=False):
 def mm_tn(a, b, out=None, accumulate=False):
     """a (K,M), b (K,N) -> a.T @ b, (M,N); ``accumulate`` adds to ``out`` instead of overwriting it."""
     assert out is not None or not accumulate
-    if _USE_TORCH or a.shape[0] == 0:
+    if not _plain(a, b) or a.shape[0] == 0:
         r = torch.mm(a.t(), b)
         if out is None:
             return r

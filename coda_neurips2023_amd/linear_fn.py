@@ -27,9 +27,7 @@ def tn_gemm(dy, x):
         if rows and dy.is_contiguous() and x.is_contiguous():
             nc = p // rows
             return torch.bmm(dy.view(nc, rows, -1).transpose(1, 2), x.view(nc, rows, -1)).sum(0)
-    if dy.is_cuda and dy.dim() == 2 and dy.dtype == torch.float32:
-        return gemm.mm_tn(dy, x)
-    return torch.mm(dy.t(), x)
+    return gemm.mm_tn(dy, x)  # (falls back to torch.mm for anything but 2-D fp32 CUDA operands)
 
 
 class _Linear(torch.autograd.Function):
