@@ -77,8 +77,27 @@ def parse():
     return p.parse_args()
 
 
+def build_dry_workload(dev):
+    """CODA_BENCH_DRY=1 (tests/test_bench_dry.py): a toy torch module on the CPU in place of the detector, so
+    that THIS FILE's control flow -- warm-up, barriers, timed loop, max over ranks, the steps after the timed
+    region, one JSON line from rank 0 -- can be exercised with several gloo ranks on a machine without GPUs.
+    It measures nothing and takes the same branches as the model workload."""
+    torch.manual_seed(0)
+    mod = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(),
+                              torch.nn.Linear(16, 1)).to(dev).train()
+
+    def step(model, batch, pre_encoded=None):
+        if dist.is_initialized():  # stands in for the SyncBatchNorm statistics exchange of the forward pass
+            dist.all_reduce(torch.ones(32))
+        return model(batch["point_clouds"].reshape(-1, 3)).square().mean()
+
+    return mod, step, "dry run of bench.py's control flow (toy CPU module, no kernels, numbers meaningless)", "dry"
+
+
 def build_workload(kind, dev):
     """Returns (module, step_fn(model, batch) -> loss, description, kind)."""
+    if os.environ.get("CODA_BENCH_DRY") == "1":
+        return build_dry_workload(dev)
     if kind in ("auto", "model"):
         return build_model_workload(dev)
     torch.manual_seed(0)
@@ -231,17 +250,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    dry = os.environ.get("CODA_BENCH_DRY") == "1"  # control-flow test on CPU, see build_dry_workload()
+    assert dry or torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     # dev-only smoke mode for 1-GPU boxes: all ranks on cuda:0 over gloo (RCCL refuses two ranks per
     # device); exercises the DDP + SyncBatchNorm code path, its numbers mean nothing
     one_device = os.environ.get("CODA_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:
+        if one_device or dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -253,13 +281,13 @@ def main():
     model = mod
     if world > 1:
         # reference: SyncBatchNorm + DDP (main.py:993-996)
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(mod)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        model = mod if dry else torch.nn.SyncBatchNorm.convert_sync_batchnorm(mod)  # (SyncBN needs GPU modules)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if dry else [local_rank])
 
     # synthetic inputs, resident in HBM before timing; a few distinct batches cycle
     pool = []
     for i in range(4):
-        pc, mn, mx = make_batch(B_PER_GPU, N_POINTS, seed=1234 + rank * 1000 + i)
+        pc, mn, mx = make_batch(B_PER_GPU, 64 if dry else N_POINTS, seed=1234 + rank * 1000 + i)
         pool.append({"point_clouds": torch.from_numpy(pc).to(dev),
                      "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
@@ -271,7 +299,7 @@ def main():
         print("[bench] --graph on applies to the single-process model workload only; running eagerly",
               file=sys.stderr)
     # fused=True: one multi-tensor kernel per parameter group instead of ~10 foreach launches
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=not dry)
     prefetch = args.prefetch == "on" and kind == "model"
 
     def one_step_eager(i):
@@ -325,7 +353,7 @@ def main():
     # the set-abstraction stage (and its side-stream sampling) is enqueued eagerly in both modes
     timing = _ext.enable_kernel_timing(["query_and_group_xyz", "ball_query", "furthest_point_sampling"])
     # every rank records (same overhead on all ranks); rank 0 reports
-    attn_timed = kind == "model"
+    attn_timed = kind in ("model", "dry")
     if attn_timed:
         from coda_neurips2023_amd import attention_core
     if attn_timed and graph is None:
@@ -333,14 +361,14 @@ def main():
         attention_core.enable_kernel_timing(1024)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     _ext.disable_kernel_timing()
     if world > 1:
@@ -362,7 +390,7 @@ def main():
         attention_core.enable_kernel_timing(0)
         for i in range(args.steps):
             one_step_eager(i)
-        torch.cuda.synchronize()
+        sync()
         attn_ms_all = attention_core.collect_kernel_timing()
         attention_core.disable_kernel_timing()
         if graph is not None:
@@ -478,8 +506,10 @@ def main():
         }
         if others:
             out["roofline_others"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(kind)
+        if dry:
+            out.update(metric="dry run (control flow only)", data="none", dtype="f32")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

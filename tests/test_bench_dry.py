@@ -1,0 +1,52 @@
+"""bench.py's control flow without a GPU (CODA_BENCH_DRY=1: a toy CPU module takes the detector's place,
+every branch of the measurement loop is the real one): the process terminates, rank 0 prints exactly one
+JSON line with the driver's contract fields, and with two gloo ranks every rank runs the same sequence of
+collectives (a rank-0-only step after the timed region once deadlocked the DDP all-reduce)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _run(cmd, port=None):
+    env = dict(os.environ, CODA_BENCH_DRY="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(out, world, steps, warmup):
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["n_gpus"] == world and out["steps"] == steps and out["warmup"] == warmup
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    assert abs(out["value"] - world * out["config"]["scenes_per_gpu"] / (out["ms_per_step"] * 1e-3)) < 0.01 * out["value"]
+    assert out["config"]["parallelism"] == f"dp{world}"
+    for k in ["bound", "achieved", "peak", "unit", "frac", "traffic"]:
+        assert k in out["roofline"], k
+
+
+def test_single_process_flow():
+    out = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1"])
+    _check(out, 1, 3, 1)
+    assert "cpu_baseline" not in out  # the dry run measures nothing, least of all the oracle
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_run_the_same_collectives():
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "3",
+                "--warmup", "1"])
+    _check(out, 2, 3, 1)
