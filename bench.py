@@ -20,6 +20,8 @@ scenes/s over all ranks, plus
 * ``cpu_baseline`` the CPU oracle port (C ops + torch-CPU layers) on the host
                    cores, bounded sample, rank 0 at N=1 only.
 
+CODA_BENCH_DRY=1 runs this file's control flow on the CPU with a toy module (tests/test_bench_dry.py).
+
 Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL); scenes
 shard data-parallel (weak scaling, 8 scenes per GPU); the only exchange is the
 DDP gradient all-reduce (+ SyncBatchNorm statistics), as in the reference
