@@ -28,6 +28,7 @@ DDP gradient all-reduce (+ SyncBatchNorm statistics), as in the reference
 (main.py:993-996).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -361,17 +362,35 @@ def main():
     if attn_timed and graph is None:
         # long-sequence launches only (encoder self-attention: 12 kernels per step) inside the timed region
         attention_core.enable_kernel_timing(1024)
+    # Python's cyclic collector: a full pass over the ~2e5 long-lived objects of torch + the model costs
+    # 40-90 ms of host time, which would land in one unlucky step.  Collect now and move everything that
+    # survived the warm-up to the permanent generation (young-generation passes stay on); what the collector
+    # still costs inside the timed region is measured and reported.
+    gc.collect()
+    gc.freeze()
+    gc_stat = {"n": 0, "ms": 0.0, "t": 0.0}
+
+    def gc_probe(phase, info):
+        if phase == "start":
+            gc_stat["t"] = time.perf_counter()
+        else:
+            gc_stat["n"] += 1
+            gc_stat["ms"] += (time.perf_counter() - gc_stat["t"]) * 1e3
+
+    gc.callbacks.append(gc_probe)
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    t_host = time.perf_counter() - t0  # the host thread is done enqueueing; the GPU may still be working
     sync()
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(gc_probe)
     _ext.disable_kernel_timing()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -504,6 +523,11 @@ def main():
                                     "step, inside the timed region); padded group copies are computed once"
                                     if prefetch else "in line")},
             "roofline": roofline,
+            # host side of the timed region on rank 0: time until the last step was enqueued (close to the wall
+            # time when the host is the bottleneck -- or when the GPU is and the launch queue fills up) and what
+            # Python's garbage collector took of it
+            "host": {"enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
+                     "gc_passes": gc_stat["n"], "gc_ms_per_step": round(gc_stat["ms"] / args.steps, 4)},
             "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
         }
         if others:
