@@ -78,6 +78,8 @@ SIGNATURES = {
     # include/coda_gemm.h
     "coda_gemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                _P, ctypes.c_longlong, _P, _c_int, _P]),
+    "coda_gemm_tn_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_longlong, ctypes.c_longlong,
+                                  ctypes.c_longlong, _c_int, _P]),
     "coda_mha_timing_enable": (_c_int, [_c_int]),
     "coda_mha_timing_collect": (_c_int, [_P, _P, _P, _P, _c_int]),
 }

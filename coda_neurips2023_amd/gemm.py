@@ -15,6 +15,9 @@ import torch
 from . import _lib
 
 _USE_TORCH = os.environ.get("CODA_GEMM", "") == "torch"  # dev A/B switch
+# EXPERIMENTAL, off by default: weight gradients through the hand-written split-rows MFMA kernel
+# (coda_gemm_tn_f32, csrc/gemm_tn.hip) instead of the library GEMM / the split-K bmm + sum
+TN_KERNEL = os.environ.get("CODA_TN_KERNEL", "0") == "1"
 
 
 def _plain(*ts):
@@ -78,4 +81,12 @@ def mm_tn(a, b, out=None, accumulate=False):
             return r
         return out.add_(r) if accumulate else out.copy_(r)
     a, b = _rows(a), _rows(b)
+    if TN_KERNEL and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
+        if out is None:
+            out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+        st = _lib.load().coda_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], b.shape[1],
+                                          a.stride(0), b.stride(0), out.stride(0), 1 if accumulate else 0,
+                                          _lib.current_stream_handle())
+        _lib.check(st, "coda_gemm_tn_f32")
+        return out
     return _run(1, 0, a.shape[1], b.shape[1], a.shape[0], a, b, out, None, accumulate)

@@ -20,7 +20,7 @@ _CHUNK = 2048
 def tn_gemm(dy, x):
     """dy (P, Co), x (P, Ci) -> dy^T x (Co, Ci), reduction over P split into chunks."""
     p = dy.shape[0]
-    if p >= _MIN_ROWS:
+    if p >= _MIN_ROWS and not gemm.TN_KERNEL:
         rows = _CHUNK if p % _CHUNK == 0 else 0
         if p >= (1 << 18) and p % 16384 == 0:
             rows = 16384

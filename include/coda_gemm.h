@@ -28,6 +28,15 @@ int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a,
                   long long lda, const float *b, long long ldb, float *c, long long ldc,
                   const float *bias, int accumulate, void *stream);
 
+/* EXPERIMENTAL (round 1: compiled, not yet run on hardware, nothing calls it unless CODA_TN_KERNEL=1):
+ * out (co x ci, row stride ldout) [+]= dy^T x with dy (rows x co, row stride lddy), x (rows x ci, row stride
+ * ldx) -- the weight gradient of a token-wise linear layer (replaces `torch.mm(dy.t(), x)` / the split-K
+ * `bmm + sum` of linear_fn.tn_gemm).  Hand-written fp32 MFMA kernel, reduction over the rows split across
+ * workgroups and combined with fp32 atomics (summation order not fixed).  co and ci must be multiples of 32
+ * (CODA_EINVAL otherwise).  accumulate == 0: out is zeroed first. */
+int coda_gemm_tn_f32(const float *dy, const float *x, float *out, int rows, int co, int ci,
+                     long long lddy, long long ldx, long long ldout, int accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
