@@ -7,6 +7,7 @@ the others down) and prints one line; the parent prints the matrix.
     python tools/graph_repro.py <variant>  # one variant, in this process
 
 Variant = <what>:<eager step before the capture 0|1>
+  mgc      the same toy tail through torch.cuda.make_graphed_callables (PyTorch's own fwd/bwd capture)
   torch    pure-PyTorch toy tail (Linear / LayerNorm / ReLU / BatchNorm1d), no kernel of this repository
   modules  tiny detector, module-by-module layer path (CODA_LAYERS=modules): torch ops + the attention core
   layers   tiny detector, fused kernels as separate autograd nodes (CODA_LAYER_NODES=ops, CODA_DECODER_NODE=layers)
@@ -17,8 +18,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WHAT = ["torch", "modules", "layers", "fused"]
-ENV = {"torch": {}, "modules": {"CODA_LAYERS": "modules"},
+WHAT = ["mgc", "torch", "modules", "layers", "fused"]
+ENV = {"mgc": {}, "torch": {}, "modules": {"CODA_LAYERS": "modules"},
        "layers": {"CODA_LAYER_NODES": "ops", "CODA_DECODER_NODE": "layers"}, "fused": {}}
 
 
@@ -31,6 +32,31 @@ def run_variant(what, eager_first):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
 
+    if what == "mgc":
+        model = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.LayerNorm(128), torch.nn.ReLU(),
+                                    torch.nn.Linear(128, 8)).to(dev).train()
+        xs = [torch.randn(512, 64, device=dev) for _ in range(3)]
+        if eager_first:
+            model(xs[0]).square().mean().backward()
+            model.zero_grad(set_to_none=True)
+        ref = []
+        for x in xs:
+            model.zero_grad(set_to_none=True)
+            loss = model(x).square().mean()
+            loss.backward()
+            ref.append((float(loss), [p.grad.clone() for p in model.parameters()]))
+        graphed = torch.cuda.make_graphed_callables(model, (xs[0].clone(),))
+        worst = 0.0
+        for i in (1, 2, 0, 0, 2, 1):
+            model.zero_grad(set_to_none=True)
+            loss = graphed(xs[i]).square().mean()
+            loss.backward()
+            worst = max(worst, abs(float(loss) - ref[i][0]) / abs(ref[i][0]))
+            for p, r in zip(model.parameters(), ref[i][1]):
+                worst = max(worst, float((p.grad - r).abs().max() / (r.abs().max() + 1e-12)))
+        print(f"RESULT {what}:{int(eager_first)} worst relative difference eager vs replay = {worst:.3e} "
+              f"-> {'PASS' if worst < 1e-4 else 'MISMATCH'}", flush=True)
+        return
     if what == "torch":
         model = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.LayerNorm(128), torch.nn.ReLU(),
                                     torch.nn.Linear(128, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(),
