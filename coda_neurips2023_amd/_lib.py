@@ -23,6 +23,8 @@ _c_size_t = ctypes.c_size_t
 _P = _c_void_p
 SIGNATURES = {
     "coda_version": (ctypes.c_char_p, []),
+    "coda_set_distance_mode": (_c_int, [_c_int]),
+    "coda_get_distance_mode": (_c_int, []),
     "coda_furthest_point_sampling_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "coda_furthest_point_sampling_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _P]),
     "coda_gather_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),

@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kBqWaves = 4;  // waves per workgroup
 
-template <int C>
+template <int C, int DM>
 __global__ __launch_bounds__(kBqWaves * kWave) void ball_query_scan_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int32_t *__restrict__ idx,
     float *__restrict__ grouped, int n, int m, float r2, float inv_radius, int nsample,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBqWaves * kWave) void ball_query_scan_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       if (cnt[c] < nsample) {  // ball_query_gpu.cu:30 `cnt < nsample`
-        const float d2 = sqdist3(__fsub_rn(cx[c], x), __fsub_rn(cy[c], y), __fsub_rn(cz[c], z));
+        const float d2 = sqdist3<DM>(__fsub_rn(cx[c], x), __fsub_rn(cy[c], y), __fsub_rn(cz[c], z));
         const bool hit = valid && d2 < r2;  // :36 strict
         const uint64_t mask = __ballot(hit);
         if (mask) {
@@ -129,20 +129,23 @@ template <int C>
 int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b, int n,
                 int m, float radius, int nsample, int normalize, hipStream_t s) {
   const size_t lds = sizeof(int32_t) * kBqWaves * C * static_cast<size_t>(nsample);
-  auto kern = ball_query_scan_kernel<C>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-  }
   const float r2 = radius * radius;  // ball_query_gpu.cu:25 (fp32 product)
   const float inv_radius = 1.0f / radius;
   dim3 grid(ceil_div(m, kBqWaves * C) * b);
   clear_sticky_error();
-  hipLaunchKernelGGL(kern, grid, dim3(kBqWaves * kWave), lds, s, new_xyz, xyz, idx, grouped, n, m,
-                     r2, inv_radius, nsample, normalize, b);
-  return launch_status();
+  int st = CODA_OK;
+  CODA_DISPATCH_DM(distance_mode(), {
+    auto kern = ball_query_scan_kernel<C, DM>;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) st = static_cast<int>(e);
+    }
+    if (st == CODA_OK)
+      hipLaunchKernelGGL(kern, grid, dim3(kBqWaves * kWave), lds, s, new_xyz, xyz, idx, grouped, n, m, r2,
+                         inv_radius, nsample, normalize, b);
+  });
+  return st != CODA_OK ? st : launch_status();
 }
 
 int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b,

@@ -54,6 +54,9 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 // Cell coordinate along one axis: floor((v - o) * inv) clamped to [0, g-1].
 // Evaluated identically for points and centres; the clamp is monotone, so a hit
 // (|dv| < r <= cell/(1+1e-3)) always lies within +-1 cell of the centre's cell.
+// (In every distance mode d2 >= fl(dv*dv) for each axis -- the contracted sums only add
+// non-negative terms before a monotone rounding -- so d2 < fl(r*r) still bounds |dv| by
+// r*(1 + 2^-23), far inside the 1e-3 margin.)
 __device__ __forceinline__ int cell_coord(float v, float o, float inv, int g) {
   float u = floorf((v - o) * inv);
   u = fminf(fmaxf(u, 0.0f), static_cast<float>(g - 1));
@@ -256,6 +259,7 @@ __device__ __forceinline__ int rank_and_keep(float4 *buf, int h, int keep, int l
   return rank_and_keep_n<kHitCap / kWave>(buf, h, keep, lane);
 }
 
+template <int DM>
 __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int n,
     const unsigned char *__restrict__ ws, size_t scene_stride, int32_t *__restrict__ idx,
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
     const bool valid = t < total;
     float4 p = make_float4(0, 0, 0, 0);
     if (valid) p = records[src];
-    const float d2 = sqdist3(__fsub_rn(cx, p.x), __fsub_rn(cy, p.y), __fsub_rn(cz, p.z));
+    const float d2 = sqdist3<DM>(__fsub_rn(cx, p.x), __fsub_rn(cy, p.y), __fsub_rn(cz, p.z));
     const bool hit = valid && d2 < r2;  // same fp32 expression as the scan: ball_query_gpu.cu:34-36
     const uint64_t mask = __ballot(hit);
     const int add = __popcll(mask);
@@ -386,8 +390,10 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
   const int st = launch_build(grid_build_kernel);
   if (st != CODA_OK) return st;
   const float r2 = radius * radius;
-  hipLaunchKernelGGL(grid_query_kernel, dim3(ceil_div(m, kQueryWaves) * b), dim3(kQueryWaves * kWave), 0, s,
-                     new_xyz, xyz, n, ws, stride, idx, grouped, m, r2, 1.0f / radius, nsample, normalize, b);
+  CODA_DISPATCH_DM(distance_mode(),
+                   hipLaunchKernelGGL(grid_query_kernel<DM>, dim3(ceil_div(m, kQueryWaves) * b),
+                                      dim3(kQueryWaves * kWave), 0, s, new_xyz, xyz, n, ws, stride, idx, grouped, m,
+                                      r2, 1.0f / radius, nsample, normalize, b));
   return launch_status();
 }
 

@@ -23,12 +23,40 @@ inline int launch_status() {
   return e == hipSuccess ? CODA_OK : static_cast<int>(e);
 }
 
-// Squared distance in the reference's source order, one rounding per
-// operation.  The translation units are compiled with -ffp-contract=off; the
-// explicit __f*_rn intrinsics make the contract independent of flags.
-__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
-  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+// ---- distance arithmetic mode (include/coda_pointnet2.h, "Arithmetic contract") ----
+// The reference evaluates `dx*dx + dy*dy + dz*dz` (sampling_gpu.cu:103-107,
+// ball_query_gpu.cu:34-35, interpolate_gpu.cu:36) and `p1*w1 + p2*w2 + p3*w3`
+// (interpolate_gpu.cu:101-102) in a binary built by nvcc with the default
+// -fmad=true (setup.py:26-28), i.e. with FMA contraction.  Which contraction is
+// not recoverable without nvcc, so the kernels implement all three candidates
+// and the mode is selected at run time (coda_set_distance_mode):
+//   0  no contraction:            (a*a' + b*b') + c*c'      one rounding per operation
+//   1  fma(c,c', fma(a,a', b*b'))  (first product of the inner sum contracted: LLVM/NVVM order)
+//   2  fma(c,c', fma(b,b', a*a'))
+// The translation units are compiled with -ffp-contract=off; the explicit
+// __f*_rn intrinsics make every mode independent of compiler flags.
+constexpr int kDistanceModes = 3;
+constexpr int kDefaultDistanceMode = 1;
+int distance_mode();  // version.hip: process-wide, atomic
+
+template <int DM>
+__device__ __forceinline__ float dot3(float a, float a2, float b, float b2, float c, float c2) {
+  if constexpr (DM == 1) return __fmaf_rn(c, c2, __fmaf_rn(a, a2, __fmul_rn(b, b2)));
+  else if constexpr (DM == 2) return __fmaf_rn(c, c2, __fmaf_rn(b, b2, __fmul_rn(a, a2)));
+  else return __fadd_rn(__fadd_rn(__fmul_rn(a, a2), __fmul_rn(b, b2)), __fmul_rn(c, c2));
 }
+template <int DM>
+__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+  return dot3<DM>(dx, dx, dy, dy, dz, dz);
+}
+
+// CODA_DISPATCH_DM(mode, stmt): runs `stmt` with `DM` bound to the compile-time mode.
+#define CODA_DISPATCH_DM(mode, ...)                              \
+  switch (mode) {                                                \
+    case 0: { constexpr int DM = 0; __VA_ARGS__; } break;        \
+    case 2: { constexpr int DM = 2; __VA_ARGS__; } break;        \
+    default: { constexpr int DM = 1; __VA_ARGS__; } break;       \
+  }
 
 __device__ __forceinline__ int wave_id() {
   return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);

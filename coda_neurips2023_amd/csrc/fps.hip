@@ -30,8 +30,9 @@ namespace {
 // `(double)mag <= 1e-3` (sampling_gpu.cu:104) for a float mag is `mag <= T`
 // with T the largest float not above the double 0.001: 1e-3f rounds UP to
 // 0x3A83126F (0.00100000005), so T = 0x3A83126E.
+template <int DM>
 __device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
-  const float mag = sqdist3(x, y, z);
+  const float mag = sqdist3<DM>(x, y, z);
   return mag <= __uint_as_float(0x3A83126Eu);
 }
 
@@ -126,7 +127,7 @@ __device__ __forceinline__ void out_flush(const int32_t *s_out, int j, int m, in
 }
 
 // ---- register-resident kernel: P points per thread, THREADS per scene --------
-template <int P, int THREADS>
+template <int P, int THREADS, int DM>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restrict__ xyz, int n,
                                                           int m, int log2T,
                                                           int32_t *__restrict__ idx) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
       // running min distance: 1e10 (sampling.cpp:75-77); -1 marks a point that
       // never takes part (skip rule :103-104): fminf(d, -1) stays -1 and
       // `-1 > best` is false for best >= -1.
-      t[i] = fps_skipped(x[i], y[i], z[i]) ? -1.0f : 1e10f;
+      t[i] = fps_skipped<DM>(x[i], y[i], z[i]) ? -1.0f : 1e10f;
     } else {
       x[i] = y[i] = z[i] = 0.0f;
       t[i] = -1.0f;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float *__restric
     int besti = 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-      const float d = sqdist3(__fsub_rn(x[i], cx), __fsub_rn(y[i], cy), __fsub_rn(z[i], cz));
+      const float d = sqdist3<DM>(__fsub_rn(x[i], cx), __fsub_rn(y[i], cy), __fsub_rn(z[i], cz));
       const float d2 = fminf(d, t[i]);  // :109
       t[i] = d2;                        // :110
       // strict '>' in ascending i: thread-local ties keep the lowest k, and
@@ -250,7 +251,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int P>  // points per thread (even); 512 threads, n in [512, 512*P]
+template <int P, int DM>  // points per thread (even); 512 threads, n in [512, 512*P]
 __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__ xyz, int n, int m,
                                                        int32_t *__restrict__ idx) {
   constexpr int THREADS = 512, H = P / 2;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
       px = pts[k * 3 + 0];
       py = pts[k * 3 + 1];
       pz = pts[k * 3 + 2];
-      pt = fps_skipped(px, py, pz) ? -1.0f : 1e10f;  // see fps_reg_kernel
+      pt = fps_skipped<DM>(px, py, pz) ? -1.0f : 1e10f;  // see fps_reg_kernel
     }
     x[i / 2][i % 2] = px;
     y[i / 2][i % 2] = py;
@@ -292,7 +293,10 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const f32x2 dx = x[h] - cx2, dy = y[h] - cy2, dz = z[h] - cz2;
-      const f32x2 d = (dx * dx + dy * dy) + dz * dz;  // -ffp-contract=off: source order, no FMA
+      f32x2 d;  // -ffp-contract=off: exactly the operations written here (common.hip.h, dot3)
+      if constexpr (DM == 1) d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+      else if constexpr (DM == 2) d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      else d = (dx * dx + dy * dy) + dz * dz;
       t[2 * h] = vmin(d[0], t[2 * h]);
       t[2 * h + 1] = vmin(d[1], t[2 * h + 1]);
       best = vmax3(best, t[2 * h], t[2 * h + 1]);
@@ -330,7 +334,8 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
 
 template <int P>
 void launch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStream_t s) {
-  hipLaunchKernelGGL((fps_t512_kernel<P>), dim3(b), dim3(512), 0, s, xyz, n, m, idx);
+  CODA_DISPATCH_DM(distance_mode(),
+                   hipLaunchKernelGGL((fps_t512_kernel<P, DM>), dim3(b), dim3(512), 0, s, xyz, n, m, idx));
 }
 
 bool dispatch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStream_t s) {
@@ -358,7 +363,11 @@ bool dispatch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStrea
 // is no closer than its maximum running distance cannot change and is skipped:
 //     d(k) >= LB(box) >= max_b temp >= temp[k]  =>  min(d(k), temp[k]) == temp[k]
 // LB is evaluated with the same rounded operations as d on the clamped sample, and rounding is
-// monotone, so LB <= d(k) holds bit-exactly for every k in the box: the selected indices are
+// monotone, so LB <= d(k) holds bit-exactly for every k in the box.  That argument covers every
+// distance mode of common.hip.h: per axis |fl(q_a - c_a)| <= |fl(p_a - c_a)| (q = clamp(c, box)),
+// and each of fl(u*u), fl(u*u + t) [= fma(u, u, t)] and fl(s + t) is non-decreasing in |u|, s, t >= 0,
+// so the contracted forms fma(dz,dz, fma(dx,dx, dy*dy)) are monotone in (|dx|,|dy|,|dz|) like the
+// uncontracted one: the selected indices are
 // IDENTICAL to the exhaustive scan's, only the work differs (measured: ~3% of the buckets are
 // touched per round on room-like clouds).  The arg-max runs over the cached per-bucket maxima
 // with the composite (distance, bitrev(k mod T), k) order of the kernels above.
@@ -390,13 +399,14 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 }
 
 // Update the points of one bucket against the new sample and refresh its cached maximum.
+template <int DM>
 __device__ __forceinline__ void bucket_update(float px, float py, float pz, float &t, const uint32_t *s_keys,
                                               int slot, float cx, float cy, float cz, BucketMeta &md) {
   const uint32_t key = s_keys[slot * kBucketThreads + threadIdx.x];  // issued early, used after the max
   // opaque copy: keeps the compiler from hoisting the distance arithmetic of ALL buckets out of
   // the loop over the active ones (it is loop-invariant there, and pruning it is the point)
   asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
-  const float d = sqdist3(__fsub_rn(px, cx), __fsub_rn(py, cy), __fsub_rn(pz, cz));
+  const float d = sqdist3<DM>(__fsub_rn(px, cx), __fsub_rn(py, cy), __fsub_rn(pz, cz));
   asm volatile("v_min_f32 %0, %1, %0" : "+v"(t) : "v"(d));  // in place; lanes without a point keep -1
   const float wmax = wave_max_f32(t);
   const uint32_t cand = (t == wmax) ? key : 0xffffffffu;
@@ -410,7 +420,7 @@ __device__ __forceinline__ void bucket_update(float px, float py, float pz, floa
   }
 }
 
-template <int SL>  // register slots (buckets) per wave; n <= 64 * kBucketWaves * SL
+template <int SL, int DM>  // register slots (buckets) per wave; n <= 64 * kBucketWaves * SL
 __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float *__restrict__ xyz, int n, int m,
                                                                     int log2T, float4 *__restrict__ sorted,
                                                                     int32_t *__restrict__ idx) {
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int k = tid; k < n; k += kBucketThreads) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
-    if (!fps_skipped(x, y, z)) {
+    if (!fps_skipped<DM>(x, y, z)) {
       lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
       hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
     }
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   // ---- prologue 2: counting sort by Morton cell into `rec` (x, y, z, index)
   for (int k = tid; k < n; k += kBucketThreads) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
-    if (!fps_skipped(x, y, z)) atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
+    if (!fps_skipped<DM>(x, y, z)) atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
   }
   __syncthreads();
   {  // exclusive scan of the 4096 counters: 8 per thread
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   for (int q = 0; q < kBucketWaves; ++q) nvalid += s_wsum[q];
   for (int k = tid; k < n; k += kBucketThreads) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
-    if (!fps_skipped(x, y, z)) {
+    if (!fps_skipped<DM>(x, y, z)) {
       const unsigned int pos = atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
       rec[pos] = make_float4(x, y, z, __uint_as_float(static_cast<uint32_t>(k)));
     }
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
     // lane s: can bucket s change?  LB = |clamp(c, box) - c|^2 with the rounding of sqdist3
     const float qx = fminf(fmaxf(cx, md.lox), md.hix), qy = fminf(fmaxf(cy, md.loy), md.hiy),
                 qz = fminf(fmaxf(cz, md.loz), md.hiz);
-    const float lb = sqdist3(__fsub_rn(qx, cx), __fsub_rn(qy, cy), __fsub_rn(qz, cz));
+    const float lb = sqdist3<DM>(__fsub_rn(qx, cx), __fsub_rn(qy, cy), __fsub_rn(qz, cz));
     unsigned long long mask = __ballot(lane < SL && lb < md.maxt);
     if (mask != 0ull) {
       while (mask != 0ull) {
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
         switch (sl) {
 #define CODA_FPS_CASE(J)                                                                   \
   case J:                                                                                  \
-    if (J < SL) bucket_update(px[J < SL ? J : 0], py[J < SL ? J : 0], pz[J < SL ? J : 0],  \
+    if (J < SL) bucket_update<DM>(px[J < SL ? J : 0], py[J < SL ? J : 0], pz[J < SL ? J : 0],  \
                               t[J < SL ? J : 0], s_keys, J, cx, cy, cz, md);                \
     break;
           CODA_FPS_CASE(0) CODA_FPS_CASE(1) CODA_FPS_CASE(2) CODA_FPS_CASE(3) CODA_FPS_CASE(4)
@@ -619,16 +629,19 @@ bool bucket_eligible(int n, int m) { return n >= kBucketMinPoints && n <= kBucke
 template <int SL>
 int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
   constexpr size_t lds = sizeof(uint32_t) * SL * kBucketThreads;
-  auto kern = fps_bucket_kernel<SL>;
-  static bool raised = false;  // per SL: static + dynamic LDS exceeds the 64 KB default
-  if (!raised && lds + 20 * 1024 > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-    raised = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx);
-  return CODA_OK;
+  int st = CODA_OK;
+  CODA_DISPATCH_DM(distance_mode(), {
+    auto kern = fps_bucket_kernel<SL, DM>;
+    static bool raised = false;  // per (SL, DM): static + dynamic LDS exceeds the 64 KB default
+    if (!raised && lds + 20 * 1024 > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) st = static_cast<int>(e);
+      else raised = true;
+    }
+    if (st == CODA_OK) hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx);
+  });
+  return st;
 }
 
 int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
@@ -641,7 +654,7 @@ int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws
 }
 
 // ---- streaming fallback: any n; running distances in LDS or in workspace -------
-template <int THREADS>
+template <int THREADS, int DM>
 __global__ __launch_bounds__(THREADS) void fps_stream_kernel(const float *__restrict__ xyz, int n,
                                                              int m, int log2T,
                                                              float *__restrict__ temp_global,
@@ -657,7 +670,7 @@ __global__ __launch_bounds__(THREADS) void fps_stream_kernel(const float *__rest
   int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
 
   for (int k = tid; k < n; k += THREADS)
-    temp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
+    temp[k] = fps_skipped<DM>(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
   if (tid == 0) out[0] = 0;
   float cx = pts[0], cy = pts[1], cz = pts[2];
 
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(THREADS) void fps_stream_kernel(const float *__rest
     float best = -1.0f;
     int bestk = 0;
     for (int k = tid; k < n; k += THREADS) {  // each thread only touches its own temp[k]
-      const float d = sqdist3(__fsub_rn(pts[k * 3 + 0], cx), __fsub_rn(pts[k * 3 + 1], cy),
+      const float d = sqdist3<DM>(__fsub_rn(pts[k * 3 + 0], cx), __fsub_rn(pts[k * 3 + 1], cy),
                               __fsub_rn(pts[k * 3 + 2], cz));
       const float d2 = fminf(d, temp[k]);
       temp[k] = d2;
@@ -689,8 +702,8 @@ __global__ __launch_bounds__(THREADS) void fps_stream_kernel(const float *__rest
 
 template <int P, int THREADS>
 void launch_reg(const float *xyz, int b, int n, int m, int log2T, int32_t *idx, hipStream_t s) {
-  hipLaunchKernelGGL((fps_reg_kernel<P, THREADS>), dim3(b), dim3(THREADS), 0, s, xyz, n, m, log2T,
-                     idx);
+  CODA_DISPATCH_DM(distance_mode(), hipLaunchKernelGGL((fps_reg_kernel<P, THREADS, DM>), dim3(b), dim3(THREADS), 0,
+                                                        s, xyz, n, m, log2T, idx));
 }
 
 // The thread-local strict '>' scan is only rank-ordered when every point of a
@@ -768,20 +781,23 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   if (!done) done = dispatch_reg(xyz, b, n, m, log2T, idx, s);
   if (!done) {
     const size_t lds_need = kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
-    auto kern = fps_stream_kernel<kStreamThreads>;
-    if (lds_need <= kLdsBudget) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds_need));
-      if (e != hipSuccess) return static_cast<int>(e);
-      hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), lds_need, s, xyz, n, m, log2T,
-                         static_cast<float *>(nullptr), idx);
-    } else {
-      if (!workspace || workspace_bytes < sizeof(float) * static_cast<size_t>(b) * n)
-        return CODA_ENOSPC;
-      hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), kStreamKeyBytes, s, xyz, n, m, log2T,
-                         static_cast<float *>(workspace), idx);
-    }
+    const bool in_lds = lds_need <= kLdsBudget;
+    if (!in_lds && (!workspace || workspace_bytes < sizeof(float) * static_cast<size_t>(b) * n)) return CODA_ENOSPC;
+    int st = CODA_OK;
+    CODA_DISPATCH_DM(distance_mode(), {
+      auto kern = fps_stream_kernel<kStreamThreads, DM>;
+      if (in_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_need));
+        if (e != hipSuccess) st = static_cast<int>(e);
+        else hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), lds_need, s, xyz, n, m, log2T,
+                                static_cast<float *>(nullptr), idx);
+      } else {
+        hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), kStreamKeyBytes, s, xyz, n, m, log2T,
+                           static_cast<float *>(workspace), idx);
+      }
+    });
+    if (st != CODA_OK) return st;
   }
   return launch_status();
 }

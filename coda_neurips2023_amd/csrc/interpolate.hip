@@ -19,6 +19,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTile = 1024;  // known points per LDS tile (12 KiB)
 
+template <int DM>
 __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float *__restrict__ unknown,
                                                             const float *__restrict__ known,
                                                             float *__restrict__ dist2,
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float *__restr
     for (int t = threadIdx.x; t < cnt * 3; t += kThreads) s_known[t] = K[static_cast<size_t>(k0) * 3 + t];
     __syncthreads();
     for (int kk = 0; kk < cnt; ++kk) {
-      const float d = sqdist3(__fsub_rn(ux, s_known[kk * 3 + 0]), __fsub_rn(uy, s_known[kk * 3 + 1]),
+      const float d = sqdist3<DM>(__fsub_rn(ux, s_known[kk * 3 + 0]), __fsub_rn(uy, s_known[kk * 3 + 1]),
                               __fsub_rn(uz, s_known[kk * 3 + 2]));
       const int k = k0 + kk;
       if (d < best1) {
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float *__restr
   }
 }
 
-// out[b,c,j] = (p[i1]*w1 + p[i2]*w2) + p[i3]*w3   (:101-102, source order)
+// out[b,c,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3   (:101-102), rounded per the distance mode (dot3)
+template <int DM>
 __global__ __launch_bounds__(kThreads) void three_interpolate_kernel(
     const float *__restrict__ points, const int32_t *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ out, int c, int m, int n) {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void three_interpolate_kernel(
   for (int l = blockIdx.y; l < c; l += gridDim.y) {
     const float *P = points + (static_cast<size_t>(bi) * c + l) * m;
     out[(static_cast<size_t>(bi) * c + l) * n + j] =
-        __fadd_rn(__fadd_rn(__fmul_rn(P[i1], w1), __fmul_rn(P[i2], w2)), __fmul_rn(P[i3], w3));
+        dot3<DM>(P[i1], w1, P[i2], w2, P[i3], w3);
   }
 }
 
@@ -110,8 +112,9 @@ CODA_API int coda_three_nn_f32(const float *unknown, const float *known, float *
   if (b == 0 || n == 0) return CODA_OK;
   if (!unknown || !dist2 || !idx || (m > 0 && !known)) return CODA_EINVAL;
   clear_sticky_error();
-  hipLaunchKernelGGL(three_nn_kernel, dim3(ceil_div(n, kThreads), b), dim3(kThreads), 0,
-                     static_cast<hipStream_t>(stream), unknown, known, dist2, idx, n, m);
+  CODA_DISPATCH_DM(distance_mode(),
+                   hipLaunchKernelGGL(three_nn_kernel<DM>, dim3(ceil_div(n, kThreads), b), dim3(kThreads), 0,
+                                      static_cast<hipStream_t>(stream), unknown, known, dist2, idx, n, m));
   return launch_status();
 }
 
@@ -124,8 +127,9 @@ CODA_API int coda_three_interpolate_f32(const float *points, const int32_t *idx,
   if (!points || !idx || !weight || !out || m == 0) return CODA_EINVAL;
   dim3 grid(ceil_div(n, kThreads), c < 64 ? c : 64, b);
   clear_sticky_error();
-  hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(kThreads), 0,
-                     static_cast<hipStream_t>(stream), points, idx, weight, out, c, m, n);
+  CODA_DISPATCH_DM(distance_mode(),
+                   hipLaunchKernelGGL(three_interpolate_kernel<DM>, grid, dim3(kThreads), 0,
+                                      static_cast<hipStream_t>(stream), points, idx, weight, out, c, m, n));
   return launch_status();
 }
 

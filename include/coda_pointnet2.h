@@ -19,11 +19,10 @@
  *    CODA_EINVAL (-1) for invalid arguments, CODA_ENOSPC (-2) if `workspace`
  *    is too small.  (The reference prints and exit(-1)s on launch failure,
  *    include/cuda_utils.h:32-41; the binding raises instead.)
- *  - Re-entrant and thread-safe: no global mutable state.
+ *  - Re-entrant and thread-safe; the only process-wide state is the distance
+ *    arithmetic mode below (an atomic int read once per call).
  *
- * Arithmetic contract (parity): distances are evaluated in fp32, source order
- * of the reference expression, one rounding per operation, no FMA contraction:
- *   d2 = ((dx*dx + dy*dy) + dz*dz).
+ * Arithmetic contract (parity): see "distance arithmetic mode" below.
  */
 #ifndef CODA_POINTNET2_H
 #define CODA_POINTNET2_H
@@ -41,6 +40,27 @@ extern "C" {
 
 /* Library identification: returns "coda_hip gfx950 <abi-version>". */
 const char *coda_version(void);
+
+/* ---- distance arithmetic mode ---------------------------------------------------
+ * The reference's kernels evaluate  dx*dx + dy*dy + dz*dz  (sampling_gpu.cu:103-107,
+ * ball_query_gpu.cu:34-35, interpolate_gpu.cu:36) and  p1*w1 + p2*w2 + p3*w3
+ * (interpolate_gpu.cu:101-102) in fp32 inside a binary that nvcc builds with its
+ * default -fmad=true (third_party_pointnet2/pointnet2/setup.py:26-28 passes no -fmad
+ * flag), i.e. WITH fused-multiply-add contraction.  The contraction nvcc picks cannot
+ * be read off the sources, so all three candidates are implemented bit-exactly and the
+ * mode is process-wide and switchable (every distance / interpolation kernel of this
+ * library follows it; FPS indices, ball_query rows and three_nn change with it only
+ * where two candidates are within one rounding of each other):
+ *   0  no contraction           (a*a' + b*b') + c*c'           one rounding per operation
+ *   1  fma(c,c', fma(a,a', b*b'))   DEFAULT: the first product of the inner sum is
+ *                                   contracted, the LLVM / NVVM combiner order
+ *   2  fma(c,c', fma(b,b', a*a'))
+ * Initial value: environment variable CODA_DISTANCE_MODE (0|1|2) if set, else 1.
+ * coda_set_distance_mode returns CODA_EINVAL for any other value.  The CPU oracle
+ * (oracle/pointnet2_oracle.c, `fma_mode`) has the same three modes; parity tests
+ * run all three.                                                              */
+int coda_set_distance_mode(int mode);
+int coda_get_distance_mode(void);
 
 /* ---- furthest_point_sampling ------------------------------------------------
  * Replaces furthest_point_sampling(points (B,N,3) f32, nsamples) -> (B,m) i32
@@ -115,8 +135,8 @@ int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz,
  * three_nn: 3 nearest `known` (B,m,3) of each `unknown` (B,n,3); strict `<`
  *   insertion in ascending k (ties -> lowest k); writes squared distances
  *   dist2 (B,n,3) and idx (B,n,3).            src/interpolate_gpu.cu:12-71
- * three_interpolate: out[b,c,j] = (p[i1]*w1 + p[i2]*w2) + p[i3]*w3
- *                                             src/interpolate_gpu.cu:75-115
+ * three_interpolate: out[b,c,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3, rounded as the
+ *   distance arithmetic mode says             src/interpolate_gpu.cu:75-115
  * three_interpolate_grad: scatter-add of grad_out*w into zeroed (B,C,m)
  *                                             src/interpolate_gpu.cu:119-158 */
 int coda_three_nn_f32(const float *unknown, const float *known, float *dist2,

@@ -17,13 +17,14 @@
  * Every function cites the reference file:line it follows (paths relative to
  * third_party_pointnet2/pointnet2/_ext_src/).
  *
- * Floating point: the canonical arithmetic is source order, one rounding per
- * operation (build with -ffp-contract=off).  The reference is built by nvcc
- * with the default -fmad=true (setup.py:22-25 passes no flag), whose
- * contraction of `a*a + b*b + c*c` is not recoverable without nvcc;
- * `fma_mode` selects the two plausible contractions for sensitivity studies:
- *   0  none (canonical):        (a*a + b*b) + c*c
- *   1  fma(c,c, fma(a,a, b*b))  (LLVM DAGCombiner order)
+ * Floating point: built with -ffp-contract=off, so exactly the operations
+ * written in dot3() are executed.  The reference is built by nvcc with the
+ * default -fmad=true (setup.py:26-28 passes no -fmad flag), whose contraction
+ * of `a*a + b*b + c*c` is not recoverable without nvcc; `fma_mode` selects the
+ * candidate (same numbering and same default as the library's
+ * coda_set_distance_mode, include/coda_pointnet2.h):
+ *   0  none:                    (a*a + b*b) + c*c
+ *   1  fma(c,c, fma(a,a, b*b))  (LLVM / NVVM combiner order)   DEFAULT
  *   2  fma(c,c, fma(b,b, a*a))
  */
 #include <math.h>
@@ -33,7 +34,7 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
-static int g_fma_mode = 0;
+static int g_fma_mode = 1;
 
 ORACLE_API void oracle_set_fma_mode(int mode) { g_fma_mode = mode; }
 ORACLE_API int oracle_get_fma_mode(void) { return g_fma_mode; }

@@ -46,8 +46,15 @@ def _i(a):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
+DEFAULT_FMA_MODE = 1  # same default as the library (include/coda_pointnet2.h, distance arithmetic mode)
+
+
 def set_fma_mode(mode):
     lib().oracle_set_fma_mode(ctypes.c_int(mode))
+
+
+def get_fma_mode():
+    return int(lib().oracle_get_fma_mode())
 
 
 def opt_n_threads(n):

@@ -23,14 +23,52 @@ def oracle():
     return O
 
 
+def set_distance_mode(mode):
+    """Put the oracle AND (when built) the HIP library into distance-arithmetic mode `mode`
+    (include/coda_pointnet2.h).  Golden fixtures carry the mode they were generated in."""
+    from oracle import pointnet2_oracle as O
+    O.set_fma_mode(int(mode))
+    from coda_neurips2023_amd import _lib
+    if os.path.exists(_lib.LIB_PATH):
+        assert _lib.load().coda_set_distance_mode(int(mode)) == 0
+
+
+def fixture_mode(npz):
+    """Distance mode a golden .npz was generated in (files from before the key existed: 0)."""
+    return int(npz["fma_mode"]) if "fma_mode" in npz.files else 0
+
+
+@pytest.fixture(autouse=True)
+def _distance_mode_default():
+    """Every test starts (and leaves) with oracle and library in the documented default mode."""
+    from oracle import pointnet2_oracle as O
+    O.build()
+    set_distance_mode(O.DEFAULT_FMA_MODE)
+    yield
+    set_distance_mode(O.DEFAULT_FMA_MODE)
+
+
 @pytest.fixture(scope="session")
-def golden_ops():
+def _golden_ops_file():
     return np.load(os.path.join(GOLDEN, "pointnet2_ops.npz"))
 
 
 @pytest.fixture(scope="session")
-def golden_sa():
+def _golden_sa_file():
     return np.load(os.path.join(GOLDEN, "sa_module.npz"))
+
+
+@pytest.fixture
+def golden_ops(_golden_ops_file, _distance_mode_default):
+    """The op fixture; switches oracle + library to the mode it was generated in."""
+    set_distance_mode(fixture_mode(_golden_ops_file))
+    return _golden_ops_file
+
+
+@pytest.fixture
+def golden_sa(_golden_sa_file, _distance_mode_default):
+    set_distance_mode(fixture_mode(_golden_sa_file))
+    return _golden_sa_file
 
 
 @pytest.fixture(scope="session")

@@ -86,7 +86,11 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+FMA_MODE = O.DEFAULT_FMA_MODE  # distance-arithmetic mode of the oracle ops while generating
+
+
 def _save(name, **arrays):
+    arrays["fma_mode"] = np.int32(O.get_fma_mode())
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
@@ -293,29 +297,86 @@ def golden_model():
 
     args = _args()
     cfg = SunrgbdAnonymousAlignedImageDatasetConfig(if_print=False, args=args)
-    pre, enc, dec = M.build_preencoder(args), M.build_encoder(args), M.build_decoder(args)
-    model = M.Model3DETRPredictedBoxDistillationHead(pre, enc, dec, cfg, encoder_dim=256, decoder_dim=args.dec_dim,
-                                                     mlp_dropout=0.0, num_queries=args.nqueries,
-                                                     if_with_clip_train=False, args=args)
-    fill_deterministic(model, seed=9)
+
+    # ---- kink margins.  A ReLU whose pre-activation lies within fp32 rounding of 0, or a max-pool
+    # whose two largest DISTINCT candidates do, takes a different branch under any other summation
+    # order (CPU vs GPU, conv vs GEMM), and in this 16k-row toy problem one such flip moves the
+    # first-layer gradients by ~1 %.  The input scene is therefore chosen, among `SEARCH` seeds, as
+    # the one whose smallest margin (in units of the tensor's std) is largest; the fixture then
+    # holds at 1e-3 for any fp32 implementation.  Recorded by wrapping F.relu / F.max_pool2d BEFORE
+    # the reference modules are constructed (the transformer layers bind F.relu at construction).
+    import torch.nn.functional as F
+    margins = []
+    real_relu, real_pool = F.relu, F.max_pool2d
+
+    def relu_probe(x, inplace=False):
+        with torch.no_grad():
+            margins.append(float(x.abs().min() / (x.std() + 1e-30)))
+        return real_relu(x, inplace=inplace)
+
+    def pool_probe(x, *a, **k):
+        with torch.no_grad():
+            top = x.topk(2, dim=-1).values if x.shape[-1] > 1 else None
+            if top is not None:
+                gap = top[..., 0] - top[..., 1]
+                gap = gap[gap > 0]  # exact ties are padded duplicates of one row: identical everywhere
+                if gap.numel():
+                    margins.append(float(gap.min() / (x.std() + 1e-30)))
+        return real_pool(x, *a, **k)
+
+    F.relu, F.max_pool2d = relu_probe, pool_probe
+    try:
+        pre, enc, dec = M.build_preencoder(args), M.build_encoder(args), M.build_decoder(args)
+        model = M.Model3DETRPredictedBoxDistillationHead(pre, enc, dec, cfg, encoder_dim=256,
+                                                         decoder_dim=args.dec_dim, mlp_dropout=0.0,
+                                                         num_queries=args.nqueries, if_with_clip_train=False,
+                                                         args=args)
+        fill_deterministic(model, seed=9)
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+
+        def forward(inputs):
+            point_clouds = inputs["point_clouds"]
+            enc_xyz, enc_features, enc_inds = model.run_encoder(point_clouds)
+            enc_features = model.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+            dims = [inputs["point_cloud_dims_min"], inputs["point_cloud_dims_max"]]
+            query_xyz, query_embed = model.get_query_embeddings(enc_xyz, dims)
+            enc_pos = model.pos_embedding(enc_xyz, input_range=dims).permute(2, 0, 1)
+            query_embed = query_embed.permute(2, 0, 1)
+            tgt = torch.zeros_like(query_embed)
+            box_features = model.decoder(tgt, enc_features, query_pos=query_embed, pos=enc_pos)[0]
+            pred = model.get_box_predictions(query_xyz, dims, box_features, point_clouds, inputs)
+            return enc_xyz, enc_features, enc_inds, query_xyz, box_features, pred
+
+        def scene(seed):
+            pc, mn, mx = make_batch(2, 1024, seed=seed)
+            return pc, mn, mx, {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
+                                "point_cloud_dims_max": torch.from_numpy(mx)}
+
+        SEARCH = int(os.environ.get("CODA_GOLDEN_SEARCH", "160"))
+        best = (-1.0, None)
+        for seed in range(31, 31 + SEARCH):
+            model.load_state_dict(state0)
+            worst = []
+            for mode in ["train", "eval"]:  # the same two passes the fixture records
+                model.train(mode == "train")
+                margins.clear()
+                with torch.no_grad():
+                    forward(scene(seed)[3])
+                worst.append(min(margins))
+            if min(worst) > best[0]:
+                best = (min(worst), seed)
+        print(f"model_tiny: scene seed {best[1]} has the largest kink margin {best[0]:.2e} (of {SEARCH} seeds)")
+        model.load_state_dict(state0)
+    finally:
+        F.relu, F.max_pool2d = real_relu, real_pool
     out = {"state_keys": np.array(sorted(model.state_dict().keys())),
-           "state_shapes": np.array([str(tuple(model.state_dict()[k].shape)) for k in sorted(model.state_dict())])}
-    pc, mn, mx = make_batch(2, 1024, seed=31)
-    inputs = {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
-              "point_cloud_dims_max": torch.from_numpy(mx)}
+           "state_shapes": np.array([str(tuple(model.state_dict()[k].shape)) for k in sorted(model.state_dict())]),
+           "scene_seed": np.int32(best[1]), "kink_margin": np.float64(best[0])}
+    pc, mn, mx, inputs = scene(best[1])
     for mode in ["train", "eval"]:
         model.train(mode == "train")
         model.zero_grad()
-        point_clouds = inputs["point_clouds"]
-        enc_xyz, enc_features, enc_inds = model.run_encoder(point_clouds)
-        enc_features = model.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
-        dims = [inputs["point_cloud_dims_min"], inputs["point_cloud_dims_max"]]
-        query_xyz, query_embed = model.get_query_embeddings(enc_xyz, dims)
-        enc_pos = model.pos_embedding(enc_xyz, input_range=dims).permute(2, 0, 1)
-        query_embed = query_embed.permute(2, 0, 1)
-        tgt = torch.zeros_like(query_embed)
-        box_features = model.decoder(tgt, enc_features, query_pos=query_embed, pos=enc_pos)[0]
-        pred = model.get_box_predictions(query_xyz, dims, box_features, point_clouds, inputs)
+        enc_xyz, enc_features, enc_inds, query_xyz, box_features, pred = forward(inputs)
         o = pred["outputs"]
         out.update({f"{mode}_enc_xyz": _np(enc_xyz), f"{mode}_enc_inds": _np(enc_inds),
                     f"{mode}_enc_features": _np(enc_features), f"{mode}_query_xyz": _np(query_xyz),
@@ -425,6 +486,7 @@ def golden_criterion():
 
 if __name__ == "__main__":
     O.build()
+    O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -15,6 +15,16 @@ from coda_neurips2023_amd.synthetic_scenes import make_batch, make_scene
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["dm0", "dm1", "dm2"])
+def distance_mode(request, _distance_mode_default):
+    """Every op test runs in all three distance-arithmetic modes (include/coda_pointnet2.h):
+    the HIP kernels must be bit-exact against the oracle in the same mode.  Tests that use a
+    golden fixture switch to the fixture's mode (conftest.golden_ops)."""
+    from conftest import set_distance_mode
+    set_distance_mode(request.param)
+    return request.param
+
+
 def cu(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
