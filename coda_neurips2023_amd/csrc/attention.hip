@@ -21,71 +21,14 @@
 // The backward runs as two kernels (dK/dV owned per key block, dQ owned per query
 // block): no atomics, deterministic, at the price of recomputing S twice.
 #include "coda_attention.h"
-#include "common.hip.h"
+#include "attention_common.hip.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <vector>
 
 namespace coda {
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kTile = 32;  // keys (or queries) per MFMA tile
-constexpr float kLog2e = 1.4426950408889634f;
-
-__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// Counter-based dropout, identical in forward and backward: one 32-bit hash (lowbias32) of
-// (seed, b*h, query, key >> 1) serves the two keys of an aligned pair, 16 bits each, so the
-// kernels whose lanes hold a query and whose registers hold consecutive keys (forward, dQ) pay
-// one hash per two probabilities.
-__device__ __forceinline__ uint32_t drop_hash(uint32_t c, uint32_t q, uint32_t s_len, uint32_t key) {
-  uint32_t x = (q * s_len + (key & ~1u)) ^ c;
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ uint32_t drop_const(uint32_t seed, uint32_t bh) { return (bh * 0x9E3779B9u) ^ seed ^ (bh << 27); }
-__device__ __forceinline__ bool drop_keep_lo(uint32_t h, uint32_t thresh16) { return (h & 0xffffu) >= thresh16; }
-__device__ __forceinline__ bool drop_keep_hi(uint32_t h, uint32_t thresh16) { return (h >> 16) >= thresh16; }
-__device__ __forceinline__ bool drop_keep(uint32_t h, uint32_t key, uint32_t thresh16) {
-  return ((key & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
-}
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-struct MhaParams {
-  const float *q, *k, *v;
-  const uint8_t *mask;
-  float *out, *lse;
-  int b, h, l, s;
-  int ldq, ldk, ldv;  // floats between consecutive batch rows of q / k / v (H*D when dense)
-  float scale, inv_keep;
-  uint32_t thresh16, seed;
-  const uint64_t *seed_dev;  // optional device-resident seed (graph replays draw fresh masks)
-  int xcd_map;               // XCD-aware workgroup -> (tile, head) mapping (tile_head())
-};
-
-// XCD-aware workgroup -> (tile, batch*head) mapping.  Workgroups are dispatched round-robin over the 8
-// XCDs in linear-id order (x fastest), so with the plain grid (x = tile, y = head) the tiles of one head
-// are spread over all 8 XCDs and every private L2 pulls every head's K/V (or Q/dO) from the fabric:
-// FETCH_SIZE showed 2.8-5x the algorithmic bytes.  Here the workgroups that share a head share an XCD.
-struct TileHead {
-  int tile, bh;
-};
-__device__ __forceinline__ TileHead tile_head(int xcd_map) {
-  const int T = gridDim.x, BH = gridDim.y;
-  if (!xcd_map || (BH & 7) != 0) return {static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y)};
-  const int i = blockIdx.x + T * blockIdx.y;
-  const int j = i >> 3;
-  return {j % T, (j / T) * 8 + (i & 7)};
-}
-
-__device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint64_t *seed_dev) {
-  if (!seed_dev) return seed;
-  const uint64_t v = *seed_dev;
-  return seed ^ static_cast<uint32_t>(v) ^ static_cast<uint32_t>(v >> 32) * 0x9E3779B9u;
-}
 
 // Cooperative copy of `rows` x D floats (row stride `gstride` floats) into a padded LDS tile.
 template <int D, int THREADS, int ROWS = kTile>
@@ -354,24 +297,6 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m + __logf(lsum) : -INFINITY;
   }
 }
-
-// ---------------------------------------------------------------------------------------
-// Backward.  delta[b,h,q] = sum_dv dout * out  (row-wise), then
-//   P  = exp(scale*QK^T - lse)         Pd = dropout(P)
-//   dV = Pd^T dO      dP = dO V^T (dropout-masked, /keep)     dS = P * (dP - delta) * scale
-//   dK = dS^T Q       dQ = dS K
-struct MhaBwdParams {
-  const float *q, *k, *v, *out, *lse, *dout;
-  const uint8_t *mask;
-  float *dq, *dk, *dv, *delta;
-  int b, h, l, s;
-  int ldq, ldk, ldv;
-  int lddq, lddk, lddv;  // floats between consecutive batch rows of dq / dk / dv (H*D when dense)
-  int xcd_map;
-  float scale, inv_keep;
-  uint32_t thresh16, seed;
-  const uint64_t *seed_dev;
-};
 
 template <int D>
 __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
@@ -933,9 +858,26 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   return launch_status();
 }
 
+// 0: fp32 MFMA operands (default), 1: bf16 MFMA operands (attention_bf16.hip); coda_mha_set_mfma_dtype
+std::atomic<int> g_mfma_dtype{-1};
+int mfma_dtype() {
+  int v = g_mfma_dtype.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv("CODA_ATTN_DTYPE");
+    v = (e && (e[0] == 'b' || e[0] == '1')) ? 1 : 0;
+    g_mfma_dtype.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 template <int D>
 int launch_fwd(const MhaParams &p, hipStream_t s) {
   clear_sticky_error();
+  if (mfma_dtype() == 1) {
+    KernelTimer timer(0, p.l, p.s, s);
+    const int st = mha_fwd_bf16(p, D, s);
+    return st != CODA_OK ? st : launch_status();
+  }
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
   return gen ? launch_fwd_g<D, true>(p, s) : launch_fwd_g<D, false>(p, s);
 }
@@ -1004,6 +946,17 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
     KernelTimer timer(1, p.l, p.s, s);
     hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
   }
+  if (mfma_dtype() == 1) {
+    int st;
+    {
+      KernelTimer timer(2, p.l, p.s, s);
+      st = mha_bwd_dkv_bf16(p, D, s);
+    }
+    if (st != CODA_OK) return st;
+    KernelTimer timer(3, p.l, p.s, s);
+    st = mha_bwd_dq_bf16(p, D, s);
+    return st != CODA_OK ? st : launch_status();
+  }
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
   return gen ? launch_bwd_g<D, true>(p, s) : launch_bwd_g<D, false>(p, s);
 }
@@ -1066,6 +1019,14 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   return d == 64 ? launch_bwd<64>(p, st) : launch_bwd<128>(p, st);
 }
+
+CODA_API int coda_mha_set_mfma_dtype(int dtype) {
+  if (dtype != 0 && dtype != 1) return CODA_EINVAL;
+  coda::g_mfma_dtype.store(dtype, std::memory_order_relaxed);
+  return CODA_OK;
+}
+
+CODA_API int coda_mha_get_mfma_dtype(void) { return coda::mfma_dtype(); }
 
 CODA_API int coda_mha_timing_enable(int min_len) {
   using namespace coda;

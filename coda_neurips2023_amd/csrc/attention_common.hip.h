@@ -1,0 +1,91 @@
+// attention_common.hip.h -- parameter blocks and small device helpers shared by the fp32-MFMA
+// (attention.hip) and bf16-MFMA (attention_bf16.hip) attention kernels.
+#pragma once
+#include "common.hip.h"
+
+namespace coda {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 32;  // keys (or queries) per MFMA tile
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Counter-based dropout, identical in forward and backward: one 32-bit hash (lowbias32) of
+// (seed, b*h, query, key >> 1) serves the two keys of an aligned pair, 16 bits each, so the
+// kernels whose lanes hold a query and whose registers hold consecutive keys (forward, dQ) pay
+// one hash per two probabilities.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t c, uint32_t q, uint32_t s_len, uint32_t key) {
+  uint32_t x = (q * s_len + (key & ~1u)) ^ c;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_const(uint32_t seed, uint32_t bh) { return (bh * 0x9E3779B9u) ^ seed ^ (bh << 27); }
+__device__ __forceinline__ bool drop_keep_lo(uint32_t h, uint32_t thresh16) { return (h & 0xffffu) >= thresh16; }
+__device__ __forceinline__ bool drop_keep_hi(uint32_t h, uint32_t thresh16) { return (h >> 16) >= thresh16; }
+__device__ __forceinline__ bool drop_keep(uint32_t h, uint32_t key, uint32_t thresh16) {
+  return ((key & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct MhaParams {
+  const float *q, *k, *v;
+  const uint8_t *mask;
+  float *out, *lse;
+  int b, h, l, s;
+  int ldq, ldk, ldv;  // floats between consecutive batch rows of q / k / v (H*D when dense)
+  float scale, inv_keep;
+  uint32_t thresh16, seed;
+  const uint64_t *seed_dev;  // optional device-resident seed (graph replays draw fresh masks)
+  int xcd_map;               // XCD-aware workgroup -> (tile, head) mapping (tile_head())
+};
+
+// XCD-aware workgroup -> (tile, batch*head) mapping.  Workgroups are dispatched round-robin over the 8
+// XCDs in linear-id order (x fastest), so with the plain grid (x = tile, y = head) the tiles of one head
+// are spread over all 8 XCDs and every private L2 pulls every head's K/V (or Q/dO) from the fabric:
+// FETCH_SIZE showed 2.8-5x the algorithmic bytes.  Here the workgroups that share a head share an XCD.
+struct TileHead {
+  int tile, bh;
+};
+__device__ __forceinline__ TileHead tile_head(int xcd_map) {
+  const int T = gridDim.x, BH = gridDim.y;
+  if (!xcd_map || (BH & 7) != 0) return {static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y)};
+  const int i = blockIdx.x + T * blockIdx.y;
+  const int j = i >> 3;
+  return {j % T, (j / T) * 8 + (i & 7)};
+}
+
+__device__ __forceinline__ uint32_t effective_seed(uint32_t seed, const uint64_t *seed_dev) {
+  if (!seed_dev) return seed;
+  const uint64_t v = *seed_dev;
+  return seed ^ static_cast<uint32_t>(v) ^ static_cast<uint32_t>(v >> 32) * 0x9E3779B9u;
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward.  delta[b,h,q] = sum_dv dout * out  (row-wise), then
+//   P  = exp(scale*QK^T - lse)         Pd = dropout(P)
+//   dV = Pd^T dO      dP = dO V^T (dropout-masked, /keep)     dS = P * (dP - delta) * scale
+//   dK = dS^T Q       dQ = dS K
+struct MhaBwdParams {
+  const float *q, *k, *v, *out, *lse, *dout;
+  const uint8_t *mask;
+  float *dq, *dk, *dv, *delta;
+  int b, h, l, s;
+  int ldq, ldk, ldv;
+  int lddq, lddk, lddv;  // floats between consecutive batch rows of dq / dk / dv (H*D when dense)
+  int xcd_map;
+  float scale, inv_keep;
+  uint32_t thresh16, seed;
+  const uint64_t *seed_dev;
+};
+
+
+// attention_bf16.hip: the same three kernels with bf16 MFMA operands (fp32 tensors, fp32 accumulation
+// and softmax); launched by attention.hip's dispatchers inside their timing brackets.
+int mha_fwd_bf16(const MhaParams &p, int d, hipStream_t s);
+int mha_bwd_dkv_bf16(const MhaBwdParams &p, int d, hipStream_t s);
+int mha_bwd_dq_bf16(const MhaBwdParams &p, int d, hipStream_t s);
+
+}  // namespace coda

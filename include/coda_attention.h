@@ -58,6 +58,16 @@ int coda_mha_bwd_f32(const float *q, const float *k, const float *v,
                      int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
                      float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *stream);
 
+/* MFMA operand type of the two entry points above (process-wide, like the distance mode of
+ * coda_pointnet2.h): 0 = fp32 operands (v_mfma_f32_32x32x2_f32, default), 1 = bf16 operands
+ * (v_mfma_f32_32x32x16_bf16): Q, K, V, dO and the probabilities are rounded to bf16 on their way
+ * into the matrix cores, accumulation / softmax / lse / every tensor in memory stay fp32.  This is
+ * BASELINE.json configs[4] ("bf16 MFMA attention"); parity target there is 2e-2 relative to the
+ * fp32 reference (bf16 has 8 significand bits).  Dropout masks are identical in both modes.
+ * Initial value: environment variable CODA_ATTN_DTYPE ("bf16" or "1") selects 1, else 0. */
+int coda_mha_set_mfma_dtype(int dtype);
+int coda_mha_get_mfma_dtype(void);
+
 /* Measurement aid (bench.py's live roofline figures; no reference counterpart).  While
  * enabled, each kernel launched by coda_mha_fwd_f32 / coda_mha_bwd_f32 for a problem with
  * l >= min_len and s >= min_len is bracketed by two HIP events on the launch stream.
