@@ -78,16 +78,16 @@ __device__ __forceinline__ bf16x8 load_frag(const float *row, bool valid, float 
 }
 
 // NTILES tiles of 32 rows x D fp32, fetched by the 256 threads as 4 x 4 blocks (see the header).
-template <int D, int NTILES>
+template <int D, int NTILES, int THREADS = kThreads>
 struct Fetch {
-  static constexpr int CB = D / 4, BLK = NTILES * 8 * CB, PER = BLK / kThreads;
-  static_assert(BLK % kThreads == 0, "tile set must split evenly over the workgroup");
+  static constexpr int CB = D / 4, BLK = NTILES * 8 * CB, PER = BLK / THREADS;
+  static_assert(BLK % THREADS == 0, "tile set must split evenly over the workgroup");
   float4 v[PER][4];
 
   __device__ __forceinline__ void load(const float *g, size_t gstride, int row0, int nrows, int tid) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int blk = tid + u * kThreads;
+      const int blk = tid + u * THREADS;
       const int tile = blk / (8 * CB), rb = (blk / CB) % 8, cb = blk % CB;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -100,7 +100,7 @@ struct Fetch {
   __device__ __forceinline__ void store_rm(unsigned char *lds, int tid) const {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int blk = tid + u * kThreads;
+      const int blk = tid + u * THREADS;
       const int tile = blk / (8 * CB), rb = (blk / CB) % 8, cb = blk % CB;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -111,7 +111,7 @@ struct Fetch {
   __device__ __forceinline__ void store_tr(unsigned char *lds, int tid) const {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int blk = tid + u * kThreads;
+      const int blk = tid + u * THREADS;
       const int tile = blk / (8 * CB), rb = (blk / CB) % 8, cb = blk % CB;
       unsigned char *base = lds + tile * Lay<D>::TRB + (4 * cb) * Lay<D>::TS + 8 * rb;
       *reinterpret_cast<bf16x4 *>(base) = cvt4(v[u][0].x, v[u][1].x, v[u][2].x, v[u][3].x);
@@ -136,10 +136,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 // SPLIT = false: wave w owns queries (tile*4 + w)*32 .. +31 and walks all 4 key tiles of a stage.
 // SPLIT = true:  the 4 waves share 32 queries, wave w takes key tile w of every stage; the partial
 //                (m, l, O) are merged through LDS (decoder shapes: 256 / 512 queries).
-template <int D, bool SPLIT, bool GEN>
-__global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_fwd_bf16_kernel(MhaParams p) {
+template <int D, bool SPLIT, bool GEN, int NW = 4>
+__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_fwd_bf16_kernel(MhaParams p) {
   using L = Lay<D>;
-  constexpr int NT = D / 32, KC = D / 16, TILES = 4;
+  constexpr int NT = D / 32, KC = D / 16, TILES = NW;  // SPLIT: one key tile per wave per stage
+  static_assert(SPLIT || NW == 4, "the long-sequence kernel runs 4 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *s_k = smem, *s_vt = smem + TILES * L::ROWB;
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_fwd_bf16_kern
   const bool use_drop = p.thresh16 != 0u;
   const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
 
-  Fetch<D, TILES> fk, fv;
+  Fetch<D, TILES, NW * kWave> fk, fv;
   fk.load(kbase, kstride, 0, p.s, tid);
   fv.load(vbase, vstride, 0, p.s, tid);
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_fwd_bf16_kern
     __syncthreads();
     if (w > 0) return;
     float m_all = m;
-    for (int ww = 1; ww < 4; ++ww) m_all = fmaxf(m_all, s_f[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
+    for (int ww = 1; ww < NW; ++ww) m_all = fmaxf(m_all, s_f[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
     const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
     const float f0 = fast_exp2((m - m_ref) * kLog2e);
     lsum *= f0;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_fwd_bf16_kern
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] *= f0;
-    for (int ww = 1; ww < 4; ++ww) {
+    for (int ww = 1; ww < NW; ++ww) {
       const float *sl = s_f + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
       const float fw = fast_exp2((sl[(NT * 16) * kWave + lane] - m_ref) * kLog2e);
       lsum += sl[(NT * 16 + 1) * kWave + lane] * fw;
@@ -453,10 +454,11 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
 // ---------------------------------------------------------------------------------------------- dQ
 // A wave owns 32 queries (Q, dO fragments in registers as B operands of S^T = K Q^T and dP^T = V dO^T);
 // K comes through LDS in both images (row-major for S^T, transposed for dQ = dS K), V row-major.
-template <int D, bool SPLIT, bool GEN>
-__global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dq_bf16_kernel(MhaBwdParams p) {
+template <int D, bool SPLIT, bool GEN, int NW = 4>
+__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_bwd_dq_bf16_kernel(MhaBwdParams p) {
   using L = Lay<D>;
-  constexpr int NT = D / 32, KC = D / 16, TILES = 4;
+  constexpr int NT = D / 32, KC = D / 16, TILES = NW;
+  static_assert(SPLIT || NW == 4, "the long-sequence kernel runs 4 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *s_k = smem, *s_v = s_k + TILES * L::ROWB, *s_kt = s_v + TILES * L::ROWB;
 
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dq_bf16_k
 #pragma unroll
   for (int t = 0; t < NT; ++t) dq[t] = zero16();
 
-  Fetch<D, TILES> fk, fv;
+  Fetch<D, TILES, NW * kWave> fk, fv;
   fk.load(kbase, kstride, 0, p.s, tid);
   fv.load(vbase, vstride, 0, p.s, tid);
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dq_bf16_k
     }
     __syncthreads();
     if (w > 0) return;
-    for (int ww = 1; ww < 4; ++ww) {
+    for (int ww = 1; ww < NW; ++ww) {
       const float *sl = s_f + static_cast<size_t>(ww - 1) * (NT * 16) * kWave;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -613,6 +615,12 @@ int fwd_launch(const MhaParams &p, hipStream_t s) {
     auto kern = mha_fwd_bf16_kernel<D, false, GEN>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+  } else if (D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
+    // at most one workgroup per CU: 8 waves / 8 key tiles per stage put twice the bytes in flight per CU
+    // (measured 64 -> 53 us at 256 x 2048, but 87 -> 101 us at 512 x 2048 where two 4-wave workgroups share a CU)
+    auto kern = mha_fwd_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4)>;
+    if ((st = raise_lds(kern, 2 * lds)) != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), 2 * lds, s, p);
   } else {
     auto kern = mha_fwd_bf16_kernel<D, true, GEN>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
@@ -648,6 +656,10 @@ int dq_launch(const MhaBwdParams &p, hipStream_t s) {
     auto kern = mha_bwd_dq_bf16_kernel<D, false, GEN>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+  } else if (D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
+    auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4)>;
+    if ((st = raise_lds(kern, 2 * lds)) != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), 2 * lds, s, p);
   } else {
     auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;

@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
-"""Attention kernel timings on the model's shapes (HIP events, same process / same box). Dev tool."""
-import sys, os
+"""Attention kernel timings on the model's shapes, per kernel (HIP events around each launch inside the
+library, coda_mha_timing_*), for both MFMA operand types.  Dev tool.
+
+    python tools/bench_attn.py [fp32|bf16|both] [dropout_p]
+"""
+import os
+import sys
+
 import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from coda_neurips2023_amd import attention_core as core
+from coda_neurips2023_amd import attention_core as core  # noqa: E402
 
 dev = torch.device("cuda:0")
+FLOPS = {"fwd": 4, "dkv": 8, "dq": 6}  # executed MFMA flops per (l * s * d * b * h)
 
 
 def run(l, s, b=8, h=4, d=64, p=0.1, reps=20):
@@ -17,21 +25,29 @@ def run(l, s, b=8, h=4, d=64, p=0.1, reps=20):
     for _ in range(3):
         out, _ = core.attention(q, k, v, None, 0.125, p, False)
         out.backward(go)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tf = tb = 0.0
+    torch.cuda.synchronize()
+    core.enable_kernel_timing(0)
     for _ in range(reps):
-        ev[0].record()
         out, _ = core.attention(q, k, v, None, 0.125, p, False)
-        ev[1].record()
         out.backward(go)
-        ev[2].record()
-        torch.cuda.synchronize()
-        tf += ev[0].elapsed_time(ev[1])
-        tb += ev[1].elapsed_time(ev[2])
-    flops = 4.0 * l * s * d * b * h
-    print(f"L={l} S={s} p={p}: fwd {1e3 * tf / reps:7.1f} us ({flops / (tf / reps) / 1e9:5.1f} TF/s)  "
-          f"bwd {1e3 * tb / reps:7.1f} us ({2.5 * flops / (tb / reps) / 1e9:5.1f} TF/s useful)")
+    rec = core.collect_kernel_timing()
+    core.disable_kernel_timing()
+    line = f"L={l:5d} S={s:5d} d={d:3d} p={p}:"
+    for kind in ("fwd", "delta", "dkv", "dq"):
+        ms = sorted(rec[(kind, l, s)])
+        med = ms[len(ms) // 2]
+        line += f"  {kind} {1e3 * med:7.1f} us"
+        if kind in FLOPS:
+            line += f" ({FLOPS[kind] * l * s * d * b * h / med / 1e9:6.1f} TF/s)"
+    print(line)
 
 
-for shape in [(2048, 2048), (256, 2048), (256, 256)]:
-    run(*shape)
+which = sys.argv[1] if len(sys.argv) > 1 else "both"
+p = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+for dt in (["fp32", "bf16"] if which == "both" else [which]):
+    core.set_mfma_dtype(dt)
+    print(f"--- MFMA operands: {dt}")
+    for shape in [(2048, 2048), (256, 2048), (256, 256), (512, 2048), (512, 512)]:
+        run(*shape, p=p)
+    run(256, 2048, d=128, h=4, p=p)
+core.set_mfma_dtype("fp32")
