@@ -54,6 +54,7 @@ RADIUS = 0.2
 BQ_GROUP_BYTES_PER_SCENE = (12 * N_POINTS + 12 * M_CENTRES + 4 * M_CENTRES * NSAMPLE) + \
                            (4 * M_CENTRES * NSAMPLE + 12 * N_POINTS + 12 * M_CENTRES * NSAMPLE)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 # MFMA flops of one attention kernel per (query, key, model-channel) triple: forward QK^T + PV;
 # dK/dV kernel S = QK^T (recomputed), dP = dO V^T, dV = P^T dO, dK = dS^T Q; dQ kernel S, dP, dQ = dS K.
@@ -70,8 +71,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="auto", choices=["auto", "sa", "model"])
+    p.add_argument("--workload", default="auto", choices=["auto", "sa", "model", "model40k"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the extra single-GPU configurations (configs[1] set abstraction, configs[4] share: "
+                        "40k points / 512 queries / bf16 attention) that follow the headline measurement")
     p.add_argument("--graph", default="off", choices=["on", "off"],
                    help="EXPERIMENTAL (model workload, one process): replay everything behind the set-abstraction "
                         "stage (encoder, decoder, heads, loss; forward + backward) as one captured hipGraph")
@@ -103,6 +107,10 @@ def build_workload(kind, dev):
         return build_dry_workload(dev)
     if kind in ("auto", "model"):
         return build_model_workload(dev)
+    if kind == "model40k":  # profiling aid: the configs[4] share as the main workload (bf16 attention, 512 queries)
+        from coda_neurips2023_amd import attention_core
+        attention_core.set_mfma_dtype("bf16")
+        return build_model_workload(dev, nq=512, config_tag="configs[4], one GPU's share", attn="bf16")
     torch.manual_seed(0)
     mod = pointnet2_modules.PointnetSAModuleVotes(radius=RADIUS, nsample=NSAMPLE, npoint=M_CENTRES,
                                                   mlp=[0, 64, 128, 256], normalize_xyz=True).to(dev)
@@ -117,8 +125,8 @@ def build_workload(kind, dev):
     return mod, step, desc, "sa"
 
 
-def build_model_workload(dev):
-    """configs[2]: full model_3detr enc(3L)+dec(8L, 256 queries) fwd+bwd, 20k pts, batch 8, fp32,
+def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32"):
+    """configs[2] (and, with nq=512 on 40k-point scenes and bf16 MFMA attention, the one-GPU share of configs[4]): full model_3detr enc(3L)+dec(8L, 256 queries) fwd+bwd, 20k pts, batch 8, fp32,
     dropout on (enc/dec 0.1, heads 0.3) as in training.  Loss: the two CLIP-space alignment
     terms (criterion.py:598-644, 924-943) on synthetic unit-norm text / image embeddings with a
     fixed synthetic proposal<->GT assignment, plus plain L1 / CE terms on the box heads so every
@@ -131,7 +139,7 @@ def build_model_workload(dev):
     from coda_neurips2023_amd.model_3detr import build_model, default_args
 
     torch.manual_seed(0)
-    ncls, nq = 10, 256
+    ncls = 10
     gen = torch.Generator().manual_seed(1)
     text = F.normalize(torch.randn(ncls, 512, generator=gen), dim=-1)
     img_emb = F.normalize(torch.randn(B_PER_GPU, nq, 512, generator=gen), dim=-1).to(dev)
@@ -147,7 +155,8 @@ def build_model_workload(dev):
         return outputs
 
     cfg = HotPathDatasetConfig()
-    model, _ = build_model(default_args(), cfg, text_features_fg_norm=text, region_embedding_provider=provider)
+    model, _ = build_model(default_args(nqueries=nq), cfg, text_features_fg_norm=text,
+                           region_embedding_provider=provider)
     model.to(dev).train()
     crit = SetCriterion(None, cfg, {}, train_range_max=ncls).to(dev)
     ngt = 64
@@ -192,11 +201,79 @@ def build_model_workload(dev):
         loss = loss + nl * st["angle_residual_normalized"].abs().mean()
         return loss
 
-    desc = ("configs[2]: full model_3detr (SA 20000->2048 r=0.2 ns=64, enc 3L d=256 h=4, dec 8L d=256 h=4, "
-            "256 queries, 6 heads incl. 512-d CLIP-space head) fwd+bwd, batch=8/GPU, fp32, dropout on; "
+    desc = (f"{config_tag}: full model_3detr (SA {'40000' if nq == 512 else '20000'}->2048 r=0.2 ns=64, enc 3L d=256 "
+            f"h=4, dec 8L d=256 h=4, {nq} queries, 6 heads incl. 512-d CLIP-space head) fwd+bwd, batch=8/GPU, "
+            f"{'fp32 tensors, bf16 MFMA attention (fp32 accumulate/softmax)' if attn == 'bf16' else 'fp32'}, dropout on; "
             "loss = alignment losses (10 classes, synthetic embeddings) + L1/CE on box heads for all 8 "
             "decoder layers; matcher/gIoU (SURVEY 8f next) not included")
     return model, step, desc, "model"
+
+
+def run_extra(kind, dev, steps, warmup):
+    """The other single-GPU configurations of BASELINE.json next to the headline, so that the driver's default
+    command times them too: configs[1] (set abstraction only) and the one-GPU share of configs[4] (40 000-point
+    scenes, 512 queries, bf16 MFMA attention).  Same loop as the headline: `warmup` untimed steps, `steps` timed
+    steps between synchronisations, optimizer step inside, inputs resident in HBM."""
+    from coda_neurips2023_amd import attention_core
+    n_points = N_POINTS
+    prefetch = False
+    if kind == "sa":
+        mod, step_fn, desc, _ = build_workload("sa", dev)
+    else:
+        attention_core.set_mfma_dtype("bf16")
+        n_points = 40000
+        mod, step_fn, desc, _ = build_model_workload(dev, nq=512, config_tag="configs[4], one GPU's share", attn="bf16")
+        prefetch = True
+    try:
+        pool = []
+        for i in range(3):
+            pc, mn, mx = make_batch(B_PER_GPU, n_points, seed=4321 + i)
+            pool.append({"point_clouds": torch.from_numpy(pc).to(dev), "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
+                         "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
+        opt = torch.optim.AdamW(mod.parameters(), lr=1e-4, fused=True)
+
+        def one(i):
+            if prefetch:
+                mod.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)
+            opt.zero_grad(set_to_none=True)
+            step_fn(mod, pool[i % len(pool)]).backward()
+            opt.step()
+
+        for i in range(warmup):
+            one(i)
+        attn_ms = {}
+        if kind != "sa":
+            attention_core.enable_kernel_timing(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if kind != "sa":
+            attn_ms = attention_core.collect_kernel_timing()
+            attention_core.disable_kernel_timing()
+    finally:
+        attention_core.set_mfma_dtype("fp32")
+    out = {"metric": "scenes/sec fwd+bwd", "value": round(B_PER_GPU * steps / dt, 3), "unit": "scenes/s", "n_gpus": 1,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+           "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": n_points,
+                      "sampling": "FPS + ball query of batch i+1 on a side stream during step i" if prefetch else "in line"}}
+    if attn_ms:
+        # bf16 MFMA: executed flops over the dense bf16 peak; these kernels are bound by the softmax VALU work and
+        # by K/V delivery, not by the matrix cores (DESIGN.md section 4)
+        kern = {}
+        for (k, l, s_len), samples in sorted(attn_ms.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
+            if k == "delta":
+                continue
+            ms = sum(samples) / len(samples)
+            tf = ATTN_FLOPS[k] * l * s_len * 256 * B_PER_GPU / (ms * 1e-3) / 1e12
+            kern[f"{k}_{l}x{s_len}"] = {"avg_launch_ms": round(ms, 5), "achieved_tflops": round(tf, 1),
+                                        "frac_of_bf16_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+        out["attention_kernels_bf16"] = kern
+    del mod, opt, pool
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(kind):
@@ -290,7 +367,8 @@ def main():
     # synthetic inputs, resident in HBM before timing; a few distinct batches cycle
     pool = []
     for i in range(4):
-        pc, mn, mx = make_batch(B_PER_GPU, 64 if dry else N_POINTS, seed=1234 + rank * 1000 + i)
+        n_points = 64 if dry else (40000 if args.workload == "model40k" else N_POINTS)
+        pc, mn, mx = make_batch(B_PER_GPU, n_points, seed=1234 + rank * 1000 + i)
         pool.append({"point_clouds": torch.from_numpy(pc).to(dev),
                      "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
@@ -532,6 +610,12 @@ def main():
         }
         if others:
             out["roofline_others"] = others
+        if world == 1 and not dry and not args.no_extras and kind == "model" and args.workload != "model40k":
+            # extra keys, measured by this same command right after the headline (fewer steps: they are
+            # secondary lines; the headline's timed region above is untouched by them)
+            ex_steps, ex_warm = max(5, min(args.steps, 10)), 3
+            out["extra_configs"] = {"configs[1]_sa_only": run_extra("sa", dev, ex_steps, ex_warm),
+                                    "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm)}
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(kind)
         if dry:
