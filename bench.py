@@ -186,7 +186,9 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32"):
                        gt_text_correlation_embedding_mask=o["gt_text_correlation_embedding_mask"],
                        weak_box_cate_label=o["weak_box_cate_label"],
                        weak_confidence_weight=o["weak_confidence_weight"])
-        # every decoder layer is supervised (criterion.py:1205-1215): per-layer terms, summed over layers
+        # every decoder layer is supervised (criterion.py:1205-1215): per-layer terms, summed over layers;
+        # both alignment terms come out of one fused pass, evaluated once here as the criterion's drivers do
+        st = dict(st, _fused_alignment=crit._fused_alignment(st, targets, assign_st))
         loss = crit.stacked_loss_predicted_region_embed_l1(st, targets, assign_st)[
             "loss_predicted_region_embed_l1"].sum()
         loss = loss + crit.stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(st, targets, assign_st)[

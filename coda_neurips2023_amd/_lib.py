@@ -71,6 +71,8 @@ SIGNATURES = {
                                          _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
     "coda_align_loss_bwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P, _P,
                                          _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
+    # include/coda_box_ops.h
+    "coda_generalized_box3d_iou_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     # include/coda_attention.h
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _P]),

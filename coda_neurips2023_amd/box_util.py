@@ -5,8 +5,14 @@ config (utils/box_util.py:346-358 ``rotz_tensor_batch``, :383-424
 ``get_3d_box_batch_tensor_xyz``, :427-490 ``flip_axis_to_camera_tensor`` /
 ``roty_batch_tensor`` / ``get_3d_box_batch_tensor``).  Corner ORDER and the
 sign conventions are the reference's (the loss and the evaluation index them).
+
+``generalized_box3d_iou`` (utils/box_util.py:861-875) is the matcher's gIoU cost: one HIP launch
+for the whole (B, K1, K2) matrix (``include/coda_box_ops.h``) instead of the reference's host-side
+triple loop.
 """
 import torch
+
+from . import _lib
 
 # corner sign patterns, one row per corner: (x, y, z) multipliers of (l, w|h, h|w)/2
 _SIGNS_XYZ = ((-1, 1, 1), (1, 1, 1), (1, -1, 1), (-1, -1, 1),
@@ -83,3 +89,35 @@ def get_3d_box_batch_tensor_xyz(box_size, angle, center):
 def get_3d_box_batch_tensor(box_size, angle, center):
     """Corners in the camera frame (x: l, y: h, z: w), rotation about y."""
     return _corners(box_size, angle, center, _SIGNS_CAM, (0, 2, 1), roty_batch_tensor)
+
+
+# Deployments of the reference that built utils/box_intersection.pyx only clip the first four GT
+# columns of a scene when boxes are rotated (`K2 = rect2.shape[2]`, box_intersection.pyx:181); set
+# this to 4 to reproduce that, leave it at -1 for the documented (TorchScript) behaviour.
+ROTATED_K2_LIMIT = -1
+
+
+def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, return_inter_vols_only=False,
+                          needs_grad=False):
+    """corners1 (B,K1,8,3), corners2 (B,K2,8,3), nums_k2 (B) -> (B,K1,K2) gIoU (utils/box_util.py:861-875).
+    Forward only: the reference differentiates it only for loss_giou_weight > 0, which no CoDA recipe uses."""
+    if needs_grad:
+        raise NotImplementedError("generalized_box3d_iou: gradients (loss_giou_weight > 0) are outside the hot "
+                                  "path of the CoDA recipes (scripts/*.sh pass --loss_giou_weight 0)")
+    if not corners1.is_cuda:
+        raise RuntimeError("CPU not supported")
+    assert corners1.dim() == 4 and corners2.dim() == 4 and corners1.shape[2:] == (8, 3) == corners2.shape[2:]
+    assert corners1.shape[0] == corners2.shape[0]
+    b, k1, k2 = corners1.shape[0], corners1.shape[1], corners2.shape[1]
+    c1 = corners1.detach().to(torch.float32).contiguous()
+    c2 = corners2.detach().to(torch.float32).contiguous()
+    nums = nums_k2.to(device=c1.device, dtype=torch.int32).contiguous() if nums_k2 is not None else None
+    out = torch.empty((b, k1, k2), dtype=torch.float32, device=c1.device)
+    with torch.cuda.device(c1.device):
+        st = _lib.load().coda_generalized_box3d_iou_f32(c1.data_ptr(), c2.data_ptr(),
+                                                        nums.data_ptr() if nums is not None else None,
+                                                        out.data_ptr(), b, k1, k2, int(bool(rotated_boxes)),
+                                                        int(bool(return_inter_vols_only)), int(ROTATED_K2_LIMIT),
+                                                        _lib.current_stream_handle())
+    _lib.check(st, "generalized_box3d_iou")
+    return out

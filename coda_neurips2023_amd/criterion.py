@@ -13,9 +13,13 @@ and the box terms they are summed with (``loss_sem_cls_softmax_skip_none_gt_samp
 names, dictionary keys and normalisers are the reference's.
 
 The Hungarian ``Matcher`` (:12-86) is restated as is (host-side scipy, like the
-reference).  The 3D gIoU that feeds its cost (utils/box_util.py:655-875, Cython
-polygon clipping) is SURVEY.md 8f "next": ``giou_fn`` is a constructor hook and,
-when absent, the gIoU cost term is zero.
+reference).  The 3D gIoU that feeds its cost (utils/box_util.py:655-875; host-side
+polygon clipping in the reference) is one HIP launch per call
+(``box_util.generalized_box3d_iou``, ``include/coda_box_ops.h``).
+
+``build_criterion(args, dataset_config)`` (:1219-1281) assembles matcher + weight dictionary
+from the reference's argparse names; a non-zero weight for a term that is not one of the live
+terms above raises ``NotImplementedError`` at construction instead of being dropped.
 """
 import numpy as np
 import torch
@@ -84,12 +88,64 @@ class Matcher(nn.Module):
                 "proposal_matched_mask": proposal_matched_mask}
 
 
+# every key of the reference's loss_weight_dict (criterion.py:1247-1279) -> the argparse attribute
+_WEIGHT_ARGS = {
+    "loss_giou_weight": "loss_giou_weight",
+    "loss_sem_cls_weight": "loss_sem_cls_weight",
+    "loss_sem_cls_softmax_weight": "loss_sem_cls_softmax_weight",
+    "loss_sem_cls_softmax_skip_none_gt_sample_weight": "loss_sem_cls_softmax_skip_none_gt_sample_weight",
+    "loss_sem_cls_softmax_2d_box_iou_supervised_skip_none_gt_sample_weight":
+        "loss_sem_cls_softmax_2d_box_iou_supervised_skip_none_gt_sample_weight",
+    "loss_sem_cls_softmax_skip_none_gt_sample_en_discovery_objectness_weight":
+        "loss_sem_cls_softmax_skip_none_gt_sample_en_discovery_objectness_weight",
+    "loss_sem_cls_softmax_skip_none_gt_sample_keep_discovery_objectness_weight":
+        "loss_sem_cls_softmax_skip_none_gt_sample_keep_discovery_objectness_weight",
+    "loss_sem_cls_softmax_discovery_novel_objectness_weight": "loss_sem_cls_softmax_discovery_novel_objectness_weight",
+    "loss_no_object_weight": "loss_no_object_weight",
+    "loss_angle_cls_weight": "loss_angle_cls_weight",
+    "loss_angle_reg_weight": "loss_angle_reg_weight",
+    "loss_center_weight": "loss_center_weight",
+    "loss_size_weight": "loss_size_weight",
+    "loss_contrastive_weight": "loss_contrastive_weight",
+    "loss_sem_focal_cls_weight": "loss_sem_focal_cls_weight",
+    "loss_contrast_object_text_weight": "loss_contrast_object_text",  # (sic: no _weight in the flag, :1264)
+    "loss_region_embed_weight": "loss_region_embed_weight",
+    "loss_predicted_region_embed_l1_weight": "loss_predicted_region_embed_l1_weight",
+    "loss_predicted_region_embed_l1_only_last_layer_weight": "loss_predicted_region_embed_l1_only_last_layer_weight",
+    "loss_predicted_region_embed_cos_weight": "loss_predicted_region_embed_cos_weight",
+    "loss_3d_2d_region_embed_weight": "loss_3d_2d_region_embed_weight",
+    "loss_no_object_contrast_weight": "loss_no_object_contrast_weight",
+    "loss_image_seen_class_weight": "loss_image_seen_class_weight",
+    "loss_batchwise_contrastive_weight": "loss_batchwise_contrastive_weight",
+    "loss_feat_seen_sigmoid_loss_weight": "loss_feat_seen_sigmoid_loss_weight",
+    "loss_feat_seen_softmax_loss_weight": "loss_feat_seen_softmax_loss_weight",
+    "loss_feat_seen_softmax_weakly_loss_weight": "loss_feat_seen_softmax_weakly_loss_weight",
+    "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi_weight":
+        "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi_weight",
+    "loss_feat_seen_softmax_iou_match_weakly_loss_with_novel_cate_confi_weight":
+        "loss_feat_seen_softmax_iou_match_weakly_loss_with_novel_cate_confi_weight",
+    "loss_feat_seen_softmax_loss_with_novel_cate_confi_weight": "loss_feat_seen_softmax_loss_with_novel_cate_confi_weight",
+    "loss_feat_seen_sigmoid_with_full_image_loss_weight": "loss_feat_seen_sigmoid_with_full_image_loss_weight",
+    "loss_prompt_softmax_weight": "loss_prompt_softmax_weight",
+    "loss_prompt_sigmoid_weight": "loss_prompt_sigmoid_weight",
+}
+# weights whose loss value comes out of a term under another name (loss_angle -> two values)
+_PRODUCED_BY = {"loss_angle_cls": "loss_angle", "loss_angle_reg": "loss_angle"}
+
+
 class SetCriterion(nn.Module):
-    def __init__(self, matcher, dataset_config, loss_weight_dict, train_range_max=37,
-                 confidence_type="clip-max-prob", giou_fn=None, args=None):
+    """criterion.py:88-168.  Same positional arguments as the reference's constructor."""
+
+    def __init__(self, matcher, dataset_config, loss_weight_dict, train_range_max=37, only_image_class=False,
+                 only_prompt_loss=False, args=None, confidence_type="clip-max-prob", giou_fn="default"):
         super().__init__()
+        if only_image_class or only_prompt_loss:
+            raise NotImplementedError("only_image_class / only_prompt_loss criteria (criterion.py:1163-1179) are not "
+                                      "part of the CoDA training recipes and are outside the hot path")
         self.dataset_config = dataset_config
         self.matcher = matcher
+        if giou_fn == "default":
+            from .box_util import generalized_box3d_iou as giou_fn
         self.giou_fn = giou_fn
         loss_weight_dict = dict(loss_weight_dict)
         semcls_percls_weights = torch.ones(dataset_config.num_semcls + 1)
@@ -100,9 +156,12 @@ class SetCriterion(nn.Module):
         self.register_buffer("seen_semcls_percls_weights", seen)
         self.loss_weight_dict = loss_weight_dict
         self.confidence_type = getattr(args, "confidence_type", confidence_type) if args else confidence_type
+        # read like the reference (:104,128-133); they only steer terms outside the live set
+        self.if_skip_no_seen_scene_objectness = getattr(args, "if_skip_no_seen_scene_objectness", False)
+        self.if_only_seen_in_loss = getattr(args, "if_only_seen_in_loss", False)
+        self.confidence_type_in_datalayer = getattr(args, "confidence_type_in_datalayer", "clip-max-prob")
         self.layer_batched = True  # evaluate all decoder layers in one pass when the model hands them stacked
         self.fused_alignment = True  # GPU fp32: both alignment terms from one HIP pass (align_loss.py)
-        self._align_cache = None
         assert self.confidence_type in ["non-confidence", "objectness", "clip+objectness", "clip-max-prob"]
         self.loss_functions = {
             "loss_sem_cls_softmax_skip_none_gt_sample": self.loss_sem_cls_softmax_skip_none_gt_sample,
@@ -114,6 +173,18 @@ class SetCriterion(nn.Module):
             "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi":
                 self.loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi,
         }
+        missing = [k for k, w in loss_weight_dict.items() if w > 1e-32
+                   and _PRODUCED_BY.get(k[:-len("_weight")], k[:-len("_weight")]) not in self.loss_functions]
+        if missing:
+            raise NotImplementedError(
+                "non-zero weights for loss terms outside the CoDA recipes' live set: " + ", ".join(sorted(missing)))
+        if matcher is not None and getattr(matcher, "cost_giou", 0) > 0 and self.giou_fn is None:
+            raise ValueError("matcher.cost_giou > 0 needs a gIoU function (giou_fn=None was passed)")
+
+    def _live(self, name):
+        """Is term `name` evaluated?  (criterion.py:1130-1137: weight > 1e-32, or no weight key at all)"""
+        key = name + "_weight"
+        return key not in self.loss_weight_dict or self.loss_weight_dict[key] > 1e-32
 
     # ---- loss terms ----------------------------------------------------------------
     # Every term is written once for tensors with a leading decoder-layer axis,
@@ -226,31 +297,31 @@ class SetCriterion(nn.Module):
         return gt_box_label, gt_box_confidence
 
     def _fused_alignment(self, outputs, targets, assignments):
-        """Both alignment terms of all layers from the fused HIP pass (align_loss.py), or None when
-        the tensors are not the GPU fp32 case it covers.  Cached for the second term's call."""
+        """Both alignment terms of all layers from the fused HIP pass (align_loss.py) as
+        (l1 per layer, ce per layer), or None when that pass does not apply: tensors other than
+        GPU fp32, or a recipe in which only one of the two terms is live (stage 1 of the shipped
+        scripts: L1 only, and its datasets carry no `gt_box_seen_sem_cls_confi` for the CE labels)."""
         from . import align_loss
+        if not (self.fused_alignment and self._live("loss_predicted_region_embed_l1")
+                and self._live("loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi")):
+            return None
         emb = outputs["text_correlation_embedding"]
         gt = targets["gt_text_correlation_embedding"]
         text = targets["text_features_clip"]
-        if not self.fused_alignment or not align_loss.eligible(emb, gt, text, targets["logit_scale"]):
+        if not align_loss.eligible(emb, gt, text, targets["logit_scale"]):
             return None
-        key = (id(emb), emb._version, id(assignments["per_prop_gt_inds"]))
-        if self._align_cache is not None and self._align_cache[0] == key:
-            result, self._align_cache = self._align_cache[1], None  # second term: served, not kept alive
-            return result
         label, conf = self._alignment_labels(targets, assignments)
         weight_maps = targets["gt_text_correlation_embedding_mask"]
         l1_sum, ce_sum = align_loss.align_loss_sums(emb, gt, weight_maps, text, targets["logit_scale"], label, conf)
         ave_weight = torch.sum(weight_maps) * emb.shape[-1]
         all_num = torch.sum(conf > 1e-32, dim=(1, 2)) + 1e-32
-        result = (l1_sum / ave_weight, ce_sum / all_num)
-        self._align_cache = (key, result)
-        return result
+        return l1_sum / ave_weight, ce_sum / all_num
 
     def stacked_loss_predicted_region_embed_l1(self, outputs, targets, assignments):
         """Masked L1 between the predicted region embedding and the CLIP image
         embedding of the cropped box, / (sum(mask) * 512)."""
-        fused = self._fused_alignment(outputs, targets, assignments)
+        fused = outputs["_fused_alignment"] if "_fused_alignment" in outputs \
+            else self._fused_alignment(outputs, targets, assignments)  # the drivers evaluate it once for both terms
         if fused is not None:
             return {"loss_predicted_region_embed_l1": fused[0]}
         gt = targets["gt_text_correlation_embedding"]
@@ -263,7 +334,8 @@ class SetCriterion(nn.Module):
     def stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(self, outputs, targets, assignments):
         """CE(normalised embedding @ text^T * scale, label) * confidence, where matched
         proposals take the GT label/confidence and the others the CLIP weak label."""
-        fused = self._fused_alignment(outputs, targets, assignments)
+        fused = outputs["_fused_alignment"] if "_fused_alignment" in outputs \
+            else self._fused_alignment(outputs, targets, assignments)
         if fused is not None:
             return {"loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi": fused[1]}
         emb = outputs["text_correlation_embedding"]
@@ -303,11 +375,11 @@ class SetCriterion(nn.Module):
     # ---- drivers -------------------------------------------------------------------
     def single_output_forward(self, outputs, targets, if_region_embed=False, if_aux=False,
                               if_last_head=False):
-        if self.giou_fn is not None:
+        if self.giou_fn is not None and "gt_box_corners" in targets:
             gious = self.giou_fn(outputs["box_corners"], targets["gt_box_corners"], targets["nactual_gt"],
                                  rotated_boxes=torch.any(targets["gt_box_angles"] > 0).item(),
                                  needs_grad=False)
-        else:  # gIoU is SURVEY.md 8f "next": zero cost term
+        else:  # giou_fn=None was asked for (matcher.cost_giou == 0): zero cost term
             gious = torch.zeros(outputs["center_normalized"].shape[0], outputs["center_normalized"].shape[1],
                                 targets["gt_box_centers_normalized"].shape[1],
                                 device=outputs["center_normalized"].device)
@@ -315,13 +387,16 @@ class SetCriterion(nn.Module):
         center_dist = torch.cdist(outputs["center_normalized"], targets["gt_box_centers_normalized"], p=1)
         outputs["center_dist"] = center_dist
         assignments = self.matcher(outputs, targets)
+        if "text_correlation_embedding" in outputs and "gt_text_correlation_embedding" in targets:
+            lifted = (self._lift(outputs, self._OUT_KEYS), self._lift(assignments, self._ASSIGN_KEYS))
+            fused = self._fused_alignment(lifted[0], targets, lifted[1])
+            outputs["_fused_alignment"] = None if fused is None else tuple(t for t in fused)
 
         losses = {}
         for k, fn in self.loss_functions.items():
-            loss_wt_key = k + "_weight"
-            if (loss_wt_key in self.loss_weight_dict and self.loss_weight_dict[loss_wt_key] > 1e-32) \
-                    or loss_wt_key not in self.loss_weight_dict:
+            if self._live(k):
                 losses.update(fn(outputs, targets, assignments))
+        outputs.pop("_fused_alignment", None)
 
         final_loss = 0
         for k, w in self.loss_weight_dict.items():
@@ -339,12 +414,13 @@ class SetCriterion(nn.Module):
         center = stacked["center_normalized"]
         nl, bsz, nq = center.shape[:3]
         ngt = targets["gt_box_centers_normalized"].shape[1]
-        if self.giou_fn is not None:
+        if self.giou_fn is not None and "gt_box_corners" in targets:
+            # all decoder layers are extra scenes of ONE launch (the reference: one host loop per layer)
             rotated = torch.any(targets["gt_box_angles"] > 0).item()
-            gious = torch.stack([self.giou_fn(stacked["box_corners"][l], targets["gt_box_corners"],
-                                              targets["nactual_gt"], rotated_boxes=rotated, needs_grad=False)
-                                 for l in range(nl)])
-        else:  # gIoU is SURVEY.md 8f "next": zero cost term
+            gious = self.giou_fn(stacked["box_corners"].flatten(0, 1), targets["gt_box_corners"].repeat(nl, 1, 1, 1),
+                                 targets["nactual_gt"].repeat(nl), rotated_boxes=rotated,
+                                 needs_grad=False).view(nl, bsz, nq, ngt)
+        else:  # giou_fn=None was asked for (matcher.cost_giou == 0): zero cost term
             gious = torch.zeros(nl, bsz, nq, ngt, device=center.device)
         gt_centers = targets["gt_box_centers_normalized"]
         center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)
@@ -357,12 +433,12 @@ class SetCriterion(nn.Module):
         assignments = {"per_prop_gt_inds": flat_assign["per_prop_gt_inds"].view(nl, bsz, nq),
                        "proposal_matched_mask": flat_assign["proposal_matched_mask"].view(nl, bsz, nq)}
         outs = dict(stacked, center_dist=center_dist.view(nl, bsz, nq, ngt), gious=gious)
+        outs["_fused_alignment"] = self._fused_alignment(outs, targets, assignments) \
+            if "gt_text_correlation_embedding" in targets else None
 
         losses = {}
         for k in self.loss_functions:
-            loss_wt_key = k + "_weight"
-            if (loss_wt_key in self.loss_weight_dict and self.loss_weight_dict[loss_wt_key] > 1e-32) \
-                    or loss_wt_key not in self.loss_weight_dict:
+            if self._live(k):
                 losses.update(getattr(self, "stacked_" + k)(outs, targets, assignments))
         final = 0
         for k, w in self.loss_weight_dict.items():
@@ -400,3 +476,14 @@ class SetCriterion(nn.Module):
                 for interm_key in interm_loss_dict:
                     loss_dict[f"{interm_key}_{k}"] = interm_loss_dict[interm_key]
         return loss, loss_dict
+
+
+def build_criterion(args, dataset_config):
+    """criterion.py:1219-1281: Hungarian matcher + the loss-weight dictionary from the reference's
+    argparse names (main.py:154-205).  Flags this namespace does not carry count as 0."""
+    if getattr(args, "only_image_class", False) or getattr(args, "only_prompt_loss", False):
+        raise NotImplementedError("only_image_class / only_prompt_loss criteria are outside the hot path")
+    matcher = Matcher(cost_class=args.matcher_cls_cost, cost_giou=args.matcher_giou_cost,
+                      cost_center=args.matcher_center_cost, cost_objectness=args.matcher_objectness_cost)
+    loss_weight_dict = {key: getattr(args, attr, 0) for key, attr in _WEIGHT_ARGS.items()}
+    return SetCriterion(matcher, dataset_config, loss_weight_dict, train_range_max=args.train_range_max, args=args)

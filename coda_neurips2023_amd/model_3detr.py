@@ -89,7 +89,7 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
                  if_keep_box=False, if_select_box_by_objectness=False, keep_objectness=0.5,
                  online_nms_update_novel_label=False, online_nms_update_accumulate_novel_label=False,
                  online_nms_update_accumulate_epoch=10, distillation_box_num=32, args=None,
-                 text_features_fg_norm=None, region_embedding_provider=None):
+                 text_features_fg_norm=None, region_embedding_provider=None, clip_model=None, logit_scale=None):
         super().__init__()
         self.if_with_fake_classes = if_with_fake_classes
         self.num_cls_predict = num_cls_predict
@@ -105,15 +105,32 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         self.eval_layer_id = getattr(args, "eval_layer_id", -1) if args is not None else -1
         self.if_clip_superset = False
 
-        # Products of the (out-of-scope) CLIP text tower: normalised prompt embeddings and the
-        # frozen temperature (reference: clip_model.logit_scale, :367).
+        # The CLIP towers themselves are outside the hot path (weights are not redistributable here):
+        # the constructor takes their PRODUCTS -- the normalised prompt embeddings, the frozen
+        # temperature -- and, optionally, the loaded CLIP module, which is then exposed under the
+        # attribute names main.py / engine.py poke (`clip_model`, `res_encoder`, engine.py:85-117;
+        # absent attributes take the reference's own "no clip here" branch).  `CLIP_LOADER` below lets
+        # build_model(args, dataset_config) obtain them without extra keyword arguments.
         self.region_embedding_provider = region_embedding_provider
+        if clip_model is not None:
+            for prm in clip_model.parameters():
+                prm.requires_grad = False           # models/model_3detr.py:330-331
+            self.clip_model = clip_model
+            self.res_encoder = clip_model.visual    # :333
+            if logit_scale is None:
+                logit_scale = clip_model.logit_scale  # aliased, as in the reference (:367)
         if text_features_fg_norm is not None:
             self.register_buffer("text_features_fg_norm", text_features_fg_norm.to(torch.float32),
                                  persistent=False)
-            self.train_range_max = text_features_fg_norm.shape[0]
+            self.train_range_max = int(getattr(args, "train_range_max", 0) or text_features_fg_norm.shape[0])
             self.test_range_max = text_features_fg_norm.shape[0]
-            self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / 0.07), requires_grad=False)
+            if isinstance(logit_scale, nn.Parameter):
+                self.logit_scale = logit_scale
+            else:
+                # released CLIP checkpoints carry logit_scale = ln(100) (temperature 100 after the clip at
+                # :1796); a caller with another checkpoint passes its value
+                value = math.log(100.0) if logit_scale is None else float(logit_scale)
+                self.logit_scale = nn.Parameter(torch.ones([]) * value, requires_grad=False)
         else:
             self.text_features_fg_norm = None
 
@@ -391,7 +408,15 @@ def build_decoder(args):
     return TransformerDecoder(decoder_layer, num_layers=args.dec_nlayers, return_intermediate=True)
 
 
+# Optional hook: callable(args, dataset_config) -> dict with any of `text_features_fg_norm`,
+# `logit_scale`, `clip_model`, `region_embedding_provider`.  A deployment next to the reference sets it
+# once so that main.py's `build_model(args, dataset_config)` call is unchanged.
+CLIP_LOADER = None
+
+
 def build_3detr_predictedbox_distillation_head(args, dataset_config, **extra):
+    if CLIP_LOADER is not None and "text_features_fg_norm" not in extra:
+        extra = dict(CLIP_LOADER(args, dataset_config), **extra)
     pre_encoder = build_preencoder(args)
     encoder = build_encoder(args)
     decoder = build_decoder(args)

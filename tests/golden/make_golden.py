@@ -484,12 +484,40 @@ def golden_criterion():
     _save("criterion.npz", **out)
 
 
+def golden_giou():
+    """generalized_box3d_iou (utils/box_util.py:861-875 -> the TorchScript tensor path, :655-745) on
+    seeded boxes built with the reference's own corner builder: rotated and axis-aligned, with
+    overlapping pairs, padded GT columns and a degenerate box."""
+    import utils.box_util as RB  # the REFERENCE module
+    gen = torch.Generator().manual_seed(8)
+    B, K1, K2 = 3, 12, 6
+    out = {}
+
+    def boxes(n, rotated):
+        centre = torch.rand(B, n, 3, generator=gen) * 2.0
+        size = torch.rand(B, n, 3, generator=gen) * 1.5 + 0.2
+        angle = (torch.rand(B, n, generator=gen) - 0.5) * 3.0 if rotated else torch.zeros(B, n)
+        return RB.get_3d_box_batch_tensor(size, angle, centre), angle
+
+    for tag, rotated in [("rot", True), ("axis", False)]:
+        c1, _ = boxes(K1, rotated)
+        c2, ang2 = boxes(K2, rotated)
+        c2[0, 1] = c1[0, 3]          # an identical pair (gIoU 1)
+        c2[1, 0, 4:] = c2[1, 0, :4]  # zero-height GT box
+        nums = torch.tensor([K2, 4, 0])
+        g = RB.generalized_box3d_iou(c1, c2, nums, rotated_boxes=rotated, needs_grad=False)
+        v = RB.generalized_box3d_iou(c1, c2, nums, rotated_boxes=rotated, return_inter_vols_only=True)
+        out.update({f"{tag}_corners1": _np(c1), f"{tag}_corners2": _np(c2), f"{tag}_nums": _np(nums).astype(np.int32),
+                    f"{tag}_gious": _np(g), f"{tag}_inter_vols": _np(v)})
+    _save("giou.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion"]
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou"]
     for w in which:
         globals()["golden_" + w]()

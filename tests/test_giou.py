@@ -1,0 +1,76 @@
+"""Generalized 3D IoU (the matcher's cost term): the numpy oracle against the
+vectors produced by the reference's own function (tests/golden/giou.npz), and the HIP kernel
+(coda_generalized_box3d_iou_f32, through box_util.generalized_box3d_iou) against both."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "giou.npz"))
+TOL = 2e-5  # fp32; torch.dot's summation order on <= 8 clip vertices is the only freedom
+
+
+@pytest.mark.parametrize("tag,rotated", [("rot", True), ("axis", False)])
+def test_oracle_matches_reference_vectors(tag, rotated):
+    from oracle import box_giou_oracle as BO
+    got = BO.generalized_box3d_iou(G[f"{tag}_corners1"], G[f"{tag}_corners2"], G[f"{tag}_nums"], rotated)
+    np.testing.assert_allclose(got, G[f"{tag}_gious"], atol=TOL, rtol=TOL)
+    vols = BO.generalized_box3d_iou(G[f"{tag}_corners1"], G[f"{tag}_corners2"], G[f"{tag}_nums"], rotated,
+                                    return_inter_vols_only=True)
+    np.testing.assert_allclose(vols, G[f"{tag}_inter_vols"], atol=TOL, rtol=TOL)
+    # the identical pair: gIoU 1 when axis-aligned; below 1 when rotated (the enclosing box is axis-aligned)
+    same = G[f"{tag}_gious"][0, 3, 1]
+    assert abs(same - 1.0) < 1e-4 if not rotated else 0.0 < same < 1.0
+    assert not G[f"{tag}_gious"][1, :, 4:].any() and not G[f"{tag}_gious"][2].any()  # padded GT columns
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,rotated", [("rot", True), ("axis", False)])
+def test_kernel_matches_reference_vectors(dev, tag, rotated):
+    from coda_neurips2023_amd import box_util
+    c1, c2 = torch.from_numpy(G[f"{tag}_corners1"]).to(dev), torch.from_numpy(G[f"{tag}_corners2"]).to(dev)
+    nums = torch.from_numpy(G[f"{tag}_nums"]).to(dev)
+    got = box_util.generalized_box3d_iou(c1, c2, nums, rotated_boxes=rotated)
+    np.testing.assert_allclose(got.cpu().numpy(), G[f"{tag}_gious"], atol=TOL, rtol=TOL)
+    vols = box_util.generalized_box3d_iou(c1, c2, nums, rotated_boxes=rotated, return_inter_vols_only=True)
+    np.testing.assert_allclose(vols.cpu().numpy(), G[f"{tag}_inter_vols"], atol=TOL, rtol=TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rotated", [True, False])
+def test_kernel_matches_oracle_on_random_boxes(dev, rotated):
+    from coda_neurips2023_amd import box_util
+    from oracle import box_giou_oracle as BO
+    gen = torch.Generator().manual_seed(3)
+    B, K1, K2 = 4, 40, 9
+    def boxes(n):
+        centre = torch.rand(B, n, 3, generator=gen) * 1.5
+        size = torch.rand(B, n, 3, generator=gen) * 1.2 + 0.1
+        angle = (torch.rand(B, n, generator=gen) - 0.5) * 6.0 if rotated else torch.zeros(B, n)
+        return box_util.get_3d_box_batch_tensor(size, angle, centre)
+    c1, c2 = boxes(K1), boxes(K2)
+    nums = torch.tensor([9, 5, 0, 1])
+    got = box_util.generalized_box3d_iou(c1.to(dev), c2.to(dev), nums.to(dev), rotated_boxes=rotated).cpu().numpy()
+    ref = BO.generalized_box3d_iou(c1.numpy(), c2.numpy(), nums.numpy(), rotated)
+    np.testing.assert_allclose(got, ref, atol=TOL, rtol=TOL)
+    assert (np.abs(ref) > 1e-3).mean() > 0.3  # the case is not trivially empty
+    # the Cython deployment quirk: rotated clipping only for GT columns < 4
+    if rotated:
+        box_util.ROTATED_K2_LIMIT = 4
+        try:
+            lim = box_util.generalized_box3d_iou(c1.to(dev), c2.to(dev), nums.to(dev), rotated_boxes=True).cpu().numpy()
+        finally:
+            box_util.ROTATED_K2_LIMIT = -1
+        ref_lim = BO.generalized_box3d_iou(c1.numpy(), c2.numpy(), nums.numpy(), True, rotated_k2_limit=4)
+        np.testing.assert_allclose(lim, ref_lim, atol=TOL, rtol=TOL)
+        assert not np.allclose(lim, got)
+
+
+def test_cpu_and_grad_requests_are_rejected():
+    from coda_neurips2023_amd import box_util
+    c = torch.zeros(1, 2, 8, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        box_util.generalized_box3d_iou(c, c, None)
+    with pytest.raises(NotImplementedError):
+        box_util.generalized_box3d_iou(c, c, None, needs_grad=True)
