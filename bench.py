@@ -76,9 +76,6 @@ def parse():
     p.add_argument("--no-extras", action="store_true",
                    help="skip the extra single-GPU configurations (configs[1] set abstraction, configs[4] share: "
                         "40k points / 512 queries / bf16 attention) that follow the headline measurement")
-    p.add_argument("--graph", default="off", choices=["on", "off"],
-                   help="EXPERIMENTAL (model workload, one process): replay everything behind the set-abstraction "
-                        "stage (encoder, decoder, heads, loss; forward + backward) as one captured hipGraph")
     p.add_argument("--prefetch", choices=["on", "off"], default="on",
                    help="model workload: sample (FPS) batch i+1 on a side stream during step i")
     return p.parse_args()
@@ -375,12 +372,6 @@ def main():
                      "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
     raw_model = model.module if hasattr(model, "module") else model
-    # EXPERIMENTAL, opt-in (--graph on): hipGraph replay of everything behind the set-abstraction stage
-    # (step_graph.GraphedTail, see its docstring for the status).  The default is the eager step.
-    use_graph = kind == "model" and world == 1 and args.graph == "on"
-    if args.graph == "on" and not use_graph:
-        print("[bench] --graph on applies to the single-process model workload only; running eagerly",
-              file=sys.stderr)
     # fused=True: one multi-tensor kernel per parameter group instead of ~10 foreach launches
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=not dry)
     prefetch = args.prefetch == "on" and kind == "model"
@@ -395,40 +386,8 @@ def main():
         loss.backward()
         opt.step()
 
-    graph = None
-    if use_graph:
-        from coda_neurips2023_amd.step_graph import GraphedTail
-
-        def tail_fn(xyz, feat, inds, pc, dims_min, dims_max):
-            batch = {"point_clouds": pc, "point_cloud_dims_min": dims_min, "point_cloud_dims_max": dims_max}
-            return step_fn(raw_model, batch, pre_encoded=(xyz, feat, inds))
-
-        b0 = pool[0]
-        with torch.no_grad():
-            xyz0, feat0, inds0 = raw_model.run_pre_encoder(b0["point_clouds"])
-        sa_params = list(raw_model.pre_encoder.parameters())
-        sa_ids = {id(p) for p in sa_params}
-        graph = GraphedTail(tail_fn, [xyz0, feat0.requires_grad_(True), inds0, b0["point_clouds"],
-                                      b0["point_cloud_dims_min"], b0["point_cloud_dims_max"]],
-                            [p for p in raw_model.parameters() if id(p) not in sa_ids])
-        if prefetch:
-            # the host has time to spare now: wait for the side stream's row counts instead of dropping them
-            raw_model.prefetch_sampling(pool[0], wait_for=None)
-            raw_model._sampling_prefetcher.wait_for_counts = True
-
-    def one_step_graph(i):
-        if prefetch:
-            raw_model.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)
-        b = pool[i % len(pool)]
-        for p in sa_params:
-            p.grad = None
-        xyz, feat, inds = raw_model.run_pre_encoder(b["point_clouds"])  # eager: data-dependent row counts
-        _, grads = graph.replay(xyz, feat.detach(), inds, b["point_clouds"], b["point_cloud_dims_min"],
-                                b["point_cloud_dims_max"])
-        feat.backward(grads[1])
-        opt.step()
-
-    one_step = one_step_graph if graph is not None else one_step_eager
+    graph = None  # (a hipGraph replay of the step is not available on this stack: DESIGN.md section 7)
+    one_step = one_step_eager
 
     for i in range(args.warmup):
         one_step(i)

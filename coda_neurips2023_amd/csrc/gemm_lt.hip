@@ -23,6 +23,7 @@ struct Plan {
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
   hipblasLtMatmulAlgo_t algo;
   size_t workspace = 0;
+  int status = CODA_OK;  // != CODA_OK: the library refused this shape (cached verdict)
 };
 
 using Key = std::tuple<int, int, int, int, int, long long, long long, long long, int>;
@@ -35,9 +36,14 @@ struct State {
   std::unordered_map<hipStream_t, void *> workspaces;
 };
 
+// one State per device: the hipBLASLt handle, the plans' heuristics and the workspaces belong to it
 State &state() {
-  static State s;
-  return s;
+  static std::mutex mu;
+  static std::map<int, State> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  return per_device[dev];
 }
 
 int lt_error(hipblasStatus_t st) { return -(2000 + static_cast<int>(st)); }
@@ -48,7 +54,25 @@ int lt_error(hipblasStatus_t st) { return -(2000 + static_cast<int>(st)); }
     if (st_ != HIPBLAS_STATUS_SUCCESS) return lt_error(st_); \
   } while (0)
 
+int make_plan_checked(State &s, const Key &key, Plan &p);
+
+// Plan creation: any failure means "the library has nothing for this problem" and is reported as
+// -(3000 + hipblasStatus) -- the caller may route that ONE shape elsewhere -- with the descriptors
+// released and the verdict cached (Plan::status), so a refused shape is not re-queried on every call.
 int make_plan(State &s, const Key &key, Plan &p) {
+  const int st = make_plan_checked(s, key, p);
+  if (st != CODA_OK) {
+    if (p.lc) (void)hipblasLtMatrixLayoutDestroy(p.lc);
+    if (p.lb) (void)hipblasLtMatrixLayoutDestroy(p.lb);
+    if (p.la) (void)hipblasLtMatrixLayoutDestroy(p.la);
+    if (p.desc) (void)hipblasLtMatmulDescDestroy(p.desc);
+    p = Plan{};
+    p.status = st <= -2000 ? st - 1000 : st;
+  }
+  return p.status;
+}
+
+int make_plan_checked(State &s, const Key &key, Plan &p) {
   const auto [transa, transb, m, n, k, lda, ldb, ldc, has_bias] = key;
   LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
   // library operand 1 = B, operand 2 = A (see the header comment)
@@ -97,11 +121,11 @@ CODA_API int coda_gemm_f32(int transa, int transb, int m, int n, int k, const fl
   auto it = s.plans.find(key);
   if (it == s.plans.end()) {
     Plan p;
-    const int st = make_plan(s, key, p);
-    if (st != CODA_OK) return st;
+    (void)make_plan(s, key, p);
     it = s.plans.emplace(key, p).first;
   }
   Plan &p = it->second;
+  if (p.status != CODA_OK) return p.status;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   void *ws = nullptr;
   if (p.workspace) {

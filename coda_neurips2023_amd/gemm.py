@@ -15,8 +15,9 @@ import torch
 from . import _lib
 
 _USE_TORCH = os.environ.get("CODA_GEMM", "") == "torch"  # dev A/B switch
-# EXPERIMENTAL, off by default: weight gradients through the hand-written split-rows MFMA kernel
-# (coda_gemm_tn_f32, csrc/gemm_tn.hip) instead of the library GEMM / the split-K bmm + sum
+# Off by default: weight gradients through the hand-written split-rows MFMA kernel (coda_gemm_tn_f32,
+# csrc/gemm_tn.hip; parity-tested on hardware in tests/test_gemm_gpu.py) instead of the library GEMM /
+# the split-K bmm + sum.  CODA_TN_KERNEL=1 routes every mm_tn through it; `kernel=True` one call.
 TN_KERNEL = os.environ.get("CODA_TN_KERNEL", "0") == "1"
 
 
@@ -39,8 +40,10 @@ def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
     st = _lib.load().coda_gemm_f32(transa, transb, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                                    out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
                                    1 if accumulate else 0, _lib.current_stream_handle())
-    if st <= -2000:
-        # hipBLASLt has no kernel for this problem (odd leading dimensions): PyTorch's own GEMM path
+    if -4000 < st <= -3000:
+        # hipBLASLt could not PLAN this problem (-(3000 + hipblasStatus): no heuristic result, odd leading
+        # dimensions): PyTorch's own GEMM path for this shape.  Execution failures (-(2000 + status)) and
+        # everything else are errors and raise below.
         a2 = a.t() if transa else a
         b2 = b.t() if transb else b
         ref = torch.mm(a2, b2) if bias is None else torch.addmm(bias, a2, b2)
@@ -72,7 +75,7 @@ def mm(a, b, out=None, accumulate=False):
     return _run(0, 0, a.shape[0], b.shape[1], a.shape[1], a, b, out, None, accumulate)
 
 
-def mm_tn(a, b, out=None, accumulate=False):
+def mm_tn(a, b, out=None, accumulate=False, kernel=None):
     """a (K,M), b (K,N) -> a.T @ b, (M,N); ``accumulate`` adds to ``out`` instead of overwriting it."""
     assert out is not None or not accumulate
     if not _plain(a, b) or a.shape[0] == 0:
@@ -81,7 +84,7 @@ def mm_tn(a, b, out=None, accumulate=False):
             return r
         return out.add_(r) if accumulate else out.copy_(r)
     a, b = _rows(a), _rows(b)
-    if TN_KERNEL and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
+    if (TN_KERNEL if kernel is None else kernel) and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
         if out is None:
             out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
         st = _lib.load().coda_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], b.shape[1],

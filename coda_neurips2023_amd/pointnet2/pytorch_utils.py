@@ -1,96 +1,48 @@
-"""SharedMLP and its conv/BN building blocks.
+"""The shared point-wise MLP of a set-abstraction module.
 
-Mirror of third_party_pointnet2/pointnet2/pytorch_utils.py:8-117 restricted to
-what the set-abstraction path instantiates.  Module/attribute names are kept so
-that ``state_dict`` keys match the reference checkpoints
-(``mlp_module.layer{i}.conv.weight``, ``mlp_module.layer{i}.bn.bn.{weight,bias,
-running_mean,running_var,num_batches_tracked}``).
+What the reference's checkpoints pin down (third_party_pointnet2/pointnet2/pytorch_utils.py:8-33
+as instantiated by pointnet2_modules.py:205-206) is a naming contract, not a class hierarchy:
+
+    mlp_module.layer{i}.conv.weight                        (C_out, C_in, 1, 1), no bias when normed
+    mlp_module.layer{i}.bn.bn.{weight, bias, running_mean, running_var, num_batches_tracked}
+
+with each layer computing ReLU(BatchNorm2d(Conv2d_1x1(x))) on a (B, C, npoint, nsample) tensor.
+This file provides exactly that.  The fused channels-last path (fused_sa_mlp.py) reads the same
+parameters through ``layer.conv`` / ``layer.bn.bn`` and recognises a layer by its three children
+``conv, bn, activation``.
 """
-from typing import List
-
 import torch.nn as nn
 
 
-class _BNBase(nn.Sequential):
-    """BatchNorm wrapped in a Sequential under the child name ``bn``
-    (pytorch_utils.py:36-44): weight = 1, bias = 0 at init."""
+class _Norm(nn.Module):
+    """BatchNorm2d held under the attribute ``bn`` (gives the ``bn.bn.*`` checkpoint keys).
+    SyncBatchNorm conversion replaces the inner module in place."""
 
-    def __init__(self, in_size, batch_norm=None, name=""):
+    def __init__(self, channels):
         super().__init__()
-        self.add_module(name + "bn", batch_norm(in_size))
-        nn.init.constant_(self[0].weight, 1.0)
-        nn.init.constant_(self[0].bias, 0)
+        self.bn = nn.BatchNorm2d(channels)  # affine, weight 1 / bias 0: torch's defaults
+
+    def forward(self, x):
+        return self.bn(x)
 
 
-class BatchNorm1d(_BNBase):
-    def __init__(self, in_size: int, *, name: str = ""):
-        super().__init__(in_size, batch_norm=nn.BatchNorm1d, name=name)
-
-
-class BatchNorm2d(_BNBase):
-    def __init__(self, in_size: int, name: str = ""):
-        super().__init__(in_size, batch_norm=nn.BatchNorm2d, name=name)
-
-
-class _ConvBase(nn.Sequential):
-    """conv (+ bn) (+ activation), or the pre-activation order when ``preact``
-    (pytorch_utils.py:64-117).  The conv has a bias only when there is no BN."""
-
-    def __init__(self, in_size, out_size, kernel_size, stride, padding, activation, bn, init,
-                 conv=None, batch_norm=None, bias=True, preact=False, name=""):
-        super().__init__()
-        bias = bias and (not bn)
-        conv_unit = conv(in_size, out_size, kernel_size=kernel_size, stride=stride,
-                         padding=padding, bias=bias)
-        init(conv_unit.weight)
-        if bias:
-            nn.init.constant_(conv_unit.bias, 0)
-        bn_unit = None
-        if bn:
-            bn_unit = batch_norm(in_size if preact else out_size)
-        if preact:
-            if bn_unit is not None:
-                self.add_module(name + "bn", bn_unit)
-            if activation is not None:
-                self.add_module(name + "activation", activation)
-        self.add_module(name + "conv", conv_unit)
-        if not preact:
-            if bn_unit is not None:
-                self.add_module(name + "bn", bn_unit)
-            if activation is not None:
-                self.add_module(name + "activation", activation)
-
-
-class Conv1d(_ConvBase):
-    def __init__(self, in_size: int, out_size: int, *, kernel_size: int = 1, stride: int = 1,
-                 padding: int = 0, activation=nn.ReLU(inplace=True), bn: bool = False,
-                 init=nn.init.kaiming_normal_, bias: bool = True, preact: bool = False,
-                 name: str = ""):
-        super().__init__(in_size, out_size, kernel_size, stride, padding, activation, bn, init,
-                         conv=nn.Conv1d, batch_norm=BatchNorm1d, bias=bias, preact=preact,
-                         name=name)
-
-
-class Conv2d(_ConvBase):
-    def __init__(self, in_size: int, out_size: int, *, kernel_size=(1, 1), stride=(1, 1),
-                 padding=(0, 0), activation=nn.ReLU(inplace=True), bn: bool = False,
-                 init=nn.init.kaiming_normal_, bias: bool = True, preact: bool = False,
-                 name: str = ""):
-        super().__init__(in_size, out_size, kernel_size, stride, padding, activation, bn, init,
-                         conv=nn.Conv2d, batch_norm=BatchNorm2d, bias=bias, preact=preact,
-                         name=name)
+def _pointwise_layer(c_in, c_out, normed):
+    layer = nn.Sequential()
+    conv = nn.Conv2d(c_in, c_out, kernel_size=1, bias=not normed)
+    nn.init.kaiming_normal_(conv.weight)  # the reference's initialisation (pytorch_utils.py:98,165)
+    if conv.bias is not None:
+        nn.init.zeros_(conv.bias)
+    layer.add_module("conv", conv)
+    if normed:
+        layer.add_module("bn", _Norm(c_out))
+    layer.add_module("activation", nn.ReLU(inplace=True))
+    return layer
 
 
 class SharedMLP(nn.Sequential):
-    """Stack of 1x1 Conv2d(+BN)+ReLU named ``layer{i}`` (pytorch_utils.py:8-33)."""
+    """``SharedMLP([c0, c1, ..., cn], bn=True)``: n point-wise layers named ``layer0 .. layer{n-1}``."""
 
-    def __init__(self, args: List[int], *, bn: bool = False, activation=nn.ReLU(inplace=True),
-                 preact: bool = False, first: bool = False, name: str = ""):
+    def __init__(self, widths, *, bn=False):
         super().__init__()
-        for i in range(len(args) - 1):
-            plain_first = first and preact and i == 0
-            self.add_module(
-                name + "layer{}".format(i),
-                Conv2d(args[i], args[i + 1], bn=(not plain_first) and bn,
-                       activation=None if plain_first else activation, preact=preact),
-            )
+        for i, (c_in, c_out) in enumerate(zip(widths[:-1], widths[1:])):
+            self.add_module(f"layer{i}", _pointwise_layer(c_in, c_out, bn))

@@ -14,8 +14,10 @@
  * transposed; likewise transb (B stored n x k).  bias: optional n floats added to every row.
  * accumulate != 0: the product is added to the existing C (beta = 1) instead of overwriting it.
  *
- * Return values and stream semantics as in coda_pointnet2.h; a hipBLASLt failure is reported as
- * -(2000 + hipblasStatus_t).  The library keeps one 32 MiB workspace per stream it is called on.
+ * Return values and stream semantics as in coda_pointnet2.h.  A problem hipBLASLt cannot PLAN (no
+ * heuristic result, unsupported leading dimension) is reported as -(3000 + hipblasStatus_t) -- the
+ * verdict is cached per shape, descriptors released -- and a failure of the matmul call itself as
+ * -(2000 + hipblasStatus_t).  State (handle, plans, one 32 MiB workspace per stream) is kept per device.
  */
 #ifndef CODA_GEMM_H
 #define CODA_GEMM_H
@@ -28,7 +30,7 @@ int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a,
                   long long lda, const float *b, long long ldb, float *c, long long ldc,
                   const float *bias, int accumulate, void *stream);
 
-/* EXPERIMENTAL (round 1: compiled, not yet run on hardware, nothing calls it unless CODA_TN_KERNEL=1):
+/* Opt-in (CODA_TN_KERNEL=1 or gemm.mm_tn(..., kernel=True); parity-tested on MI355X, tests/test_gemm_gpu.py):
  * out (co x ci, row stride ldout) [+]= dy^T x with dy (rows x co, row stride lddy), x (rows x ci, row stride
  * ldx) -- the weight gradient of a token-wise linear layer (replaces `torch.mm(dy.t(), x)` / the split-K
  * `bmm + sum` of linear_fn.tn_gemm).  Hand-written fp32 MFMA kernel, reduction over the rows split across
