@@ -13,218 +13,198 @@
 // point index with an all-pairs count in LDS, and emits ranks < nsample; the
 // output is bit-identical to the serial scan.
 //
-// Kernel A (one 1024-thread workgroup per scene): bounding box of the finite
-//   points, cell histogram with LDS atomics, exclusive scan, scatter of
-//   (x, y, z, index) records into cell order.  Workspace layout per scene:
-//   GridHeader | cell_start[kCellMax + 1] | records[N] (float4).
-// Kernel B (one wave per centre): lanes 0..8 fetch the nine x-contiguous cell
-//   ranges, a wave prefix sum flattens them into one candidate list so that
-//   every lane of every 64-wide chunk has work, hits are compacted with
-//   ballot/mbcnt into an LDS buffer, ranked, and written as one 256-B row
-//   (+ the centred / normalised xyz of the fused QueryAndGroup path).
+// Grid: the integer lattice floor(p / cell), cell = 1.001 * radius, folded onto a
+// 32 x 32 x 16 torus (cell index = lattice coordinate mod 32 / 32 / 16).  No bounding box
+// is needed (round 1 spent a third of the build on one) and the grid never has to "grow
+// until it fits": lattice cells a period apart share a table entry, their points are then
+// candidates of each other's centres and fail the distance test like any other miss
+// (6.4 m x 6.4 m x 3.2 m at r = 0.2: an indoor scene does not alias at all).
+//
+// Build (ONE launch, 8 workgroups per scene, no inter-workgroup communication): see grid_build_kernel.
+// Round 1's build was one workgroup per scene reading the cloud three times (bounding box, histogram,
+// scatter) and scanning 32768 counters: 44-65 us on 8 of 256 CUs.
+// Workspace per scene: cell_start[16385] | pad | records[N] (float4).
+// Query (one wave per centre): lanes 0..8 fetch the nine x-contiguous cell ranges
+//   (18 half-ranges when the three x cells wrap around the torus), a wave prefix sum
+//   flattens them into one candidate list so that every lane of every 64-wide chunk has
+//   work, hits are compacted with ballot/mbcnt into an LDS buffer, ranked, and written as
+//   one 256-B row (+ the centred / normalised xyz of the fused QueryAndGroup path).
 #include "common.hip.h"
 
 namespace coda {
 
-constexpr int kCellMax = 32768;       // cells per scene (128 KiB of LDS counters)
-constexpr int kGridThreads = 1024;
-constexpr int kGridUnroll = 8;         // points per thread whose loads are in flight together
+constexpr int kGridX = 32, kGridY = 32, kGridZ = 16;   // cells per axis of the torus (powers of two)
+constexpr int kCells = kGridX * kGridY * kGridZ;       // 16384 table entries per scene
+constexpr int kBuildThreads = 512;    // 8 waves = 2 per SIMD: 256 VGPRs per thread for the resident points
+constexpr int kKeepMax = 12;          // groups of four points per thread the build keeps in registers (n <= 24576)
 constexpr int kHitCap = 256;          // LDS hit records per wave (4 KiB)
 constexpr int kQueryWaves = 4;
 constexpr int kGridMinPoints = 1024;  // below this the scan kernel is cheaper than building a grid
 constexpr int kGridMaxSample = 128;   // nsample + one 64-wide chunk must fit kHitCap
 
-struct GridHeader {
-  float ox, oy, oz, inv_cell;
-  int gx, gy, gz, count;
-};
-
 inline size_t grid_scene_bytes(int n) {
-  return sizeof(GridHeader) + sizeof(int) * (kCellMax + 1) + sizeof(float4) * static_cast<size_t>(n);
+  return sizeof(int) * (kCells + 4) + sizeof(float4) * static_cast<size_t>(n);
 }
 
 namespace {
 
-__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
-
-__device__ __forceinline__ bool finite3(float x, float y, float z) {
-  return isfinite(x) && isfinite(y) && isfinite(z);
+// Lattice coordinate along one axis: floor(v * inv_cell) as ONE saturating conversion
+// (v_cvt_flr_i32_f32: floor + convert, +-Inf / overflow clamp to INT_MIN / INT_MAX, NaN gives 0).
+// Evaluated identically for points and centres and monotone in v, so a hit
+// (|dv| < r(1 + 2^-23) <= cell / (1 + 1e-3), see the distance-mode note in common.hip.h) lies within
+// +-1 lattice cell of the centre's cell.  Non-finite points simply land in SOME cell: they are
+// candidates there and fail `d2 < r2` like in the reference's scan (every comparison with NaN is false,
+// Inf - x = Inf), so they need no special casing.
+__device__ __forceinline__ int lattice(float v, float inv_cell) {
+  int r;
+  const float u = __fmul_rn(v, inv_cell);
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(u));
+  return r;
+}
+// lattice coordinate -> torus coordinate (two's complement & = mathematical mod for negatives too)
+__device__ __forceinline__ int fold_x(int c) { return c & (kGridX - 1); }
+__device__ __forceinline__ int fold_y(int c) { return c & (kGridY - 1); }
+__device__ __forceinline__ int fold_z(int c) { return c & (kGridZ - 1); }
+__device__ __forceinline__ int cell_of(float x, float y, float z, float inv_cell) {
+  return (fold_z(lattice(z, inv_cell)) * kGridY + fold_y(lattice(y, inv_cell))) * kGridX + fold_x(lattice(x, inv_cell));
 }
 
-// Cell coordinate along one axis: floor((v - o) * inv) clamped to [0, g-1].
-// Evaluated identically for points and centres; the clamp is monotone, so a hit
-// (|dv| < r <= cell/(1+1e-3)) always lies within +-1 cell of the centre's cell.
-// (In every distance mode d2 >= fl(dv*dv) for each axis -- the contracted sums only add
-// non-negative terms before a monotone rounding -- so d2 < fl(r*r) still bounds |dv| by
-// r*(1 + 2^-23), far inside the 1e-3 margin.)
-__device__ __forceinline__ int cell_coord(float v, float o, float inv, int g) {
-  float u = floorf((v - o) * inv);
-  u = fminf(fmaxf(u, 0.0f), static_cast<float>(g - 1));
-  return static_cast<int>(u);
+struct SceneWs {
+  int *cell_start;
+  float4 *records;
+};
+__device__ __forceinline__ SceneWs scene_ws(unsigned char *ws, size_t scene_stride, int scene) {
+  unsigned char *base = ws + static_cast<size_t>(scene) * scene_stride;
+  SceneWs r;
+  r.cell_start = reinterpret_cast<int *>(base);
+  r.records = reinterpret_cast<float4 *>(base + sizeof(int) * (kCells + 4));
+  return r;
 }
 
-// LDS counter index with one pad word per 32 counters: thread t scanning its 32 consecutive
-// counters then touches banks (t + i) mod 32 -- conflict-free -- instead of a single bank.
-__device__ __forceinline__ int cidx(int c) { return c + (c >> 5); }
-constexpr int kCntWords = kCellMax + (kCellMax >> 5);
+// ---- build -------------------------------------------------------------------------------------
+// kSlabs workgroups per scene; workgroup j owns the table entries [j, j+1) * kCells / kSlabs.  Every
+// workgroup walks ALL points of the scene (from L2 after the first one; 4 points = three 16-B loads per
+// thread and step), counts its own cells with LDS atomics and, in a register, the points that fall into
+// lower slabs -- that count is its base offset, so the slabs need no communication at all.  Scan of its
+// 2048 counters, then the scatter of its own points with returning LDS atomics.  G = groups of four
+// points a thread keeps in registers across the two passes (0: the cloud is read again).
+constexpr int kSlabs = 8;
+constexpr int kSlabCells = kCells / kSlabs;               // 2048
+constexpr int kPerThread = kSlabCells / kBuildThreads;    // 4 counters per thread in the scan
 
-// The three passes over the points (bounding box, histogram, scatter) are latency-bound
-// loops (load -> dependent LDS atomic), so each pass handles kGridUnroll points per thread
-// per iteration with all their loads issued up front.
-__global__ __launch_bounds__(kGridThreads) void grid_build_kernel(const float *__restrict__ xyz,
-                                                                  int n, float radius,
+struct Quad {  // four consecutive points
+  float v[12];
+};
+__device__ __forceinline__ Quad load_quad(const float *__restrict__ pts, int g, int n, bool vec) {
+  Quad q;
+  const int k0 = 4 * g;
+  if (vec && k0 + 3 < n) {
+    const float4 a = *reinterpret_cast<const float4 *>(pts + k0 * 3), b = *reinterpret_cast<const float4 *>(pts + k0 * 3 + 4),
+                 c = *reinterpret_cast<const float4 *>(pts + k0 * 3 + 8);
+    q.v[0] = a.x; q.v[1] = a.y; q.v[2] = a.z; q.v[3] = a.w; q.v[4] = b.x; q.v[5] = b.y; q.v[6] = b.z; q.v[7] = b.w;
+    q.v[8] = c.x; q.v[9] = c.y; q.v[10] = c.z; q.v[11] = c.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q.v[i] = (k0 * 3 + i < n * 3) ? pts[k0 * 3 + i] : 0.0f;  // past the end: index-checked below
+  }
+  return q;
+}
+
+template <int G>
+__global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float *__restrict__ xyz, int n, float inv_cell,
                                                                   unsigned char *__restrict__ ws,
-                                                                  size_t scene_stride) {
-  // one dynamic LDS carve (static LDS is capped at 64 KiB): counters | reductions | header
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int *s_cnt = reinterpret_cast<int *>(smem);
-  float(*s_red)[kGridThreads / kWave] =
-      reinterpret_cast<float(*)[kGridThreads / kWave]>(smem + sizeof(int) * kCntWords);
-  int *s_wave_sum = reinterpret_cast<int *>(smem + sizeof(int) * kCntWords + sizeof(float) * 6 * (kGridThreads / kWave));
-  GridHeader &s_hdr = *reinterpret_cast<GridHeader *>(smem + sizeof(int) * kCntWords +
-                                                      sizeof(float) * 7 * (kGridThreads / kWave));
+                                                                  size_t scene_stride, int vec) {
+  __shared__ __attribute__((aligned(16))) int s_cnt[kSlabCells];
+  __shared__ int s_red[2][kBuildThreads / kWave];
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const int scene = blockIdx.x / kSlabs, slab = blockIdx.x % kSlabs;
+  const int lo = slab * kSlabCells;
+  const float *__restrict__ pts = xyz + static_cast<size_t>(scene) * n * 3;
+  const SceneWs w = scene_ws(ws, scene_stride, scene);
+  const int ngroups = (n + 3) / 4;
 
-  const int tid = threadIdx.x;
-  const int lane = lane_id();
-  const int w = wave_id();
-  const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
-  unsigned char *base = ws + static_cast<size_t>(blockIdx.x) * scene_stride;
-  GridHeader *hdr = reinterpret_cast<GridHeader *>(base);
-  int *cell_start = reinterpret_cast<int *>(base + sizeof(GridHeader));
-  float4 *records = reinterpret_cast<float4 *>(base + sizeof(GridHeader) + sizeof(int) * (kCellMax + 1));
-
-  // for_each_point(f): f(k, x, y, z) for every point of the scene, kGridUnroll loads in flight
-  auto for_each_point = [&](auto &&f) {
-    for (int base = 0; base < n; base += kGridThreads * kGridUnroll) {
-      float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
+  for (int c = tid; c < kSlabCells; c += kBuildThreads) s_cnt[c] = 0;
+  constexpr int GG = G > 0 ? G : 1;
+  Quad q[GG];
+  if (G > 0) {
 #pragma unroll
-      for (int u = 0; u < kGridUnroll; ++u) {
-        const int k = base + u * kGridThreads + tid;
-        // out-of-range slots become non-finite and are skipped like NaN/Inf points
-        x[u] = k < n ? pts[k * 3 + 0] : INFINITY;
-        y[u] = k < n ? pts[k * 3 + 1] : INFINITY;
-        z[u] = k < n ? pts[k * 3 + 2] : INFINITY;
+    for (int i = 0; i < GG; ++i) q[i] = load_quad(pts, tid + i * kBuildThreads, n, vec != 0);
+  }
+  __syncthreads();
+  // ---- count my cells; count the points of lower slabs
+  int below = 0;
+  auto count_quad = [&](const Quad &qq, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = qq.v[3 * j], y = qq.v[3 * j + 1], z = qq.v[3 * j + 2];
+      if (4 * g + j < n) {
+        const int c = cell_of(x, y, z, inv_cell) - lo;
+        if (c < 0) ++below;
+        else if (c < kSlabCells) atomicAdd(&s_cnt[c], 1);
       }
-#pragma unroll
-      for (int u = 0; u < kGridUnroll; ++u) f(base + u * kGridThreads + tid, x[u], y[u], z[u]);
     }
   };
-
-  // ---- 1. bounding box of the finite points
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for_each_point([&](int, float x, float y, float z) {
-    if (finite3(x, y, z)) {
-      lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
-      lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
-      lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
-    }
-  });
+  if (G > 0) {
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    for (int off = 32; off > 0; off >>= 1) {
-      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
-    }
-    if (lane == 0) {
-      s_red[a][w] = lo[a];
-      s_red[3 + a][w] = hi[a];
-    }
+    for (int i = 0; i < GG; ++i) count_quad(q[i], tid + i * kBuildThreads);
+  } else {
+    for (int g = tid; g < ngroups; g += kBuildThreads) count_quad(load_quad(pts, g, n, vec != 0), g);
   }
-  for (int c = tid; c < kCntWords; c += kGridThreads) s_cnt[c] = 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off);
+  if (lane == 0) s_red[0][wv] = below;
   __syncthreads();
-  if (tid == 0) {
-    float mn[3], mx[3];
-    for (int a = 0; a < 3; ++a) {
-      mn[a] = INFINITY;
-      mx[a] = -INFINITY;
-      for (int i = 0; i < kGridThreads / kWave; ++i) {
-        mn[a] = fminf(mn[a], s_red[a][i]);
-        mx[a] = fmaxf(mx[a], s_red[3 + a][i]);
-      }
-    }
-    GridHeader h;
-    h.count = 0;
-    if (!(mn[0] <= mx[0])) {  // no finite point at all
-      h.ox = h.oy = h.oz = 0.0f;
-      h.inv_cell = 0.0f;
-      h.gx = h.gy = h.gz = 1;
-    } else {
-      // cell >= radius * (1 + 1e-3); grow it until the grid fits kCellMax cells
-      float cell = fmaxf(radius * 1.001f, 1e-30f);
-      int gx, gy, gz;
-      for (;;) {
-        const float fx = floorf((mx[0] - mn[0]) / cell), fy = floorf((mx[1] - mn[1]) / cell),
-                    fz = floorf((mx[2] - mn[2]) / cell);
-        if (fx < 16000.0f && fy < 16000.0f && fz < 16000.0f) {
-          gx = static_cast<int>(fx) + 1;
-          gy = static_cast<int>(fy) + 1;
-          gz = static_cast<int>(fz) + 1;
-          if (static_cast<long long>(gx) * gy * gz <= kCellMax) break;
-        }
-        cell *= 1.1f;
-      }
-      h.ox = mn[0]; h.oy = mn[1]; h.oz = mn[2];
-      h.inv_cell = 1.0f / cell;
-      h.gx = gx; h.gy = gy; h.gz = gz;
-    }
-    s_hdr = h;
-  }
-  __syncthreads();
-  const GridHeader h = s_hdr;
-  const int ncell = h.gx * h.gy * h.gz;
-
-  // ---- 2. histogram
-  for_each_point([&](int, float x, float y, float z) {
-    if (finite3(x, y, z)) {
-      const int c = (cell_coord(z, h.oz, h.inv_cell, h.gz) * h.gy + cell_coord(y, h.oy, h.inv_cell, h.gy)) * h.gx +
-                    cell_coord(x, h.ox, h.inv_cell, h.gx);
-      atomicAdd(&s_cnt[cidx(c)], 1);
-    }
-  });
-  __syncthreads();
-
-  // ---- 3. exclusive scan over kCellMax counters (32 consecutive per thread)
-  constexpr int kPer = kCellMax / kGridThreads;
-  static_assert(kPer == 32, "cidx() padding assumes 32 counters per thread");
-  int sum = 0;
-#pragma unroll 8
-  for (int i = 0; i < kPer; ++i) sum += s_cnt[cidx(tid * kPer + i)];
+  // ---- exclusive scan of my 2048 counters (4 consecutive per thread), offset by the lower slabs' points
+  int base = 0;
+  for (int i = 0; i < kBuildThreads / kWave; ++i) base += s_red[0][i];
+  const int4 cnt = *reinterpret_cast<const int4 *>(s_cnt + tid * kPerThread);
+  static_assert(kPerThread == 4, "scan step below handles one int4 per thread");
+  const int sum = cnt.x + cnt.y + cnt.z + cnt.w;
   int incl = sum;
+#pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
-    const int v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
+    const int up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
   }
-  if (lane == kWave - 1) s_wave_sum[w] = incl;
+  if (lane == kWave - 1) s_red[1][wv] = incl;
   __syncthreads();
-  int wave_off = 0;
-  for (int i = 0; i < w; ++i) wave_off += s_wave_sum[i];
-  int run = wave_off + incl - sum;
-#pragma unroll 8
-  for (int i = 0; i < kPer; ++i) {
-    const int c = tid * kPer + i;
-    const int cnt = s_cnt[cidx(c)];
-    s_cnt[cidx(c)] = run;  // becomes the scatter cursor
-    if (c <= ncell) cell_start[c] = run;
-    run += cnt;
-  }
-  if (tid == kGridThreads - 1) {
-    if (ncell == kCellMax) cell_start[kCellMax] = run;
-    GridHeader out = h;
-    out.count = run;
-    *hdr = out;
-  }
+  int run = base + incl - sum;
+  for (int i = 0; i < wv; ++i) run += s_red[1][i];
+  int4 start;
+  start.x = run; run += cnt.x;
+  start.y = run; run += cnt.y;
+  start.z = run; run += cnt.z;
+  start.w = run; run += cnt.w;
+  *reinterpret_cast<int4 *>(s_cnt + tid * kPerThread) = start;                   // scatter cursors
+  *reinterpret_cast<int4 *>(w.cell_start + lo + tid * kPerThread) = start;
+  if (slab == kSlabs - 1 && tid == kBuildThreads - 1) w.cell_start[kCells] = run;
   __syncthreads();
-
-  // ---- 4. scatter (x, y, z, index) records into cell order (order inside a cell is
-  //         arbitrary; the query ranks hits by index)
-  for_each_point([&](int k, float x, float y, float z) {
-    if (finite3(x, y, z)) {
-      const int c = (cell_coord(z, h.oz, h.inv_cell, h.gz) * h.gy + cell_coord(y, h.oy, h.inv_cell, h.gy)) * h.gx +
-                    cell_coord(x, h.ox, h.inv_cell, h.gx);
-      const int pos = atomicAdd(&s_cnt[cidx(c)], 1);
-      records[pos] = make_float4(x, y, z, __int_as_float(k));
+  // ---- scatter my points (order inside a cell is arbitrary; the query ranks hits by index)
+  auto scatter_quad = [&](const Quad &qq, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = qq.v[3 * j], y = qq.v[3 * j + 1], z = qq.v[3 * j + 2];
+      if (4 * g + j < n) {
+        const int c = cell_of(x, y, z, inv_cell) - lo;
+        if (c >= 0 && c < kSlabCells) {
+          const int pos = atomicAdd(&s_cnt[c], 1);
+          w.records[pos] = make_float4(x, y, z, __int_as_float(4 * g + j));
+        }
+      }
     }
-  });
+  };
+  if (G > 0) {
+#pragma unroll
+    for (int i = 0; i < GG; ++i) {
+      // opaque copies: the cell index is RE-computed (a few VALU ops) instead of being carried across the
+      // scan in a register per point -- registers are what limits the points a thread can keep
+#pragma unroll
+      for (int e = 0; e < 12; ++e) asm volatile("" : "+v"(q[i].v[e]));
+      scatter_quad(q[i], tid + i * kBuildThreads);
+    }
+  } else {
+    for (int g = tid; g < ngroups; g += kBuildThreads) scatter_quad(load_quad(pts, g, n, vec != 0), g);
+  }
 }
 
 // Keep only the `keep` smallest-index records of buf[0..h): all-pairs rank in LDS.
@@ -262,8 +242,8 @@ __device__ __forceinline__ int rank_and_keep(float4 *buf, int h, int keep, int l
 template <int DM>
 __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int n,
-    const unsigned char *__restrict__ ws, size_t scene_stride, int32_t *__restrict__ idx,
-    float *__restrict__ grouped, int m, float r2, float inv_radius, int nsample, int normalize,
+    unsigned char *__restrict__ ws, size_t scene_stride, int32_t *__restrict__ idx,
+    float *__restrict__ grouped, int m, float r2, float inv_radius, float inv_cell, int nsample, int normalize,
     int nscenes) {
   __shared__ float4 s_hits[kQueryWaves][kHitCap];
 
@@ -277,44 +257,44 @@ __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
   const int j = (blockIdx.x / nscenes) * kQueryWaves + w;
   if (j >= m) return;  // wave-uniform, no workgroup barrier in this kernel
 
-  const unsigned char *base = ws + static_cast<size_t>(bi) * scene_stride;
-  const GridHeader h = *reinterpret_cast<const GridHeader *>(base);
-  const int *__restrict__ cell_start = reinterpret_cast<const int *>(base + sizeof(GridHeader));
-  const float4 *__restrict__ records =
-      reinterpret_cast<const float4 *>(base + sizeof(GridHeader) + sizeof(int) * (kCellMax + 1));
+  const SceneWs sw = scene_ws(ws, scene_stride, bi);
+  const int *__restrict__ cell_start = sw.cell_start;
+  const float4 *__restrict__ records = sw.records;
   float4 *buf = s_hits[w];
 
   const float *ctr = new_xyz + (static_cast<size_t>(bi) * m + j) * 3;
   const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
-  const int icx = cell_coord(cx, h.ox, h.inv_cell, h.gx);
-  const int icy = cell_coord(cy, h.oy, h.inv_cell, h.gy);
-  const int icz = cell_coord(cz, h.oz, h.inv_cell, h.gz);
+  const int icx = lattice(cx, inv_cell), icy = lattice(cy, inv_cell), icz = lattice(cz, inv_cell);
 
-  // lanes 0..8: one (dy, dz) row of up to three x-adjacent (memory-contiguous) cells
+  // nine (dy, dz) rows of three x-adjacent cells.  On the torus the three cells are memory-contiguous
+  // unless they straddle the row end: lanes 0..8 hold the part up to the row end, lanes 9..17 the
+  // wrapped remainder (empty, and not visited, when xs <= 29 -- wave-uniform).
+  const int xs = fold_x(icx - 1);
+  const int first = min(3, kGridX - xs);
+  const int nranges = first < 3 ? 18 : 9;
   int start = 0, len = 0;
-  if (lane < 9 && h.count > 0) {
-    const int iy = icy + (lane % 3) - 1, iz = icz + (lane / 3) - 1;
-    if (iy >= 0 && iy < h.gy && iz >= 0 && iz < h.gz) {
-      const int x0 = max(icx - 1, 0), x1 = min(icx + 1, h.gx - 1);
-      const int c0 = (iz * h.gy + iy) * h.gx + x0;
-      start = cell_start[c0];
-      len = cell_start[c0 + (x1 - x0 + 1)] - start;
-    }
+  if (lane < nranges) {
+    const int row = lane < 9 ? lane : lane - 9;
+    const int iy = fold_y(icy + (row % 3) - 1), iz = fold_z(icz + (row / 3) - 1);
+    const int rowbase = (iz * kGridY + iy) * kGridX;
+    const int c0 = lane < 9 ? rowbase + xs : rowbase;
+    const int ncell = lane < 9 ? first : 3 - first;
+    start = cell_start[c0];
+    len = cell_start[c0 + ncell] - start;
   }
   int incl = len;
-  for (int off = 1; off < 16; off <<= 1) {
+  for (int off = 1; off < 32; off <<= 1) {
     const int v = __shfl_up(incl, off);
     if (lane >= off) incl += v;
   }
-  const int total = __builtin_amdgcn_readlane(incl, 8);
+  const int total = __builtin_amdgcn_readlane(incl, 17);
 
   const uint64_t below = (1ull << lane) - 1ull;
   int nhits = 0;
   for (int t0 = 0; t0 < total; t0 += kWave) {
     const int t = t0 + lane;
     int src = -1;
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
+    for (int r = 0; r < nranges; ++r) {
       const int r_incl = __builtin_amdgcn_readlane(incl, r);
       const int r_len = __builtin_amdgcn_readlane(len, r);
       const int r_start = __builtin_amdgcn_readlane(start, r);
@@ -374,26 +354,22 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
                     int m, float radius, int nsample, int normalize, void *workspace, hipStream_t s) {
   const size_t stride = (grid_scene_bytes(n) + 255) & ~static_cast<size_t>(255);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
+  const float cell = fmaxf(radius * 1.001f, 1e-30f);
+  const float inv_cell = 1.0f / cell;
   clear_sticky_error();
-  const size_t lds = sizeof(int) * kCntWords + sizeof(float) * 7 * (kGridThreads / kWave) + sizeof(GridHeader);
-  auto launch_build = [&](auto kern) -> int {
-    static bool lds_set = false;  // once per process: keeps the launch path graph-capturable
-    if (!lds_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      lds_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(kGridThreads), lds, s, xyz, n, radius, ws, stride);
-    return CODA_OK;
-  };
-  const int st = launch_build(grid_build_kernel);
-  if (st != CODA_OK) return st;
+  // 16-B loads of four points need a 16-B aligned scene base: n % 4 == 0 (and an aligned tensor)
+  const int vec = (n % 4 == 0 && (reinterpret_cast<uintptr_t>(xyz) & 15) == 0) ? 1 : 0;
+  const int per = ceil_div(ceil_div(n, 4), kBuildThreads);  // groups of four points per thread
+  const dim3 bgrid(b * kSlabs);
+  if (per <= 2) hipLaunchKernelGGL(grid_build_kernel<2>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec);
+  else if (per <= 6) hipLaunchKernelGGL(grid_build_kernel<6>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec);
+  else if (per <= kKeepMax) hipLaunchKernelGGL(grid_build_kernel<kKeepMax>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec);
+  else hipLaunchKernelGGL(grid_build_kernel<0>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec);
   const float r2 = radius * radius;
   CODA_DISPATCH_DM(distance_mode(),
                    hipLaunchKernelGGL(grid_query_kernel<DM>, dim3(ceil_div(m, kQueryWaves) * b),
                                       dim3(kQueryWaves * kWave), 0, s, new_xyz, xyz, n, ws, stride, idx, grouped, m,
-                                      r2, 1.0f / radius, nsample, normalize, b));
+                                      r2, 1.0f / radius, inv_cell, nsample, normalize, b));
   return launch_status();
 }
 

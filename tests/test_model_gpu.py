@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _golden_distance_mode(_distance_mode_default):
     """FPS / ball_query inside the model run in the mode the fixture was generated in."""
-    from conftest import fixture_mode, set_distance_mode
+    from tests._modes import fixture_mode, set_distance_mode
     set_distance_mode(fixture_mode(G))
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_tiny.npz"))
 RTOL = 1e-3

@@ -20,7 +20,7 @@ def distance_mode(request, _distance_mode_default):
     """Every op test runs in all three distance-arithmetic modes (include/coda_pointnet2.h):
     the HIP kernels must be bit-exact against the oracle in the same mode.  Tests that use a
     golden fixture switch to the fixture's mode (conftest.golden_ops)."""
-    from conftest import set_distance_mode
+    from tests._modes import set_distance_mode
     set_distance_mode(request.param)
     return request.param
 

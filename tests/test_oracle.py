@@ -48,7 +48,7 @@ def _numpy_formulation_mode(request, _distance_mode_default):
     """The independent numpy formulations below (_sqd, fps_closed_form) are written without FMA,
     i.e. distance mode 0; tests that use a golden fixture switch to the fixture's mode afterwards
     (conftest.golden_ops), and test_dot3_modes_exact pins modes 1 and 2 against exact arithmetic."""
-    from conftest import set_distance_mode
+    from tests._modes import set_distance_mode
     if "golden_ops" not in request.fixturenames:
         set_distance_mode(0)
 
