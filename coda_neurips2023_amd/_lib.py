@@ -82,6 +82,8 @@ SIGNATURES = {
     # include/coda_gemm.h
     "coda_gemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                _P, ctypes.c_longlong, _P, _c_int, _P]),
+    "coda_sgemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
+                                ctypes.c_longlong, _P, _c_int, _P]),
     "coda_gemm_tn_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_longlong, ctypes.c_longlong,
                                   ctypes.c_longlong, _c_int, _P]),
     "coda_mha_set_mfma_dtype": (_c_int, [_c_int]),

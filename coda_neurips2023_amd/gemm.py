@@ -34,9 +34,25 @@ def _rows(t):
     return t
 
 
+# Launch-sized products (the decoder's 2048 x 256 x 256 family, ~200 per training step) go to the own
+# fp32-MFMA kernel coda_sgemm_f32 (csrc/gemm_nn.hip): about half the host time per call of the library path
+# and 7 vs 11 us on the GPU; larger problems stay with hipBLASLt, which reaches 75-80 % of the fp32 matrix peak
+# there (tools/bench_gemm.py).  CODA_SGEMM=0 switches the own kernel off (A/B).
+_OWN_SMALL = os.environ.get("CODA_SGEMM", "1") != "0"
+_OWN_MAX_MN = 2048 * 256
+
+
 def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if _OWN_SMALL and not transa and m * n <= _OWN_MAX_MN and m % 64 == 0 and n % 64 == 0 and k % 128 == 0:
+        st = _lib.load().coda_sgemm_f32(transb, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                        out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
+                                        1 if accumulate else 0, _lib.current_stream_handle())
+        if st == 0:
+            return out
+        if st != _lib.CODA_ENOSPC:  # ENOSPC = "not this kernel's shape / alignment": library path below
+            raise RuntimeError(f"coda_sgemm_f32 failed ({st}) for transb={transb} m={m} n={n} k={k}")
     st = _lib.load().coda_gemm_f32(transa, transb, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                                    out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
                                    1 if accumulate else 0, _lib.current_stream_handle())
@@ -84,7 +100,9 @@ def mm_tn(a, b, out=None, accumulate=False, kernel=None):
             return r
         return out.add_(r) if accumulate else out.copy_(r)
     a, b = _rows(a), _rows(b)
-    if (TN_KERNEL if kernel is None else kernel) and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
+    if kernel is None:  # short reductions: the own split-rows kernel (12 vs 15 us at 2048 rows); long ones: library
+        kernel = TN_KERNEL or (_OWN_SMALL and a.shape[0] <= 4096 and a.shape[1] * b.shape[1] <= 256 * 256)
+    if kernel and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
         if out is None:
             out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
         st = _lib.load().coda_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], b.shape[1],

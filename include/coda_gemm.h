@@ -30,6 +30,15 @@ int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a,
                   long long lda, const float *b, long long ldb, float *c, long long ldc,
                   const float *bias, int accumulate, void *stream);
 
+/* Own fp32-MFMA kernel for the same product (csrc/gemm_nn.hip), used for the launch-sized problems of the
+ * transformer stacks where the library costs ~14 us of host time per call:
+ *   transb != 0:  C (m x n) [+]= A (m x k) . B^T + bias,  B (n x k)     (y = x W^T + b)
+ *   transb == 0:  C (m x n) [+]= A (m x k) . B,           B (k x n)     (dx = dy W)
+ * Constraints: m, n multiples of 64, k a multiple of 32, lda / ldb multiples of 4 floats, a and b 16-B
+ * aligned; any other problem returns CODA_ENOSPC ("not this kernel's shape": use coda_gemm_f32). */
+int coda_sgemm_f32(int transb, int m, int n, int k, const float *a, long long lda, const float *b,
+                   long long ldb, float *c, long long ldc, const float *bias, int accumulate, void *stream);
+
 /* Opt-in (CODA_TN_KERNEL=1 or gemm.mm_tn(..., kernel=True); parity-tested on MI355X, tests/test_gemm_gpu.py):
  * out (co x ci, row stride ldout) [+]= dy^T x with dy (rows x co, row stride lddy), x (rows x ci, row stride
  * ldx) -- the weight gradient of a token-wise linear layer (replaces `torch.mm(dy.t(), x)` / the split-K

@@ -88,3 +88,34 @@ def test_tn_kernel(dev, rows, co, ci):
     assert rel(packed[co:2 * co], 2 * ref) < 1e-5
     wide = torch.randn(rows, 3 * co, generator=g).to(dev)          # column slice as dY (row stride 3*co)
     assert rel(gemm.mm_tn(wide[:, co:2 * co], x, kernel=True), (wide[:, co:2 * co].double().t() @ x.double()).float()) < 1e-5
+
+
+@pytest.mark.parametrize("m,n,k,transb", [(2048, 256, 256, True), (2048, 256, 256, False), (64, 64, 128, True),
+                                          (256, 128, 384, False), (16384, 256, 256, True), (16384, 128, 256, False),
+                                          (4096, 192, 96, True), (128, 64, 32, False)])
+def test_own_sgemm_kernels(dev, m, n, k, transb):
+    """coda_sgemm_f32 (csrc/gemm_nn.hip): the split-K kernel for launch-sized problems and the 64x64-tile kernel,
+    both operand forms, bias, accumulation, row-strided operands; against fp64."""
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + n + k)
+    a_full = torch.randn(m, k + 8, generator=g).to(dev)
+    a = a_full[:, 4:4 + k]  # row stride k + 8, 16-B aligned offset
+    b = (torch.randn(n, k, generator=g) if transb else torch.randn(k, n, generator=g)).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    out = torch.full((m, n + 4), 3.0, device=dev)[:, :n]
+    ref = a.double() @ (b.double().t() if transb else b.double())
+
+    def call(bias_t, acc):
+        st = lib.coda_sgemm_f32(1 if transb else 0, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                out.data_ptr(), out.stride(0), bias_t.data_ptr() if bias_t is not None else None, acc,
+                                _lib.current_stream_handle())
+        assert st == 0, st
+    call(bias, 0)
+    assert rel(out, (ref + bias.double()).float()) < 1e-5
+    call(None, 1)
+    assert rel(out, (2 * ref + bias.double()).float()) < 1e-5
+    # shapes outside the kernel's tiling are refused, not mangled
+    st = lib.coda_sgemm_f32(1, 48, 64, 128, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                            out.stride(0), None, 0, _lib.current_stream_handle())
+    assert st == _lib.CODA_ENOSPC
