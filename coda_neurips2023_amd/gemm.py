@@ -100,8 +100,10 @@ def mm_tn(a, b, out=None, accumulate=False, kernel=None):
             return r
         return out.add_(r) if accumulate else out.copy_(r)
     a, b = _rows(a), _rows(b)
-    if kernel is None:  # short reductions: the own split-rows kernel (12 vs 15 us at 2048 rows); long ones: library
-        kernel = TN_KERNEL or (_OWN_SMALL and a.shape[0] <= 4096 and a.shape[1] * b.shape[1] <= 256 * 256)
+    if kernel is None:
+        # own split-rows kernel: 12 vs 15 us at 2048 rows, but its output has to be zeroed first (one more
+        # 4.5 us launch per call, rocprof r02): a wash in the step, so the library stays the default
+        kernel = TN_KERNEL
     if kernel and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
         if out is None:
             out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
