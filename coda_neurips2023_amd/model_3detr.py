@@ -201,8 +201,7 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
     def run_pre_encoder(self, point_clouds):
         """The set-abstraction stage alone: -> (xyz (B,M,3), features (B,C,M), inds (B,M)).  Its result
         can be handed back to ``forward(..., pre_encoded=...)``: the stage has data-dependent shapes
-        (de-duplicated groups) while everything behind it is static and can replay as a hipGraph
-        (step_graph.GraphedTail)."""
+        (de-duplicated groups) while everything behind it is static."""
         xyz, features = self._break_up_pc(point_clouds)
         prepared = None
         if hasattr(self, "_sampling_prefetcher"):
