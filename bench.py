@@ -494,8 +494,9 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
             # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate
-            # rocprofv3 --pmc passes: profiles/r01_pmc_ball_query.md
-            "traffic": 25234432,
+            # rocprofv3 --pmc passes of tools/bench_ops.py: profiles/r02_pmc_ball_query.md (not collected in this run)
+            "traffic": 35683584,
+            "traffic_source": "profiles/r02_pmc_ball_query.md",
             "bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
             # same operator, same inputs, GPU otherwise idle (only reported when the timed region ran it
@@ -528,8 +529,9 @@ def main():
                                   "the timed region replays this kernel inside a hipGraph (no per-launch events can "
                                   "be read back): HIP events around each launch (coda_mha_timing_*, launch stream) in "
                                   "`steps` eagerly enqueued steps of the same workload right after it")
-            # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes): profiles/README.md
+            # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes), not collected in this run
             roofline["traffic"] = ATTN_DKV_TRAFFIC
+            roofline["traffic_source"] = "profiles/r01_pmc_attention_hbm.md (kernel unchanged since)"
             t_bwd = sum(sum(attn_ms[(k, 2048, 2048)]) / len(attn_ms[(k, 2048, 2048)])
                         for k in ("delta", "dkv", "dq") if (k, 2048, 2048) in attn_ms)
             # SURVEY 8d's count for the whole backward with recomputation: 12 * Lq * Lk * d over delta + dK/dV + dQ
