@@ -10,6 +10,11 @@ from . import box_util
 
 
 class HotPathDatasetConfig:
+    # the corner builders below are the SUN-RGBD / ScanNet ones (flip to camera + get_3d_box_batch_tensor, and
+    # get_3d_box_batch_tensor_xyz): lets the model use the fused decoder (box_decode.py).  A reference dataset
+    # config object can opt in by setting the same attribute.
+    standard_corner_builders = True
+
     def __init__(self, num_semcls=1, num_angle_bin=12, max_num_obj=64, image_size=(730, 531)):
         self.num_semcls = num_semcls
         self.num_angle_bin = num_angle_bin

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import fused_bn_mlp
+from . import box_decode, fused_bn_mlp
 from .helpers import GenericMLP
 from .pointnet2.pointnet2_modules import PointnetSAModuleVotes
 from .pointnet2.pointnet2_utils import SamplingPrefetcher, furthest_point_sample
@@ -253,10 +253,17 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
 
         cls_logits = raw["sem_cls_head"]
         text_correlation_embedding = raw["text_correlation_head"]
-        center_offset = raw["center_head"].sigmoid() - 0.5
-        size_normalized = raw["size_head"].sigmoid()
         angle_logits = raw["angle_cls_head"]
         angle_residual_normalized = raw["angle_residual_head"]
+        decode_in = (raw["center_head"], raw["size_head"], angle_logits, angle_residual_normalized, cls_logits)
+        if box_decode.eligible(decode_in, query_xyz, point_cloud_dims, self.box_processor.dataset_config):
+            # one kernel per direction for the whole element-wise tail below (csrc/box_decode.hip)
+            dec = box_decode.decode(*decode_in, query_xyz, point_cloud_dims)
+            stacked = dict(dec, sem_cls_logits=cls_logits, text_correlation_embedding=text_correlation_embedding,
+                           angle_logits=angle_logits, angle_residual_normalized=angle_residual_normalized)
+            return self._layer_dicts(stacked, num_layers, point_clouds)
+        center_offset = raw["center_head"].sigmoid() - 0.5
+        size_normalized = raw["size_head"].sigmoid()
         angle_residual = angle_residual_normalized * (np.pi / angle_residual_normalized.shape[-1])
 
         # Box decoding (models/model_3detr.py:1683-1731).  The reference decodes the num_layers
@@ -311,6 +318,10 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             "box_corners": box_corners,
             "box_corners_xyz": box_corners_xyz,
         }
+        return self._layer_dicts(stacked, num_layers, point_clouds)
+
+    @staticmethod
+    def _layer_dicts(stacked, num_layers, point_clouds):
         outputs = [dict({k: v[l] for k, v in stacked.items()}, point_clouds=point_clouds)
                    for l in range(num_layers)]
         # `stacked_outputs` ((num_layers, batch, ...) per key, last decoder layer at index -1) is this

@@ -1,5 +1,6 @@
 /*
- * coda_box_ops.h -- C ABI of the box geometry the matcher needs.
+ * coda_box_ops.h -- C ABI of the box geometry: the matcher's gIoU and the box decoder
+ * (8f rank 3).
  *
  * coda_generalized_box3d_iou_f32 replaces utils/box_util.py:655-745
  * (generalized_box3d_iou_tensor; dispatcher :861-875), which SetCriterion.single_output_forward
@@ -39,6 +40,39 @@ int coda_generalized_box3d_iou_f32(const float *corners1, const float *corners2,
                                    const int32_t *nums_k2, float *out, int b, int k1, int k2,
                                    int rotated, int inter_vols_only, int rotated_k2_limit,
                                    void *stream);
+
+/* ---- box decoding ----------------------------------------------------------
+ * Everything `get_box_predictions` computes from the six heads' raw outputs for all decoder layers
+ * (models/model_3detr.py:1683-1731 with BoxProcessor :56-127, utils/pc_util.py:38-73 and the corner
+ * builders utils/box_util.py:383-490 as the SUN-RGBD / ScanNet dataset configs wire them), one thread
+ * per (layer, scene, query) row instead of ~70 element-wise / reduction / tiny-GEMM launches per
+ * direction:
+ *   center_unnormalized = query_xyz + (sigmoid(center_raw) - 0.5)
+ *   center_normalized   = (center_unnormalized - dims_min) / (dims_max - dims_min)
+ *   size_normalized     = sigmoid(size_raw);  size_unnormalized = size_normalized * max(dims_max - dims_min, 0.1)
+ *   angle_residual      = angle_residual_normalized * (pi / nbin)
+ *   angle_continuous    = (2 pi / nbin) * argmax(angle_logits) + angle_residual[argmax], minus 2 pi if > pi
+ *   box_corners         = camera-frame corners (flip_axis_to_camera + get_3d_box_batch_tensor)
+ *   box_corners_xyz     = depth-frame corners (get_3d_box_batch_tensor_xyz)
+ *   sem_cls_prob, objectness_prob = softmax(sem_cls_logits)[:-1], 1 - softmax(...)[-1]
+ * Inputs are addressed as (layer, scene, query, channel) through element strides (sl, sb, sq; channels
+ * contiguous), so the heads' (layer, query, scene) buffers are read in place; `rows` = nl * b * nq;
+ * query_xyz (b, nq, 3), dims_min / dims_max (b, 3).  Outputs are dense (nl, b, nq, ...).
+ * The backward takes the gradients of the differentiable outputs (any pointer may be NULL = zero) and
+ * returns d center_raw, d size_raw (rows x 3) and d angle_residual_normalized (rows x nbin), dense. */
+int coda_box_decode_fwd_f32(const float *center_raw, const float *size_raw, const float *angle_logits,
+                            const float *angle_res_norm, const float *cls_logits, const long long *strides,
+                            const float *query_xyz, const float *dims_min, const float *dims_max, int nl, int b,
+                            int nq, int nbin, int ncls1, float *center_norm, float *center_unnorm,
+                            float *size_norm, float *size_unnorm, float *angle_residual, float *angle_cont,
+                            float *corners, float *corners_xyz, float *cls_prob, float *obj_prob, void *stream);
+int coda_box_decode_bwd_f32(const float *center_raw, const float *size_raw, const float *angle_logits,
+                            const float *angle_res_norm, const long long *strides, const float *dims_min,
+                            const float *dims_max, int nl, int b, int nq, int nbin, const float *g_center_norm,
+                            const float *g_center_unnorm, const float *g_size_norm, const float *g_size_unnorm,
+                            const float *g_angle_residual, const float *g_angle_cont, const float *g_corners,
+                            const float *g_corners_xyz, float *d_center_raw, float *d_size_raw,
+                            float *d_angle_res_norm, void *stream);
 
 #ifdef __cplusplus
 }

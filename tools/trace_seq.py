@@ -8,7 +8,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # step boundary: FPS kernel with the large template arg marks the start of a step
-starts = [i for i, r in enumerate(rows) if "fps_t512_kernel<40>" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if ("fps_t512_kernel<4" in r["Kernel_Name"])]
 a, b = starts[-2], starts[-1]
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
