@@ -162,6 +162,7 @@ class SetCriterion(nn.Module):
         self.confidence_type_in_datalayer = getattr(args, "confidence_type_in_datalayer", "clip-max-prob")
         self.layer_batched = True  # evaluate all decoder layers in one pass when the model hands them stacked
         self.fused_alignment = True  # GPU fp32: both alignment terms from one HIP pass (align_loss.py)
+        self.fused_box_losses = True  # GPU fp32: the four matched box terms from one HIP pass (box_loss.py)
         assert self.confidence_type in ["non-confidence", "objectness", "clip+objectness", "clip-max-prob"]
         self.loss_functions = {
             "loss_sem_cls_softmax_skip_none_gt_sample": self.loss_sem_cls_softmax_skip_none_gt_sample,
@@ -226,7 +227,32 @@ class SetCriterion(nn.Module):
         card_err = (pred_objects.float() - targets["nactual_gt"]).abs().mean(-1)
         return {"loss_cardinality": card_err}
 
+    def _fused_box_terms(self, outputs, targets, assignments):
+        """{loss name: per-layer value} of the four matched box terms from the fused pass (box_loss.py), with the
+        reference's normalisers, or None when that pass does not apply."""
+        from . import box_loss
+        live = ["loss_sem_cls_softmax_skip_none_gt_sample", "loss_angle", "loss_center", "loss_size"]
+        if not (self.fused_box_losses and all(self._live(k) for k in live)
+                and all(k in outputs for k in box_loss._KEYS) and box_loss.eligible(outputs, targets, assignments)):
+            return None
+        sums = box_loss.layer_sums(outputs, targets, assignments, self.semcls_percls_weights,
+                                   self.dataset_config.num_angle_bin)
+        has_object = (targets["gt_box_present"].sum(dim=1) != 0).to(sums.dtype)
+        nq = outputs["sem_cls_logits"].shape[2]
+        res = {"loss_sem_cls_softmax_skip_none_gt_sample": sums[:, 0] / (has_object.sum() * nq + 1e-32)}
+        if targets["num_boxes_replica"] > 0:
+            nb = targets["num_boxes"]
+            res.update(loss_angle_cls=sums[:, 1] / nb, loss_angle_reg=sums[:, 2] / nb,
+                       loss_center=sums[:, 3] / nb if nb > 0 else sums[:, 3], loss_size=sums[:, 4] / nb)
+        else:  # no box on this worker: zero terms that keep the heads in the graph (:894-897, 1035-1037, 1100-1102)
+            res.update(loss_angle_cls=sums[:, 1] * 0, loss_angle_reg=sums[:, 2] * 0, loss_center=sums[:, 3] * 0,
+                       loss_size=sums[:, 4] * 0)
+        return res
+
     def stacked_loss_sem_cls_softmax_skip_none_gt_sample(self, outputs, targets, assignments):
+        if outputs.get("_fused_box_terms") is not None:
+            return {"loss_sem_cls_softmax_skip_none_gt_sample":
+                    outputs["_fused_box_terms"]["loss_sem_cls_softmax_skip_none_gt_sample"]}
         pred_logits = outputs["sem_cls_logits"]
         gt_box_label = self._gather_gt(targets["gt_box_sem_cls_label"], assignments["per_prop_gt_inds"])
         gt_box_label = torch.where(assignments["proposal_matched_mask"].int() == 0,
@@ -239,6 +265,9 @@ class SetCriterion(nn.Module):
         return {"loss_sem_cls_softmax_skip_none_gt_sample": final_loss}
 
     def stacked_loss_angle(self, outputs, targets, assignments):
+        if outputs.get("_fused_box_terms") is not None:
+            f = outputs["_fused_box_terms"]
+            return {"loss_angle_cls": f["loss_angle_cls"], "loss_angle_reg": f["loss_angle_reg"]}
         angle_logits = outputs["angle_logits"]
         angle_residual = outputs["angle_residual_normalized"]
         if targets["num_boxes_replica"] > 0:
@@ -260,6 +289,8 @@ class SetCriterion(nn.Module):
         return {"loss_angle_cls": angle_cls_loss, "loss_angle_reg": angle_reg_loss}
 
     def stacked_loss_center(self, outputs, targets, assignments):
+        if outputs.get("_fused_box_terms") is not None:
+            return {"loss_center": outputs["_fused_box_terms"]["loss_center"]}
         center_dist = outputs["center_dist"]
         if targets["num_boxes_replica"] > 0:
             center_loss = torch.gather(center_dist, 3, assignments["per_prop_gt_inds"].unsqueeze(-1)).squeeze(-1)
@@ -271,6 +302,8 @@ class SetCriterion(nn.Module):
         return {"loss_center": center_loss}
 
     def stacked_loss_size(self, outputs, targets, assignments):
+        if outputs.get("_fused_box_terms") is not None:
+            return {"loss_size": outputs["_fused_box_terms"]["loss_size"]}
         pred_box_sizes = outputs["size_normalized"]
         if targets["num_boxes_replica"] > 0:
             gt_box_sizes = self._gather_gt(targets["gt_box_sizes_normalized"], assignments["per_prop_gt_inds"])
@@ -423,7 +456,7 @@ class SetCriterion(nn.Module):
         else:  # giou_fn=None was asked for (matcher.cost_giou == 0): zero cost term
             gious = torch.zeros(nl, bsz, nq, ngt, device=center.device)
         gt_centers = targets["gt_box_centers_normalized"]
-        center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)
+        center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)  # matcher + loss_center
         flat_out = {"sem_cls_prob": stacked["sem_cls_prob"].flatten(0, 1),
                     "objectness_prob": stacked["objectness_prob"].flatten(0, 1),
                     "center_dist": center_dist, "gious": gious.flatten(0, 1)}
@@ -435,6 +468,7 @@ class SetCriterion(nn.Module):
         outs = dict(stacked, center_dist=center_dist.view(nl, bsz, nq, ngt), gious=gious)
         outs["_fused_alignment"] = self._fused_alignment(outs, targets, assignments) \
             if "gt_text_correlation_embedding" in targets else None
+        outs["_fused_box_terms"] = self._fused_box_terms(outs, targets, assignments)
 
         losses = {}
         for k in self.loss_functions:

@@ -74,6 +74,31 @@ int coda_box_decode_bwd_f32(const float *center_raw, const float *size_raw, cons
                             const float *g_corners_xyz, float *d_center_raw, float *d_size_raw,
                             float *d_angle_res_norm, void *stream);
 
+/* ---- matched box losses (criterion.py:219-246, 834-900, 1015-1104) -----------------------------------
+ * The four box terms SetCriterion evaluates for every decoder layer once the matcher has assigned
+ * proposals to ground-truth boxes, as per-row partial sums (rows = nl * b * nq, 5 floats per row):
+ *   [0] w[y] * CE(sem_cls_logits, y) * has_object[b]        y = gt label if matched else background (K-1)
+ *   [1] matched * CE(angle_logits, gt_angle_class)           [2] matched * huber(res_norm[gt bin] - gt_res_norm)
+ *   [3] matched * |center_norm - gt_center|_1                [4] matched * |size_norm - gt_size|_1
+ * with the ground-truth row of a proposal = gt_inds[row].  The caller sums the rows of a layer and applies
+ * the reference's normalisers (#scenes-with-objects * nq, num_boxes) and weights; the backward takes the
+ * resulting per-layer scalars g (nl x 5) and writes the gradients of the five inputs (dense, (rows, C)).
+ * Inputs are addressed through element strides like coda_box_decode_fwd_f32 (5 x 3: sem_cls_logits,
+ * angle_logits, angle_res_norm, center_norm, size_norm).  gt_res_norm is already divided by pi / nbin. */
+int coda_box_loss_fwd_f32(const float *sem_logits, const float *angle_logits, const float *angle_res_norm,
+                          const float *center_norm, const float *size_norm, const long long *strides,
+                          const int64_t *gt_inds, const float *matched, const int64_t *gt_sem_label,
+                          const int64_t *gt_angle_class, const float *gt_res_norm, const float *gt_center,
+                          const float *gt_size, const float *has_object, const float *sem_class_weight, int nl,
+                          int b, int nq, int ngt, int nsem, int nbin, float *partial, void *stream);
+int coda_box_loss_bwd_f32(const float *sem_logits, const float *angle_logits, const float *angle_res_norm,
+                          const float *center_norm, const float *size_norm, const long long *strides,
+                          const int64_t *gt_inds, const float *matched, const int64_t *gt_sem_label,
+                          const int64_t *gt_angle_class, const float *gt_res_norm, const float *gt_center,
+                          const float *gt_size, const float *has_object, const float *sem_class_weight, int nl,
+                          int b, int nq, int ngt, int nsem, int nbin, const float *g, float *d_sem, float *d_angle,
+                          float *d_res, float *d_center, float *d_size, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
