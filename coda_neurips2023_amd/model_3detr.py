@@ -19,7 +19,6 @@ callable that adds ``gt_text_correlation_embedding(_mask)`` etc. to the output
 dictionary like the crop branch does, :1102-1103).
 """
 import math
-from functools import partial
 
 import numpy as np
 import torch
@@ -35,46 +34,41 @@ from .transformer import (MaskedTransformerEncoder, TransformerDecoder, Transfor
 
 
 class BoxProcessor(object):
-    """Converts the MLP-head outputs into boxes (models/model_3detr.py:56-127)."""
+    """Turns the heads' raw outputs into boxes (the torch formulation; ``box_decode.py`` is the fused one).
+    Method names and signatures are the reference's (models/model_3detr.py:56-127): ``main.py`` / the evaluation
+    code receive this object from ``build_model``."""
 
     def __init__(self, dataset_config):
         self.dataset_config = dataset_config
 
     def compute_predicted_center(self, center_offset, query_xyz, point_cloud_dims):
-        center_unnormalized = query_xyz + center_offset
-        center_normalized = shift_scale_points(center_unnormalized, src_range=point_cloud_dims)
-        return center_normalized, center_unnormalized
+        """offsets are relative to the query position; also returned in units of the scene's bounding box"""
+        absolute = query_xyz + center_offset
+        return shift_scale_points(absolute, src_range=point_cloud_dims), absolute
 
     def compute_predicted_size(self, size_normalized, point_cloud_dims):
-        scene_scale = point_cloud_dims[1] - point_cloud_dims[0]
-        scene_scale = torch.clamp(scene_scale, min=1e-1)
-        return scale_points(size_normalized, mult_factor=scene_scale)
+        extent = (point_cloud_dims[1] - point_cloud_dims[0]).clamp(min=1e-1)
+        return scale_points(size_normalized, mult_factor=extent)
 
     def compute_predicted_angle(self, angle_logits, angle_residual):
-        if angle_logits.shape[-1] == 1:
-            # datasets without rotation: keep the heads in the graph (:80-85)
-            angle = angle_logits * 0 + angle_residual * 0
-            return angle.squeeze(-1).clamp(min=0)
-        angle_per_cls = 2 * np.pi / self.dataset_config.num_angle_bin
-        pred_angle_class = angle_logits.argmax(dim=-1).detach()
-        angle_center = angle_per_cls * pred_angle_class
-        angle = angle_center + angle_residual.gather(2, pred_angle_class.unsqueeze(-1)).squeeze(-1)
-        # reference: `angle[mask] = angle[mask] - 2*pi` (boolean indexing = host sync); same values
-        # without the sync, so the step stays capturable in a hipGraph
+        nbin = angle_logits.shape[-1]
+        if nbin == 1:  # datasets without rotation: angle 0, with both heads kept in the autograd graph
+            return (angle_logits * 0 + angle_residual * 0).squeeze(-1).clamp(min=0)
+        winner = angle_logits.argmax(dim=-1).detach()
+        angle = winner * (2 * np.pi / self.dataset_config.num_angle_bin) \
+            + angle_residual.gather(2, winner.unsqueeze(-1)).squeeze(-1)
+        # wrap into (-pi, pi] without boolean indexing (which would synchronise with the host)
         return torch.where(angle > np.pi, angle - 2 * np.pi, angle)
 
     def compute_objectness_and_cls_prob(self, cls_logits):
-        cls_prob = torch.nn.functional.softmax(cls_logits, dim=-1)
-        objectness_prob = 1 - cls_prob[..., -1]
-        return cls_prob[..., :-1], objectness_prob
+        prob = torch.softmax(cls_logits, dim=-1)
+        return prob[..., :-1], 1 - prob[..., -1]  # (class probabilities, 1 - P(background))
 
     def box_parametrization_to_corners(self, box_center_unnorm, box_size_unnorm, box_angle):
-        return self.dataset_config.box_parametrization_to_corners(box_center_unnorm, box_size_unnorm,
-                                                                  box_angle)
+        return self.dataset_config.box_parametrization_to_corners(box_center_unnorm, box_size_unnorm, box_angle)
 
     def box_parametrization_to_corners_xyz(self, box_center_unnorm, box_size_unnorm, box_angle):
-        return self.dataset_config.box_parametrization_to_corners_xyz(box_center_unnorm,
-                                                                      box_size_unnorm, box_angle)
+        return self.dataset_config.box_parametrization_to_corners_xyz(box_center_unnorm, box_size_unnorm, box_angle)
 
 
 class Model3DETRPredictedBoxDistillationHead(nn.Module):
@@ -149,26 +143,18 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         self.box_processor = BoxProcessor(dataset_config)
 
     def build_mlp_heads(self, dataset_config, decoder_dim, mlp_dropout):
-        mlp_func = partial(GenericMLP, norm_fn_name="bn1d", activation="relu", use_conv=True,
-                           hidden_dims=[decoder_dim, decoder_dim], dropout=mlp_dropout,
-                           input_dim=decoder_dim)
+        """Six heads on the decoder features, each Conv1d(k=1)+BN+ReLU+Dropout x2 then a linear output: objectness /
+        class logits (+1 = "not an object"), centre offset, size, angle bin, per-bin angle residual, and the 512-d
+        embedding in CLIP's joint space.  The registration order fixes the ``state_dict`` layout."""
         if self.if_with_fake_classes:
             self.num_cls_predict += 1
-        # +1: background / not-an-object class
-        semcls_head = mlp_func(output_dim=self.num_cls_predict + 1)
-        text_correlation_head = mlp_func(output_dim=512)  # CLIP joint space
-        center_head = mlp_func(output_dim=3)
-        size_head = mlp_func(output_dim=3)
-        angle_cls_head = mlp_func(output_dim=dataset_config.num_angle_bin)
-        angle_reg_head = mlp_func(output_dim=dataset_config.num_angle_bin)
-        self.mlp_heads = nn.ModuleDict([
-            ("sem_cls_head", semcls_head),
-            ("center_head", center_head),
-            ("size_head", size_head),
-            ("angle_cls_head", angle_cls_head),
-            ("angle_residual_head", angle_reg_head),
-            ("text_correlation_head", text_correlation_head),
-        ])
+        widths = {"sem_cls_head": self.num_cls_predict + 1, "center_head": 3, "size_head": 3,
+                  "angle_cls_head": dataset_config.num_angle_bin, "angle_residual_head": dataset_config.num_angle_bin,
+                  "text_correlation_head": 512}
+        self.mlp_heads = nn.ModuleDict(
+            (name, GenericMLP(input_dim=decoder_dim, hidden_dims=[decoder_dim, decoder_dim], output_dim=width,
+                              norm_fn_name="bn1d", activation="relu", use_conv=True, dropout=mlp_dropout))
+            for name, width in widths.items())
 
     def get_query_embeddings(self, encoder_xyz, point_cloud_dims):
         query_inds = furthest_point_sample(encoder_xyz, self.num_queries).long()
@@ -330,20 +316,17 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         return {"outputs": outputs[-1], "aux_outputs": outputs[:-1], "stacked_outputs": stacked}
 
     def get_class_scores(self, box_predictions):
-        """Open-vocabulary class scores: softmax(normalised embedding @ text^T * scale)
-        (models/model_3detr.py:1742-1764)."""
-        if self.eval_layer_id != -1:
-            for key in box_predictions["aux_outputs"][self.eval_layer_id].keys():
-                box_predictions["outputs"][key] = box_predictions["aux_outputs"][self.eval_layer_id][key]
-        outputs = box_predictions["outputs"]
-        text_features_clip = outputs["text_features_clip"].to(torch.float32)
-        temperature_param = outputs["logit_scale"]
-        emb = outputs["text_correlation_embedding"]
-        emb = emb / (emb.norm(dim=-1, keepdim=True) + 1e-32)
-        correlation_map = torch.bmm(emb, text_features_clip.permute(0, 2, 1)) * temperature_param
-        scores = torch.nn.functional.softmax(correlation_map, dim=-1)
-        outputs["sem_cls_prob"] = scores
-        return box_predictions, outputs["sem_cls_prob"], outputs["objectness_prob"]
+        """Open-vocabulary class scores of the evaluated decoder layer: softmax over the prompts of
+        (unit-norm region embedding . text embedding) * temperature.  Overwrites ``sem_cls_prob``."""
+        if self.eval_layer_id != -1:  # evaluate an intermediate decoder layer instead of the last one
+            box_predictions["outputs"].update(box_predictions["aux_outputs"][self.eval_layer_id])
+        out = box_predictions["outputs"]
+        region = out["text_correlation_embedding"]
+        region = region / (region.norm(dim=-1, keepdim=True) + 1e-32)
+        prompts = out["text_features_clip"].to(torch.float32)
+        logits = torch.bmm(region, prompts.transpose(1, 2)) * out["logit_scale"]
+        out["sem_cls_prob"] = torch.softmax(logits, dim=-1)
+        return box_predictions, out["sem_cls_prob"], out["objectness_prob"]
 
     def forward(self, inputs, encoder_only=False, if_test=False, if_real_test=False, curr_epoch=-1,
                 if_cmp_class=False, pre_encoded=None):

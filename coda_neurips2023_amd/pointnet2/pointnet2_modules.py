@@ -1,11 +1,10 @@
 """Set-abstraction / feature-propagation modules.
 
-Mirror of third_party_pointnet2/pointnet2/pointnet2_modules.py for the classes
-the CoDA models build: ``PointnetSAModuleVotes`` (:161-268, the pre-encoder and
-the masked encoder's interim down-sampling, models/model_3detr.py:3935-3972) and
-``PointnetFPModule`` (:352-411, the three_nn / three_interpolate consumer).
-Class names, constructor keywords, forward signature/returns and ``state_dict``
-keys are those of the reference.
+The two classes of third_party_pointnet2/pointnet2/pointnet2_modules.py that the CoDA models build:
+``PointnetSAModuleVotes`` (:161-268: the pre-encoder and the masked encoder's interim down-sampling,
+models/model_3detr.py:3935-3972) and ``PointnetFPModule`` (:352-411, the three_nn / three_interpolate
+consumer).  Class names, constructor keywords, forward signature / returns and ``state_dict`` keys
+(``mlp_module.layer{i}...``, ``mlp.layer{i}...``) are the reference's; the bodies are this package's.
 """
 from typing import List
 
@@ -18,38 +17,28 @@ from . import pytorch_utils as pt_utils
 
 
 class PointnetSAModuleVotes(nn.Module):
-    """FPS -> gather -> ball-query grouping -> shared MLP -> pooling, returning
-    the sampled indices as well (pointnet2_modules.py:161-268)."""
+    """One set-abstraction level: sample ``npoint`` centres (FPS), group ``nsample`` neighbours within
+    ``radius`` of each, run the shared MLP over every group and pool it; the sampled indices are returned as
+    well ("votes" variant).  ``npoint=None`` groups the whole cloud into one region."""
 
-    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None,
-                 nsample: int = None, bn: bool = True, use_xyz: bool = True,
-                 pooling: str = "max", sigma: float = None, normalize_xyz: bool = False,
-                 sample_uniformly: bool = False, ret_unique_cnt: bool = False):
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pooling: str = "max", sigma: float = None,
+                 normalize_xyz: bool = False, sample_uniformly: bool = False, ret_unique_cnt: bool = False):
         super().__init__()
-        self.npoint = npoint
-        self.radius = radius
-        self.nsample = nsample
-        self.pooling = pooling
-        self.mlp_module = None
-        self.use_xyz = use_xyz
-        self.sigma = sigma
-        if self.sigma is None:
-            self.sigma = self.radius / 2
-        self.normalize_xyz = normalize_xyz
-        self.ret_unique_cnt = ret_unique_cnt
-
-        if npoint is not None:
-            self.grouper = pointnet2_utils.QueryAndGroup(
-                radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
-                normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly,
-                ret_unique_cnt=ret_unique_cnt)
-        else:
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.pooling, self.use_xyz = pooling, use_xyz
+        self.normalize_xyz, self.ret_unique_cnt = normalize_xyz, ret_unique_cnt
+        self.sigma = sigma if sigma is not None else (radius / 2 if radius is not None else None)  # "rbf" pooling width
+        if npoint is None:
             self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
-
-        mlp_spec = mlp
-        if use_xyz and len(mlp_spec) > 0:
-            mlp_spec[0] += 3  # in place, like the reference (:201-203)
-        self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
+        else:
+            self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                                                         normalize_xyz=normalize_xyz,
+                                                         sample_uniformly=sample_uniformly,
+                                                         ret_unique_cnt=ret_unique_cnt)
+        if use_xyz and mlp:
+            mlp[0] += 3  # the caller's list grows by the xyz channels IN PLACE, as with the reference's module
+        self.mlp_module = pt_utils.SharedMLP(mlp, bn=bn)
 
     def _fused(self, xyz, features):
         return (self.npoint is not None and not self.ret_unique_cnt and not self.grouper.sample_uniformly
@@ -89,14 +78,11 @@ class PointnetSAModuleVotes(nn.Module):
             return prepared["new_xyz"], pooled.view(b, npoint, -1).permute(0, 2, 1), prepared["inds"]
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-        else:
-            assert inds.shape[1] == self.npoint
-        if self.npoint is not None:
-            xyz_flipped = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds)
-            new_xyz = new_xyz.transpose(1, 2).contiguous()
-        else:
-            new_xyz = None
+        elif inds.shape[1] != self.npoint:
+            raise AssertionError("inds must hold npoint indices per scene")
+        new_xyz = None
+        if self.npoint is not None:  # (B,N,3) -> (B,3,N) -> gather -> (B,npoint,3)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
 
         if self._fused(xyz, features):
             # xyz-only set abstraction (the model's pre-encoder): fused ball query + grouping into
@@ -106,34 +92,30 @@ class PointnetSAModuleVotes(nn.Module):
             b, npoint = new_xyz.shape[0], new_xyz.shape[1]
             pooled = fused_sa_mlp.fused_mlp_pool(grouped_cl.view(-1, 3), b * npoint, self.nsample,
                                                  self.mlp_module, idx=idx)
-            new_features = pooled.view(b, npoint, -1).permute(0, 2, 1)  # (B, mlp[-1], npoint)
-            return new_xyz, new_features, inds
+            return new_xyz, pooled.view(b, npoint, -1).permute(0, 2, 1), inds  # (B, mlp[-1], npoint)
 
-        if not self.ret_unique_cnt:
-            grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
-        else:
-            grouped_features, grouped_xyz, unique_cnt = self.grouper(xyz, new_xyz, features)
+        grouped = self.grouper(xyz, new_xyz, features)  # (features, xyz[, distinct counts])
+        per_sample = self.mlp_module(grouped[0])        # (B, mlp[-1], npoint, nsample)
+        new_features = self._pool(per_sample, grouped[1]).squeeze(-1)
+        return (new_xyz, new_features, inds) + tuple(grouped[2:])
 
-        new_features = self.mlp_module(grouped_features)  # (B, mlp[-1], npoint, nsample)
+    def _pool(self, per_sample, grouped_xyz):
+        """(B,C,npoint,nsample) -> (B,C,npoint,1) by the configured pooling."""
+        window = [1, per_sample.shape[3]]
         if self.pooling == "max":
-            new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)])
-        elif self.pooling == "avg":
-            new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)])
-        elif self.pooling == "rbf":
-            # radial-basis weighted sum over the samples (:254-258)
-            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1, keepdim=False) / (self.sigma ** 2) / 2)
-            new_features = torch.sum(new_features * rbf.unsqueeze(1), -1, keepdim=True) / float(
-                self.nsample)
-        new_features = new_features.squeeze(-1)  # (B, mlp[-1], npoint)
-
-        if not self.ret_unique_cnt:
-            return new_xyz, new_features, inds
-        return new_xyz, new_features, inds, unique_cnt
+            return F.max_pool2d(per_sample, kernel_size=window)
+        if self.pooling == "avg":
+            return F.avg_pool2d(per_sample, kernel_size=window)
+        if self.pooling == "rbf":  # Gaussian of the neighbour's distance to its centre, averaged over the samples
+            kernel = torch.exp(-grouped_xyz.pow(2).sum(1) / (self.sigma ** 2) / 2)
+            return (per_sample * kernel.unsqueeze(1)).sum(-1, keepdim=True) / float(self.nsample)
+        return per_sample
 
 
 class PointnetFPModule(nn.Module):
-    """Feature propagation: inverse-distance interpolation from the 3 nearest
-    known points, then a shared MLP (pointnet2_modules.py:352-411)."""
+    """Feature propagation: every ``unknown`` point takes the inverse-distance weighted mean of the features
+    of its three nearest ``known`` points (``three_nn`` / ``three_interpolate``), concatenated with its own
+    features if any, through a shared MLP.  ``known=None`` broadcasts one global feature."""
 
     def __init__(self, *, mlp: List[int], bn: bool = True):
         super().__init__()
@@ -141,18 +123,11 @@ class PointnetFPModule(nn.Module):
 
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
-        if known is not None:
+        if known is None:
+            carried = known_feats.expand(known_feats.shape[0], known_feats.shape[1], unknown.shape[1])
+        else:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
-            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
-        else:
-            interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
-
-        if unknow_feats is not None:
-            new_features = torch.cat([interpolated_feats, unknow_feats], dim=1)
-        else:
-            new_features = interpolated_feats
-        new_features = self.mlp(new_features.unsqueeze(-1))
-        return new_features.squeeze(-1)
+            inverse = 1.0 / (dist + 1e-8)
+            carried = pointnet2_utils.three_interpolate(known_feats, idx, inverse / inverse.sum(dim=2, keepdim=True))
+        stacked = carried if unknow_feats is None else torch.cat((carried, unknow_feats), dim=1)
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)

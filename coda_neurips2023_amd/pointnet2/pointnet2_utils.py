@@ -1,8 +1,10 @@
-"""Autograd wrappers and grouping modules over ``pointnet2._ext``.
+"""Autograd front-ends and grouping modules over ``pointnet2._ext``.
 
-Mirror of third_party_pointnet2/pointnet2/pointnet2_utils.py:48-420: same
-function names, argument order and differentiability.  The operators
-themselves run in ``libcoda_hip.so`` (see ``_ext.py``).
+API contract of third_party_pointnet2/pointnet2/pointnet2_utils.py:48-420 -- the ``Function`` classes
+``FurthestPointSampling``, ``GatherOperation``, ``ThreeNN``, ``ThreeInterpolate``, ``GroupingOperation``,
+``BallQuery`` with their lower-case ``.apply`` aliases, and the modules ``QueryAndGroup`` / ``GroupAll`` with
+the reference's constructor keywords, argument order and differentiability.  The operators themselves run in
+``libcoda_hip.so`` (``_ext.py``); this file only connects them to autograd.
 """
 import torch
 import torch.nn as nn
@@ -11,19 +13,27 @@ from torch.autograd import Function
 from . import _ext
 
 
-class FurthestPointSampling(Function):
-    """xyz (B,N,3), npoint -> (B,npoint) int32; non-differentiable
-    (pointnet2_utils.py:48-74)."""
+class _IndexProducer(Function):
+    """Base of the operators that only produce indices: nothing is differentiable, so the backward returns
+    one ``None`` per forward argument."""
+
+    @classmethod
+    def _nones(cls, n):
+        return (None,) * n
+
+
+class FurthestPointSampling(_IndexProducer):
+    """(xyz (B,N,3), npoint) -> sampled indices (B,npoint) int32."""
 
     @staticmethod
     def forward(ctx, xyz, npoint):
-        fps_inds = _ext.furthest_point_sampling(xyz, npoint)
-        ctx.mark_non_differentiable(fps_inds)
-        return fps_inds
+        picked = _ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(picked)
+        return picked
 
     @staticmethod
-    def backward(ctx, grad_out=None):
-        return None, None
+    def backward(ctx, *_):
+        return FurthestPointSampling._nones(2)
 
 
 furthest_point_sample = FurthestPointSampling.apply
@@ -103,183 +113,167 @@ class SamplingPrefetcher:
 
 
 class GatherOperation(Function):
-    """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (pointnet2_utils.py:80-111)."""
+    """(features (B,C,N), idx (B,npoint)) -> features[..., idx] (B,C,npoint); adjoint = scatter-add."""
 
     @staticmethod
     def forward(ctx, features, idx):
-        ctx.for_backwards = (idx, features.size(1), features.size(2))
+        ctx.save_for_backward(idx)
+        ctx.n_source = features.shape[2]
         return _ext.gather_points(features, idx)
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, _, n = ctx.for_backwards
-        return _ext.gather_points_grad(grad_out.contiguous(), idx, n), None
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n_source), None
 
 
 gather_operation = GatherOperation.apply
 
 
-class ThreeNN(Function):
-    """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) L2, idx (B,n,3))
-    (pointnet2_utils.py:117-145); the op returns squared distances, sqrt here."""
+class ThreeNN(_IndexProducer):
+    """(unknown (B,n,3), known (B,m,3)) -> (L2 distances (B,n,3), indices (B,n,3)) of the three nearest
+    known points.  The operator returns squared distances; the root is taken here, as in the reference."""
 
     @staticmethod
     def forward(ctx, unknown, known):
-        dist2, idx = _ext.three_nn(unknown, known)
-        ctx.mark_non_differentiable(idx)
-        return torch.sqrt(dist2), idx
+        squared, nearest = _ext.three_nn(unknown, known)
+        ctx.mark_non_differentiable(nearest)
+        return squared.sqrt(), nearest
 
     @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None
+    def backward(ctx, *_):
+        return ThreeNN._nones(2)
 
 
 three_nn = ThreeNN.apply
 
 
 class ThreeInterpolate(Function):
-    """features (B,c,m), idx (B,n,3), weight (B,n,3) -> (B,c,n)
-    (pointnet2_utils.py:151-202)."""
+    """(features (B,c,m), idx (B,n,3), weight (B,n,3)) -> weighted sum of three features per point (B,c,n)."""
 
     @staticmethod
     def forward(ctx, features, idx, weight):
-        ctx.three_interpolate_for_backward = (idx, weight, features.size(2))
+        ctx.save_for_backward(idx, weight)
+        ctx.m_source = features.shape[2]
         return _ext.three_interpolate(features, idx, weight)
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, weight, m = ctx.three_interpolate_for_backward
-        grad_features = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, m)
-        return grad_features, None, None
+        idx, weight = ctx.saved_tensors
+        return _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m_source), None, None
 
 
 three_interpolate = ThreeInterpolate.apply
 
 
 class GroupingOperation(Function):
-    """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)
-    (pointnet2_utils.py:208-251)."""
+    """(features (B,C,N), idx (B,npoint,nsample)) -> (B,C,npoint,nsample); adjoint = scatter-add."""
 
     @staticmethod
     def forward(ctx, features, idx):
-        ctx.for_backwards = (idx, features.size(2))
+        ctx.save_for_backward(idx)
+        ctx.n_source = features.shape[2]
         return _ext.group_points(features, idx)
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, n = ctx.for_backwards
-        return _ext.group_points_grad(grad_out.contiguous(), idx, n), None
+        (idx,) = ctx.saved_tensors
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n_source), None
 
 
 grouping_operation = GroupingOperation.apply
 
 
-class BallQuery(Function):
-    """radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3) -> (B,npoint,nsample)
-    int32; non-differentiable (pointnet2_utils.py:257-285)."""
+class BallQuery(_IndexProducer):
+    """(radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3)) -> neighbour indices (B,npoint,nsample) int32."""
 
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
-        inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
-        ctx.mark_non_differentiable(inds)
-        return inds
+        neighbours = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(neighbours)
+        return neighbours
 
     @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
+    def backward(ctx, *_):
+        return BallQuery._nones(4)
 
 
 ball_query = BallQuery.apply
 
 
-class QueryAndGroup(nn.Module):
-    """Ball query + grouping (pointnet2_utils.py:291-373).
+def _pack(primary, *optional):
+    """(value, (flag, extra), ...) -> value alone, or a tuple with the requested extras appended."""
+    extras = [extra for wanted, extra in optional if wanted]
+    return primary if not extras else (primary, *extras)
 
-    When the coordinates carry no gradient (always the case for an input
-    cloud) the xyz branch runs as ONE fused kernel that emits ``idx`` and the
-    centred / normalised ``grouped_xyz`` directly; otherwise the reference's
-    op-by-op sequence is kept so autograd sees the same graph.
+
+class QueryAndGroup(nn.Module):
+    """Ball query around ``new_xyz`` + grouping of the neighbours' coordinates (relative to their centre,
+    optionally in units of the radius) and features.
+
+    When the coordinates carry no gradient (always the case for an input cloud) the coordinate branch is ONE
+    fused kernel that emits the indices and the centred / normalised ``grouped_xyz`` together; otherwise the
+    separate operators are chained so that autograd sees every step.
     """
 
-    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False,
-                 normalize_xyz=False, sample_uniformly=False, ret_unique_cnt=False):
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False,
+                 sample_uniformly=False, ret_unique_cnt=False):
         super().__init__()
+        if ret_unique_cnt and not sample_uniformly:
+            raise AssertionError("ret_unique_cnt needs sample_uniformly")
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
-        self.ret_grouped_xyz = ret_grouped_xyz
-        self.normalize_xyz = normalize_xyz
-        self.sample_uniformly = sample_uniformly
-        self.ret_unique_cnt = ret_unique_cnt
-        if self.ret_unique_cnt:
-            assert self.sample_uniformly
+        self.ret_grouped_xyz, self.ret_unique_cnt = ret_grouped_xyz, ret_unique_cnt
+        self.normalize_xyz, self.sample_uniformly = normalize_xyz, sample_uniformly
 
     def _resample_uniformly(self, idx):
-        # pointnet2_utils.py:333-342 -- host loop; never enabled by CoDA.
-        unique_cnt = torch.zeros((idx.shape[0], idx.shape[1]))
-        for i_batch in range(idx.shape[0]):
-            for i_region in range(idx.shape[1]):
-                unique_ind = torch.unique(idx[i_batch, i_region, :])
-                num_unique = unique_ind.shape[0]
-                unique_cnt[i_batch, i_region] = num_unique
-                sample_ind = torch.randint(0, num_unique, (self.nsample - num_unique,),
-                                           dtype=torch.long)
-                all_ind = torch.cat((unique_ind, unique_ind[sample_ind]))
-                idx[i_batch, i_region, :] = all_ind
-        return idx, unique_cnt
+        """Replace the padding of every ball (copies of its first hit) by a uniform draw from the ball's
+        distinct members (host-side; an option of the reference that CoDA never switches on)."""
+        rows = idx.view(-1, self.nsample)
+        counts = torch.zeros(rows.shape[0])
+        for r, row in enumerate(rows):
+            members = torch.unique(row)
+            counts[r] = members.numel()
+            refill = members[torch.randint(0, members.numel(), (self.nsample - members.numel(),), dtype=torch.long)]
+            rows[r] = torch.cat((members, refill))
+        return idx, counts.view(idx.shape[:2])
+
+    def _grouped_coordinates(self, xyz, new_xyz):
+        if not (self.sample_uniformly or xyz.requires_grad or new_xyz.requires_grad):
+            idx, grouped = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample, self.normalize_xyz)
+            return idx, grouped, None
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        counts = None
+        if self.sample_uniformly:
+            idx, counts = self._resample_uniformly(idx)
+        grouped = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B,3,npoint,nsample)
+        grouped = grouped - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if self.normalize_xyz:
+            grouped = grouped / self.radius
+        return idx, grouped, counts
 
     def forward(self, xyz, new_xyz, features=None):
-        fused = not (self.sample_uniformly or xyz.requires_grad or new_xyz.requires_grad)
-        unique_cnt = None
-        if fused:
-            idx, grouped_xyz = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample,
-                                                        self.normalize_xyz)
-        else:
-            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-            if self.sample_uniformly:
-                idx, unique_cnt = self._resample_uniformly(idx)
-            xyz_trans = xyz.transpose(1, 2).contiguous()
-            grouped_xyz = grouping_operation(xyz_trans, idx)  # (B,3,npoint,nsample)
-            grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
-            if self.normalize_xyz:
-                grouped_xyz /= self.radius
-
-        if features is not None:
-            # the masked encoder hands over a permuted view (transformer.py:199-201); the
-            # reference op would assert on it, here it is made dense
-            grouped_features = grouping_operation(features.contiguous(), idx)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        idx, grouped_xyz, unique_cnt = self._grouped_coordinates(xyz, new_xyz)
+        if features is None:
+            if not self.use_xyz:
+                raise AssertionError("Cannot have not features and not use xyz as a feature!")
             new_features = grouped_xyz
-
-        ret = [new_features]
-        if self.ret_grouped_xyz:
-            ret.append(grouped_xyz)
-        if self.ret_unique_cnt:
-            ret.append(unique_cnt)
-        return ret[0] if len(ret) == 1 else tuple(ret)
+        else:
+            # (the masked encoder hands over a permuted view, which the operator wants dense)
+            new_features = grouping_operation(features.contiguous(), idx)
+            if self.use_xyz:
+                new_features = torch.cat((grouped_xyz, new_features), dim=1)
+        return _pack(new_features, (self.ret_grouped_xyz, grouped_xyz), (self.ret_unique_cnt, unique_cnt))
 
 
 class GroupAll(nn.Module):
-    """Group every point into one region (pointnet2_utils.py:376-420)."""
+    """The degenerate grouper: the whole cloud is one group, (B,C,N) -> (B,3+C,1,N)."""
 
     def __init__(self, use_xyz=True, ret_grouped_xyz=False):
         super().__init__()
-        self.use_xyz = use_xyz
-        self.ret_grouped_xyz = ret_grouped_xyz
+        self.use_xyz, self.ret_grouped_xyz = use_xyz, ret_grouped_xyz
 
     def forward(self, xyz, new_xyz, features=None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
-        if features is not None:
-            grouped_features = features.unsqueeze(2)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            new_features = grouped_xyz
-        if self.ret_grouped_xyz:
-            return new_features, grouped_xyz
-        return new_features
+        coords = xyz.transpose(1, 2).unsqueeze(2)
+        parts = ([coords] if (self.use_xyz or features is None) else []) + ([] if features is None else [features.unsqueeze(2)])
+        new_features = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+        return _pack(new_features, (self.ret_grouped_xyz, coords))

@@ -109,7 +109,43 @@ def _tile_mask_per_head(mask, nhead):
     return mask.unsqueeze(1).repeat(1, nhead, 1, 1).view(bsz * nhead, n, n)
 
 
+def _sublayer(x, norm, branch, drop, pre_norm):
+    """One residual sub-layer: pre-norm ``x + drop(branch(norm(x)))``, post-norm ``norm(x + drop(branch(x)))``
+    (``norm=None``: no normalisation on that side)."""
+    if pre_norm:
+        return x + drop(branch(x if norm is None else norm(x)))
+    y = x + drop(branch(x))
+    return y if norm is None else norm(y)
+
+
+def _plus(t, pos):
+    return t if pos is None else t + pos
+
+
+def _xavier_matrices(module, weight_init_name):
+    init = WEIGHT_INIT_DICT[weight_init_name]
+    for prm in module.parameters():
+        if prm.dim() > 1:  # matrices only: norm scales and biases keep their defaults
+            init(prm)
+
+
+class _FeatureMapIO:
+    """``transpose_swap``: the caller holds (B, C, H, W) feature maps instead of (tokens, B, C) sequences."""
+
+    def __init__(self, enabled, ref):
+        self.shape = tuple(ref.shape) if enabled else None
+
+    def seq(self, t):
+        return t if (self.shape is None or t is None) else t.flatten(2).permute(2, 0, 1)
+
+    def back(self, t):
+        return t if self.shape is None else t.permute(1, 2, 0).view(*self.shape).contiguous()
+
+
 class TransformerEncoder(nn.Module):
+    """Stack of encoder layers; ``forward`` returns ``(xyz, features, None)`` like the masked variant (which
+    can down-sample and then reports the kept indices)."""
+
     def __init__(self, encoder_layer, num_layers, norm=None, weight_init_name="xavier_uniform"):
         super().__init__()
         self.layers = get_clones(encoder_layer, num_layers)
@@ -118,65 +154,53 @@ class TransformerEncoder(nn.Module):
         self._reset_parameters(weight_init_name)
 
     def _reset_parameters(self, weight_init_name):
-        func = WEIGHT_INIT_DICT[weight_init_name]
-        for p in self.parameters():
-            if p.dim() > 1:
-                func(p)
+        _xavier_matrices(self, weight_init_name)
+
+    def _layer_masks(self, mask):
+        """One (B, n, n) mask or a list of them -> per-layer (B*nhead, n, n) masks (None: unmasked)."""
+        if mask is None:
+            return [None] * len(self.layers)
+        per_layer = mask if isinstance(mask, list) else [mask] * len(self.layers)
+        if len(per_layer) != len(self.layers):
+            raise AssertionError("one mask per encoder layer expected")
+        return [_tile_mask_per_head(m, layer.nhead) for m, layer in zip(per_layer, self.layers)]
 
     def forward(self, src, mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 xyz: Optional[Tensor] = None, transpose_swap: Optional[bool] = False):
-        if transpose_swap:
-            bs, c, h, w = src.shape
-            src = src.flatten(2).permute(2, 0, 1)
-            if pos is not None:
-                pos = pos.flatten(2).permute(2, 0, 1)
-        output = src
-        orig_mask = mask
-        if orig_mask is not None and isinstance(orig_mask, list):
-            assert len(orig_mask) == len(self.layers)
-        elif orig_mask is not None:
-            orig_mask = [mask for _ in range(len(self.layers))]
-
-        if TransformerEncoderLayer.fusable(self.layers, output) and (self.norm is None
-                                                                     or isinstance(self.norm, nn.LayerNorm)):
-            pend = _Pending(output)
-            for idx, layer in enumerate(self.layers):
-                if orig_mask is not None:
-                    mask = _tile_mask_per_head(orig_mask[idx], layer.nhead)
-                pend = layer.forward_fused(pend, mask, src_key_padding_mask, pos)
+        io = _FeatureMapIO(transpose_swap, src)
+        x, pos = io.seq(src), io.seq(pos)
+        masks = self._layer_masks(mask)
+        if TransformerEncoderLayer.fusable(self.layers, x) and (self.norm is None or isinstance(self.norm, nn.LayerNorm)):
+            pend = _Pending(x)
+            for layer, m in zip(self.layers, masks):
+                pend = layer.forward_fused(pend, m, src_key_padding_mask, pos)
             s, y, _ = _resolve(pend, self.norm)
-            output = s if self.norm is None else y
+            x = s if self.norm is None else y
         else:
-            for idx, layer in enumerate(self.layers):
-                if orig_mask is not None:
-                    mask = _tile_mask_per_head(orig_mask[idx], layer.nhead)
-                output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
+            for layer, m in zip(self.layers, masks):
+                x = layer(x, src_mask=m, src_key_padding_mask=src_key_padding_mask, pos=pos)
             if self.norm is not None:
-                output = self.norm(output)
-        if transpose_swap:
-            output = output.permute(1, 2, 0).view(bs, c, h, w).contiguous()
-        xyz_inds = None
-        return xyz, output, xyz_inds
+                x = self.norm(x)
+        return xyz, io.back(x), None
 
 
 class TransformerDecoder(nn.Module):
+    """Stack of decoder layers with one shared output norm; ``return_intermediate`` stacks the normed output of
+    every layer (the detector supervises all of them).  Returns ``(output(s), attention maps or [])``."""
+
     def __init__(self, decoder_layer, num_layers, norm_fn_name="ln", return_intermediate=False,
                  weight_init_name="xavier_uniform"):
         super().__init__()
         self.layers = get_clones(decoder_layer, num_layers)
         self.num_layers = num_layers
-        self.norm = None
-        if norm_fn_name is not None:
-            self.norm = NORM_DICT[norm_fn_name](self.layers[0].linear2.out_features)
+        width = self.layers[0].linear2.out_features
+        self.norm = None if norm_fn_name is None else NORM_DICT[norm_fn_name](width)
         self.return_intermediate = return_intermediate
         self._reset_parameters(weight_init_name)
 
     def _reset_parameters(self, weight_init_name):
-        func = WEIGHT_INIT_DICT[weight_init_name]
-        for p in self.parameters():
-            if p.dim() > 1:
-                func(p)
+        _xavier_matrices(self, weight_init_name)
 
     def forward(self, tgt, memory, image_features_clip=None, text_features_clip=None,
                 tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
@@ -184,39 +208,25 @@ class TransformerDecoder(nn.Module):
                 memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 query_pos: Optional[Tensor] = None, transpose_swap: Optional[bool] = False,
                 return_attn_weights: Optional[bool] = False):
-        if transpose_swap:
-            bs, c, h, w = memory.shape
-            memory = memory.flatten(2).permute(2, 0, 1)  # (bs, c, t) -> (t, bs, c)
-            if pos is not None:
-                pos = pos.flatten(2).permute(2, 0, 1)
-        if not return_attn_weights and self.norm is not None and isinstance(self.norm, nn.LayerNorm) \
+        io = _FeatureMapIO(transpose_swap, memory)
+        memory, pos = io.seq(memory), io.seq(pos)
+        if not return_attn_weights and isinstance(self.norm, nn.LayerNorm) \
                 and TransformerDecoderLayer.fusable(self.layers, tgt):
             return self._forward_fused(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
                                        memory_key_padding_mask, pos, query_pos), []
-        output = tgt
-        intermediate = []
-        attns = []
+        x, per_layer, maps = tgt, [], []
         for layer in self.layers:
-            output, attn = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
-                                 tgt_key_padding_mask=tgt_key_padding_mask,
-                                 memory_key_padding_mask=memory_key_padding_mask, pos=pos,
-                                 query_pos=query_pos, return_attn_weights=return_attn_weights)
+            x, attn = layer(x, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                            tgt_key_padding_mask=tgt_key_padding_mask,
+                            memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos,
+                            return_attn_weights=return_attn_weights)
+            maps.append(attn)
             if self.return_intermediate:
-                intermediate.append(self.norm(output))
-            if return_attn_weights:
-                attns.append(attn)
-
-        if self.norm is not None:
-            output = self.norm(output)
-            if self.return_intermediate:
-                intermediate.pop()
-                intermediate.append(output)
-        if return_attn_weights:
-            attns = torch.stack(attns)
-        if self.return_intermediate:
-            return torch.stack(intermediate), attns
-        return output, attns
-
+                # (the reference's intermediate outputs go through the norm, which it therefore requires here)
+                per_layer.append(self.norm(x))
+        last = x if self.norm is None else (per_layer[-1] if per_layer else self.norm(x))
+        attns = torch.stack(maps) if return_attn_weights else []
+        return (torch.stack(per_layer) if self.return_intermediate else last), attns
 
     def _uniform_layers(self):
         """All layers share dropout rates / head count / eps and have biases (the stack node reads
@@ -271,43 +281,35 @@ class MaskedTransformerEncoder(TransformerEncoder):
         self.interim_downsampling = interim_downsampling
 
     def compute_mask(self, xyz, radius, dist=None):
+        """-> (bool (B, n, n) with True = farther than ``radius`` = not attended, pairwise distances for reuse)."""
         with torch.no_grad():
-            if dist is None or dist.shape[1] != xyz.shape[1]:
+            if dist is None or dist.shape[1] != xyz.shape[1]:  # (the cloud was down-sampled since)
                 dist = torch.cdist(xyz, xyz, p=2)
-            mask = dist >= radius  # True = outside the radius = not attended
-        return mask, dist
+            return dist >= radius, dist
 
     def forward(self, src, mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 xyz: Optional[Tensor] = None, transpose_swap: Optional[bool] = False):
-        if transpose_swap:
-            bs, c, h, w = src.shape
-            src = src.flatten(2).permute(2, 0, 1)
-            if pos is not None:
-                pos = pos.flatten(2).permute(2, 0, 1)
-        output = src
-        xyz_dist = None
-        xyz_inds = None
-        fused = TransformerEncoderLayer.fusable(self.layers, output)
-        for idx, layer in enumerate(self.layers):
-            mask = None
-            if self.masking_radius[idx] > 0:
-                mask, xyz_dist = self.compute_mask(xyz, self.masking_radius[idx], xyz_dist)
-                mask = _tile_mask_per_head(mask, layer.nhead)
+        io = _FeatureMapIO(transpose_swap, src)
+        x, pos = io.seq(src), io.seq(pos)
+        dist, kept = None, None
+        fused = TransformerEncoderLayer.fusable(self.layers, x)
+        for depth, (layer, radius) in enumerate(zip(self.layers, self.masking_radius)):
+            local = None
+            if radius > 0:
+                local, dist = self.compute_mask(xyz, radius, dist)
+                local = _tile_mask_per_head(local, layer.nhead)
             if fused:
-                output = _resolve(layer.forward_fused(_Pending(output), mask, src_key_padding_mask, pos))[0]
+                x = _resolve(layer.forward_fused(_Pending(x), local, src_key_padding_mask, pos))[0]
             else:
-                output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
-            if idx == 0 and self.interim_downsampling:
-                # (npoints, batch, channel) -> (batch, channel, npoints) for the SA module
-                output = output.permute(1, 2, 0)
-                xyz, output, xyz_inds = self.interim_downsampling(xyz, output)
-                output = output.permute(2, 0, 1)
+                x = layer(x, src_mask=local, src_key_padding_mask=src_key_padding_mask, pos=pos)
+            if depth == 0 and self.interim_downsampling:
+                # the set-abstraction module works on (batch, channel, points)
+                xyz, x, kept = self.interim_downsampling(xyz, x.permute(1, 2, 0))
+                x = x.permute(2, 0, 1)
         if self.norm is not None:
-            output = self.norm(output)
-        if transpose_swap:
-            output = output.permute(1, 2, 0).view(bs, c, h, w).contiguous()
-        return xyz, output, xyz_inds
+            x = self.norm(x)
+        return xyz, io.back(x), kept
 
     def extra_repr(self):
         radius_str = ", ".join(["%.2f" % (x) for x in self.masking_radius])
@@ -336,39 +338,39 @@ class TransformerEncoderLayer(nn.Module):
         self.nhead = nhead
 
     def with_pos_embed(self, tensor, pos: Optional[Tensor]):
-        return tensor if pos is None else tensor + pos
+        return _plus(tensor, pos)
+
+    def _blocks(self, src, src_mask, src_key_padding_mask, pos, want_weights):
+        """Self-attention (queries / keys carry the positional embedding, values do not) and the feed-forward
+        block as two residual sub-layers; pre- or post-norm by ``normalize_before``.  In the post-norm order the
+        attention block is only normed when ``use_norm_fn_on_input`` is set (the reference never sets it)."""
+        maps = []
+
+        def attend(t):
+            qk = _plus(t, pos)
+            out, w = self.self_attn(qk, qk, value=t, attn_mask=src_mask, key_padding_mask=src_key_padding_mask,
+                                    need_weights=want_weights)
+            maps.append(w)
+            return out
+
+        pre = self.normalize_before
+        norm1 = self.norm1 if (pre or getattr(self, "use_norm_fn_on_input", False)) else None
+        x = _sublayer(src, norm1, attend, self.dropout1, pre)
+        if self.use_ffn:
+            x = _sublayer(x, self.norm2, lambda t: _ffn(self, t), self.dropout2, pre)
+        return x, maps[0]
 
     def forward_post(self, src, src_mask: Optional[Tensor] = None,
                      src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None):
-        q = k = self.with_pos_embed(src, pos)
-        src2 = self.self_attn(q, k, value=src, attn_mask=src_mask,
-                              key_padding_mask=src_key_padding_mask, need_weights=False)[0]
-        src = src + self.dropout1(src2)
-        if getattr(self, "use_norm_fn_on_input", False):  # attribute never set by the reference (:455)
-            src = self.norm1(src)
-        if self.use_ffn:
-            src2 = _ffn(self, src)
-            src = src + self.dropout2(src2)
-            src = self.norm2(src)
-        return src
+        assert not self.normalize_before
+        return self._blocks(src, src_mask, src_key_padding_mask, pos, False)[0]
 
     def forward_pre(self, src, src_mask: Optional[Tensor] = None,
                     src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                     return_attn_weights: Optional[Tensor] = False):
-        src2 = self.norm1(src)
-        value = src2
-        q = k = self.with_pos_embed(src2, pos)
-        src2, attn_weights = self.self_attn(q, k, value=value, attn_mask=src_mask,
-                                            key_padding_mask=src_key_padding_mask,
-                                            need_weights=bool(return_attn_weights))
-        src = src + self.dropout1(src2)
-        if self.use_ffn:
-            src2 = self.norm2(src)
-            src2 = _ffn(self, src2)
-            src = src + self.dropout2(src2)
-        if return_attn_weights:
-            return src, attn_weights
-        return src
+        assert self.normalize_before
+        out, weights = self._blocks(src, src_mask, src_key_padding_mask, pos, bool(return_attn_weights))
+        return (out, weights) if return_attn_weights else out
 
     @staticmethod
     def fusable(layers, x):
@@ -396,9 +398,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, src_mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 return_attn_weights: Optional[Tensor] = False):
-        if self.normalize_before:
-            return self.forward_pre(src, src_mask, src_key_padding_mask, pos, return_attn_weights)
-        return self.forward_post(src, src_mask, src_key_padding_mask, pos)
+        out, weights = self._blocks(src, src_mask, src_key_padding_mask, pos,
+                                    bool(return_attn_weights) and self.normalize_before)
+        return (out, weights) if (return_attn_weights and self.normalize_before) else out
 
     def extra_repr(self):
         st = ""
@@ -429,7 +431,31 @@ class TransformerDecoderLayer(nn.Module):
         self.normalize_before = normalize_before
 
     def with_pos_embed(self, tensor, pos: Optional[Tensor]):
-        return tensor if pos is None else tensor + pos
+        return _plus(tensor, pos)
+
+    def _blocks(self, tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos,
+                query_pos, want_weights):
+        """Self-attention over the queries, cross-attention into the encoder memory (keys carry ``pos``, queries
+        ``query_pos``, values neither) and the feed-forward block: three residual sub-layers."""
+        maps = []
+
+        def self_attend(t):
+            qk = _plus(t, query_pos)
+            return self.self_attn(qk, qk, value=t, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask,
+                                  need_weights=False)[0]
+
+        def cross_attend(t):
+            out, w = self.multihead_attn(query=_plus(t, query_pos), key=_plus(memory, pos), value=memory,
+                                         attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,
+                                         need_weights=want_weights)
+            maps.append(w)
+            return out
+
+        pre = self.normalize_before
+        x = _sublayer(tgt, self.norm1, self_attend, self.dropout1, pre)
+        x = _sublayer(x, self.norm2, cross_attend, self.dropout2, pre)
+        x = _sublayer(x, self.norm3, lambda t: _ffn(self, t), self.dropout3, pre)
+        return x, (maps[0] if want_weights else None)
 
     def forward_post(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
                      memory_mask: Optional[Tensor] = None,
@@ -437,24 +463,9 @@ class TransformerDecoderLayer(nn.Module):
                      memory_key_padding_mask: Optional[Tensor] = None,
                      pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None,
                      return_attn_weights: Optional[bool] = False):
-        q = k = self.with_pos_embed(tgt, query_pos)
-        tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask,
-                              key_padding_mask=tgt_key_padding_mask, need_weights=False)[0]
-        tgt = tgt + self.dropout1(tgt2)
-        tgt = self.norm1(tgt)
-        tgt2, attn = self.multihead_attn(query=self.with_pos_embed(tgt, query_pos),
-                                         key=self.with_pos_embed(memory, pos), value=memory,
-                                         attn_mask=memory_mask,
-                                         key_padding_mask=memory_key_padding_mask,
-                                         need_weights=bool(return_attn_weights))
-        tgt = tgt + self.dropout2(tgt2)
-        tgt = self.norm2(tgt)
-        tgt2 = _ffn(self, tgt)
-        tgt = tgt + self.dropout3(tgt2)
-        tgt = self.norm3(tgt)
-        if return_attn_weights:
-            return tgt, attn
-        return tgt, None
+        assert not self.normalize_before
+        return self._blocks(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos,
+                            query_pos, bool(return_attn_weights))
 
     def forward_pre(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
                     memory_mask: Optional[Tensor] = None,
@@ -462,24 +473,9 @@ class TransformerDecoderLayer(nn.Module):
                     memory_key_padding_mask: Optional[Tensor] = None,
                     pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None,
                     return_attn_weights: Optional[bool] = False):
-        tgt2 = self.norm1(tgt)
-        q = k = self.with_pos_embed(tgt2, query_pos)
-        tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask,
-                              key_padding_mask=tgt_key_padding_mask, need_weights=False)[0]
-        tgt = tgt + self.dropout1(tgt2)
-        tgt2 = self.norm2(tgt)
-        tgt2, attn = self.multihead_attn(query=self.with_pos_embed(tgt2, query_pos),
-                                         key=self.with_pos_embed(memory, pos), value=memory,
-                                         attn_mask=memory_mask,
-                                         key_padding_mask=memory_key_padding_mask,
-                                         need_weights=bool(return_attn_weights))
-        tgt = tgt + self.dropout2(tgt2)
-        tgt2 = self.norm3(tgt)
-        tgt2 = _ffn(self, tgt2)
-        tgt = tgt + self.dropout3(tgt2)
-        if return_attn_weights:
-            return tgt, attn
-        return tgt, None
+        assert self.normalize_before
+        return self._blocks(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos,
+                            query_pos, bool(return_attn_weights))
 
     @staticmethod
     def fusable(layers, x):
@@ -506,8 +502,5 @@ class TransformerDecoderLayer(nn.Module):
                 tgt_key_padding_mask: Optional[Tensor] = None,
                 memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 query_pos: Optional[Tensor] = None, return_attn_weights: Optional[bool] = False):
-        if self.normalize_before:
-            return self.forward_pre(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
-                                    memory_key_padding_mask, pos, query_pos, return_attn_weights)
-        return self.forward_post(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask,
-                                 memory_key_padding_mask, pos, query_pos, return_attn_weights)
+        return self._blocks(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos,
+                            query_pos, bool(return_attn_weights))
