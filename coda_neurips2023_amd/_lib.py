@@ -73,10 +73,12 @@ SIGNATURES = {
                                          _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
     # include/coda_box_ops.h
     "coda_generalized_box3d_iou_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_generalized_box3d_iou_devflag_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P, _c_int, _c_int, _P]),
     "coda_box_decode_fwd_f32": (_c_int, [_P] * 9 + [_c_int] * 5 + [_P] * 10 + [_P]),
     "coda_box_decode_bwd_f32": (_c_int, [_P] * 7 + [_c_int] * 4 + [_P] * 8 + [_P] * 3 + [_P]),
     "coda_box_loss_fwd_f32": (_c_int, [_P] * 15 + [_c_int] * 6 + [_P, _P]),
     "coda_box_loss_bwd_f32": (_c_int, [_P] * 15 + [_c_int] * 6 + [_P] * 6 + [_P]),
+    "coda_hungarian_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     # include/coda_attention.h
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _P]),

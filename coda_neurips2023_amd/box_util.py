@@ -100,7 +100,8 @@ ROTATED_K2_LIMIT = -1
 def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, return_inter_vols_only=False,
                           needs_grad=False):
     """corners1 (B,K1,8,3), corners2 (B,K2,8,3), nums_k2 (B) -> (B,K1,K2) gIoU (utils/box_util.py:861-875).
-    Forward only: the reference differentiates it only for loss_giou_weight > 0, which no CoDA recipe uses."""
+    ``rotated_boxes``: a bool, or a one-element bool / uint8 tensor on the boxes' device (the kernel reads it
+    there: no host read-back).  Forward only: the reference differentiates it only for loss_giou_weight > 0, which no CoDA recipe uses."""
     if needs_grad:
         raise NotImplementedError("generalized_box3d_iou: gradients (loss_giou_weight > 0) are outside the hot "
                                   "path of the CoDA recipes (scripts/*.sh pass --loss_giou_weight 0)")
@@ -114,10 +115,16 @@ def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, retur
     nums = nums_k2.to(device=c1.device, dtype=torch.int32).contiguous() if nums_k2 is not None else None
     out = torch.empty((b, k1, k2), dtype=torch.float32, device=c1.device)
     with torch.cuda.device(c1.device):
-        st = _lib.load().coda_generalized_box3d_iou_f32(c1.data_ptr(), c2.data_ptr(),
-                                                        nums.data_ptr() if nums is not None else None,
-                                                        out.data_ptr(), b, k1, k2, int(bool(rotated_boxes)),
-                                                        int(bool(return_inter_vols_only)), int(ROTATED_K2_LIMIT),
-                                                        _lib.current_stream_handle())
+        nums_ptr = nums.data_ptr() if nums is not None else None
+        if torch.is_tensor(rotated_boxes) and rotated_boxes.is_cuda:
+            flag = rotated_boxes.reshape(-1)[:1].to(device=c1.device, dtype=torch.uint8)
+            st = _lib.load().coda_generalized_box3d_iou_devflag_f32(
+                c1.data_ptr(), c2.data_ptr(), nums_ptr, out.data_ptr(), b, k1, k2, flag.data_ptr(),
+                int(bool(return_inter_vols_only)), int(ROTATED_K2_LIMIT), _lib.current_stream_handle())
+        else:
+            st = _lib.load().coda_generalized_box3d_iou_f32(c1.data_ptr(), c2.data_ptr(), nums_ptr,
+                                                            out.data_ptr(), b, k1, k2, int(bool(rotated_boxes)),
+                                                            int(bool(return_inter_vols_only)), int(ROTATED_K2_LIMIT),
+                                                            _lib.current_stream_handle())
     _lib.check(st, "generalized_box3d_iou")
     return out

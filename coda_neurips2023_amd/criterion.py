@@ -21,7 +21,10 @@ polygon clipping in the reference) is one HIP launch per call
 from the reference's argparse names; a non-zero weight for a term that is not one of the live
 terms above raises ``NotImplementedError`` at construction instead of being dropped.
 """
+import os
+
 import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -48,8 +51,13 @@ def all_reduce_average(tensor):
 class Matcher(nn.Module):
     """Hungarian assignment of proposals to ground-truth boxes (criterion.py:12-86)."""
 
-    def __init__(self, cost_class, cost_objectness, cost_giou, cost_center):
+    def __init__(self, cost_class, cost_objectness, cost_giou, cost_center, solver=None):
+        """``solver``: "auto" (default; env CODA_MATCHER overrides) solves on the device when the costs live there
+        and the shape fits the kernel, "device" insists on it, "scipy" is the reference's host route."""
         super().__init__()
+        self.solver = solver or os.environ.get("CODA_MATCHER", "auto")
+        if self.solver not in ("auto", "device", "scipy"):
+            raise ValueError(f"Matcher solver {self.solver!r}: expected auto, device or scipy")
         self.cost_class = cost_class
         self.cost_objectness = cost_objectness
         self.cost_giou = cost_giou
@@ -57,8 +65,6 @@ class Matcher(nn.Module):
 
     @torch.no_grad()
     def forward(self, outputs, targets):
-        from scipy.optimize import linear_sum_assignment
-
         pred_cls_prob = outputs["sem_cls_prob"]
         batchsize, nqueries = pred_cls_prob.shape[0], pred_cls_prob.shape[1]
         ngt = targets["gt_box_sem_cls_label"].shape[1]
@@ -69,10 +75,43 @@ class Matcher(nn.Module):
         center_mat = outputs["center_dist"].detach()
         giou_mat = -outputs["gious"].detach()
         final_cost = (self.cost_class * class_mat + self.cost_objectness * objectness_mat
-                      + self.cost_center * center_mat + self.cost_giou * giou_mat)
-        final_cost = final_cost.detach().cpu().numpy()  # host round trip, as in the reference
+                      + self.cost_center * center_mat + self.cost_giou * giou_mat).detach()
 
-        dev = pred_cls_prob.device
+        if final_cost.is_cuda and self.solver != "scipy":
+            solved = self._solve_on_device(final_cost.float().contiguous(), nactual_gt)
+            if solved is not None:
+                return solved
+            if self.solver == "device":
+                raise RuntimeError("Matcher(solver='device'): problem outside the device solver's limits "
+                                   "(nq <= 1024, ngt <= 128, nq >= ngt)")
+        return self._solve_on_host(final_cost, nactual_gt)
+
+    def _solve_on_device(self, final_cost, nactual_gt):
+        """All problems of the batch in one launch of the shortest-augmenting-path kernel (csrc/hungarian.hip);
+        no host round trip.  None when the shape is outside the kernel's limits."""
+        from . import _lib
+
+        nprob, nq, ngt = final_cost.shape
+        inds = torch.empty((nprob, nq), dtype=torch.int64, device=final_cost.device)
+        mask = torch.empty((nprob, nq), dtype=torch.float32, device=final_cost.device)
+        nact = nactual_gt.to(device=final_cost.device, dtype=torch.int64).contiguous()
+        with torch.cuda.device(final_cost.device):
+            st = _lib.load().coda_hungarian_f32(final_cost.data_ptr(), nact.data_ptr(), inds.data_ptr(),
+                                                mask.data_ptr(), nprob, nq, ngt, _lib.current_stream_handle())
+        if st == _lib.CODA_ENOSPC:
+            return None
+        _lib.check(st, "coda_hungarian_f32")
+        return {"assignments": _LazyAssignments(inds, mask, nact), "per_prop_gt_inds": inds,
+                "proposal_matched_mask": mask}
+
+    @staticmethod
+    def _solve_on_host(final_cost, nactual_gt):
+        """The reference's route (criterion.py:67-79): cost matrix to the host, scipy per scene."""
+        from scipy.optimize import linear_sum_assignment
+
+        dev = final_cost.device
+        batchsize, nqueries = final_cost.shape[0], final_cost.shape[1]
+        final_cost = final_cost.cpu().numpy()
         per_prop_gt_inds = torch.zeros([batchsize, nqueries], dtype=torch.int64, device=dev)
         proposal_matched_mask = torch.zeros([batchsize, nqueries], dtype=torch.float32, device=dev)
         assignments = []
@@ -86,6 +125,33 @@ class Matcher(nn.Module):
             assignments.append(assign)
         return {"assignments": assignments, "per_prop_gt_inds": per_prop_gt_inds,
                 "proposal_matched_mask": proposal_matched_mask}
+
+
+class _LazyAssignments:
+    """The reference's ``assignments`` entry -- per scene ``[proposal indices, GT indices]`` (criterion.py:70-79)
+    -- derived from the device solver's outputs only when something indexes it (none of the live loss terms
+    do): building the index lists needs the match count on the host, i.e. a synchronisation."""
+
+    def __init__(self, inds, mask, nactual):
+        self._inds, self._mask, self._nactual = inds, mask, nactual
+        self._built = None
+
+    def _build(self):
+        if self._built is None:
+            self._built = []
+            for b in range(self._inds.shape[0]):
+                rows = torch.nonzero(self._mask[b] > 0).flatten()
+                self._built.append([rows, self._inds[b, rows]] if rows.numel() else [])
+        return self._built
+
+    def __len__(self):
+        return self._inds.shape[0]
+
+    def __getitem__(self, b):
+        return self._build()[b]
+
+    def __iter__(self):
+        return iter(self._build())
 
 
 # every key of the reference's loss_weight_dict (criterion.py:1247-1279) -> the argparse attribute
@@ -163,6 +229,9 @@ class SetCriterion(nn.Module):
         self.layer_batched = True  # evaluate all decoder layers in one pass when the model hands them stacked
         self.fused_alignment = True  # GPU fp32: both alignment terms from one HIP pass (align_loss.py)
         self.fused_box_losses = True  # GPU fp32: the four matched box terms from one HIP pass (box_loss.py)
+        # GPU: keep num_boxes / num_boxes_replica / the rotated-GT flag as device scalars instead of the reference's
+        # three .item() read-backs (criterion.py:1147,1164-1170), so the host keeps enqueueing through the criterion
+        self.device_scalars = True
         assert self.confidence_type in ["non-confidence", "objectness", "clip+objectness", "clip-max-prob"]
         self.loss_functions = {
             "loss_sem_cls_softmax_skip_none_gt_sample": self.loss_sem_cls_softmax_skip_none_gt_sample,
@@ -240,7 +309,13 @@ class SetCriterion(nn.Module):
         has_object = (targets["gt_box_present"].sum(dim=1) != 0).to(sums.dtype)
         nq = outputs["sem_cls_logits"].shape[2]
         res = {"loss_sem_cls_softmax_skip_none_gt_sample": sums[:, 0] / (has_object.sum() * nq + 1e-32)}
-        if targets["num_boxes_replica"] > 0:
+        if torch.is_tensor(targets["num_boxes_replica"]):
+            # device scalars: num_boxes is clamped to >= 1 and a replica without boxes has an all-zero matched mask,
+            # i.e. zero sums -- the same zeros the branch below produces, without reading the count back
+            nb = targets["num_boxes"]
+            res.update(loss_angle_cls=sums[:, 1] / nb, loss_angle_reg=sums[:, 2] / nb, loss_center=sums[:, 3] / nb,
+                       loss_size=sums[:, 4] / nb)
+        elif targets["num_boxes_replica"] > 0:
             nb = targets["num_boxes"]
             res.update(loss_angle_cls=sums[:, 1] / nb, loss_angle_reg=sums[:, 2] / nb,
                        loss_center=sums[:, 3] / nb if nb > 0 else sums[:, 3], loss_size=sums[:, 4] / nb)
@@ -410,8 +485,7 @@ class SetCriterion(nn.Module):
                               if_last_head=False):
         if self.giou_fn is not None and "gt_box_corners" in targets:
             gious = self.giou_fn(outputs["box_corners"], targets["gt_box_corners"], targets["nactual_gt"],
-                                 rotated_boxes=torch.any(targets["gt_box_angles"] > 0).item(),
-                                 needs_grad=False)
+                                 rotated_boxes=self._rotated_flag(targets), needs_grad=False)
         else:  # giou_fn=None was asked for (matcher.cost_giou == 0): zero cost term
             gious = torch.zeros(outputs["center_normalized"].shape[0], outputs["center_normalized"].shape[1],
                                 targets["gt_box_centers_normalized"].shape[1],
@@ -439,6 +513,15 @@ class SetCriterion(nn.Module):
                 final_loss += losses[name]
         return final_loss, losses
 
+    def _rotated_flag(self, targets):
+        """criterion.py:1147: are any GT boxes rotated?  A device flag for this package's gIoU kernel when
+        ``device_scalars`` is on, the reference's host bool otherwise (any other ``giou_fn``)."""
+        from . import box_util
+        flag = torch.any(targets["gt_box_angles"] > 0)
+        if self.device_scalars and flag.is_cuda and self.giou_fn is box_util.generalized_box3d_iou:
+            return flag
+        return flag.item()
+
     def stacked_forward(self, stacked, targets):
         """Matching + every live loss term for all decoder layers at once.  ``stacked[k]`` is
         (L,B,nq,...) with the last decoder layer at index L-1 (what ``outputs`` /
@@ -449,7 +532,7 @@ class SetCriterion(nn.Module):
         ngt = targets["gt_box_centers_normalized"].shape[1]
         if self.giou_fn is not None and "gt_box_corners" in targets:
             # all decoder layers are extra scenes of ONE launch (the reference: one host loop per layer)
-            rotated = torch.any(targets["gt_box_angles"] > 0).item()
+            rotated = self._rotated_flag(targets)
             gious = self.giou_fn(stacked["box_corners"].flatten(0, 1), targets["gt_box_corners"].repeat(nl, 1, 1, 1),
                                  targets["nactual_gt"].repeat(nl), rotated_boxes=rotated,
                                  needs_grad=False).view(nl, bsz, nq, ngt)
@@ -489,10 +572,14 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets):
         nactual_gt = targets["gt_box_present"].sum(axis=1).long()
-        num_boxes = torch.clamp(all_reduce_average(nactual_gt.sum()), min=1).item()
+        num_boxes = torch.clamp(all_reduce_average(nactual_gt.sum()), min=1)
         targets["nactual_gt"] = nactual_gt
-        targets["num_boxes"] = num_boxes
-        targets["num_boxes_replica"] = nactual_gt.sum().item()
+        if self.device_scalars and nactual_gt.is_cuda and self.layer_batched and "stacked_outputs" in outputs:
+            targets["num_boxes"] = num_boxes.to(torch.float32)
+            targets["num_boxes_replica"] = nactual_gt.sum()
+        else:
+            targets["num_boxes"] = num_boxes.item()
+            targets["num_boxes_replica"] = nactual_gt.sum().item()
         for key in ["text_features_clip", "logit_scale", "gt_text_correlation_embedding",
                     "gt_text_correlation_embedding_mask", "weak_box_cate_label", "weak_confidence_weight"]:
             if key in outputs["outputs"]:

@@ -73,9 +73,10 @@ __device__ __forceinline__ float edge_len(const float *c, int i, int j) {  // bo
 __global__ __launch_bounds__(256) void giou_kernel(const float *__restrict__ corners1, const float *__restrict__ corners2,
                                                    const int32_t *__restrict__ nums_k2, float *__restrict__ out,
                                                    int k1n, int k2n, long long total, int rotated, int vols_only,
-                                                   int k2_limit) {
+                                                   int k2_limit, const unsigned char *__restrict__ rotated_dev) {
   const long long t = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (t >= total) return;
+  if (rotated_dev) rotated = *rotated_dev != 0;  // the flag lives on the device: no host read-back of the angles
   const int k2 = static_cast<int>(t % k2n), k1 = static_cast<int>((t / k2n) % k1n);
   const int b = static_cast<int>(t / (static_cast<long long>(k2n) * k1n));
   const bool real = !nums_k2 || k2 < nums_k2[b];
@@ -136,9 +137,29 @@ __global__ __launch_bounds__(256) void giou_kernel(const float *__restrict__ cor
 }  // namespace
 }  // namespace coda
 
+namespace {
+int launch_giou(const float *corners1, const float *corners2, const int32_t *nums_k2, float *out, int b, int k1, int k2,
+                int rotated, const unsigned char *rotated_dev, int inter_vols_only, int rotated_k2_limit, void *stream);
+}
+
 CODA_API int coda_generalized_box3d_iou_f32(const float *corners1, const float *corners2, const int32_t *nums_k2,
                                             float *out, int b, int k1, int k2, int rotated, int inter_vols_only,
                                             int rotated_k2_limit, void *stream) {
+  return launch_giou(corners1, corners2, nums_k2, out, b, k1, k2, rotated, nullptr, inter_vols_only, rotated_k2_limit,
+                     stream);
+}
+
+CODA_API int coda_generalized_box3d_iou_devflag_f32(const float *corners1, const float *corners2, const int32_t *nums_k2,
+                                                    float *out, int b, int k1, int k2, const unsigned char *rotated_flag,
+                                                    int inter_vols_only, int rotated_k2_limit, void *stream) {
+  if (!rotated_flag) return CODA_EINVAL;
+  return launch_giou(corners1, corners2, nums_k2, out, b, k1, k2, 0, rotated_flag, inter_vols_only, rotated_k2_limit,
+                     stream);
+}
+
+namespace {
+int launch_giou(const float *corners1, const float *corners2, const int32_t *nums_k2, float *out, int b, int k1, int k2,
+                int rotated, const unsigned char *rotated_dev, int inter_vols_only, int rotated_k2_limit, void *stream) {
   using namespace coda;
   if (b < 0 || k1 < 0 || k2 < 0) return CODA_EINVAL;
   const long long total = static_cast<long long>(b) * k1 * k2;
@@ -147,6 +168,7 @@ CODA_API int coda_generalized_box3d_iou_f32(const float *corners1, const float *
   clear_sticky_error();
   hipLaunchKernelGGL(giou_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), corners1, corners2, nums_k2, out, k1, k2, total, rotated,
-                     inter_vols_only, rotated_k2_limit);
+                     inter_vols_only, rotated_k2_limit, rotated_dev);
   return launch_status();
 }
+}  // namespace

@@ -41,6 +41,13 @@ int coda_generalized_box3d_iou_f32(const float *corners1, const float *corners2,
                                    int rotated, int inter_vols_only, int rotated_k2_limit,
                                    void *stream);
 
+/* Same, with the rotated / axis-aligned choice read from device memory (one byte, non-zero = rotated): the
+ * reference derives it as torch.any(gt_box_angles > 0).item() (criterion.py:1147), a host synchronisation in
+ * the middle of the training step; callers that keep the comparison's result on the device pass it here. */
+int coda_generalized_box3d_iou_devflag_f32(const float *corners1, const float *corners2, const int32_t *nums_k2,
+                                           float *out, int b, int k1, int k2, const unsigned char *rotated_flag,
+                                           int inter_vols_only, int rotated_k2_limit, void *stream);
+
 /* ---- box decoding ----------------------------------------------------------
  * Everything `get_box_predictions` computes from the six heads' raw outputs for all decoder layers
  * (models/model_3detr.py:1683-1731 with BoxProcessor :56-127, utils/pc_util.py:38-73 and the corner
@@ -73,6 +80,21 @@ int coda_box_decode_bwd_f32(const float *center_raw, const float *size_raw, cons
                             const float *g_angle_residual, const float *g_angle_cont, const float *g_corners,
                             const float *g_corners_xyz, float *d_center_raw, float *d_size_raw,
                             float *d_angle_res_norm, void *stream);
+
+/* ---- Hungarian assignment (criterion.py:27-86, Matcher.forward) -----------------------------------------
+ * Replaces the per-scene scipy.optimize.linear_sum_assignment calls on the host (one D2H copy of the cost
+ * tensor and one host solve per scene and decoder layer): one workgroup per problem solves the rectangular
+ * assignment "every real GT box gets a distinct proposal, minimum total cost" with the shortest-augmenting-path
+ * algorithm scipy uses (Crouse's rectangular LSAP: dual variables in fp64, one augmentation per GT box), the
+ * proposals spread over the threads.
+ *   cost (nprob, nq, ngt) float32 (criterion.py:58-66), nactual (nprob) int64 = real GT boxes per problem.
+ *   per_prop_gt_inds (nprob, nq) int64: GT index of a matched proposal, 0 otherwise (criterion.py:72-74, 80);
+ *   matched_mask (nprob, nq) float32: 1 for matched proposals (:75-77, 81).
+ * The optimum is unique unless costs tie exactly; under exact ties the total cost equals scipy's while the
+ * chosen proposals may differ.  Limits: nq <= 1024, ngt <= 128, (nq * ngt * 4 + nq * 24) bytes of LDS <= 160 KiB;
+ * CODA_ENOSPC otherwise (callers fall back to the host solver). */
+int coda_hungarian_f32(const float *cost, const int64_t *nactual, int64_t *per_prop_gt_inds, float *matched_mask,
+                       int nprob, int nq, int ngt, void *stream);
 
 /* ---- matched box losses (criterion.py:219-246, 834-900, 1015-1104) -----------------------------------
  * The four box terms SetCriterion evaluates for every decoder layer once the matcher has assigned

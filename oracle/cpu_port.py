@@ -27,6 +27,17 @@ def attention_ref(q, k, v, mask, scale, dropout_p, need_weights):
     return out.permute(2, 0, 1, 3), (probs if need_weights else None)
 
 
+def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, return_inter_vols_only=False,
+                          needs_grad=False):
+    """box_util.generalized_box3d_iou's signature on CPU tensors, from oracle/box_giou_oracle.c."""
+    from . import box_giou_oracle as BO
+    assert not needs_grad
+    out = BO.generalized_box3d_iou_c(corners1.detach().numpy(), corners2.detach().numpy(),
+                                     None if nums_k2 is None else nums_k2.numpy(), bool(rotated_boxes),
+                                     return_inter_vols_only)
+    return torch.from_numpy(out)
+
+
 @contextlib.contextmanager
 def patched():
     from coda_neurips2023_amd import attention_core

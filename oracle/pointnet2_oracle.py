@@ -20,9 +20,9 @@ _lib = None
 
 
 def build(force=False):
-    """Compile oracle/pointnet2_oracle.c with gcc (seconds)."""
-    src = os.path.join(_HERE, "pointnet2_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    """Compile oracle/pointnet2_oracle.c + box_giou_oracle.c with gcc (seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in ("pointnet2_oracle.c", "box_giou_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _SO
 

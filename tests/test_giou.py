@@ -25,6 +25,31 @@ def test_oracle_matches_reference_vectors(tag, rotated):
     assert not G[f"{tag}_gious"][1, :, 4:].any() and not G[f"{tag}_gious"][2].any()  # padded GT columns
 
 
+@pytest.mark.parametrize("tag,rotated", [("rot", True), ("axis", False)])
+def test_c_oracle_matches_reference_vectors_and_numpy_oracle(tag, rotated):
+    """oracle/box_giou_oracle.c (what the CPU port of the step calls): the reference's vectors, and bit-for-bit
+    the numpy loops on random boxes (same operations in the same order, one rounding each)."""
+    from coda_neurips2023_amd import box_util
+    from oracle import box_giou_oracle as BO
+    got = BO.generalized_box3d_iou_c(G[f"{tag}_corners1"], G[f"{tag}_corners2"], G[f"{tag}_nums"], rotated)
+    np.testing.assert_allclose(got, G[f"{tag}_gious"], atol=TOL, rtol=TOL)
+    vols = BO.generalized_box3d_iou_c(G[f"{tag}_corners1"], G[f"{tag}_corners2"], G[f"{tag}_nums"], rotated,
+                                      return_inter_vols_only=True)
+    np.testing.assert_allclose(vols, G[f"{tag}_inter_vols"], atol=TOL, rtol=TOL)
+    gen = torch.Generator().manual_seed(11)
+    B, K1, K2 = 2, 12, 6
+    def boxes(n):
+        centre = torch.rand(B, n, 3, generator=gen) * 1.5
+        size = torch.rand(B, n, 3, generator=gen) * 1.2 + 0.1
+        angle = (torch.rand(B, n, generator=gen) - 0.5) * 6.0 if rotated else torch.zeros(B, n)
+        return box_util.get_3d_box_batch_tensor(size, angle, centre).numpy()
+    c1, c2, nums = boxes(K1), boxes(K2), np.array([6, 3])
+    for limit in (-1, 4):
+        a = BO.generalized_box3d_iou_c(c1, c2, nums, rotated, rotated_k2_limit=limit)
+        b = BO.generalized_box3d_iou(c1, c2, nums, rotated, rotated_k2_limit=limit)
+        np.testing.assert_allclose(a, b, atol=2e-6, rtol=2e-6)  # numpy's dot may sum the <= 8 shoelace terms pairwise
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,rotated", [("rot", True), ("axis", False)])
 def test_kernel_matches_reference_vectors(dev, tag, rotated):
@@ -52,6 +77,10 @@ def test_kernel_matches_oracle_on_random_boxes(dev, rotated):
     c1, c2 = boxes(K1), boxes(K2)
     nums = torch.tensor([9, 5, 0, 1])
     got = box_util.generalized_box3d_iou(c1.to(dev), c2.to(dev), nums.to(dev), rotated_boxes=rotated).cpu().numpy()
+    # the choice read from device memory (coda_generalized_box3d_iou_devflag_f32): same values, no host flag
+    flag = torch.tensor(rotated, device=dev)
+    via_flag = box_util.generalized_box3d_iou(c1.to(dev), c2.to(dev), nums.to(dev), rotated_boxes=flag).cpu().numpy()
+    assert np.array_equal(got, via_flag)
     ref = BO.generalized_box3d_iou(c1.numpy(), c2.numpy(), nums.numpy(), rotated)
     np.testing.assert_allclose(got, ref, atol=TOL, rtol=TOL)
     assert (np.abs(ref) > 1e-3).mean() > 0.3  # the case is not trivially empty
