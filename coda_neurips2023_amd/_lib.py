@@ -78,6 +78,7 @@ SIGNATURES = {
     "coda_box_decode_bwd_f32": (_c_int, [_P] * 7 + [_c_int] * 4 + [_P] * 8 + [_P] * 3 + [_P]),
     "coda_box_loss_fwd_f32": (_c_int, [_P] * 15 + [_c_int] * 6 + [_P, _P]),
     "coda_box_loss_bwd_f32": (_c_int, [_P] * 15 + [_c_int] * 6 + [_P] * 6 + [_P]),
+    "coda_matcher_cost_f32": (_c_int, [_P] * 8 + [_c_float] * 4 + [_P] * 3 + [_c_int] * 5 + [_P, _c_int, _P]),
     "coda_hungarian_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     # include/coda_attention.h
     "coda_mha_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -142,6 +143,27 @@ def current_stream_handle():
     """Raw hipStream_t of torch's current stream on the current device (cheap: no Stream object)."""
     import torch
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+def on_tensor_device(pick=lambda *a, **k: a[0]):
+    """Decorator for the module entry points (``forward`` of the mirrors): the launchers below them take the raw
+    stream of torch's CURRENT device, so when the tensor ``pick(*args, **kwargs)`` returns lives on another GPU
+    the call runs under ``torch.cuda.device(that GPU)`` (autograd restores the forward's device for the backward
+    nodes itself).  One integer comparison on the usual path."""
+    import functools
+
+    import torch
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def guarded(self, *args, **kwargs):
+            t = pick(*args, **kwargs)
+            if torch.is_tensor(t) and t.is_cuda and t.device.index != torch.cuda.current_device():
+                with torch.cuda.device(t.device):
+                    return fn(self, *args, **kwargs)
+            return fn(self, *args, **kwargs)
+        return guarded
+    return deco
 
 
 def check(status, what):

@@ -128,3 +128,35 @@ def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, retur
                                                             _lib.current_stream_handle())
     _lib.check(st, "generalized_box3d_iou")
     return out
+
+
+def matcher_cost(corners1, corners2, nums_k2, center1, center2, cls_prob, labels, objectness, weights,
+                 rotated_boxes=True):
+    """The matcher's inputs in one pass (coda_matcher_cost_f32): gIoU (B,K1,K2) as ``generalized_box3d_iou``,
+    the L1 centre distances ``torch.cdist(center1, center2, p=1)`` and the cost matrix of criterion.py:50-66,
+    ``w_class * -cls_prob[..., labels] + w_objectness * -objectness + w_center * L1 + w_giou * -gIoU`` with
+    ``weights = (w_class, w_objectness, w_center, w_giou)``.  No gradients (the matcher runs under no_grad and
+    the centre loss has its own pass).  Returns (gious, center_dist, cost)."""
+    if not corners1.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, k1, k2 = corners1.shape[0], corners1.shape[1], corners2.shape[1]
+    f32 = dict(dtype=torch.float32, device=corners1.device)
+    c1, c2 = corners1.detach().to(torch.float32).contiguous(), corners2.detach().to(torch.float32).contiguous()
+    a1, a2 = center1.detach().to(torch.float32).contiguous(), center2.detach().to(torch.float32).contiguous()
+    prob, obj = cls_prob.detach().to(torch.float32).contiguous(), objectness.detach().to(torch.float32).contiguous()
+    lab = labels.to(torch.int64).contiguous()
+    assert a1.shape == (b, k1, 3) and a2.shape == (b, k2, 3) and prob.shape[:2] == (b, k1) and obj.shape == (b, k1)
+    assert lab.shape == (b, k2)
+    nums = nums_k2.to(device=c1.device, dtype=torch.int32).contiguous() if nums_k2 is not None else None
+    gious, dist, cost = (torch.empty((b, k1, k2), **f32) for _ in range(3))
+    with torch.cuda.device(c1.device):
+        flag = None
+        if torch.is_tensor(rotated_boxes) and rotated_boxes.is_cuda:
+            flag = rotated_boxes.reshape(-1)[:1].to(device=c1.device, dtype=torch.uint8)
+        st = _lib.load().coda_matcher_cost_f32(
+            c1.data_ptr(), c2.data_ptr(), nums.data_ptr() if nums is not None else None, a1.data_ptr(), a2.data_ptr(),
+            prob.data_ptr(), lab.data_ptr(), obj.data_ptr(), *(float(w) for w in weights), gious.data_ptr(),
+            dist.data_ptr(), cost.data_ptr(), b, k1, k2, prob.shape[2], int(flag is None and bool(rotated_boxes)),
+            flag.data_ptr() if flag is not None else None, int(ROTATED_K2_LIMIT), _lib.current_stream_handle())
+    _lib.check(st, "coda_matcher_cost_f32")
+    return gious, dist, cost

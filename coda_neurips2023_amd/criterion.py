@@ -29,6 +29,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+
 
 def huber_loss(error, delta=1.0):
     """utils/misc.py huber: 0.5*q^2 + delta*(|e|-q), q = min(|e|, delta)."""
@@ -64,6 +66,7 @@ class Matcher(nn.Module):
         self.cost_center = cost_center
 
     @torch.no_grad()
+    @_lib.on_tensor_device(lambda outputs, targets: outputs["sem_cls_prob"])
     def forward(self, outputs, targets):
         pred_cls_prob = outputs["sem_cls_prob"]
         batchsize, nqueries = pred_cls_prob.shape[0], pred_cls_prob.shape[1]
@@ -76,7 +79,12 @@ class Matcher(nn.Module):
         giou_mat = -outputs["gious"].detach()
         final_cost = (self.cost_class * class_mat + self.cost_objectness * objectness_mat
                       + self.cost_center * center_mat + self.cost_giou * giou_mat).detach()
+        return self.solve(final_cost, nactual_gt)
 
+    @torch.no_grad()
+    def solve(self, final_cost, nactual_gt):
+        """Assignment for a ready cost tensor (nprob, nq, ngt): on the device when it lives there and fits the
+        kernel, else the reference's host route."""
         if final_cost.is_cuda and self.solver != "scipy":
             solved = self._solve_on_device(final_cost.float().contiguous(), nactual_gt)
             if solved is not None:
@@ -89,8 +97,6 @@ class Matcher(nn.Module):
     def _solve_on_device(self, final_cost, nactual_gt):
         """All problems of the batch in one launch of the shortest-augmenting-path kernel (csrc/hungarian.hip);
         no host round trip.  None when the shape is outside the kernel's limits."""
-        from . import _lib
-
         nprob, nq, ngt = final_cost.shape
         inds = torch.empty((nprob, nq), dtype=torch.int64, device=final_cost.device)
         mask = torch.empty((nprob, nq), dtype=torch.float32, device=final_cost.device)
@@ -232,6 +238,7 @@ class SetCriterion(nn.Module):
         # GPU: keep num_boxes / num_boxes_replica / the rotated-GT flag as device scalars instead of the reference's
         # three .item() read-backs (criterion.py:1147,1164-1170), so the host keeps enqueueing through the criterion
         self.device_scalars = True
+        self.fused_matcher_cost = True  # GPU fp32: gIoU + L1 centre distance + weighted cost matrix in one launch
         assert self.confidence_type in ["non-confidence", "objectness", "clip+objectness", "clip-max-prob"]
         self.loss_functions = {
             "loss_sem_cls_softmax_skip_none_gt_sample": self.loss_sem_cls_softmax_skip_none_gt_sample,
@@ -513,6 +520,13 @@ class SetCriterion(nn.Module):
                 final_loss += losses[name]
         return final_loss, losses
 
+    def _fused_cost_applies(self, stacked, targets):
+        from . import box_util
+        c = stacked["center_normalized"]
+        return (self.fused_matcher_cost and c.is_cuda and c.dtype == torch.float32 and type(self.matcher) is Matcher
+                and self.giou_fn is box_util.generalized_box3d_iou and "gt_box_corners" in targets
+                and "box_corners" in stacked)
+
     def _rotated_flag(self, targets):
         """criterion.py:1147: are any GT boxes rotated?  A device flag for this package's gIoU kernel when
         ``device_scalars`` is on, the reference's host bool otherwise (any other ``giou_fn``)."""
@@ -530,28 +544,46 @@ class SetCriterion(nn.Module):
         center = stacked["center_normalized"]
         nl, bsz, nq = center.shape[:3]
         ngt = targets["gt_box_centers_normalized"].shape[1]
-        if self.giou_fn is not None and "gt_box_corners" in targets:
-            # all decoder layers are extra scenes of ONE launch (the reference: one host loop per layer)
-            rotated = self._rotated_flag(targets)
-            gious = self.giou_fn(stacked["box_corners"].flatten(0, 1), targets["gt_box_corners"].repeat(nl, 1, 1, 1),
-                                 targets["nactual_gt"].repeat(nl), rotated_boxes=rotated,
-                                 needs_grad=False).view(nl, bsz, nq, ngt)
-        else:  # giou_fn=None was asked for (matcher.cost_giou == 0): zero cost term
-            gious = torch.zeros(nl, bsz, nq, ngt, device=center.device)
         gt_centers = targets["gt_box_centers_normalized"]
-        center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)  # matcher + loss_center
-        flat_out = {"sem_cls_prob": stacked["sem_cls_prob"].flatten(0, 1),
-                    "objectness_prob": stacked["objectness_prob"].flatten(0, 1),
-                    "center_dist": center_dist, "gious": gious.flatten(0, 1)}
         flat_tgt = {"gt_box_sem_cls_label": targets["gt_box_sem_cls_label"].repeat(nl, 1),
                     "nactual_gt": targets["nactual_gt"].repeat(nl)}
-        flat_assign = self.matcher(flat_out, flat_tgt)
+        center_dist = l1_dist = None
+        if self._fused_cost_applies(stacked, targets):
+            # gIoU, L1 centre distance and the weighted cost matrix of all layers from one launch; the distances
+            # carry no gradient (the matched centre term below has its own pass, or recomputes them)
+            from . import box_util
+            m = self.matcher
+            gious, l1_dist, cost = box_util.matcher_cost(
+                stacked["box_corners"].flatten(0, 1), targets["gt_box_corners"].repeat(nl, 1, 1, 1),
+                flat_tgt["nactual_gt"], center.flatten(0, 1), gt_centers.repeat(nl, 1, 1),
+                stacked["sem_cls_prob"].flatten(0, 1), flat_tgt["gt_box_sem_cls_label"],
+                stacked["objectness_prob"].flatten(0, 1),
+                (m.cost_class, m.cost_objectness, m.cost_center, m.cost_giou), self._rotated_flag(targets))
+            gious = gious.view(nl, bsz, nq, ngt)
+            flat_assign = m.solve(cost, flat_tgt["nactual_gt"])
+        else:
+            if self.giou_fn is not None and "gt_box_corners" in targets:
+                # all decoder layers are extra scenes of ONE launch (the reference: one host loop per layer)
+                rotated = self._rotated_flag(targets)
+                gious = self.giou_fn(stacked["box_corners"].flatten(0, 1), targets["gt_box_corners"].repeat(nl, 1, 1, 1),
+                                     targets["nactual_gt"].repeat(nl), rotated_boxes=rotated,
+                                     needs_grad=False).view(nl, bsz, nq, ngt)
+            else:  # giou_fn=None was asked for (matcher.cost_giou == 0): zero cost term
+                gious = torch.zeros(nl, bsz, nq, ngt, device=center.device)
+            center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)  # matcher + loss_center
+            flat_out = {"sem_cls_prob": stacked["sem_cls_prob"].flatten(0, 1),
+                        "objectness_prob": stacked["objectness_prob"].flatten(0, 1),
+                        "center_dist": center_dist, "gious": gious.flatten(0, 1)}
+            flat_assign = self.matcher(flat_out, flat_tgt)
         assignments = {"per_prop_gt_inds": flat_assign["per_prop_gt_inds"].view(nl, bsz, nq),
                        "proposal_matched_mask": flat_assign["proposal_matched_mask"].view(nl, bsz, nq)}
-        outs = dict(stacked, center_dist=center_dist.view(nl, bsz, nq, ngt), gious=gious)
+        outs = dict(stacked, gious=gious)
+        outs["_fused_box_terms"] = self._fused_box_terms(outs, targets, assignments)
+        if center_dist is None and outs["_fused_box_terms"] is None:  # the torch centre term differentiates these
+            center_dist = torch.cdist(center.reshape(nl * bsz, nq, -1), gt_centers.repeat(nl, 1, 1), p=1)
+        outs["center_dist"] = (l1_dist if center_dist is None else center_dist).view(nl, bsz, nq, ngt)
         outs["_fused_alignment"] = self._fused_alignment(outs, targets, assignments) \
             if "gt_text_correlation_embedding" in targets else None
-        outs["_fused_box_terms"] = self._fused_box_terms(outs, targets, assignments)
 
         losses = {}
         for k in self.loss_functions:
@@ -570,6 +602,7 @@ class SetCriterion(nn.Module):
                 loss_dict[f"{name}_{l}"] = per_layer[l]
         return final.sum(), loss_dict
 
+    @_lib.on_tensor_device(lambda outputs, targets: targets["gt_box_present"])
     def forward(self, outputs, targets):
         nactual_gt = targets["gt_box_present"].sum(axis=1).long()
         num_boxes = torch.clamp(all_reduce_average(nactual_gt.sum()), min=1)

@@ -70,10 +70,22 @@ __device__ __forceinline__ float edge_len(const float *c, int i, int j) {  // bo
   return sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-6f));
 }
 
+// The matcher's cost matrix next to the gIoU (criterion.py:58-66): -prob[label] * w_class - objectness *
+// w_objectness + L1(centres) * w_center - gIoU * w_giou, one rounding per operation in the reference's order
+// (explicit _rn intrinsics: no FMA contraction), so the device costs are the ones the torch expressions give.
+struct CostArgs {
+  const float *center1, *center2, *cls_prob, *objectness;
+  const int64_t *labels;
+  float *center_dist, *cost;
+  float w_class, w_objectness, w_center, w_giou;
+  int ncls;
+};
+
 __global__ __launch_bounds__(256) void giou_kernel(const float *__restrict__ corners1, const float *__restrict__ corners2,
                                                    const int32_t *__restrict__ nums_k2, float *__restrict__ out,
                                                    int k1n, int k2n, long long total, int rotated, int vols_only,
-                                                   int k2_limit, const unsigned char *__restrict__ rotated_dev) {
+                                                   int k2_limit, const unsigned char *__restrict__ rotated_dev,
+                                                   CostArgs ca) {
   const long long t = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (t >= total) return;
   if (rotated_dev) rotated = *rotated_dev != 0;  // the flag lives on the device: no host read-back of the angles
@@ -132,6 +144,21 @@ __global__ __launch_bounds__(256) void giou_kernel(const float *__restrict__ cor
   float giou = inter_vol / union_vol - (1.0f - union_vol / enclosing);
   if (!good || !real) giou = 0.0f;
   out[t] = giou;
+  if (ca.cost) {
+    const float *a = ca.center1 + (static_cast<size_t>(b) * k1n + k1) * 3;
+    const float *g = ca.center2 + (static_cast<size_t>(b) * k2n + k2) * 3;
+    // torch.cdist(p=1) on 3 coordinates: lanes 0..2 of a shuffle-down tree, i.e. (|d0| + |d2|) + |d1|
+    const float d0 = fabsf(__fsub_rn(a[0], g[0])), d1 = fabsf(__fsub_rn(a[1], g[1])), d2 = fabsf(__fsub_rn(a[2], g[2]));
+    const float l1 = __fadd_rn(__fadd_rn(d0, d2), d1);
+    ca.center_dist[t] = l1;
+    const int64_t label = ca.labels[static_cast<size_t>(b) * k2n + k2];
+    const float p = ca.cls_prob[(static_cast<size_t>(b) * k1n + k1) * ca.ncls + label];
+    const float o = ca.objectness[static_cast<size_t>(b) * k1n + k1];
+    float c = __fadd_rn(__fmul_rn(ca.w_class, -p), __fmul_rn(ca.w_objectness, -o));
+    c = __fadd_rn(c, __fmul_rn(ca.w_center, l1));
+    c = __fadd_rn(c, __fmul_rn(ca.w_giou, -giou));
+    ca.cost[t] = c;
+  }
 }
 
 }  // namespace
@@ -139,7 +166,8 @@ __global__ __launch_bounds__(256) void giou_kernel(const float *__restrict__ cor
 
 namespace {
 int launch_giou(const float *corners1, const float *corners2, const int32_t *nums_k2, float *out, int b, int k1, int k2,
-                int rotated, const unsigned char *rotated_dev, int inter_vols_only, int rotated_k2_limit, void *stream);
+                int rotated, const unsigned char *rotated_dev, int inter_vols_only, int rotated_k2_limit, void *stream,
+                coda::CostArgs ca = coda::CostArgs{});
 }
 
 CODA_API int coda_generalized_box3d_iou_f32(const float *corners1, const float *corners2, const int32_t *nums_k2,
@@ -157,9 +185,25 @@ CODA_API int coda_generalized_box3d_iou_devflag_f32(const float *corners1, const
                      stream);
 }
 
+CODA_API int coda_matcher_cost_f32(const float *corners1, const float *corners2, const int32_t *nums_k2,
+                                   const float *center1, const float *center2, const float *cls_prob,
+                                   const int64_t *labels, const float *objectness, float w_class, float w_objectness,
+                                   float w_center, float w_giou, float *gious, float *center_dist, float *cost, int b,
+                                   int k1, int k2, int ncls, int rotated, const unsigned char *rotated_flag,
+                                   int rotated_k2_limit, void *stream) {
+  if (ncls <= 0) return CODA_EINVAL;
+  if (static_cast<long long>(b) * k1 * k2 > 0 &&
+      (!center1 || !center2 || !cls_prob || !labels || !objectness || !center_dist || !cost))
+    return CODA_EINVAL;
+  coda::CostArgs ca{center1, center2, cls_prob, objectness, labels, center_dist, cost,
+                    w_class, w_objectness, w_center, w_giou, ncls};
+  return launch_giou(corners1, corners2, nums_k2, gious, b, k1, k2, rotated, rotated_flag, 0, rotated_k2_limit, stream, ca);
+}
+
 namespace {
 int launch_giou(const float *corners1, const float *corners2, const int32_t *nums_k2, float *out, int b, int k1, int k2,
-                int rotated, const unsigned char *rotated_dev, int inter_vols_only, int rotated_k2_limit, void *stream) {
+                int rotated, const unsigned char *rotated_dev, int inter_vols_only, int rotated_k2_limit, void *stream,
+                coda::CostArgs ca) {
   using namespace coda;
   if (b < 0 || k1 < 0 || k2 < 0) return CODA_EINVAL;
   const long long total = static_cast<long long>(b) * k1 * k2;
@@ -168,7 +212,7 @@ int launch_giou(const float *corners1, const float *corners2, const int32_t *num
   clear_sticky_error();
   hipLaunchKernelGGL(giou_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), corners1, corners2, nums_k2, out, k1, k2, total, rotated,
-                     inter_vols_only, rotated_k2_limit, rotated_dev);
+                     inter_vols_only, rotated_k2_limit, rotated_dev, ca);
   return launch_status();
 }
 }  // namespace

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import box_decode, fused_bn_mlp
+from . import _lib, box_decode, fused_bn_mlp
 from .helpers import GenericMLP
 from .pointnet2.pointnet2_modules import PointnetSAModuleVotes
 from .pointnet2.pointnet2_utils import SamplingPrefetcher, furthest_point_sample
@@ -328,6 +328,7 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         out["sem_cls_prob"] = torch.softmax(logits, dim=-1)
         return box_predictions, out["sem_cls_prob"], out["objectness_prob"]
 
+    @_lib.on_tensor_device(lambda inputs, *a, **k: inputs.get("point_clouds"))
     def forward(self, inputs, encoder_only=False, if_test=False, if_real_test=False, curr_epoch=-1,
                 if_cmp_class=False, pre_encoded=None):
         """models/model_3detr.py:1767-1817.  ``pre_encoded`` (this package's addition): the result of

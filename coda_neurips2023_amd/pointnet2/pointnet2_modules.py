@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib
 from . import _ext, fused_sa_mlp, pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -63,6 +64,7 @@ class PointnetSAModuleVotes(nn.Module):
         return {"xyz": xyz, "inds": inds, "new_xyz": new_xyz, "idx": idx, "grouped_cl": grouped_cl,
                 "counts": (cnt, goff, tot), "total_host": total_host}
 
+    @_lib.on_tensor_device()
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None,
                 inds: torch.Tensor = None, prepared: dict = None):
         """xyz (B,N,3), features (B,C,N) or None, inds (B,npoint) or None ->
@@ -121,6 +123,7 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
+    @_lib.on_tensor_device()
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         if known is None:

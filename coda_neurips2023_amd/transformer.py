@@ -21,6 +21,7 @@ from torch import Tensor, nn
 
 import os
 
+from . import _lib
 from . import attention_core as _core
 from . import fused_blocks as _fb
 from . import fused_layers as _fl
@@ -165,6 +166,7 @@ class TransformerEncoder(nn.Module):
             raise AssertionError("one mask per encoder layer expected")
         return [_tile_mask_per_head(m, layer.nhead) for m, layer in zip(per_layer, self.layers)]
 
+    @_lib.on_tensor_device()
     def forward(self, src, mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 xyz: Optional[Tensor] = None, transpose_swap: Optional[bool] = False):
@@ -202,6 +204,7 @@ class TransformerDecoder(nn.Module):
     def _reset_parameters(self, weight_init_name):
         _xavier_matrices(self, weight_init_name)
 
+    @_lib.on_tensor_device()
     def forward(self, tgt, memory, image_features_clip=None, text_features_clip=None,
                 tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
                 tgt_key_padding_mask: Optional[Tensor] = None,
@@ -287,6 +290,7 @@ class MaskedTransformerEncoder(TransformerEncoder):
                 dist = torch.cdist(xyz, xyz, p=2)
             return dist >= radius, dist
 
+    @_lib.on_tensor_device()
     def forward(self, src, mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 xyz: Optional[Tensor] = None, transpose_swap: Optional[bool] = False):
@@ -395,6 +399,7 @@ class TransformerEncoderLayer(nn.Module):
         s, y, _ = _resolve(pend, self.norm2)
         return _Pending(s, _ffn_fused(self, y), self.linear2.bias, _drop_p(self.dropout2))
 
+    @_lib.on_tensor_device()
     def forward(self, src, src_mask: Optional[Tensor] = None,
                 src_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
                 return_attn_weights: Optional[Tensor] = False):
@@ -497,6 +502,7 @@ class TransformerDecoderLayer(nn.Module):
                              p=_drop_p(self.dropout2))
         return _Pending(s, _ffn_fused(self, y), self.linear2.bias, _drop_p(self.dropout3))
 
+    @_lib.on_tensor_device()
     def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None,
                 memory_mask: Optional[Tensor] = None,
                 tgt_key_padding_mask: Optional[Tensor] = None,

@@ -81,6 +81,21 @@ int coda_box_decode_bwd_f32(const float *center_raw, const float *size_raw, cons
                             const float *g_corners_xyz, float *d_center_raw, float *d_size_raw,
                             float *d_angle_res_norm, void *stream);
 
+/* ---- the matcher's cost matrix (criterion.py:50-66) -------------------------------------------------------
+ * gIoU as above plus, in the same pass, the L1 centre distance torch.cdist(center_normalized,
+ * gt_box_centers_normalized, p=1) (criterion.py:1153) and
+ *   cost = w_class * -cls_prob[label of GT] + w_objectness * -objectness + w_center * L1 + w_giou * -gIoU
+ * evaluated with one rounding per operation in the reference's left-to-right order.  Replaces one gather, the
+ * cdist kernel (750 us for 64 x 256 x 64 pairs on MI355X) and seven elementwise passes over (b, k1, k2).
+ *   center1 (b,k1,3), center2 (b,k2,3), cls_prob (b,k1,ncls), labels (b,k2) int64 in [0,ncls), objectness (b,k1);
+ *   outputs gious, center_dist, cost: (b,k1,k2) each.  rotated_flag: device byte or NULL (then `rotated`).
+ *   labels are trusted to be in range (they index the dataset's class table). */
+int coda_matcher_cost_f32(const float *corners1, const float *corners2, const int32_t *nums_k2, const float *center1,
+                          const float *center2, const float *cls_prob, const int64_t *labels, const float *objectness,
+                          float w_class, float w_objectness, float w_center, float w_giou, float *gious,
+                          float *center_dist, float *cost, int b, int k1, int k2, int ncls, int rotated,
+                          const unsigned char *rotated_flag, int rotated_k2_limit, void *stream);
+
 /* ---- Hungarian assignment (criterion.py:27-86, Matcher.forward) -----------------------------------------
  * Replaces the per-scene scipy.optimize.linear_sum_assignment calls on the host (one D2H copy of the cost
  * tensor and one host solve per scene and decoder layer): one workgroup per problem solves the rectangular

@@ -66,3 +66,92 @@ def test_outside_limits_falls_back_to_host():
     assert torch.equal(auto["per_prop_gt_inds"], ref["per_prop_gt_inds"])
     with pytest.raises(RuntimeError):
         Matcher(0, 0, 0, 1, solver="device")(outputs, targets)
+
+
+def test_fused_cost_matrix_is_the_torch_expression():
+    """coda_matcher_cost_f32 against the reference's expressions (criterion.py:50-66, 1153): the L1 distances are
+    torch.cdist's bit for bit, the gIoU is the stand-alone kernel's, the weighted cost is the torch arithmetic's."""
+    from coda_neurips2023_amd import box_util
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(9)
+    b, k1, k2, ncls = 5, 96, 17, 11
+    def boxes(n):
+        centre = torch.rand(b, n, 3, generator=gen) * 1.5
+        size = torch.rand(b, n, 3, generator=gen) * 1.2 + 0.1
+        angle = (torch.rand(b, n, generator=gen) - 0.5) * 6.0
+        return box_util.get_3d_box_batch_tensor(size, angle, centre).to(dev)
+    c1, c2 = boxes(k1), boxes(k2)
+    a1, a2 = torch.rand(b, k1, 3, generator=gen).to(dev), torch.rand(b, k2, 3, generator=gen).to(dev)
+    prob = torch.softmax(torch.randn(b, k1, ncls, generator=gen), -1).to(dev)
+    obj = torch.rand(b, k1, generator=gen).to(dev)
+    labels = torch.randint(0, ncls, (b, k2), generator=gen).to(dev)
+    nums = torch.tensor([17, 3, 0, 9, 1]).to(dev)
+    w = (1.0, 5.0, 5.0, 3.0)  # class, objectness, centre, gIoU (scripts/coda_sunrgbd_stage2.sh)
+    for rotated in (True, torch.tensor(True, device=dev), False):
+        gious, dist, cost = box_util.matcher_cost(c1, c2, nums, a1, a2, prob, labels, obj, w, rotated)
+        ref_g = box_util.generalized_box3d_iou(c1, c2, nums, rotated_boxes=bool(rotated))
+        ref_d = torch.cdist(a1, a2, p=1)
+        class_mat = -torch.gather(prob, 2, labels.unsqueeze(1).expand(b, k1, k2))
+        ref_c = w[0] * class_mat + w[1] * -obj.unsqueeze(-1) + w[2] * ref_d + w[3] * -ref_g
+        assert torch.equal(gious, ref_g)
+        assert torch.equal(dist, ref_d)
+        assert torch.equal(cost, ref_c)
+
+
+@pytest.mark.parametrize("rotated", [True, False])
+def test_criterion_same_loss_with_and_without_the_fused_matcher_front(rotated):
+    """SetCriterion.stacked_forward: fused cost + device solver + device scalars vs the reference-shaped route
+    (torch expressions, scipy on the host, .item() scalars) -- same assignment, same loss, same gradients."""
+    from types import SimpleNamespace
+
+    from coda_neurips2023_amd import criterion as C
+    from coda_neurips2023_amd.dataset_config import HotPathDatasetConfig
+    from coda_neurips2023_amd.box_util import get_3d_box_batch_tensor
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(21)
+    nl, bsz, nq, ngt, ncls, nbin = 3, 4, 64, 16, 10, 12
+    args = SimpleNamespace(**{a: 0 for a in C._WEIGHT_ARGS.values()})
+    for k, v in dict(loss_no_object_weight=0.05, loss_angle_cls_weight=0.1, loss_angle_reg_weight=0.5,
+                     loss_center_weight=5.0, loss_size_weight=1.0, loss_sem_cls_softmax_skip_none_gt_sample_weight=1,
+                     matcher_giou_cost=3, matcher_cls_cost=1, matcher_center_cost=5, matcher_objectness_cost=5,
+                     train_range_max=ncls).items():
+        setattr(args, k, v)
+    cfg = HotPathDatasetConfig(num_semcls=1, num_angle_bin=nbin)
+
+    def rnd(*shape):
+        return torch.rand(*shape, generator=gen)
+    nactual = torch.tensor([5, 0, 16, 1])
+    angles = (rnd(bsz, ngt) - 0.3) * 1.5 if rotated else torch.zeros(bsz, ngt)
+    targets = {"gt_box_present": (torch.arange(ngt)[None] < nactual[:, None]).float(),
+               "gt_box_sem_cls_label": torch.zeros(bsz, ngt, dtype=torch.int64),
+               "gt_box_centers_normalized": rnd(bsz, ngt, 3), "gt_box_sizes_normalized": rnd(bsz, ngt, 3),
+               "gt_box_angles": angles,
+               "gt_box_corners": get_3d_box_batch_tensor(rnd(bsz, ngt, 3) + 0.2, angles, rnd(bsz, ngt, 3) * 3),
+               "gt_angle_class_label": torch.randint(0, nbin, (bsz, ngt), generator=gen),
+               "gt_angle_residual_label": (rnd(bsz, ngt) - 0.5) * 0.2}
+    targets = {k: v.to(dev) for k, v in targets.items()}
+    base = {"sem_cls_logits": torch.randn(nl, bsz, nq, 2, generator=gen), "angle_logits": torch.randn(nl, bsz, nq, nbin, generator=gen),
+            "angle_residual_normalized": torch.randn(nl, bsz, nq, nbin, generator=gen) * 0.1,
+            "center_normalized": rnd(nl, bsz, nq, 3), "size_normalized": rnd(nl, bsz, nq, 3)}
+    corners = get_3d_box_batch_tensor(rnd(nl * bsz, nq, 3) + 0.2, (rnd(nl * bsz, nq) - 0.5) * 3, rnd(nl * bsz, nq, 3) * 3)
+    results = []
+    for fused in (True, False):
+        crit = C.build_criterion(args, cfg).to(dev)
+        crit.fused_matcher_cost = crit.device_scalars = fused
+        crit.matcher.solver = "auto" if fused else "scipy"
+        leaves = {k: v.clone().to(dev).requires_grad_(True) for k, v in base.items()}
+        stacked = dict(leaves, box_corners=corners.view(nl, bsz, nq, 8, 3).to(dev))
+        stacked["sem_cls_prob"] = torch.softmax(leaves["sem_cls_logits"], -1)[..., :-1]
+        stacked["objectness_prob"] = 1 - torch.softmax(leaves["sem_cls_logits"], -1)[..., -1]
+        outputs = {"outputs": {k: v[-1] for k, v in stacked.items()}, "stacked_outputs": stacked}
+        loss, loss_dict = crit(outputs, dict(targets))
+        loss.backward()
+        results.append((loss.detach(), {k: v.grad.clone() for k, v in leaves.items()},
+                        {k: v.detach() for k, v in loss_dict.items()}))
+    (la, ga, da), (lb, gb, db) = results
+    assert torch.allclose(la, lb, rtol=1e-6, atol=1e-6)
+    assert set(da) == set(db)
+    for k in da:
+        assert torch.allclose(da[k], db[k], rtol=1e-5, atol=1e-6), k
+    for k in ga:
+        assert torch.allclose(ga[k], gb[k], rtol=1e-5, atol=1e-7), k

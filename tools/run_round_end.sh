@@ -14,7 +14,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 rm -rf $R/gpurun_out/final_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
-  python $R/bench.py --no-cpu-baseline > $R/gpurun_out/final_prof_bench.json 2>/dev/null
+  python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/final_prof_bench.json 2>/dev/null
 rm -f $R/gpurun_out/final_prof/run_kernel_trace.csv   # tens of MB; the stats file is what gets committed
 cd $R
 python - <<'PY'
