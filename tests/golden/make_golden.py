@@ -512,12 +512,77 @@ def golden_giou():
     _save("giou.npz", **out)
 
 
+EVAL_CONFIGS = {  # name -> overrides of utils/ap_calculator.py:1021-1051's defaults
+    "default": {},                                   # 3-D NMS within a class, per-class proposals, empty boxes removed
+    "nms3d": {"cls_nms": False},
+    "nms2d": {"use_3d_nms": False},
+    "old_type": {"use_old_type_nms": True, "nms_iou": 0.5},
+    "keep_empty": {"remove_empty_box": False, "per_class_proposal": False},
+    "no_nms": {"no_nms": True, "per_class_proposal": False, "use_cls_confidence_only": True},
+}
+
+
+def golden_eval_post():
+    """parse_predictions / parse_predictions_obb (utils/ap_calculator.py:777-1018, :45-286) on a synthetic scene
+    batch: proposals around the scene's furniture (some overlapping heavily, some in empty space, two of zero
+    size), one scene whose proposals are all empty.  Stored: the inputs and, per configuration and scene, the
+    (class, proposal index, score) rows of the returned lists in the returned order."""
+    import utils.ap_calculator as RA  # the REFERENCE module (Delaunay in-hull test, utils/nms.py)
+    import utils.box_util as RB
+    gen = torch.Generator().manual_seed(17)
+    B, K, N, ncls = 3, 40, 4096, 4
+    pc, mn, mx = make_batch(B, N, seed=99)
+    pts = torch.from_numpy(pc)
+    # centres: half of them ON scene points (boxes that hold points), the rest anywhere in the scene's bbox
+    pick = torch.randint(0, N, (B, K), generator=gen)
+    on_points = torch.gather(pts, 1, pick.unsqueeze(-1).expand(-1, -1, 3))
+    anywhere = torch.from_numpy(mn)[:, None] + torch.rand(B, K, 3, generator=gen) * torch.from_numpy(mx - mn)[:, None]
+    centres = torch.where((torch.arange(K) % 2 == 0)[None, :, None], on_points, anywhere)
+    centres[:, 1::8] = centres[:, 0::8][:, :centres[:, 1::8].shape[1]] + 0.05   # near-duplicates: NMS has work to do
+    sizes = torch.rand(B, K, 3, generator=gen) * 1.2 + 0.3
+    sizes[0, 5] = 0.0   # zero boxes (all corners at the origin: the only degenerate box both variants accept --
+    sizes[1, 7] = 0.0   # qhull raises on any other flat hull)
+    angles = (torch.rand(B, K, generator=gen) - 0.5) * 3.0
+    centres[2] = torch.from_numpy(mx)[2] + 5.0 + torch.rand(K, 3, generator=gen)       # scene 2: nothing holds points
+    centres[0, 5] = 0.0
+    centres[1, 7] = 0.0
+    cam = torch.stack((centres[..., 0], -centres[..., 2], centres[..., 1]), -1)        # depth -> upright camera
+    corners = RB.get_3d_box_batch_tensor(sizes, angles, cam)
+    probs = torch.softmax(torch.randn(B, K, ncls, generator=gen) * 2, -1)
+    obj = torch.rand(B, K, generator=gen)
+    obj[0, :6] = 0.01                                                                   # below conf_thresh
+    out = {"corners": _np(corners), "points": pc, "sem_cls_probs": _np(probs), "objectness": _np(obj),
+           "centers": _np(centres), "sizes": _np(sizes), "angles": _np(angles)}
+    cfg_ds = types.SimpleNamespace(num_semcls=ncls)
+
+    def rows(lists):
+        res = []
+        for i, lst in enumerate(lists):
+            r = np.zeros((len(lst), 3), np.float64)
+            for n, item in enumerate(lst):
+                j = int(np.nonzero((_np(corners)[i] == item[1]).all(axis=(1, 2)))[0][0])
+                r[n] = (item[0], j, item[2])
+            res.append(r)
+        return res
+
+    for name, over in EVAL_CONFIGS.items():
+        cfg = RA.get_ap_config_dict(dataset_config=cfg_ds, **over)
+        for i, r in enumerate(rows(RA.parse_predictions(corners, probs, obj, pts, cfg))):
+            out[f"{name}_plain_{i}"] = r
+        cfg = RA.get_ap_config_dict(dataset_config=cfg_ds, **over)
+        lists = RA.parse_predictions_obb(corners, probs, obj, pts, cfg, centres, sizes, angles)
+        for i, r in enumerate(rows(lists)):
+            out[f"{name}_obb_{i}"] = r
+        out[f"{name}_obb_row0"] = _np(lists[0][0][3]) if lists[0] else np.zeros(0, np.float32)
+    _save("eval_post.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou"]
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post"]
     for w in which:
         globals()["golden_" + w]()
