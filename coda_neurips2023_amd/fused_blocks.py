@@ -51,13 +51,18 @@ def _ffn_forward(y, w1, b1, w2, p):
     return o, (cf, y2, h)
 
 
-def _ffn_backward(saved, do, w1, w2):
+def _ffn_backward(saved, do, w1, w2, defer=None):
     cf, y2, h = saved
     do2 = do.reshape(-1, do.shape[-1]).contiguous()
-    dw2 = tn_gemm(do2, h)
     dh = gemm.mm(do2, w2)
     dh0, db1, _ = _FfnAct.backward(cf, dh)
-    dw1 = tn_gemm(dh0, y2)
+    if defer is not None:  # weight gradients join the stack's grouped launch (gemm.DeferredWeightGrads)
+        dw2, dw1 = torch.empty_like(w2), torch.empty_like(w1)
+        defer.add(dw2, do2, h)
+        defer.add(dw1, dh0, y2)
+    else:
+        dw2 = tn_gemm(do2, h)
+        dw1 = tn_gemm(dh0, y2)
     dy = gemm.mm(dh0, w1)
     return dy, dw1, db1, dw2
 
@@ -307,17 +312,19 @@ class _DecoderStack(torch.autograd.Function):
         grads = [None] * (nl * _NP)
         ds_next = None
         dqpos = None
+        defer = gemm.DeferredWeightGrads()  # the layers' weight gradients: one grouped launch after the loop
         for l in range(nl - 1, -1, -1):
             g1, b1n, in1, ib1, ow1, ob1, g2, b2n, in2, ib2, ow2, ob2, g3, b3n, w1, fb1, w2, fb2 = layers[l]
             c1, c2, c3, (xq2, q, attn, lse, seed, seed_dev), c5, ffn_saved, cn = ctx.blocks[l]
             do, dfb2, ds3, _, dgn, dbn, _, _ = _AddLN.backward(cn, ds_next, dstack[l], None)
             dnorm_g.append(dgn)
             dnorm_b.append(dbn)
-            dy3, dw1, dfb1, dw2 = _ffn_backward(ffn_saved, do, w1, w2)
+            dy3, dw1, dfb1, dw2 = _ffn_backward(ffn_saved, do, w1, w2, defer)
             da2, dob2, ds2, _, dg3, db3n, _, _ = _AddLN.backward(c5, ds3, dy3, None)
             # cross attention backward; dK / dV go straight into layer l's column slices
             da2_2 = da2.reshape(-1, e)
-            dow2 = tn_gemm(da2_2.contiguous(), attn)
+            dow2 = torch.empty_like(ow2)
+            defer.add(dow2, da2_2.contiguous(), attn)
             dattn = gemm.mm(da2_2, ow2)
             dq = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
             delta = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
@@ -327,11 +334,12 @@ class _DecoderStack(torch.autograd.Function):
                                             bsz, nheads, nq, ns, d, e, ld_kv, ld_kv, 0, ld_kv, ld_kv, scale, p_attn, seed,
                                             seed_dev.data_ptr() if seed_dev is not None else None,
                                             _lib.current_stream_handle()), "mha_bwd")
-            gemm.mm_tn(dq, xq2, out=din2_all[l, :e])
+            defer.add(din2_all[l, :e], dq, xq2)
             _colsum_into(dib2_all[l, :e], dq.unsqueeze(0))
             dxq = gemm.mm(dq, in2[:e]).view(nq, bsz, e)
             da1, dob1, ds1, dpos2, dg2, db2n, _, _ = _AddLN.backward(c3, ds2, None if has_qpos else dxq,
                                                                      dxq if has_qpos else None)
+            c2.defer = defer
             dqk, _, dv1, din1, dib1, dow1, _, _, _ = _MHA.backward(c2, da1)
             if has_qpos:
                 g = _AddLN.backward(c1, ds1, dv1, dqk)
@@ -341,6 +349,7 @@ class _DecoderStack(torch.autograd.Function):
             ds_next = g[0]  # the block's input WAS the stream: d(stream) + d(LayerNorm path)
             grads[_NP * l:_NP * (l + 1)] = [g[4], g[5], din1, dib1, dow1, dob1, dg2, db2n, din2_all[l], dib2_all[l],
                                             dow2, dob2, dg3, db3n, dw1, dfb1, dw2, dfb2]
+        defer.flush()
         # memory side of all layers at once
         dmp2 = gemm.mm(dk_all, wk_all)
         dmem2 = gemm.mm(dv_all, wv_all)

@@ -193,8 +193,12 @@ class _MHA(torch.autograd.Function):
         dev = dout.device
         d = e // nheads
         dout2 = dout.reshape(-1, e)
+        # a stack-level backward (fused_blocks._DecoderStack) hands in a collector: weight gradients are issued
+        # together at its end (gemm.DeferredWeightGrads) instead of one launch-sized GEMM each
+        defer = getattr(ctx, "defer", None)
+        tn_into = defer.add if defer is not None else _tn_into
         dw_out = torch.empty_like(w_out)
-        _tn_into(dw_out, dout2.contiguous(), attn)
+        tn_into(dw_out, dout2.contiguous(), attn)
         dattn = gemm.mm(dout2, w_out)
         rq, rk = tgt_len * bsz, src_len * bsz
         if rq == rk:
@@ -216,9 +220,9 @@ class _MHA(torch.autograd.Function):
         else:
             _colsum_into(db_in[:e], dq.unsqueeze(0))
             _colsum_into(db_in[e:], dkv)
-        _tn_into(dw_in[:e], dq, xq2)
-        _tn_into(dw_in[e:2 * e], dk, xk2)
-        _tn_into(dw_in[2 * e:], dv, xv2)
+        tn_into(dw_in[:e], dq, xq2)
+        tn_into(dw_in[e:2 * e], dk, xk2)
+        tn_into(dw_in[2 * e:], dv, xv2)
         need_q, need_k, need_v = ctx.needs_input_grad[:3]
         dxq = dxk = dxv = None
         if same_qk and same_kv:

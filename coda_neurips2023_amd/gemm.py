@@ -113,3 +113,38 @@ def mm_tn(a, b, out=None, accumulate=False, kernel=None):
         _lib.check(st, "coda_gemm_tn_f32")
         return out
     return _run(1, 0, a.shape[1], b.shape[1], a.shape[0], a, b, out, None, accumulate)
+
+
+class DeferredWeightGrads:
+    """Collects weight-gradient products ``out = dy^T x`` during a hand-written backward and issues them in one
+    launch (``coda_grouped_gemm_tn_f32``) when ``flush()`` is called: nothing inside a backward pass reads a
+    weight gradient, and 72 launch-sized products of the decoder stack fill the chip only together.  Shapes the
+    grouped kernel does not take (columns not multiples of 64, rows not a multiple of 8, non-unit inner strides)
+    are computed on the spot with ``mm_tn``."""
+
+    def __init__(self):
+        self._rows = []   # 8 int64 per problem: the CodaTnProblem layout (include/coda_gemm.h)
+        self._keep = []   # operands stay referenced until the launch has been enqueued
+
+    def add(self, out, dy, x):
+        rows, m = dy.shape
+        n = x.shape[1]
+        if (GROUPED_TN and rows % 8 == 0 and m % 64 == 0 and n % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1
+                and out.stride(1) == 1 and dy.dtype == torch.float32 and dy.is_cuda):
+            self._rows.append((dy.data_ptr(), x.data_ptr(), out.data_ptr(), rows | (m << 32), n, dy.stride(0),
+                               x.stride(0), out.stride(0)))
+            self._keep.append((dy, x, out))
+        else:
+            mm_tn(dy, x, out=out)
+
+    def flush(self):
+        if not self._rows:
+            return
+        import numpy as np
+        table = np.array(self._rows, dtype=np.int64)
+        st = _lib.load().coda_grouped_gemm_tn_f32(table.ctypes.data, len(self._rows), _lib.current_stream_handle())
+        _lib.check(st, "coda_grouped_gemm_tn_f32")
+        self._rows, self._keep = [], []
+
+
+GROUPED_TN = os.environ.get("CODA_GROUPED_TN", "1") != "0"

@@ -48,6 +48,21 @@ int coda_sgemm_f32(int transb, int m, int n, int k, const float *a, long long ld
 int coda_gemm_tn_f32(const float *dy, const float *x, float *out, int rows, int co, int ci,
                      long long lddy, long long ldx, long long ldout, int accumulate, void *stream);
 
+/* Many weight gradients in one launch: out_p (m x n, row stride ldout) = dy_p^T x_p for every problem of the
+ * array (dy_p rows x m, x_p rows x n; replaces one `torch.mm(dy.t(), x)` per linear layer, models/transformer.py's
+ * decoder layers as autograd differentiates them).  `problems` is HOST memory, read during the call (the
+ * descriptors travel as kernel arguments, 64 problems per launch).  Deterministic (fixed summation order), out
+ * is overwritten.  Constraints: m, n multiples of 64, rows a multiple of 8; CODA_ENOSPC otherwise. */
+typedef struct CodaTnProblem {
+  const float *dy;
+  const float *x;
+  float *out;
+  int rows, m, n;
+  long long lddy, ldx, ldout;
+} CodaTnProblem;
+
+int coda_grouped_gemm_tn_f32(const CodaTnProblem *problems, int count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

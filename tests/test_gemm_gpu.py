@@ -119,3 +119,38 @@ def test_own_sgemm_kernels(dev, m, n, k, transb):
     st = lib.coda_sgemm_f32(1, 48, 64, 128, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
                             out.stride(0), None, 0, _lib.current_stream_handle())
     assert st == _lib.CODA_ENOSPC
+
+
+def test_grouped_weight_gradients(dev):
+    """coda_grouped_gemm_tn_f32 through gemm.DeferredWeightGrads: many dy^T x products in one launch -- mixed
+    shapes, slices of packed buffers as operands and outputs, more problems than one launch carries, shapes the
+    kernel does not take (computed on the spot), bit-identical results on a second run (fixed summation order)."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(2048, 256, 256)] * 70 + [(2048, 768, 256), (64, 64, 64), (8, 64, 128), (16384, 128, 256), (2048, 256, 128),
+                                        (100, 64, 64), (2048, 96, 256)]   # the last two: rows % 8 / cols % 64 fail
+    probs = []
+    for rows, m, n in shapes:
+        dy = torch.randn(rows, m, generator=g).to(dev)
+        x = torch.randn(rows, n, generator=g).to(dev)
+        probs.append((dy, x))
+    packed_dy = torch.randn(2048, 3 * 256, generator=g).to(dev)   # column slices (row stride 768)
+    packed_x = torch.randn(2048, 512, generator=g).to(dev)
+    packed_out = torch.full((3, 256, 256), float("nan"), device=dev)
+    outs = []
+    for rep in range(2):
+        d = gemm.DeferredWeightGrads()
+        res = []
+        for dy, x in probs:
+            out = torch.full((dy.shape[1], x.shape[1]), float("nan"), device=dev)
+            d.add(out, dy, x)
+            res.append(out)
+        for j in range(3):
+            d.add(packed_out[j], packed_dy[:, 256 * j:256 * (j + 1)], packed_x[:, 256:])
+        d.flush()
+        outs.append([r.clone() for r in res] + [packed_out.clone()])
+    for (dy, x), out in zip(probs, outs[0]):
+        assert rel(out, dy.t() @ x) < 1e-5, (dy.shape, x.shape)
+    for j in range(3):
+        assert rel(outs[0][-1][j], packed_dy[:, 256 * j:256 * (j + 1)].t() @ packed_x[:, 256:]) < 1e-5
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
