@@ -8,7 +8,7 @@ from types import SimpleNamespace
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from coda_neurips2023_amd import ap_calculator as AP  # noqa: E402
 from coda_neurips2023_amd.box_util import get_3d_box_batch_tensor  # noqa: E402
 from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402

@@ -4,7 +4,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from coda_neurips2023_amd import gemm  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from coda_neurips2023_amd.criterion import Matcher  # noqa: E402
 
 dev = torch.device("cuda:0")
