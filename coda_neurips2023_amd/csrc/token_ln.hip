@@ -222,6 +222,39 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float *__re
   }
 }
 
+constexpr int kMaxColsumItems = 120;  // 24 B each: 2.9 KB of kernel arguments
+struct ColsumBatch {
+  CodaColsumItem item[kMaxColsumItems];
+};
+
+// the same reduction for many (partials, out) pairs: blockIdx.y = item, blockIdx.z = group, blockIdx.x = 64 columns
+__global__ __launch_bounds__(1024) void colsum_finalize_grouped_kernel(const ColsumBatch batch) {
+  __shared__ float s_part[16][64];
+  const CodaColsumItem &it = batch.item[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) * 64 >= it.n || static_cast<int>(blockIdx.z) >= it.groups) return;  // block-uniform
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane, n = it.n, blocks = it.blocks;
+  const float *pg = it.partials + static_cast<size_t>(blockIdx.z) * blocks * n;
+  float t = 0.f;
+  if (col < n) {
+    int b = slice;
+    for (; b + 48 < blocks; b += 64) {
+      const float v0 = pg[static_cast<size_t>(b) * n + col], v1 = pg[static_cast<size_t>(b + 16) * n + col];
+      const float v2 = pg[static_cast<size_t>(b + 32) * n + col], v3 = pg[static_cast<size_t>(b + 48) * n + col];
+      t += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < blocks; b += 16) t += pg[static_cast<size_t>(b) * n + col];
+  }
+  s_part[slice][lane] = t;
+  __syncthreads();
+  if (slice == 0 && col < n) {
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r += s_part[q][lane];
+    it.out[static_cast<size_t>(blockIdx.z) * n + col] = r;
+  }
+}
+
 // per-block column sums of x (G, rows, C): partials (G, blocks, C)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long long rows, int c,
                                                              float *__restrict__ partials) {
@@ -384,6 +417,31 @@ CODA_API int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int
   return launch_status();
 }
 
+CODA_API int coda_tok_colsum_finalize_grouped_f32(const CodaColsumItem *items, int count, void *stream) {
+  if (count < 0) return CODA_EINVAL;
+  if (count == 0) return CODA_OK;
+  if (!items) return CODA_EINVAL;
+  for (int i = 0; i < count; ++i)
+    if (!items[i].partials || !items[i].out || items[i].blocks <= 0 || items[i].n <= 0 || items[i].groups <= 0)
+      return CODA_EINVAL;
+  clear_sticky_error();
+  for (int first = 0; first < count; first += kMaxColsumItems) {
+    ColsumBatch b;
+    const int m = min(kMaxColsumItems, count - first);
+    int max_n = 0, max_g = 0;
+    for (int i = 0; i < m; ++i) {
+      b.item[i] = items[first + i];
+      max_n = max(max_n, b.item[i].n);
+      max_g = max(max_g, b.item[i].groups);
+    }
+    hipLaunchKernelGGL(colsum_finalize_grouped_kernel, dim3((max_n + 63) / 64, m, max_g), dim3(1024), 0,
+                       static_cast<hipStream_t>(stream), b);
+    const int st = launch_status();
+    if (st != CODA_OK) return st;
+  }
+  return CODA_OK;
+}
+
 CODA_API int coda_tok_colsum_blocks(long long rows, int c) {
   if (rows < 0 || bad_row_c(c)) return CODA_EINVAL;
   return row_blocks(rows, c);
@@ -391,9 +449,10 @@ CODA_API int coda_tok_colsum_blocks(long long rows, int c) {
 
 CODA_API int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials, float *out,
                                  void *stream) {
-  if (groups <= 0 || rows < 0 || bad_row_c(c) || !out) return CODA_EINVAL;
+  if (groups <= 0 || rows < 0 || bad_row_c(c)) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
+    if (!out) return CODA_EINVAL;  // nothing to defer
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * groups * c, s);
     return e == hipSuccess ? CODA_OK : static_cast<int>(e);
   }
@@ -401,7 +460,8 @@ CODA_API int coda_tok_colsum_f32(const float *x, int groups, long long rows, int
   const int blocks = row_blocks(rows, c);
   clear_sticky_error();
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks, groups), dim3(256), 0, s, x, rows, c, partials);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64, groups), dim3(1024), 0, s, partials, blocks, c, out);
+  if (out)
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64, groups), dim3(1024), 0, s, partials, blocks, c, out);
   return launch_status();
 }
 

@@ -55,6 +55,7 @@ def _ffn_backward(saved, do, w1, w2, defer=None):
     cf, y2, h = saved
     do2 = do.reshape(-1, do.shape[-1]).contiguous()
     dh = gemm.mm(do2, w2)
+    cf.defer = defer
     dh0, db1, _ = _FfnAct.backward(cf, dh)
     if defer is not None:  # weight gradients join the stack's grouped launch (gemm.DeferredWeightGrads)
         dw2, dw1 = torch.empty_like(w2), torch.empty_like(w1)
@@ -316,6 +317,7 @@ class _DecoderStack(torch.autograd.Function):
         for l in range(nl - 1, -1, -1):
             g1, b1n, in1, ib1, ow1, ob1, g2, b2n, in2, ib2, ow2, ob2, g3, b3n, w1, fb1, w2, fb2 = layers[l]
             c1, c2, c3, (xq2, q, attn, lse, seed, seed_dev), c5, ffn_saved, cn = ctx.blocks[l]
+            cn.defer = c5.defer = c3.defer = c2.defer = c1.defer = defer
             do, dfb2, ds3, _, dgn, dbn, _, _ = _AddLN.backward(cn, ds_next, dstack[l], None)
             dnorm_g.append(dgn)
             dnorm_b.append(dbn)
@@ -335,11 +337,10 @@ class _DecoderStack(torch.autograd.Function):
                                             seed_dev.data_ptr() if seed_dev is not None else None,
                                             _lib.current_stream_handle()), "mha_bwd")
             defer.add(din2_all[l, :e], dq, xq2)
-            _colsum_into(dib2_all[l, :e], dq.unsqueeze(0))
+            _colsum_into(dib2_all[l, :e], dq.unsqueeze(0), defer)
             dxq = gemm.mm(dq, in2[:e]).view(nq, bsz, e)
             da1, dob1, ds1, dpos2, dg2, db2n, _, _ = _AddLN.backward(c3, ds2, None if has_qpos else dxq,
                                                                      dxq if has_qpos else None)
-            c2.defer = defer
             dqk, _, dv1, din1, dib1, dow1, _, _, _ = _MHA.backward(c2, da1)
             if has_qpos:
                 g = _AddLN.backward(c1, ds1, dv1, dqk)

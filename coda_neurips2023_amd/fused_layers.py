@@ -33,14 +33,19 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args, _stream()), name)
 
 
-def _colsum_into(out, x3):
-    """out (G*C) <- column sums of x3 (G, rows, C)."""
+def _colsum_into(out, x3, defer=None):
+    """out (G*C) <- column sums of x3 (G, rows, C).  With a collector (gemm.DeferredWeightGrads) only the
+    per-block partials are produced now; the reduction joins the collector's grouped launch."""
     g, rows, c = x3.shape
     if c % 4 or c > 1024 or 256 % (c // 4):
         torch.sum(x3, 1, out=out.view(g, c))
         return
     blocks = _lib.load().coda_tok_colsum_blocks(rows, c)
     partials = torch.empty((g, blocks, c), dtype=torch.float32, device=x3.device)
+    if defer is not None and rows > 0 and gemm.GROUPED_TN:
+        _call("coda_tok_colsum_f32", _p(x3), g, rows, c, _p(partials), None)
+        defer.add_colsum(partials, out, blocks, c, g)
+        return
     _call("coda_tok_colsum_f32", _p(x3), g, rows, c, _p(partials), _p(out))
 
 
@@ -94,8 +99,11 @@ class _AddLN(torch.autograd.Function):
         dres = torch.empty_like(s) if (has_res or p == 0.0) else None
         dx = torch.empty_like(s) if p > 0.0 else None
         sums = torch.empty(3 * c, dtype=torch.float32, device=s.device)
+        defer = getattr(ctx, "defer", None) if (rows > 0 and gemm.GROUPED_TN) else None
         _call("coda_tok_add_ln_bwd_f32", _p(dy), _p(dyp), _p(ds), _p(s), _p(mean), _p(rstd), _p(gamma), rows, c, p,
-              seed, _p(seed_dev), _p(dres), _p(dx), _p(partials), _p(sums))
+              seed, _p(seed_dev), _p(dres), _p(dx), _p(partials), None if defer is not None else _p(sums))
+        if defer is not None:  # dgamma / dbeta / dbias are closed by the stack's grouped reduction
+            defer.add_colsum(partials, sums, blocks, 3 * c)
         if dx is None:
             dx = dres
         has_ln = gamma is not None
@@ -135,7 +143,11 @@ class _FfnAct(torch.autograd.Function):
         partials = torch.empty((blocks, c), dtype=torch.float32, device=a.device)
         dz = torch.empty_like(a)
         db = torch.empty(c, dtype=torch.float32, device=a.device) if has_bias else None
-        _call("coda_tok_bias_relu_dropout_bwd_f32", _p(da), _p(a), rows, c, p, _p(dz), _p(partials), _p(db))
+        defer = getattr(ctx, "defer", None) if (has_bias and rows > 0 and gemm.GROUPED_TN) else None
+        _call("coda_tok_bias_relu_dropout_bwd_f32", _p(da), _p(a), rows, c, p, _p(dz), _p(partials),
+              None if defer is not None else _p(db))
+        if defer is not None:
+            defer.add_colsum(partials, db, blocks, c)
         return dz, db, None
 
 
@@ -216,10 +228,10 @@ class _MHA(torch.autograd.Function):
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * e, dtype=torch.float32, device=dev)
         if dqkv is not None:
-            _colsum_into(db_in, dqkv)
+            _colsum_into(db_in, dqkv, defer)
         else:
-            _colsum_into(db_in[:e], dq.unsqueeze(0))
-            _colsum_into(db_in[e:], dkv)
+            _colsum_into(db_in[:e], dq.unsqueeze(0), defer)
+            _colsum_into(db_in[e:], dkv, defer)
         tn_into(dw_in[:e], dq, xq2)
         tn_into(dw_in[e:2 * e], dk, xk2)
         tn_into(dw_in[2 * e:], dv, xv2)

@@ -124,7 +124,14 @@ class DeferredWeightGrads:
 
     def __init__(self):
         self._rows = []   # 8 int64 per problem: the CodaTnProblem layout (include/coda_gemm.h)
+        self._sums = []   # 3 int64 per open column-sum reduction: the CodaColsumItem layout (coda_token_ops.h)
         self._keep = []   # operands stay referenced until the launch has been enqueued
+
+    def add_colsum(self, partials, out, blocks, n, groups=1):
+        """Close ``out (groups, n) = sum over blocks of partials (groups, blocks, n)`` at flush time (the bias /
+        LayerNorm gradient reductions of the blocks: one grouped launch instead of one per block)."""
+        self._sums.append((partials.data_ptr(), out.data_ptr(), blocks | (n << 32), groups))
+        self._keep.append((partials, out))
 
     def add(self, out, dy, x):
         rows, m = dy.shape
@@ -138,13 +145,17 @@ class DeferredWeightGrads:
             mm_tn(dy, x, out=out)
 
     def flush(self):
-        if not self._rows:
-            return
         import numpy as np
-        table = np.array(self._rows, dtype=np.int64)
-        st = _lib.load().coda_grouped_gemm_tn_f32(table.ctypes.data, len(self._rows), _lib.current_stream_handle())
-        _lib.check(st, "coda_grouped_gemm_tn_f32")
-        self._rows, self._keep = [], []
+        if self._sums:
+            table = np.array(self._sums, dtype=np.int64)
+            st = _lib.load().coda_tok_colsum_finalize_grouped_f32(table.ctypes.data, len(self._sums),
+                                                                 _lib.current_stream_handle())
+            _lib.check(st, "coda_tok_colsum_finalize_grouped_f32")
+        if self._rows:
+            table = np.array(self._rows, dtype=np.int64)
+            st = _lib.load().coda_grouped_gemm_tn_f32(table.ctypes.data, len(self._rows), _lib.current_stream_handle())
+            _lib.check(st, "coda_grouped_gemm_tn_f32")
+        self._rows, self._sums, self._keep = [], [], []
 
 
 GROUPED_TN = os.environ.get("CODA_GROUPED_TN", "1") != "0"

@@ -110,9 +110,21 @@ int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, 
 /* out[j] = sum_b partials[b][j], j < n (n = 3*C above) */
 int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int n, float *out, void *stream);
 
+/* The same reduction for many (partials, out) pairs in one launch: a stack-level backward (the decoder as one
+ * autograd node) leaves ~70 of them open -- LayerNorm / bias gradients that nothing reads before the node
+ * returns -- and closes them together.  `items` is HOST memory read during the call (kernel arguments, 120
+ * items per launch); every item: out[g][j] = sum_b partials[g][b][j] for g < groups, j < n. */
+typedef struct CodaColsumItem {
+  const float *partials;
+  float *out;
+  int blocks, n, groups, pad_;
+} CodaColsumItem;
+int coda_tok_colsum_finalize_grouped_f32(const CodaColsumItem *items, int count, void *stream);
+
 /* Column sums of x (G, rows, C) -> out (G, C) (the bias gradients of the projections):
  * per-block partials (G, blocks, C) with blocks = coda_tok_colsum_blocks(rows, c), then a
- * fixed-order reduction (two launches of one call).  C/4 must divide 256. */
+ * fixed-order reduction (two launches of one call; out == NULL: partials only, the caller reduces them later,
+ * e.g. with coda_tok_colsum_finalize_grouped_f32).  C/4 must divide 256. */
 int coda_tok_colsum_blocks(long long rows, int c);
 int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials,
                         float *out, void *stream);
