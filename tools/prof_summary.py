@@ -17,6 +17,9 @@ def cat(nm):
         return "GenericMLP batch-norm kernels (hip)"
     if "coda" in nm and any(k in nm for k in ("add_ln", "colsum", "bias_relu_dropout")):
         return "transformer token kernels (hip)"
+    if "coda" in nm and ("sgemm" in nm or "grouped_tn" in nm or "gemm_tn" in nm): return "own fp32-MFMA GEMMs (hip)"
+    if "coda" in nm and any(k in nm for k in ("giou", "hungarian", "box_decode", "box_loss", "align_loss", "nms", "box_point")):
+        return "boxes / matcher / losses (hip)"
     if "coda" in nm: return "gather/group/interp (hip)"
     if "max_pool" in nm: return "max-pool (torch)"
     if "BatchNorm" in nm or "batch_norm" in nm: return "batch-norm (MIOpen)"
