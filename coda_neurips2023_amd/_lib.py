@@ -91,6 +91,9 @@ SIGNATURES = {
     "coda_mha_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                   ctypes.c_uint64, _P, _P]),
+    "coda_mha_bwd_parts_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
+                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                        ctypes.c_uint64, _P, _c_int, _P]),
     # include/coda_gemm.h
     "coda_gemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                _P, ctypes.c_longlong, _P, _c_int, _P]),

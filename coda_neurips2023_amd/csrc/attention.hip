@@ -889,7 +889,7 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   // double-buffered Q / dO staging pays on long query sequences (encoder: -5 %); with 256 queries
   // (decoder memory) there are only 8 stages and the prologue eats the gain
-  {
+  if (p.parts & 2) {
   KernelTimer timer(2, p.l, p.s, s);
   if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
@@ -911,6 +911,7 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
   }
+  if (!(p.parts & 4)) return launch_status();
   KernelTimer timer(3, p.l, p.s, s);
   if (p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN, true>;
@@ -942,19 +943,21 @@ template <int D>
 int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   clear_sticky_error();
   const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
-  {
+  if (p.parts & 1) {
     KernelTimer timer(1, p.l, p.s, s);
     hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
   }
   if (mfma_dtype() == 1) {
-    int st;
-    {
+    int st = CODA_OK;
+    if (p.parts & 2) {
       KernelTimer timer(2, p.l, p.s, s);
       st = mha_bwd_dkv_bf16(p, D, s);
     }
     if (st != CODA_OK) return st;
-    KernelTimer timer(3, p.l, p.s, s);
-    st = mha_bwd_dq_bf16(p, D, s);
+    if (p.parts & 4) {
+      KernelTimer timer(3, p.l, p.s, s);
+      st = mha_bwd_dq_bf16(p, D, s);
+    }
     return st != CODA_OK ? st : launch_status();
   }
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
@@ -993,7 +996,18 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
                               float *dk, float *dv, float *delta, int b, int h, int l, int s, int d,
                               int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
                               float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *stream) {
+  return coda_mha_bwd_parts_f32(q, k, v, mask, out, lse, dout, dq, dk, dv, delta, b, h, l, s, d, ldq, ldk, ldv, lddq,
+                                lddk, lddv, scale, dropout_p, seed, seed_dev, 7, stream);
+}
+
+CODA_API int coda_mha_bwd_parts_f32(const float *q, const float *k, const float *v, const uint8_t *mask,
+                                    const float *out, const float *lse, const float *dout, float *dq,
+                                    float *dk, float *dv, float *delta, int b, int h, int l, int s, int d,
+                                    int ldq, int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                                    float dropout_p, uint64_t seed, const uint64_t *seed_dev, int parts,
+                                    void *stream) {
   using namespace coda;
+  if (parts <= 0 || parts > 7) return CODA_EINVAL;
   if (lddq == 0) lddq = h * d;
   if (lddk == 0) lddk = h * d;
   if (lddv == 0) lddv = h * d;
@@ -1003,8 +1017,10 @@ CODA_API int coda_mha_bwd_f32(const float *q, const float *k, const float *v, co
     return CODA_EINVAL;
   if (b == 0 || (l == 0 && s == 0)) return CODA_OK;
   if (l == 0 || s == 0) return CODA_EINVAL;
-  if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta) return CODA_EINVAL;
+  if (!q || !k || !v || !out || !lse || !dout || !delta) return CODA_EINVAL;
+  if (((parts & 4) && !dq) || ((parts & 2) && (!dk || !dv))) return CODA_EINVAL;
   MhaBwdParams p;
+  p.parts = parts;
   p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.dout = dout; p.mask = mask;
   p.dq = dq; p.dk = dk; p.dv = dv; p.delta = delta;
   p.b = b; p.h = h; p.l = l; p.s = s;

@@ -79,6 +79,7 @@ struct MhaBwdParams {
   float scale, inv_keep;
   uint32_t thresh16, seed;
   const uint64_t *seed_dev;
+  int parts = 7;  // which launches a backward call issues: 1 = delta, 2 = dK/dV, 4 = dQ (host-side only)
 };
 
 

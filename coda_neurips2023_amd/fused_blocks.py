@@ -9,6 +9,8 @@ hand-written backward that follows the layer's data flow, models/transformer.py:
 558-594), which removes the per-block graph bookkeeping.  Values and gradients are those of
 the chained blocks (the parity tests run both, ``CODA_LAYER_NODES=ops`` selects the chain).
 """
+import os
+
 import torch
 
 from . import gemm
@@ -223,6 +225,21 @@ def encoder_layer(layer, pend, pos, mask):
 _NP = 18  # parameters per decoder layer, in the order built by `decoder_stack` below
 
 
+# CODA_DKV_STREAM=1: cross-attention dK/dV of every layer on a side stream (only dQ is on the dependency chain of
+# the decoder's backward).  Measured and left OFF: 18.9-19.1 ms/step against 18.5-18.6 in line -- the big kernel
+# competes with the chain's launch-sized kernels for CUs and the per-layer event pair costs more than the idle
+# slots it fills (same-box A/B).
+DKV_SIDE_STREAM = os.environ.get("CODA_DKV_STREAM", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 def _colsum_vec(x2):
     out = torch.empty(x2.shape[1], dtype=torch.float32, device=x2.device)
     _colsum_into(out, x2.unsqueeze(0))
@@ -314,6 +331,9 @@ class _DecoderStack(torch.autograd.Function):
         ds_next = None
         dqpos = None
         defer = gemm.DeferredWeightGrads()  # the layers' weight gradients: one grouped launch after the loop
+        side = _side_stream(dev) if DKV_SIDE_STREAM else None
+        main = torch.cuda.current_stream(dev) if side is not None else None
+        held = []
         for l in range(nl - 1, -1, -1):
             g1, b1n, in1, ib1, ow1, ob1, g2, b2n, in2, ib2, ow2, ob2, g3, b3n, w1, fb1, w2, fb2 = layers[l]
             c1, c2, c3, (xq2, q, attn, lse, seed, seed_dev), c5, ffn_saved, cn = ctx.blocks[l]
@@ -330,12 +350,26 @@ class _DecoderStack(torch.autograd.Function):
             dattn = gemm.mm(da2_2, ow2)
             dq = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
             delta = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
-            _lib.check(lib.coda_mha_bwd_f32(q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e,
-                                            mask_ptr, attn.data_ptr(), lse.data_ptr(), dattn.data_ptr(), dq.data_ptr(),
-                                            dk_all.data_ptr() + 4 * l * e, dv_all.data_ptr() + 4 * l * e, delta.data_ptr(),
-                                            bsz, nheads, nq, ns, d, e, ld_kv, ld_kv, 0, ld_kv, ld_kv, scale, p_attn, seed,
-                                            seed_dev.data_ptr() if seed_dev is not None else None,
-                                            _lib.current_stream_handle()), "mha_bwd")
+            bwd_args = (q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e, mask_ptr,
+                        attn.data_ptr(), lse.data_ptr(), dattn.data_ptr())
+            bwd_dims = (bsz, nheads, nq, ns, d, e, ld_kv, ld_kv, 0, ld_kv, ld_kv, scale, p_attn, seed,
+                        seed_dev.data_ptr() if seed_dev is not None else None)
+            dkv_ptrs = (dk_all.data_ptr() + 4 * l * e, dv_all.data_ptr() + 4 * l * e)
+            if side is None:
+                _lib.check(lib.coda_mha_bwd_f32(*bwd_args, dq.data_ptr(), *dkv_ptrs, delta.data_ptr(), *bwd_dims,
+                                                _lib.current_stream_handle()), "mha_bwd")
+            else:
+                # only dQ is on the dependency chain of this backward; dK / dV of every layer are consumed after
+                # the loop.  delta + dQ run here, the dK/dV kernel on the side stream behind an event, where it
+                # fills the CUs that the chain of launch-sized kernels below leaves idle.
+                _lib.check(lib.coda_mha_bwd_parts_f32(*bwd_args, dq.data_ptr(), None, None, delta.data_ptr(),
+                                                      *bwd_dims, 1 | 4, _lib.current_stream_handle()), "mha_bwd dq")
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                _lib.check(lib.coda_mha_bwd_parts_f32(*bwd_args, None, *dkv_ptrs, delta.data_ptr(), *bwd_dims, 2,
+                                                      side.cuda_stream), "mha_bwd dkv")
+                held.append((dattn, delta))  # read by the side stream: freed only after the join below
             defer.add(din2_all[l, :e], dq, xq2)
             _colsum_into(dib2_all[l, :e], dq.unsqueeze(0), defer)
             dxq = gemm.mm(dq, in2[:e]).view(nq, bsz, e)
@@ -351,6 +385,9 @@ class _DecoderStack(torch.autograd.Function):
             grads[_NP * l:_NP * (l + 1)] = [g[4], g[5], din1, dib1, dow1, dob1, dg2, db2n, din2_all[l], dib2_all[l],
                                             dow2, dob2, dg3, db3n, dw1, dfb1, dw2, dfb2]
         defer.flush()
+        if side is not None:
+            main.wait_stream(side)
+            held.clear()
         # memory side of all layers at once
         dmp2 = gemm.mm(dk_all, wk_all)
         dmem2 = gemm.mm(dv_all, wv_all)

@@ -58,6 +58,18 @@ int coda_mha_bwd_f32(const float *q, const float *k, const float *v,
                      int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
                      float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *stream);
 
+/* The same backward, issued in parts: bit 0 = the delta pre-pass (rowsum(dout * out) -> `delta`), bit 1 = the
+ * dK/dV kernel, bit 2 = the dQ kernel (7 = coda_mha_bwd_f32).  dK/dV and dQ both read `delta`; a caller that
+ * needs dQ first (the decoder's cross-attention: only dQ is on the dependency chain of its backward, dK/dV of all
+ * layers are consumed at the very end) issues parts 1|4 on its stream and part 2 on a second stream behind an
+ * event.  Outputs of the parts not requested may be NULL. */
+int coda_mha_bwd_parts_f32(const float *q, const float *k, const float *v,
+                           const uint8_t *mask, const float *out, const float *lse,
+                           const float *dout, float *dq, float *dk, float *dv,
+                           float *delta, int b, int h, int l, int s, int d, int ldq,
+                           int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                           float dropout_p, uint64_t seed, const uint64_t *seed_dev, int parts, void *stream);
+
 /* MFMA operand type of the two entry points above (process-wide, like the distance mode of
  * coda_pointnet2.h): 0 = fp32 operands (v_mfma_f32_32x32x2_f32, default), 1 = bf16 operands
  * (v_mfma_f32_32x32x16_bf16): Q, K, V, dO and the probabilities are rounded to bf16 on their way
