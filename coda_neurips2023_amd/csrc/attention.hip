@@ -107,12 +107,14 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
 
   float qf[HD];
+  const float qscale = p.scale * kLog2e;
 #pragma unroll
   for (int c = 0; c < HD; c += 4) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (myq < p.l)
       t = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
-    qf[c] = t.x * p.scale; qf[c + 1] = t.y * p.scale; qf[c + 2] = t.z * p.scale; qf[c + 3] = t.w * p.scale;
+    // scale * log2(e) folded into Q: S, the running maximum and lse are kept in log2 units (exp2 without a multiply)
+    qf[c] = t.x * qscale; qf[c + 1] = t.y * qscale; qf[c + 2] = t.z * qscale; qf[c + 3] = t.w * qscale;
   }
 
   f32x16 o[NT];
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     // lazy rescale: once the running row maxima have settled no lane changes its maximum and the
     // accumulators (AGPRs: a rescale costs a read-modify-write of all of them) are left alone
     if (__ballot(m_new != m) != 0ull) {
-      const float alpha = fast_exp2((m - m_safe) * kLog2e);
+      const float alpha = fast_exp2(m - m_safe);
       lsum *= alpha;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      pr[r] = fast_exp2((pr[r] - m_safe) * kLog2e);
+      pr[r] = fast_exp2(pr[r] - m_safe);
       rs += pr[r];
     }
     lsum += rs;
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {  // keys crow(r), crow(r)+1: one aligned pair
         const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
-        pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] * p.inv_keep : 0.f;
-        pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] * p.inv_keep : 0.f;
+        pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] : 0.f;  // 1 / (1 - p) is applied once, to the output row
+        pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] : 0.f;
       }
     }
 
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     float m_all = m;
     for (int ww = 1; ww < QW; ++ww) m_all = fmaxf(m_all, s_dyn[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
     const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
-    const float f0 = fast_exp2((m - m_ref) * kLog2e);
+    const float f0 = fast_exp2(m - m_ref);
     lsum *= f0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       for (int r = 0; r < 16; ++r) o[t][r] *= f0;
     for (int ww = 1; ww < QW; ++ww) {
       const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
-      const float fw = fast_exp2((sl[(NT * 16) * kWave + lane] - m_ref) * kLog2e);
+      const float fw = fast_exp2(sl[(NT * 16) * kWave + lane] - m_ref);
       lsum += sl[(NT * 16 + 1) * kWave + lane] * fw;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     m = m_all;
   }
   if (myq < p.l) {
-    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    const float inv = lsum > 0.f ? p.inv_keep / lsum : 0.f;
     float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -294,7 +296,186 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       }
     }
     if (half == 0)
-      p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m + __logf(lsum) : -INFINITY;
+      p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m * kLn2 + __logf(lsum) : -INFINITY;
+  }
+}
+
+// Long-sequence forward with the S tile of the NEXT key block already in flight: a wave issues the 32 MFMAs of
+// S_{t+1} = K_{t+1} Q^T before it starts the soft-max arithmetic of S_t, so its own VALU work (exp2, dropout hash,
+// rescale) runs under MFMAs of its own instead of leaving the matrix pipe to the other wave of the SIMD only.
+// Same staging as mha_fwd_kernel<D,4,false,false,true> (two 32-key tiles per stage, double buffered), but the
+// next stage is written to LDS in the MIDDLE of a stage -- between two barriers after its first tile -- so that
+// the prefetched S of a stage's second tile can read the next stage's first K tile.  No mask, L % 32 == 0,
+// S % 64 == 0 (host-checked).
+template <int D>
+__global__ __launch_bounds__(256) void mha_fwd_pipe_kernel(MhaParams p) {
+  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = 256, TILES = 2;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = (th.tile * 4 + w) * kTile;
+  const int myq = q0 + l31;
+  const bool wave_active = q0 < p.l;  // wave-uniform
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float qf[HD];
+  const float qscale = p.scale * kLog2e;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (myq < p.l)
+      t = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
+    // scale * log2(e) folded into Q: S, the running maximum and lse are kept in log2 units (exp2 without a multiply)
+    qf[c] = t.x * qscale; qf[c + 1] = t.y * qscale; qf[c + 2] = t.z * qscale; qf[c + 3] = t.w * qscale;
+  }
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
+
+  constexpr int kStageFloats = 2 * TILES * kTile * LS;  // one K + V stage
+  constexpr int NLD = TILES * kTile * D / 4 / THREADS;
+  constexpr int FROWS = TILES * kTile;
+  float4 rk[NLD], rv[NLD];
+
+  auto qk = [&](const float *tk) {  // S^T tile: sacc[r] = scale * <q[myq], k[crow(r, half)]>
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kf = *reinterpret_cast<const float4 *>(tk + l31 * LS + half * HD + c);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c + 1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c + 2], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c + 3], sacc, 0, 0, 0);
+    }
+    return sacc;
+  };
+  // soft-max + P V of the tile whose S is `sacc`; `next_k` (may be null): K tile whose S is computed meanwhile.
+  // The MFMAs of the next S are issued in the SAME basic block as the exp2 / dropout arithmetic and interleaved
+  // with it (one MFMA, then a few VALU instructions: a wave issues in order, so a block of 32 chained MFMAs in
+  // front of the VALU code would simply be waited out).
+  auto softmax_pv = [&](const f32x16 &sacc, int s0, const float *tv, const float *next_k) {
+    float pr[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = sacc[r];
+      tmax = fmaxf(tmax, pr[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    if (__ballot(m_new != m) != 0ull) {  // lazy rescale (see mha_fwd_kernel)
+      const float alpha = fast_exp2(m - m_safe);
+      lsum *= alpha;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m = m_new;
+    }
+    f32x16 s_next = sacc;
+    if (next_k) s_next = qk(next_k);  // wave-uniform
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = fast_exp2(pr[r] - m_safe);
+      rs += pr[r];
+    }
+    lsum += rs;
+    if (use_drop) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
+        pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] : 0.f;  // 1 / (1 - p) is applied once, to the output row
+        pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] : 0.f;
+      }
+    }
+    if (next_k) {
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of the next S
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // six VALU instructions of this tile's soft-max
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float *vrow = tv + crow(r, half) * LS + NT * l31;
+      if (NT == 2) {
+        const float2 vv = *reinterpret_cast<const float2 *>(vrow);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, pr[r], o[1], 0, 0, 0);
+      } else {
+        const float4 vv = *reinterpret_cast<const float4 *>(vrow);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, pr[r], o[1], 0, 0, 0);
+        o[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, pr[r], o[2 % NT], 0, 0, 0);
+        o[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, pr[r], o[3 % NT], 0, 0, 0);
+      }
+    }
+    return s_next;
+  };
+
+  // prologue: stage 0 straight into buffer 0, S of its first tile
+  fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, 0, p.s, tid);
+  fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, 0, p.s, tid);
+  store_tile<D, THREADS, FROWS>(s_dyn, rk, tid);
+  store_tile<D, THREADS, FROWS>(s_dyn + TILES * kTile * LS, rv, tid);
+  __syncthreads();
+  f32x16 s_cur;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
+  if (wave_active) s_cur = qk(s_dyn);
+  int stage = 0;
+  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES, ++stage) {
+    const bool more = sbase + kTile * TILES < p.s;
+    float *bk = s_dyn + (stage & 1) * kStageFloats, *bv = bk + TILES * kTile * LS;
+    float *nk = s_dyn + ((stage + 1) & 1) * kStageFloats;
+    if (more) {  // next stage: in flight during this stage's first tile
+      fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, sbase + kTile * TILES, p.s, tid);
+      fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, sbase + kTile * TILES, p.s, tid);
+    }
+    if (wave_active) s_cur = softmax_pv(s_cur, sbase, bv, bk + kTile * LS);  // first tile; S of the second ahead
+    __syncthreads();  // every wave is past the previous stage: the other buffer is free
+    if (more) {
+      store_tile<D, THREADS, FROWS>(nk, rk, tid);
+      store_tile<D, THREADS, FROWS>(nk + TILES * kTile * LS, rv, tid);
+    }
+    __syncthreads();  // the next stage is visible
+    // second tile; S of the next stage's first tile ahead of it
+    if (wave_active) s_cur = softmax_pv(s_cur, sbase + kTile, bv + kTile * LS, more ? nk : nullptr);
+  }
+
+  lsum += __shfl_xor(lsum, 32);
+  if (myq < p.l) {
+    const float inv = lsum > 0.f ? p.inv_keep / lsum : 0.f;
+    float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dv = NT * crow(r, half);
+      if (NT == 2) {
+        *reinterpret_cast<float2 *>(orow + dv) = make_float2(o[0][r] * inv, o[1][r] * inv);
+      } else {
+        *reinterpret_cast<float4 *>(orow + dv) =
+            make_float4(o[0][r] * inv, o[1][r] * inv, o[2 % NT][r] * inv, o[3 % NT][r] * inv);
+      }
+    }
+    if (half == 0)
+      p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m * kLn2 + __logf(lsum) : -INFINITY;
   }
 }
 
@@ -382,7 +563,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   auto fetch_rows = [&](int qb) {  // lse / delta of the stage's queries: one value per thread
     if (tid < kTile * QT) {
       const int qq = qb + tid;
-      r_lse = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+      r_lse = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] * kLog2e : 0.f;  // log2 units
       r_delta = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
     }
   };
@@ -404,7 +585,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
       load_tile<D, THREADS, kTile * QT>(s_do, p.dout + head_off, rstride, qbase0, p.l, tid);
       if (tid < kTile * QT) {
         const int qq = qbase0 + tid;
-        s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+        s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] * kLog2e : 0.f;
         s_delta[tid] = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
       }
       __syncthreads();
@@ -445,17 +626,18 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     }
     // lane: key = mykey, register r: query q0 + crow(r, half)
     float pd[16], ds[16];
+    const float sscale = p.scale * kLog2e;
     constexpr bool plain = !GEN;  // no mask, L and S multiples of the tile
     if (plain) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = crow(r, half);
-        const float prob = fast_exp2((sacc[r] * p.scale - t_lse[qi]) * kLog2e);  // lse = -inf cannot occur here
+        const float prob = fast_exp2(sacc[r] * sscale - t_lse[qi]);  // one fma; lse = -inf cannot occur here
         float keep = 1.f;
         if (use_drop)
           keep = drop_keep(drop_hash(dconst, q0 + qi, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
         pd[r] = prob * keep;
-        ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
+        ds[r] = prob * (pacc[r] * keep - t_delta[qi]);  // * scale: once, on the dK rows
       }
     } else {
 #pragma unroll
@@ -464,11 +646,11 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
         bool dead = qq >= p.l || mykey >= p.s;
         if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
         const float lse = t_lse[qi];
-        float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
+        float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] * sscale - lse);
         float keep = 1.f;
         if (use_drop) keep = drop_keep(drop_hash(dconst, qq, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
         pd[r] = prob * keep;
-        ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
+        ds[r] = prob * (pacc[r] * keep - t_delta[qi]);  // * scale: once, on the dK rows
       }
     }
     // dV^T? no: dV[key][dv] += sum_q Pd[q][key] dO[q][dv]  (A = Pd^T: lane = key, k = query)
@@ -547,10 +729,11 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
         float *dkrow = p.dk + (static_cast<size_t>(key) * p.b + bi) * p.lddk + hi * D + NT * l31;
         float *dvrow = p.dv + (static_cast<size_t>(key) * p.b + bi) * p.lddv + hi * D + NT * l31;
         if (NT == 2) {
-          *reinterpret_cast<float2 *>(dkrow) = make_float2(dk[0][r], dk[1][r]);
+          *reinterpret_cast<float2 *>(dkrow) = make_float2(dk[0][r] * p.scale, dk[1][r] * p.scale);
           *reinterpret_cast<float2 *>(dvrow) = make_float2(dv[0][r], dv[1][r]);
         } else {
-          *reinterpret_cast<float4 *>(dkrow) = make_float4(dk[0][r], dk[1][r], dk[2 % NT][r], dk[3 % NT][r]);
+          *reinterpret_cast<float4 *>(dkrow) = make_float4(dk[0][r] * p.scale, dk[1][r] * p.scale, dk[2 % NT][r] * p.scale,
+                                                             dk[3 % NT][r] * p.scale);
           *reinterpret_cast<float4 *>(dvrow) = make_float4(dv[0][r], dv[1][r], dv[2 % NT][r], dv[3 % NT][r]);
         }
       }
@@ -588,6 +771,7 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
 
   float qf[HD], gf[HD];
+  const float qscale = p.scale * kLog2e;
 #pragma unroll
   for (int c = 0; c < HD; c += 4) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), g = a;
@@ -595,12 +779,13 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
       a = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
       g = *reinterpret_cast<const float4 *>(p.dout + static_cast<size_t>(myq) * rstride + head_off + half * HD + c);
     }
-    qf[c] = a.x * p.scale; qf[c + 1] = a.y * p.scale; qf[c + 2] = a.z * p.scale; qf[c + 3] = a.w * p.scale;
+    // scale * log2(e) folded into Q (S in log2 units, as in the forward)
+    qf[c] = a.x * qscale; qf[c + 1] = a.y * qscale; qf[c + 2] = a.z * qscale; qf[c + 3] = a.w * qscale;
     gf[c] = g.x; gf[c + 1] = g.y; gf[c + 2] = g.z; gf[c + 3] = g.w;
   }
   float lse = 0.f, delta = 0.f;
   if (myq < p.l) {
-    lse = p.lse[static_cast<size_t>(bh) * p.l + myq];
+    lse = p.lse[static_cast<size_t>(bh) * p.l + myq] * kLog2e;  // log2 units
     delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
   }
   // rows past the end or without any admissible key: exp2(x - inf) = 0 without a per-element test
@@ -670,10 +855,10 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
           keep0 = drop_keep_lo(hsh, p.thresh16) ? p.inv_keep : 0.f;
           keep1 = drop_keep_hi(hsh, p.thresh16) ? p.inv_keep : 0.f;
         }
-        const float prob0 = fast_exp2((sacc[r] - lse_eff) * kLog2e);
-        const float prob1 = fast_exp2((sacc[r + 1] - lse_eff) * kLog2e);
-        ds[r] = prob0 * (pacc[r] * keep0 - delta) * p.scale;
-        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta) * p.scale;
+        const float prob0 = fast_exp2(sacc[r] - lse_eff);
+        const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
+        ds[r] = prob0 * (pacc[r] * keep0 - delta);  // * scale: once, on the dQ rows
+        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta);
       }
     } else {
 #pragma unroll
@@ -681,10 +866,10 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
         const int key = s0 + crow(r, half);
         bool dead = key >= p.s || myq >= p.l;
         if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
-        const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] - lse) * kLog2e);
+        const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] - lse);
         float keep = 1.f;
         if (use_drop) keep = drop_keep(drop_hash(dconst, myq, p.s, key), key, p.thresh16) ? p.inv_keep : 0.f;
-        ds[r] = prob * (pacc[r] * keep - delta) * p.scale;
+        ds[r] = prob * (pacc[r] * keep - delta);
       }
     }
     // dQ[q][d] += sum_key dS[q][key] K[key][d]   (A = dS: lane = query, k = key)
@@ -739,9 +924,10 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
       if (qq < p.l) {
         float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + NT * l31;
         if (NT == 2) {
-          *reinterpret_cast<float2 *>(row) = make_float2(dq[0][r], dq[1][r]);
+          *reinterpret_cast<float2 *>(row) = make_float2(dq[0][r] * p.scale, dq[1][r] * p.scale);
         } else {
-          *reinterpret_cast<float4 *>(row) = make_float4(dq[0][r], dq[1][r], dq[2 % NT][r], dq[3 % NT][r]);
+          *reinterpret_cast<float4 *>(row) = make_float4(dq[0][r] * p.scale, dq[1][r] * p.scale, dq[2 % NT][r] * p.scale,
+                                                          dq[3 % NT][r] * p.scale);
         }
       }
     }
@@ -822,6 +1008,12 @@ bool double_buffered() {
   return on;
 }
 
+// CODA_ATTN_PIPE=0: long-sequence forward without the S-tile prefetch (A/B)
+bool fwd_pipelined() {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_PIPE"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 template <int D, bool GEN>
 int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
@@ -830,7 +1022,12 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   KernelTimer timer(0, p.l, p.s, s);
   if (p.l >= 1024) {
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
-    if (double_buffered()) {
+    if (!GEN && p.s % (2 * kTile) == 0 && double_buffered() && fwd_pipelined()) {
+      auto kern = mha_fwd_pipe_kernel<D>;
+      int st = set_lds(kern, 4 * kTileBytes);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+    } else if (double_buffered()) {
       auto kern = mha_fwd_kernel<D, 4, false, GEN, true>;
       int st = set_lds(kern, 4 * kTileBytes);
       if (st != CODA_OK) return st;

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
   bf16x8 qf[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c)
-    qf[c] = load_frag(qbase + static_cast<size_t>(myq < p.l ? myq : 0) * qstride + 16 * c + 8 * half, myq < p.l, p.scale);
+    qf[c] = load_frag(qbase + static_cast<size_t>(myq < p.l ? myq : 0) * qstride + 16 * c + 8 * half, myq < p.l,
+                       p.scale * kLog2e);  // S, running maximum and lse in log2 units (exp2 without a multiply)
 
   f32x16 o[NT];
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       const float m_new = fmaxf(m, tmax);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
       if (__ballot(m_new != m) != 0ull) {  // lazy rescale (see attention.hip)
-        const float alpha = fast_exp2((m - m_safe) * kLog2e);
+        const float alpha = fast_exp2(m - m_safe);
         lsum *= alpha;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pr[r] = fast_exp2((pr[r] - m_safe) * kLog2e);
+        pr[r] = fast_exp2(pr[r] - m_safe);
         rs += pr[r];
       }
       lsum += rs;
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
-          pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] * p.inv_keep : 0.f;
-          pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] * p.inv_keep : 0.f;
+          pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] : 0.f;  // 1 / (1 - p): once, on the output row
+          pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] : 0.f;
         }
       }
       // O^T[dv][q] += sum_key V[key][dv] P[q][key]:  A = V^T (transposed tile), B = P^T (registers)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
     float m_all = m;
     for (int ww = 1; ww < NW; ++ww) m_all = fmaxf(m_all, s_f[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
     const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
-    const float f0 = fast_exp2((m - m_ref) * kLog2e);
+    const float f0 = fast_exp2(m - m_ref);
     lsum *= f0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       for (int r = 0; r < 16; ++r) o[t][r] *= f0;
     for (int ww = 1; ww < NW; ++ww) {
       const float *sl = s_f + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
-      const float fw = fast_exp2((sl[(NT * 16) * kWave + lane] - m_ref) * kLog2e);
+      const float fw = fast_exp2(sl[(NT * 16) * kWave + lane] - m_ref);
       lsum += sl[(NT * 16 + 1) * kWave + lane] * fw;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
   }
   if (myq < p.l) {
     // o[t][r]: head-dim component 32t + crow(r, half) of query myq -> registers 4g..4g+3 are 4 consecutive floats
-    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    const float inv = lsum > 0.f ? p.inv_keep / lsum : 0.f;
     float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4 *>(orow + 32 * t + 8 * g + 4 * half) =
             make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
-    if (half == 0) p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m + __logf(lsum) : -INFINITY;
+    if (half == 0) p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m * kLn2 + __logf(lsum) : -INFINITY;
   }
 }
 
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
   auto fetch_rows = [&](int qb) {
     if (tid < kTile * QT) {
       const int qq = qb + tid;
-      r_lse = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+      r_lse = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] * kLog2e : 0.f;  // log2 units
       r_delta = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
     }
   };
@@ -378,22 +379,23 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
       }
       // lane: key = mykey; register r: query q0 + crow(r, half)
       float pd[16], ds[16];
+      const float sscale = p.scale * kLog2e;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = crow(r, half), qq = q0 + qi;
         const float lse = t_lse[qi];
         float prob;
         if (!GEN) {
-          prob = fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
+          prob = fast_exp2(sacc[r] * sscale - lse);  // one fma
         } else {
           bool dead = qq >= p.l || mykey >= p.s;
           if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
-          prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] * p.scale - lse) * kLog2e);
+          prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] * sscale - lse);
         }
         float keep = 1.f;
         if (use_drop) keep = drop_keep(drop_hash(dconst, qq, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
         pd[r] = prob * keep;
-        ds[r] = prob * (pacc[r] * keep - t_delta[qi]) * p.scale;
+        ds[r] = prob * (pacc[r] * keep - t_delta[qi]);  // * scale: once, on the dK rows
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
         float *dvrow = p.dv + (static_cast<size_t>(key) * p.b + bi) * p.lddv + hi * D + l31;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          dkrow[32 * t] = dk[t][r];
+          dkrow[32 * t] = dk[t][r] * p.scale;
           dvrow[32 * t] = dv[t][r];
         }
       }
@@ -483,12 +485,12 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     const size_t row = static_cast<size_t>(myq < p.l ? myq : 0);
-    qf[c] = load_frag(qbase + row * qstride + 16 * c + 8 * half, myq < p.l, p.scale);
+    qf[c] = load_frag(qbase + row * qstride + 16 * c + 8 * half, myq < p.l, p.scale * kLog2e);
     gf[c] = load_frag(p.dout + row * rstride + head_off + 16 * c + 8 * half, myq < p.l, 1.0f);
   }
   float lse = 0.f, delta = 0.f;
   if (myq < p.l) {
-    lse = p.lse[static_cast<size_t>(bh) * p.l + myq];
+    lse = p.lse[static_cast<size_t>(bh) * p.l + myq] * kLog2e;  // log2 units
     delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
   }
   const float lse_eff = (myq < p.l && lse != -INFINITY) ? lse : INFINITY;  // exp2(x - inf) = 0 kills empty rows
@@ -531,10 +533,10 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
             keep0 = drop_keep_lo(hsh, p.thresh16) ? p.inv_keep : 0.f;
             keep1 = drop_keep_hi(hsh, p.thresh16) ? p.inv_keep : 0.f;
           }
-          const float prob0 = fast_exp2((sacc[r] - lse_eff) * kLog2e);
-          const float prob1 = fast_exp2((sacc[r + 1] - lse_eff) * kLog2e);
-          ds[r] = prob0 * (pacc[r] * keep0 - delta) * p.scale;
-          ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta) * p.scale;
+          const float prob0 = fast_exp2(sacc[r] - lse_eff);
+          const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
+          ds[r] = prob0 * (pacc[r] * keep0 - delta);  // * scale: once, on the dQ rows
+          ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta);
         }
       } else {
 #pragma unroll
@@ -542,10 +544,10 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
           const int key = s0 + crow(r, half);
           bool dead = key >= p.s || myq >= p.l;
           if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
-          const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2((sacc[r] - lse) * kLog2e);
+          const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] - lse);
           float keep = 1.f;
           if (use_drop) keep = drop_keep(drop_hash(dconst, myq, p.s, key), key, p.thresh16) ? p.inv_keep : 0.f;
-          ds[r] = prob * (pacc[r] * keep - delta) * p.scale;
+          ds[r] = prob * (pacc[r] * keep - delta);
         }
       }
       // dQ[q][d] += sum_key dS[q][key] K[key][d]:  A = dS (registers), B = K (transposed tile)
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       if (qq < p.l) {
         float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + l31;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) row[32 * t] = dq[t][r];
+        for (int t = 0; t < NT; ++t) row[32 * t] = dq[t][r] * p.scale;
       }
     }
   }

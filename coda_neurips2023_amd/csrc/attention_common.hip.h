@@ -9,16 +9,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 32;  // keys (or queries) per MFMA tile
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// Counter-based dropout, identical in forward and backward: one 32-bit hash (lowbias32) of
-// (seed, b*h, query, key >> 1) serves the two keys of an aligned pair, 16 bits each, so the
-// kernels whose lanes hold a query and whose registers hold consecutive keys (forward, dQ) pay
-// one hash per two probabilities.
+// Counter-based dropout, identical in forward and backward: one 32-bit hash of (seed, b*h, query, key >> 1)
+// serves the two keys of an aligned pair, 16 bits each, so the kernels whose lanes hold a query and whose
+// registers hold consecutive keys (forward, dQ) pay one hash per two probabilities.
+// The mixer is two rounds of (24-bit multiply-add, xor-shift): eight FULL-RATE integer instructions.  fp32 MFMAs
+// and VALU instructions do not overlap on this part (tools/mfma_valu_probe.hip: a wave pair takes the SUM of its
+// MFMA and VALU times), so every VALU slot of the soft-max is paid in full; the previous lowbias32 mixer spent 14
+// slots, 8 of them in two quarter-rate v_mul_lo_u32.  Keep rate, adjacent-key / adjacent-query / cross-head /
+// cross-seed correlations and row / column rate spreads are indistinguishable from lowbias32 on 1024 x 2048 grids
+// (development check, tests/test_attention_gpu.py checks rates and determinism on the device).
 __device__ __forceinline__ uint32_t drop_hash(uint32_t c, uint32_t q, uint32_t s_len, uint32_t key) {
   uint32_t x = (q * s_len + (key & ~1u)) ^ c;
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  x = __umul24(x, 0xD2B74Fu) + (x >> 8);
+  x ^= x >> 15;
+  x = __umul24(x, 0xC2B2AFu) + (x >> 11);
+  x ^= x >> 14;
   return x;
 }
 __device__ __forceinline__ uint32_t drop_const(uint32_t seed, uint32_t bh) { return (bh * 0x9E3779B9u) ^ seed ^ (bh << 27); }
