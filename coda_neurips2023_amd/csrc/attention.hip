@@ -1008,9 +1008,12 @@ bool double_buffered() {
   return on;
 }
 
-// CODA_ATTN_PIPE=0: long-sequence forward without the S-tile prefetch (A/B)
+// CODA_ATTN_PIPE=1: long-sequence forward with the S tile of the next key block issued ahead of the soft-max
+// (mha_fwd_pipe_kernel).  Measured equal (351 vs 349 us on 2048 x 2048): fp32 MFMAs and VALU instructions do
+// not execute concurrently on a SIMD of this part (tools/mfma_valu_probe.hip), so interleaving them inside a
+// wave buys nothing over the two-waves-per-SIMD overlap the plain kernel already has.  Off by default.
 bool fwd_pipelined() {
-  static const bool on = [] { const char *e = getenv("CODA_ATTN_PIPE"); return !e || atoi(e) != 0; }();
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_PIPE"); return e && atoi(e) != 0; }();
   return on;
 }
 
