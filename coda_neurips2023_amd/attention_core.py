@@ -19,14 +19,15 @@ from . import _lib
 
 
 def set_mfma_dtype(dtype):
-    """'fp32' (default) or 'bf16': operand type of the matrix-core products inside the fused attention
-    kernels (coda_mha_set_mfma_dtype, include/coda_attention.h).  Tensors stay float32 either way."""
-    code = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(dtype).replace("torch.", "")]
+    """'fp32' (default), 'bf16' or 'bf16x3': operand type of the matrix-core products inside the fused attention
+    kernels (coda_mha_set_mfma_dtype, include/coda_attention.h).  Tensors stay float32 in every mode; 'bf16x3'
+    carries each fp32 operand as three bf16 pieces and gives fp32-level results on the bf16 matrix cores."""
+    code = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x3": 2, "x3": 2}[str(dtype).replace("torch.", "")]
     _lib.check(_lib.load().coda_mha_set_mfma_dtype(code), "coda_mha_set_mfma_dtype")
 
 
 def get_mfma_dtype():
-    return "bf16" if _lib.load().coda_mha_get_mfma_dtype() == 1 else "fp32"
+    return ("fp32", "bf16", "bf16x3")[_lib.load().coda_mha_get_mfma_dtype()]
 
 
 def merge_masks(attn_mask, key_padding_mask, bsz, h, tgt_len, src_len):

@@ -25,6 +25,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace coda {
@@ -1064,7 +1065,10 @@ int mfma_dtype() {
   int v = g_mfma_dtype.load(std::memory_order_relaxed);
   if (v < 0) {
     const char *e = getenv("CODA_ATTN_DTYPE");
-    v = (e && (e[0] == 'b' || e[0] == '1')) ? 1 : 0;
+    // "bf16" / "1": bf16 operands; "bf16x3" / "x3" / "2": three bf16 pieces per fp32 operand (fp32-level results)
+    v = 0;
+    if (e && (e[0] == '2' || e[0] == 'x' || (e[0] == 'b' && strstr(e, "x3")))) v = 2;
+    else if (e && (e[0] == 'b' || e[0] == '1')) v = 1;
     g_mfma_dtype.store(v, std::memory_order_relaxed);
   }
   return v;
@@ -1076,6 +1080,11 @@ int launch_fwd(const MhaParams &p, hipStream_t s) {
   if (mfma_dtype() == 1) {
     KernelTimer timer(0, p.l, p.s, s);
     const int st = mha_fwd_bf16(p, D, s);
+    return st != CODA_OK ? st : launch_status();
+  }
+  if (mfma_dtype() == 2 && mha_x3_takes_fwd(p, D)) {
+    KernelTimer timer(0, p.l, p.s, s);
+    const int st = mha_fwd_x3(p, D, s);
     return st != CODA_OK ? st : launch_status();
   }
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
@@ -1160,8 +1169,26 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
     }
     return st != CODA_OK ? st : launch_status();
   }
+  MhaBwdParams rest = p;  // what the fp32-MFMA kernels still have to do
+  rest.parts = p.parts & ~1;
+  if (mfma_dtype() == 2) {
+    int st = CODA_OK;
+    if ((p.parts & 2) && mha_x3_takes_dkv(p, D)) {
+      KernelTimer timer(2, p.l, p.s, s);
+      st = mha_bwd_dkv_x3(p, D, s);
+      rest.parts &= ~2;
+    }
+    if (st != CODA_OK) return st;
+    if ((p.parts & 4) && mha_x3_takes_dq(p, D)) {
+      KernelTimer timer(3, p.l, p.s, s);
+      st = mha_bwd_dq_x3(p, D, s);
+      rest.parts &= ~4;
+    }
+    if (st != CODA_OK) return st;
+  }
+  if (!(rest.parts & 6)) return launch_status();
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
-  return gen ? launch_bwd_g<D, true>(p, s) : launch_bwd_g<D, false>(p, s);
+  return gen ? launch_bwd_g<D, true>(rest, s) : launch_bwd_g<D, false>(rest, s);
 }
 
 }  // namespace
@@ -1237,7 +1264,7 @@ CODA_API int coda_mha_bwd_parts_f32(const float *q, const float *k, const float 
 }
 
 CODA_API int coda_mha_set_mfma_dtype(int dtype) {
-  if (dtype != 0 && dtype != 1) return CODA_EINVAL;
+  if (dtype < 0 || dtype > 2) return CODA_EINVAL;
   coda::g_mfma_dtype.store(dtype, std::memory_order_relaxed);
   return CODA_OK;
 }

@@ -55,39 +55,95 @@ __device__ __forceinline__ bf16x8 cvt8(float a, float b, float c, float d, float
        arr[8 * (jj) + 5], arr[8 * (jj) + 6], arr[8 * (jj) + 7])
 __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+// NS = 1: operands rounded to bf16 (configs[4]).  NS = 3: every fp32 operand is carried as THREE bf16 pieces
+// x = hi + mid + lo (8 + 8 + 8 significand bits: the fp32 value exactly, each residual is computed without
+// rounding error) and a product a.b is evaluated as the six piece products of order <= 2 -- hi.hi, hi.mid,
+// mid.hi, mid.mid, hi.lo, lo.hi -- into the fp32 accumulator; what is dropped (mid.lo, lo.mid, lo.lo) is
+// <= 2^-24 relative, the size of fp32's own product rounding.  Six bf16 MFMAs cost 6/16 of one fp32 MFMA, and,
+// unlike the fp32 MFMA, they run on the matrix cores next to the soft-max VALU work.
+template <int NS>
+struct Frag {
+  bf16x8 v[NS];
+};
+template <int NS>
+struct Frag4 {
+  bf16x4 v[NS];
+};
+template <int NS>
+__device__ __forceinline__ Frag<NS> split8(f32x8 x) {
+  Frag<NS> f;
+  f.v[0] = __builtin_convertvector(x, bf16x8);
+  if constexpr (NS == 3) {
+    x = x - __builtin_convertvector(f.v[0], f32x8);
+    f.v[1] = __builtin_convertvector(x, bf16x8);
+    x = x - __builtin_convertvector(f.v[1], f32x8);
+    f.v[2] = __builtin_convertvector(x, bf16x8);
+  }
+  return f;
+}
+template <int NS>
+__device__ __forceinline__ Frag4<NS> split4(f32x4 x) {
+  Frag4<NS> f;
+  f.v[0] = __builtin_convertvector(x, bf16x4);
+  if constexpr (NS == 3) {
+    x = x - __builtin_convertvector(f.v[0], f32x4);
+    f.v[1] = __builtin_convertvector(x, bf16x4);
+    x = x - __builtin_convertvector(f.v[1], f32x4);
+    f.v[2] = __builtin_convertvector(x, bf16x4);
+  }
+  return f;
+}
+// registers 8jj .. 8jj+7 of a 16-element accumulator image as an operand
+#define CODA_SPLIT8(NS, arr, jj)                                                                          \
+  split8<NS>(f32x8{arr[8 * (jj)], arr[8 * (jj) + 1], arr[8 * (jj) + 2], arr[8 * (jj) + 3], arr[8 * (jj) + 4], \
+                   arr[8 * (jj) + 5], arr[8 * (jj) + 6], arr[8 * (jj) + 7]})
+
 // Fragment of a transposed tile for k-step jj: row `row` (a head-dim or feature index), the 8 slots of
 // this lane's half (see the header comment).
-template <int D>
-__device__ __forceinline__ bf16x8 read_tr(const unsigned char *tile, int row, int jj, int half) {
+// (`img`: bytes between the hi / mid / lo images of the tile set)
+template <int D, int NS>
+__device__ __forceinline__ Frag<NS> read_tr(const unsigned char *tile, int img, int row, int jj, int half) {
   const unsigned char *p = tile + row * Lay<D>::TS + (16 * jj + 4 * half) * 2;
-  return join(*reinterpret_cast<const bf16x4 *>(p), *reinterpret_cast<const bf16x4 *>(p + 16));
+  Frag<NS> f;
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    f.v[i] = join(*reinterpret_cast<const bf16x4 *>(p + i * img), *reinterpret_cast<const bf16x4 *>(p + i * img + 16));
+  return f;
 }
 // Fragment of a row-major tile for k-step c: row `row`, head-dim components 16c + 8*half .. +7.
-template <int D>
-__device__ __forceinline__ bf16x8 read_rm(const unsigned char *tile, int row, int c, int half) {
-  return *reinterpret_cast<const bf16x8 *>(tile + row * Lay<D>::RS + (16 * c + 8 * half) * 2);
+template <int D, int NS>
+__device__ __forceinline__ Frag<NS> read_rm(const unsigned char *tile, int img, int row, int c, int half) {
+  Frag<NS> f;
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    f.v[i] = *reinterpret_cast<const bf16x8 *>(tile + i * img + row * Lay<D>::RS + (16 * c + 8 * half) * 2);
+  return f;
 }
 // The same fragment straight from an fp32 row in global memory (operands that stay in registers).
-__device__ __forceinline__ bf16x8 load_frag(const float *row, bool valid, float scale) {
+template <int NS>
+__device__ __forceinline__ Frag<NS> load_frag(const float *row, bool valid, float scale) {
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
   if (valid) {
     a = *reinterpret_cast<const float4 *>(row);
     b = *reinterpret_cast<const float4 *>(row + 4);
   }
-  return cvt8(a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale);
+  return split8<NS>(f32x8{a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale,
+                          b.w * scale});
 }
 
 // NTILES tiles of 32 rows x D fp32, fetched by the 256 threads as 4 x 4 blocks (see the header).
 template <int D, int NTILES, int THREADS = kThreads>
 struct Fetch {
-  static constexpr int CB = D / 4, BLK = NTILES * 8 * CB, PER = BLK / THREADS;
-  static_assert(BLK % THREADS == 0, "tile set must split evenly over the workgroup");
+  static constexpr int CB = D / 4, BLK = NTILES * 8 * CB, PER = (BLK + THREADS - 1) / THREADS;
+  static_assert(BLK % THREADS == 0 || BLK < THREADS, "tile set must split evenly over the workgroup");
+  static constexpr bool kPartial = BLK < THREADS;  // one tile, 256 threads: the upper half of the workgroup idles
   float4 v[PER][4];
 
   __device__ __forceinline__ void load(const float *g, size_t gstride, int row0, int nrows, int tid) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int blk = tid + u * THREADS;
+      if (kPartial && blk >= BLK) continue;
       const int tile = blk / (8 * CB), rb = (blk / CB) % 8, cb = blk % CB;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -97,27 +153,41 @@ struct Fetch {
       }
     }
   }
-  __device__ __forceinline__ void store_rm(unsigned char *lds, int tid) const {
+  template <int NS>
+  __device__ __forceinline__ void store_rm(unsigned char *lds, int img, int tid) const {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int blk = tid + u * THREADS;
+      if (kPartial && blk >= BLK) continue;
       const int tile = blk / (8 * CB), rb = (blk / CB) % 8, cb = blk % CB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<bf16x4 *>(lds + tile * Lay<D>::ROWB + (4 * rb + i) * Lay<D>::RS + 8 * cb) =
-            cvt4(v[u][i].x, v[u][i].y, v[u][i].z, v[u][i].w);
+      for (int i = 0; i < 4; ++i) {
+        const Frag4<NS> f = split4<NS>(f32x4{v[u][i].x, v[u][i].y, v[u][i].z, v[u][i].w});
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+          *reinterpret_cast<bf16x4 *>(lds + n * img + tile * Lay<D>::ROWB + (4 * rb + i) * Lay<D>::RS + 8 * cb) = f.v[n];
+      }
     }
   }
-  __device__ __forceinline__ void store_tr(unsigned char *lds, int tid) const {
+  template <int NS>
+  __device__ __forceinline__ void store_tr(unsigned char *lds, int img, int tid) const {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int blk = tid + u * THREADS;
+      if (kPartial && blk >= BLK) continue;
       const int tile = blk / (8 * CB), rb = (blk / CB) % 8, cb = blk % CB;
       unsigned char *base = lds + tile * Lay<D>::TRB + (4 * cb) * Lay<D>::TS + 8 * rb;
-      *reinterpret_cast<bf16x4 *>(base) = cvt4(v[u][0].x, v[u][1].x, v[u][2].x, v[u][3].x);
-      *reinterpret_cast<bf16x4 *>(base + Lay<D>::TS) = cvt4(v[u][0].y, v[u][1].y, v[u][2].y, v[u][3].y);
-      *reinterpret_cast<bf16x4 *>(base + 2 * Lay<D>::TS) = cvt4(v[u][0].z, v[u][1].z, v[u][2].z, v[u][3].z);
-      *reinterpret_cast<bf16x4 *>(base + 3 * Lay<D>::TS) = cvt4(v[u][0].w, v[u][1].w, v[u][2].w, v[u][3].w);
+      const Frag4<NS> fx = split4<NS>(f32x4{v[u][0].x, v[u][1].x, v[u][2].x, v[u][3].x});
+      const Frag4<NS> fy = split4<NS>(f32x4{v[u][0].y, v[u][1].y, v[u][2].y, v[u][3].y});
+      const Frag4<NS> fz = split4<NS>(f32x4{v[u][0].z, v[u][1].z, v[u][2].z, v[u][3].z});
+      const Frag4<NS> fw = split4<NS>(f32x4{v[u][0].w, v[u][1].w, v[u][2].w, v[u][3].w});
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        *reinterpret_cast<bf16x4 *>(base + n * img) = fx.v[n];
+        *reinterpret_cast<bf16x4 *>(base + n * img + Lay<D>::TS) = fy.v[n];
+        *reinterpret_cast<bf16x4 *>(base + n * img + 2 * Lay<D>::TS) = fz.v[n];
+        *reinterpret_cast<bf16x4 *>(base + n * img + 3 * Lay<D>::TS) = fw.v[n];
+      }
     }
   }
 };
@@ -131,18 +201,32 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+template <int NS>
+__device__ __forceinline__ f32x16 mfma_x(const Frag<NS> &a, const Frag<NS> &b, f32x16 c) {
+  if constexpr (NS == 3) {  // smallest contributions first
+    c = mfma_bf16(a.v[0], b.v[2], c);
+    c = mfma_bf16(a.v[2], b.v[0], c);
+    c = mfma_bf16(a.v[1], b.v[1], c);
+    c = mfma_bf16(a.v[1], b.v[0], c);
+    c = mfma_bf16(a.v[0], b.v[1], c);
+  }
+  return mfma_bf16(a.v[0], b.v[0], c);
+}
 
 // ---------------------------------------------------------------------------------------------- forward
 // SPLIT = false: wave w owns queries (tile*4 + w)*32 .. +31 and walks all 4 key tiles of a stage.
 // SPLIT = true:  the 4 waves share 32 queries, wave w takes key tile w of every stage; the partial
 //                (m, l, O) are merged through LDS (decoder shapes: 256 / 512 queries).
-template <int D, bool SPLIT, bool GEN, int NW = 4>
-__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_fwd_bf16_kernel(MhaParams p) {
+template <int D, bool SPLIT, bool GEN, int NW = 4, int NS = 1>
+__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPLIT) ? 2 : 1)) void mha_fwd_bf16_kernel(MhaParams p) {
   using L = Lay<D>;
-  constexpr int NT = D / 32, KC = D / 16, TILES = NW;  // SPLIT: one key tile per wave per stage
+  // SPLIT: one key tile per wave per stage; three-piece operands: two tiles per stage keep the long-sequence
+  // kernel at 55 KB of LDS (two workgroups per CU)
+  constexpr int NT = D / 32, KC = D / 16, TILES = (NS == 3 && !SPLIT) ? 2 : NW;
   static_assert(SPLIT || NW == 4, "the long-sequence kernel runs 4 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *s_k = smem, *s_vt = smem + TILES * L::ROWB;
+  constexpr int IMG_K = TILES * L::ROWB, IMG_V = TILES * L::TRB;
+  unsigned char *s_k = smem, *s_vt = smem + NS * IMG_K;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
@@ -159,11 +243,11 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
   const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
 
-  bf16x8 qf[KC];
+  Frag<NS> qf[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c)
-    qf[c] = load_frag(qbase + static_cast<size_t>(myq < p.l ? myq : 0) * qstride + 16 * c + 8 * half, myq < p.l,
-                       p.scale * kLog2e);  // S, running maximum and lse in log2 units (exp2 without a multiply)
+    qf[c] = load_frag<NS>(qbase + static_cast<size_t>(myq < p.l ? myq : 0) * qstride + 16 * c + 8 * half, myq < p.l,
+                           p.scale * kLog2e);  // S, running maximum and lse in log2 units (exp2 without a multiply)
 
   f32x16 o[NT];
 #pragma unroll
@@ -177,8 +261,8 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
   fv.load(vbase, vstride, 0, p.s, tid);
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
     __syncthreads();
-    fk.store_rm(s_k, tid);
-    fv.store_tr(s_vt, tid);
+    fk.template store_rm<NS>(s_k, IMG_K, tid);
+    fv.template store_tr<NS>(s_vt, IMG_V, tid);
     __syncthreads();
     if (sbase + kTile * TILES < p.s) {
       fk.load(kbase, kstride, sbase + kTile * TILES, p.s, tid);
@@ -191,7 +275,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
 
       f32x16 sacc = zero16();
 #pragma unroll
-      for (int c = 0; c < KC; ++c) sacc = mfma_bf16(read_rm<D>(tk, l31, c, half), qf[c], sacc);
+      for (int c = 0; c < KC; ++c) sacc = mfma_x<NS>(read_rm<D, NS>(tk, IMG_K, l31, c, half), qf[c], sacc);
       // sacc[r] = scale * <q[myq], k[s0 + crow(r, half)]>
       float pr[16];
       float tmax = -INFINITY;
@@ -241,9 +325,9 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       // O^T[dv][q] += sum_key V[key][dv] P[q][key]:  A = V^T (transposed tile), B = P^T (registers)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const bf16x8 pb = CODA_CVT8(pr, jj);
+        const Frag<NS> pb = CODA_SPLIT8(NS, pr, jj);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) o[t] = mfma_bf16(read_tr<D>(tv, 32 * t + l31, jj, half), pb, o[t]);
+        for (int t = 0; t < NT; ++t) o[t] = mfma_x<NS>(read_tr<D, NS>(tv, IMG_V, 32 * t + l31, jj, half), pb, o[t]);
       }
     }
   }
@@ -301,13 +385,15 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
 // A wave owns 32 keys (K, V fragments in registers as B operands), query tiles come through LDS in both
 // images (row-major: A operands of S = Q K^T and dP = dO V^T; transposed: B operands of dV = Pd^T dO and
 // dK = dS^T Q).  QSPLIT as in attention.hip: the 4 waves share 32 keys and split the query tiles.
-template <int D, bool QSPLIT, bool GEN>
+template <int D, bool QSPLIT, bool GEN, int NS = 1>
 __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_kernel(MhaBwdParams p) {
   using L = Lay<D>;
-  constexpr int NT = D / 32, KC = D / 16, QT = QSPLIT ? 4 : 2;
+  // three-piece operands: one query tile per stage keeps the kernel at 55 KB of LDS, i.e. two workgroups per CU
+  constexpr int NT = D / 32, KC = D / 16, QT = QSPLIT ? 4 : (NS == 3 ? 1 : 2);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *s_q = smem, *s_do = s_q + QT * L::ROWB, *s_qt = s_do + QT * L::ROWB, *s_dot = s_qt + QT * L::TRB;
-  float *s_lse = reinterpret_cast<float *>(s_dot + QT * L::TRB), *s_delta = s_lse + QT * kTile;
+  constexpr int IMG_R = QT * L::ROWB, IMG_T = QT * L::TRB;
+  unsigned char *s_q = smem, *s_do = s_q + NS * IMG_R, *s_qt = s_do + NS * IMG_R, *s_dot = s_qt + NS * IMG_T;
+  float *s_lse = reinterpret_cast<float *>(s_dot + NS * IMG_T), *s_delta = s_lse + QT * kTile;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
@@ -327,12 +413,12 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
   const float *gbase = p.dout + head_off;
 
-  bf16x8 kf[KC], vf[KC];
+  Frag<NS> kf[KC], vf[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     const size_t row = static_cast<size_t>(mykey < p.s ? mykey : 0);
-    kf[c] = load_frag(kbase + row * kstride + 16 * c + 8 * half, mykey < p.s, 1.0f);
-    vf[c] = load_frag(vbase + row * vstride + 16 * c + 8 * half, mykey < p.s, 1.0f);
+    kf[c] = load_frag<NS>(kbase + row * kstride + 16 * c + 8 * half, mykey < p.s, 1.0f);
+    vf[c] = load_frag<NS>(vbase + row * vstride + 16 * c + 8 * half, mykey < p.s, 1.0f);
   }
   f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -352,10 +438,10 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
   fetch_rows(0);
   for (int qb0 = 0; qb0 < p.l; qb0 += kTile * QT) {
     __syncthreads();
-    fq.store_rm(s_q, tid);
-    fq.store_tr(s_qt, tid);
-    fg.store_rm(s_do, tid);
-    fg.store_tr(s_dot, tid);
+    fq.template store_rm<NS>(s_q, IMG_R, tid);
+    fq.template store_tr<NS>(s_qt, IMG_T, tid);
+    fg.template store_rm<NS>(s_do, IMG_R, tid);
+    fg.template store_tr<NS>(s_dot, IMG_T, tid);
     if (tid < kTile * QT) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
     __syncthreads();
     if (qb0 + kTile * QT < p.l) {
@@ -374,8 +460,8 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
       f32x16 sacc = zero16(), pacc = zero16();
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        sacc = mfma_bf16(read_rm<D>(tq, l31, c, half), kf[c], sacc);
-        pacc = mfma_bf16(read_rm<D>(tdo, l31, c, half), vf[c], pacc);
+        sacc = mfma_x<NS>(read_rm<D, NS>(tq, IMG_R, l31, c, half), kf[c], sacc);
+        pacc = mfma_x<NS>(read_rm<D, NS>(tdo, IMG_R, l31, c, half), vf[c], pacc);
       }
       // lane: key = mykey; register r: query q0 + crow(r, half)
       float pd[16], ds[16];
@@ -399,11 +485,11 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const bf16x8 pa = CODA_CVT8(pd, jj), da = CODA_CVT8(ds, jj);
+        const Frag<NS> pa = CODA_SPLIT8(NS, pd, jj), da = CODA_SPLIT8(NS, ds, jj);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          dv[t] = mfma_bf16(pa, read_tr<D>(tdot, 32 * t + l31, jj, half), dv[t]);
-          dk[t] = mfma_bf16(da, read_tr<D>(tqt, 32 * t + l31, jj, half), dk[t]);
+          dv[t] = mfma_x<NS>(pa, read_tr<D, NS>(tdot, IMG_T, 32 * t + l31, jj, half), dv[t]);
+          dk[t] = mfma_x<NS>(da, read_tr<D, NS>(tqt, IMG_T, 32 * t + l31, jj, half), dk[t]);
         }
       }
     }
@@ -456,13 +542,15 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
 // ---------------------------------------------------------------------------------------------- dQ
 // A wave owns 32 queries (Q, dO fragments in registers as B operands of S^T = K Q^T and dP^T = V dO^T);
 // K comes through LDS in both images (row-major for S^T, transposed for dQ = dS K), V row-major.
-template <int D, bool SPLIT, bool GEN, int NW = 4>
-__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_bwd_dq_bf16_kernel(MhaBwdParams p) {
+template <int D, bool SPLIT, bool GEN, int NW = 4, int NS = 1>
+__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPLIT) ? 2 : 1)) void mha_bwd_dq_bf16_kernel(MhaBwdParams p) {
   using L = Lay<D>;
-  constexpr int NT = D / 32, KC = D / 16, TILES = NW;
+  // three-piece operands: one key tile per stage (41 KB of LDS: three workgroups per CU by LDS, two by registers)
+  constexpr int NT = D / 32, KC = D / 16, TILES = (NS == 3 && !SPLIT) ? 1 : NW;
   static_assert(SPLIT || NW == 4, "the long-sequence kernel runs 4 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *s_k = smem, *s_v = s_k + TILES * L::ROWB, *s_kt = s_v + TILES * L::ROWB;
+  constexpr int IMG_R = TILES * L::ROWB, IMG_T = TILES * L::TRB;
+  unsigned char *s_k = smem, *s_v = s_k + NS * IMG_R, *s_kt = s_v + NS * IMG_R;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
@@ -481,12 +569,12 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
   const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
 
-  bf16x8 qf[KC], gf[KC];
+  Frag<NS> qf[KC], gf[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     const size_t row = static_cast<size_t>(myq < p.l ? myq : 0);
-    qf[c] = load_frag(qbase + row * qstride + 16 * c + 8 * half, myq < p.l, p.scale * kLog2e);
-    gf[c] = load_frag(p.dout + row * rstride + head_off + 16 * c + 8 * half, myq < p.l, 1.0f);
+    qf[c] = load_frag<NS>(qbase + row * qstride + 16 * c + 8 * half, myq < p.l, p.scale * kLog2e);
+    gf[c] = load_frag<NS>(p.dout + row * rstride + head_off + 16 * c + 8 * half, myq < p.l, 1.0f);
   }
   float lse = 0.f, delta = 0.f;
   if (myq < p.l) {
@@ -503,9 +591,9 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
   fv.load(vbase, vstride, 0, p.s, tid);
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
     __syncthreads();
-    fk.store_rm(s_k, tid);
-    fk.store_tr(s_kt, tid);
-    fv.store_rm(s_v, tid);
+    fk.template store_rm<NS>(s_k, IMG_R, tid);
+    fk.template store_tr<NS>(s_kt, IMG_T, tid);
+    fv.template store_rm<NS>(s_v, IMG_R, tid);
     __syncthreads();
     if (sbase + kTile * TILES < p.s) {
       fk.load(kbase, kstride, sbase + kTile * TILES, p.s, tid);
@@ -519,8 +607,8 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       f32x16 sacc = zero16(), pacc = zero16();
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        sacc = mfma_bf16(read_rm<D>(tk, l31, c, half), qf[c], sacc);
-        pacc = mfma_bf16(read_rm<D>(tv, l31, c, half), gf[c], pacc);
+        sacc = mfma_x<NS>(read_rm<D, NS>(tk, IMG_R, l31, c, half), qf[c], sacc);
+        pacc = mfma_x<NS>(read_rm<D, NS>(tv, IMG_R, l31, c, half), gf[c], pacc);
       }
       // lane: query = myq; register r: key s0 + crow(r, half)
       float ds[16];
@@ -553,9 +641,9 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 ? 2 : 1)) void mha_
       // dQ[q][d] += sum_key dS[q][key] K[key][d]:  A = dS (registers), B = K (transposed tile)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const bf16x8 da = CODA_CVT8(ds, jj);
+        const Frag<NS> da = CODA_SPLIT8(NS, ds, jj);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) dq[t] = mfma_bf16(da, read_tr<D>(tkt, 32 * t + l31, jj, half), dq[t]);
+        for (int t = 0; t < NT; ++t) dq[t] = mfma_x<NS>(da, read_tr<D, NS>(tkt, IMG_T, 32 * t + l31, jj, half), dq[t]);
       }
     }
   }
@@ -608,62 +696,82 @@ int raise_lds(K kern, size_t bytes) {
 // short query / key sequences (decoder: 256 or 512 object queries) use the split variants
 constexpr int kSplitBelow = 1024;
 
-template <int D, bool GEN>
+// Which problems the three-piece (NS = 3) kernels take; the others stay with the fp32-MFMA kernels of
+// attention.hip (same fp32-level arithmetic either way, so the two can be mixed inside one backward).
+// Measured on 2048 x 2048 (8 scenes x 4 heads, dropout 0.1; fp32-MFMA kernels: 351 / 646 / 465 us):
+//   forward 270 us, dQ 376 us, dK/dV 786 us.  The six bf16 MFMAs per product are hidden, but splitting the
+//   operands costs ~290 extra VALU instructions per 32-key tile (v_cvt_pk_bf16_f32, widen, subtract, twice) on top
+//   of the soft-max's ~240, so the kernels are VALU-bound at 1.2-1.3x the fp32 kernels instead of the 2.5x the
+//   MFMA arithmetic alone would give; dK/dV (two register-resident operand sets, two split accumulator images
+//   per tile) spills and loses.  Hence: forward and long-sequence dQ only.
+bool x3_takes_fwd(const MhaParams &p) { return p.l >= 1024; }
+bool x3_takes_dkv(const MhaBwdParams &) { return false; }
+bool x3_takes_dq(const MhaBwdParams &p) { return p.l >= 1024; }
+
+template <int D, bool GEN, int NS>
 int fwd_launch(const MhaParams &p, hipStream_t s) {
   using L = Lay<D>;
-  const size_t lds = 4 * (L::ROWB + L::TRB);
   int st;
   if (p.l >= kSplitBelow) {
-    auto kern = mha_fwd_bf16_kernel<D, false, GEN>;
+    const size_t lds = static_cast<size_t>(NS == 3 ? 2 : 4) * NS * (L::ROWB + L::TRB);
+    auto kern = mha_fwd_bf16_kernel<D, false, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
-  } else if (D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
+  } else if (NS == 1 && D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
     // at most one workgroup per CU: 8 waves / 8 key tiles per stage put twice the bytes in flight per CU
     // (measured 64 -> 53 us at 256 x 2048, but 87 -> 101 us at 512 x 2048 where two 4-wave workgroups share a CU)
-    auto kern = mha_fwd_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4)>;
-    if ((st = raise_lds(kern, 2 * lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), 2 * lds, s, p);
+    const size_t lds = 8 * (L::ROWB + L::TRB);
+    auto kern = mha_fwd_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4), 1>;
+    if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
   } else {
-    auto kern = mha_fwd_bf16_kernel<D, true, GEN>;
+    const size_t lds = static_cast<size_t>(4) * NS * (L::ROWB + L::TRB);
+    auto kern = mha_fwd_bf16_kernel<D, true, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
   }
   return CODA_OK;
 }
 
-template <int D, bool GEN>
+template <int D, bool GEN, int NS>
 int dkv_launch(const MhaBwdParams &p, hipStream_t s) {
   using L = Lay<D>;
   int st;
   if (p.s >= kSplitBelow) {
-    const size_t lds = 2 * (2 * L::ROWB + 2 * L::TRB) + sizeof(float) * 2 * kTile * 2;
-    auto kern = mha_bwd_dkv_bf16_kernel<D, false, GEN>;
+    constexpr int QT = NS == 3 ? 1 : 2;
+    const size_t lds = static_cast<size_t>(QT) * NS * (2 * L::ROWB + 2 * L::TRB) + sizeof(float) * 2 * kTile * QT;
+    auto kern = mha_bwd_dkv_bf16_kernel<D, false, GEN, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
   } else {
+    if (NS != 1) return CODA_EINVAL;  // x3_takes_dkv() keeps these shapes away
     const size_t lds = 4 * (2 * L::ROWB + 2 * L::TRB) + sizeof(float) * 2 * kTile * 4;
-    auto kern = mha_bwd_dkv_bf16_kernel<D, true, GEN>;
+    auto kern = mha_bwd_dkv_bf16_kernel<D, true, GEN, 1>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
   }
   return CODA_OK;
 }
 
-template <int D, bool GEN>
+template <int D, bool GEN, int NS>
 int dq_launch(const MhaBwdParams &p, hipStream_t s) {
   using L = Lay<D>;
-  const size_t lds = 4 * (2 * L::ROWB + L::TRB);
   int st;
   if (p.l >= kSplitBelow) {
-    auto kern = mha_bwd_dq_bf16_kernel<D, false, GEN>;
+    const size_t lds = static_cast<size_t>(NS == 3 ? 1 : 4) * NS * (2 * L::ROWB + L::TRB);
+    auto kern = mha_bwd_dq_bf16_kernel<D, false, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+  } else if (NS != 1) {
+    return CODA_EINVAL;  // x3_takes_dq() keeps these shapes away
   } else if (D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
-    auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4)>;
-    if ((st = raise_lds(kern, 2 * lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), 2 * lds, s, p);
+    const size_t lds = 8 * (2 * L::ROWB + L::TRB);
+    auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4), 1>;
+    if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
   } else {
-    auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN>;
+    const size_t lds = 4 * (2 * L::ROWB + L::TRB);
+    auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, 4, 1>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
   }
@@ -673,22 +781,38 @@ int dq_launch(const MhaBwdParams &p, hipStream_t s) {
 template <typename P>
 bool general(const P &p) { return p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0; }
 
+template <int NS>
+int fwd_any(const MhaParams &p, int d, hipStream_t s) {
+  const bool gen = general(p);
+  if (d == 64) return gen ? fwd_launch<64, true, NS>(p, s) : fwd_launch<64, false, NS>(p, s);
+  return gen ? fwd_launch<128, true, NS>(p, s) : fwd_launch<128, false, NS>(p, s);
+}
+template <int NS>
+int dkv_any(const MhaBwdParams &p, int d, hipStream_t s) {
+  const bool gen = general(p);
+  if (d == 64) return gen ? dkv_launch<64, true, NS>(p, s) : dkv_launch<64, false, NS>(p, s);
+  return gen ? dkv_launch<128, true, NS>(p, s) : dkv_launch<128, false, NS>(p, s);
+}
+template <int NS>
+int dq_any(const MhaBwdParams &p, int d, hipStream_t s) {
+  const bool gen = general(p);
+  if (d == 64) return gen ? dq_launch<64, true, NS>(p, s) : dq_launch<64, false, NS>(p, s);
+  return gen ? dq_launch<128, true, NS>(p, s) : dq_launch<128, false, NS>(p, s);
+}
+
 }  // namespace
 
-int mha_fwd_bf16(const MhaParams &p, int d, hipStream_t s) {
-  const bool gen = general(p);
-  if (d == 64) return gen ? fwd_launch<64, true>(p, s) : fwd_launch<64, false>(p, s);
-  return gen ? fwd_launch<128, true>(p, s) : fwd_launch<128, false>(p, s);
-}
-int mha_bwd_dkv_bf16(const MhaBwdParams &p, int d, hipStream_t s) {
-  const bool gen = general(p);
-  if (d == 64) return gen ? dkv_launch<64, true>(p, s) : dkv_launch<64, false>(p, s);
-  return gen ? dkv_launch<128, true>(p, s) : dkv_launch<128, false>(p, s);
-}
-int mha_bwd_dq_bf16(const MhaBwdParams &p, int d, hipStream_t s) {
-  const bool gen = general(p);
-  if (d == 64) return gen ? dq_launch<64, true>(p, s) : dq_launch<64, false>(p, s);
-  return gen ? dq_launch<128, true>(p, s) : dq_launch<128, false>(p, s);
-}
+int mha_fwd_bf16(const MhaParams &p, int d, hipStream_t s) { return fwd_any<1>(p, d, s); }
+int mha_bwd_dkv_bf16(const MhaBwdParams &p, int d, hipStream_t s) { return dkv_any<1>(p, d, s); }
+int mha_bwd_dq_bf16(const MhaBwdParams &p, int d, hipStream_t s) { return dq_any<1>(p, d, s); }
+
+// three-piece operands (fp32-level results on the bf16 matrix cores); the *_takes predicates say which
+// problems have a kernel, the caller keeps the fp32-MFMA kernel for the rest
+bool mha_x3_takes_fwd(const MhaParams &p, int d) { return d == 64 && x3_takes_fwd(p); }
+bool mha_x3_takes_dkv(const MhaBwdParams &p, int d) { return d == 64 && x3_takes_dkv(p); }
+bool mha_x3_takes_dq(const MhaBwdParams &p, int d) { return d == 64 && x3_takes_dq(p); }
+int mha_fwd_x3(const MhaParams &p, int d, hipStream_t s) { return fwd_any<3>(p, d, s); }
+int mha_bwd_dkv_x3(const MhaBwdParams &p, int d, hipStream_t s) { return dkv_any<3>(p, d, s); }
+int mha_bwd_dq_x3(const MhaBwdParams &p, int d, hipStream_t s) { return dq_any<3>(p, d, s); }
 
 }  // namespace coda

@@ -95,6 +95,13 @@ struct MhaBwdParams {
 // attention_bf16.hip: the same three kernels with bf16 MFMA operands (fp32 tensors, fp32 accumulation
 // and softmax); launched by attention.hip's dispatchers inside their timing brackets.
 int mha_fwd_bf16(const MhaParams &p, int d, hipStream_t s);
+// the same kernels with every fp32 operand carried as three bf16 pieces (fp32-level results, MFMA dtype 2)
+bool mha_x3_takes_fwd(const MhaParams &p, int d);
+bool mha_x3_takes_dkv(const MhaBwdParams &p, int d);
+bool mha_x3_takes_dq(const MhaBwdParams &p, int d);
+int mha_fwd_x3(const MhaParams &p, int d, hipStream_t s);
+int mha_bwd_dkv_x3(const MhaBwdParams &p, int d, hipStream_t s);
+int mha_bwd_dq_x3(const MhaBwdParams &p, int d, hipStream_t s);
 int mha_bwd_dkv_bf16(const MhaBwdParams &p, int d, hipStream_t s);
 int mha_bwd_dq_bf16(const MhaBwdParams &p, int d, hipStream_t s);
 

@@ -75,8 +75,16 @@ int coda_mha_bwd_parts_f32(const float *q, const float *k, const float *v,
  * (v_mfma_f32_32x32x16_bf16): Q, K, V, dO and the probabilities are rounded to bf16 on their way
  * into the matrix cores, accumulation / softmax / lse / every tensor in memory stay fp32.  This is
  * BASELINE.json configs[4] ("bf16 MFMA attention"); parity target there is 2e-2 relative to the
- * fp32 reference (bf16 has 8 significand bits).  Dropout masks are identical in both modes.
- * Initial value: environment variable CODA_ATTN_DTYPE ("bf16" or "1") selects 1, else 0. */
+ * fp32 reference (bf16 has 8 significand bits).  Dropout masks are identical in all modes.
+ * 2 = every fp32 operand carried as THREE bf16 pieces (hi + mid + lo = the fp32 value exactly) and every
+ * product evaluated as the six piece products of order <= 2 with fp32 accumulation: fp32-level results (what
+ * is dropped is <= 2^-24 relative, the size of fp32's own product rounding; tests/test_attention_x3_gpu.py
+ * measures the error against float64 next to the fp32-MFMA kernels') at 6/16 of the fp32 MFMA cost, on the
+ * matrix cores, which -- unlike the fp32 MFMA -- run concurrently with the soft-max VALU work.  EXPERIMENTAL and
+ * off by default: the operand splitting is itself VALU work, and the measured gain is 1.2-1.3x on the
+ * long-sequence forward and dQ kernels only; every other problem (dK/dV, the decoder shapes, head_dim 128) runs the
+ * fp32-MFMA kernels in this mode too.
+ * Initial value: environment variable CODA_ATTN_DTYPE: "bf16" / "1" -> 1, "bf16x3" / "x3" / "2" -> 2, else 0. */
 int coda_mha_set_mfma_dtype(int dtype);
 int coda_mha_get_mfma_dtype(void);
 
