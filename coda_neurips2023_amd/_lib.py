@@ -81,6 +81,9 @@ SIGNATURES = {
     "coda_matcher_cost_f32": (_c_int, [_P] * 8 + [_c_float] * 4 + [_P] * 3 + [_c_int] * 5 + [_P, _c_int, _P]),
     "coda_hungarian_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     "coda_grouped_gemm_tn_f32": (_c_int, [_P, _c_int, _P]),
+    "coda_gemm_x3_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
+    "coda_gemm_x3_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
+                                  ctypes.c_longlong, _P, _c_int, _P, ctypes.c_size_t, _P]),
     "coda_tok_colsum_finalize_grouped_f32": (_c_int, [_P, _c_int, _P]),
     # include/coda_eval.h
     "coda_box_point_count_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
