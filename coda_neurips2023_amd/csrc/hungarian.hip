@@ -61,7 +61,12 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
   if (n == 0) return;  // block-uniform
   for (int e = tid; e < m * n; e += kHungThreads) {  // cost^T into LDS: s_cost[i][j]
     const int j = e / n, i = e % n;
-    s_cost[i * m + j] = c[static_cast<size_t>(j) * ngt + i];
+    float v = c[static_cast<size_t>(j) * ngt + i];
+    // a diverged model can hand in NaN / inf costs (scipy raises on them): keep every cost finite so that the search
+    // below always finds a column and terminates; the assignment of such a problem is arbitrary but valid
+    if (!(v == v)) v = FLT_MAX;
+    v = fminf(fmaxf(v, -FLT_MAX), FLT_MAX);
+    s_cost[i * m + j] = v;
   }
   if (tid < n) {
     s_u[tid] = 0.0;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
     __syncthreads();
     int i = cur, sink = -1;
     double min_val = 0.0;
-    while (sink < 0) {  // block-uniform loop: every thread follows the same (i, min_val, sink)
+    for (int guard = 0; sink < 0 && guard <= m; ++guard) {  // block-uniform: every thread follows the same (i, min_val, sink); <= m steps
       if (tid == 0) s_insr[i] = 1;
       const double ui = s_u[i];
       Best mine{DBL_MAX, 2, 0x7fffffff};
@@ -108,15 +113,17 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
         for (int q = 1; q < kHungThreads / kWave; ++q)
           if (better(s_best[q], b)) b = s_best[q];
         s_pick = b;
-        s_insc[b.col] = 1;
+        if (b.col < m) s_insc[b.col] = 1;
       }
       __syncthreads();
       const Best pick = s_pick;
+      if (pick.col >= m) break;  // cannot happen with finite costs and n <= m
       min_val = pick.val;
       const int owner = s_row4col[pick.col];
       if (owner < 0) sink = pick.col;
       else i = owner;
     }
+    if (sink < 0) continue;  // (see above) leave this row unassigned
     // dual update (rows and columns that were reached), then flip the augmenting path
     if (tid < n && s_insr[tid]) {
       if (tid == cur) s_u[tid] += min_val;
@@ -140,8 +147,10 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
   }
   if (tid < n) {
     const int j = s_col4row[tid];
-    inds[j] = tid;
-    mask[j] = 1.0f;
+    if (j >= 0) {
+      inds[j] = tid;
+      mask[j] = 1.0f;
+    }
   }
 }
 

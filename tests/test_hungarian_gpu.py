@@ -155,3 +155,30 @@ def test_criterion_same_loss_with_and_without_the_fused_matcher_front(rotated):
         assert torch.allclose(da[k], db[k], rtol=1e-5, atol=1e-6), k
     for k in ga:
         assert torch.allclose(ga[k], gb[k], rtol=1e-5, atol=1e-7), k
+
+
+def test_non_finite_costs_terminate_with_a_valid_assignment():
+    """A diverged model hands the matcher NaN / inf costs (scipy raises ValueError there); the device solver must
+    neither hang nor index out of range: every real GT box still gets a distinct proposal."""
+    gen = torch.Generator().manual_seed(3)
+    nprob, nq, ngt = 6, 128, 16
+    outputs, cost = _outputs(nprob, nq, ngt, gen)
+    c = outputs["center_dist"]
+    c[0] = float("nan")
+    c[1, :, 3] = float("inf")
+    c[2, 5] = float("-inf")
+    c[3, ::2] = float("nan")
+    nactual = torch.tensor([16, 16, 16, 16, 7, 0])
+    targets = {"gt_box_sem_cls_label": torch.zeros((nprob, ngt), dtype=torch.int64, device="cuda:0"),
+               "nactual_gt": nactual.cuda()}
+    got = Matcher(0, 0, 0, 1, solver="device")(outputs, targets)
+    torch.cuda.synchronize()
+    inds, mask = got["per_prop_gt_inds"].cpu().numpy(), got["proposal_matched_mask"].cpu().numpy()
+    for b in range(nprob):
+        rows = np.nonzero(mask[b])[0]
+        assert len(rows) == int(nactual[b])
+        assert sorted(inds[b, rows].tolist()) == list(range(int(nactual[b])))
+    # the untouched problem is still solved optimally
+    r, col = linear_sum_assignment(cost[4, :, :7].numpy().astype(np.float64))
+    rows = np.nonzero(mask[4])[0]
+    assert np.isclose(cost[4].numpy()[rows, inds[4, rows]].sum(), cost[4].numpy()[r, col].sum(), atol=1e-6)
