@@ -177,7 +177,9 @@ class DeferredWeightGrads:
         rows, m = dy.shape
         n = x.shape[1]
         if (GROUPED_TN and rows % 8 == 0 and m % 64 == 0 and n % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1
-                and out.stride(1) == 1 and dy.dtype == torch.float32 and dy.is_cuda):
+                and out.stride(1) == 1 and dy.dtype == torch.float32 and dy.is_cuda
+                and (dy.stride(0) | x.stride(0) | out.stride(0)) % 2 == 0
+                and (dy.data_ptr() | x.data_ptr() | out.data_ptr()) % 8 == 0):  # the kernel's 8-byte accesses
             self._rows.append((dy.data_ptr(), x.data_ptr(), out.data_ptr(), rows | (m << 32), n, dy.stride(0),
                                x.stride(0), out.stride(0)))
             self._keep.append((dy, x, out))
