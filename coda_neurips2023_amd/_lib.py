@@ -85,6 +85,11 @@ SIGNATURES = {
     "coda_gemm_x3_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                                   ctypes.c_longlong, _P, _c_int, _P, ctypes.c_size_t, _P]),
     "coda_tok_colsum_finalize_grouped_f32": (_c_int, [_P, _c_int, _P]),
+    # include/coda_stack.h
+    "coda_decoder_stack_ws_floats": (ctypes.c_size_t, [_c_int] * 6),
+    "coda_decoder_stack_bwd_ws_floats": (ctypes.c_size_t, [_c_int] * 6),
+    "coda_decoder_stack_fwd_f32": (_c_int, [_P, _P]),
+    "coda_decoder_stack_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     # include/coda_eval.h
     "coda_box_point_count_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_nms_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_double, _c_int, _P]),

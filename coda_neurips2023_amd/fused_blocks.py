@@ -407,6 +407,137 @@ class _DecoderStack(torch.autograd.Function):
         return (ds_next, dmemory, dpos, dqpos, None, None, None, dnorm_sum[0], dnorm_sum[1], *grads)
 
 
+# ---- the same node with its per-layer launch sequences issued from C++ (include/coda_stack.h) -------------------
+#
+# _DecoderStack above enqueues ~280 launches per training step from Python (~5 ms of host time); here the layer
+# loops of forward and backward are one C call each (csrc/decoder_stack.hip runs the identical sequence through the
+# same entry points).  What stays in Python is what is not launch-bound: the two large memory projections before
+# the loop, the memory-side GEMMs after it, parameter / gradient bookkeeping.  CODA_STACK=python selects the
+# per-launch node (A/B, and the fallback for configurations the C driver does not cover).
+import ctypes  # noqa: E402
+
+STACK_IN_C = os.environ.get("CODA_STACK", "c") != "python"
+
+
+class _StackArgs(ctypes.Structure):
+    _fields_ = [("nl", ctypes.c_int), ("nq", ctypes.c_int), ("bsz", ctypes.c_int), ("e", ctypes.c_int),
+                ("ns", ctypes.c_int), ("nheads", ctypes.c_int), ("ffn", ctypes.c_int),
+                ("eps", ctypes.c_float), ("p_attn", ctypes.c_float), ("p1", ctypes.c_float), ("p2", ctypes.c_float),
+                ("p_ffn", ctypes.c_float), ("p3", ctypes.c_float), ("seed", ctypes.c_uint64),
+                ("tgt", ctypes.c_void_p), ("query_pos", ctypes.c_void_p), ("k_all", ctypes.c_void_p),
+                ("v_all", ctypes.c_void_p), ("norm_g", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
+                ("params", ctypes.c_void_p), ("outs", ctypes.c_void_p), ("ws", ctypes.c_void_p)]
+
+
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+class _DecoderStackC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tgt, memory, pos, query_pos, cfg, norm_g, norm_b, *params):
+        from . import _lib
+        from . import attention_core as _core
+        eps, nheads, p_attn, p1, p2, p_ffn, p3 = cfg
+        nl = len(params) // _NP
+        nq, bsz, e = tgt.shape
+        ns = memory.shape[0]
+        ffn = params[14].shape[0]
+        dev = tgt.device
+        lib = _lib.load()
+        layers = [params[_NP * l:_NP * (l + 1)] for l in range(nl)]
+        mem2 = memory.reshape(-1, e)
+        mp2 = mem2 if pos is None else (memory + pos).reshape(-1, e)
+        wk_all = torch.cat([lp[8][e:2 * e] for lp in layers])
+        wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
+        bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
+        bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
+        k_all = gemm.linear(mp2, wk_all, bk_all)
+        v_all = gemm.linear(mem2, wv_all, bv_all)
+        ws = torch.empty(lib.coda_decoder_stack_ws_floats(nl, nq, bsz, e, nheads, ffn), dtype=torch.float32, device=dev)
+        outs = torch.empty((nl, nq, bsz, e), dtype=torch.float32, device=dev)
+        tgt, query_pos = tgt.contiguous(), query_pos.contiguous()
+        seed = _core._next_seed()[0] if max(p_attn, p1, p2, p_ffn, p3) > 0.0 else 0
+        table = _ptr_table(params)
+        args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
+                          query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
+                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr())
+        _lib.check(lib.coda_decoder_stack_fwd_f32(ctypes.byref(args), _lib.current_stream_handle()), "decoder_stack_fwd")
+        ctx.args = (nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, pos is not None)
+        ctx.save_for_backward(tgt, query_pos, mem2, mp2, k_all, v_all, wk_all, wv_all, ws, norm_g, norm_b, *params)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dstack):
+        from . import _lib
+        nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, has_pos = ctx.args
+        saved = ctx.saved_tensors
+        tgt, query_pos, mem2, mp2, k_all, v_all, wk_all, wv_all, ws, norm_g, norm_b = saved[:11]
+        params = saved[11:]
+        dev = dstack.device
+        lib = _lib.load()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dstack = dstack.contiguous()
+        dk_all, dv_all = torch.empty_like(k_all), torch.empty_like(v_all)
+        d_tgt = torch.empty((nq, bsz, e), **f32)
+        d_qpos = torch.empty((nq, bsz, e), **f32)
+        sums = torch.empty((nl, 4, 3 * e), **f32)
+        bws = torch.empty(lib.coda_decoder_stack_bwd_ws_floats(nl, nq, bsz, e, nheads, ffn), **f32)
+        din1 = torch.empty((nl, 3 * e, e), **f32)        # self_attn.in_proj_weight
+        dib1 = torch.empty((nl, 3 * e), **f32)
+        dow1 = torch.empty((nl, e, e), **f32)
+        din2 = torch.empty((nl, 3 * e, e), **f32)        # multihead_attn.in_proj_weight (query rows by the C driver)
+        dib2 = torch.empty((nl, 3 * e), **f32)
+        dow2 = torch.empty((nl, e, e), **f32)
+        dw1 = torch.empty((nl, ffn, e), **f32)
+        dfb1 = torch.empty((nl, ffn), **f32)
+        dw2 = torch.empty((nl, e, ffn), **f32)
+        gptr = []
+        for l in range(nl):
+            row = [None] * _NP
+            row[2], row[3], row[4] = din1[l], dib1[l], dow1[l]
+            row[8], row[9], row[10] = din2[l], dib2[l], dow2[l]
+            row[14], row[15], row[16] = dw1[l], dfb1[l], dw2[l]
+            gptr += row
+        gtable = _ptr_table(gptr)
+        table = _ptr_table(params)
+        args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
+                          query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
+                          ctypes.addressof(table), None, ws.data_ptr())
+        _lib.check(lib.coda_decoder_stack_bwd_f32(ctypes.byref(args), dstack.data_ptr(), d_tgt.data_ptr(), d_qpos.data_ptr(),
+                                                  dk_all.data_ptr(), dv_all.data_ptr(), ctypes.addressof(gtable),
+                                                  sums.data_ptr(), bws.data_ptr(), _lib.current_stream_handle()),
+                   "decoder_stack_bwd")
+        # memory side of all layers at once
+        dmp2 = gemm.mm(dk_all, wk_all)
+        dmem2 = gemm.mm(dv_all, wv_all)
+        dwk = tn_gemm(dk_all, mp2)   # (nl*E, E)
+        dwv = tn_gemm(dv_all, mem2)
+        din2[:, e:2 * e].copy_(dwk.view(nl, e, e))
+        din2[:, 2 * e:].copy_(dwv.view(nl, e, e))
+        dib2[:, e:2 * e].copy_(_colsum_vec(dk_all).view(nl, e))
+        dib2[:, 2 * e:].copy_(_colsum_vec(dv_all).view(nl, e))
+        dnorm = sums[:, 3].sum(0)
+        grads = []
+        for l in range(nl):
+            s0, s1, s2, s3 = sums[l, 0], sums[l, 1], sums[l, 2], sums[l, 3]
+            grads += [s0[:e], s0[e:2 * e], din1[l], dib1[l], dow1[l], s1[2 * e:], s1[:e], s1[e:2 * e], din2[l], dib2[l],
+                      dow2[l], s2[2 * e:], s2[:e], s2[e:2 * e], dw1[l], dfb1[l], dw2[l], s3[2 * e:]]
+        dmemory = (dmp2 + dmem2).view(ns, bsz, e)
+        dpos = dmp2.view(ns, bsz, e) if has_pos else None
+        return (d_tgt, dmemory, dpos, d_qpos, None, dnorm[:e], dnorm[e:2 * e], *grads)
+
+
+def _stack_in_c_applies(decoder, tgt, memory, query_pos, self_mask, cross_mask, params):
+    if not (STACK_IN_C and query_pos is not None and self_mask is None and cross_mask is None and tgt.is_cuda):
+        return False
+    e = tgt.shape[-1]
+    heads = decoder.layers[0].self_attn.num_heads
+    if e % heads or e // heads not in (64, 128) or params[14].shape[0] % 4:
+        return False
+    return all(t.dtype == torch.float32 and t.is_contiguous() for t in (tgt, memory, *params))
+
+
 def decoder_stack(decoder, tgt, memory, pos, query_pos, self_mask, cross_mask):
     """All layers of a TransformerDecoder (pre-norm, return_intermediate) -> (num_layers, nq, B, E):
     the decoder-normed output of every layer."""
@@ -424,5 +555,8 @@ def decoder_stack(decoder, tgt, memory, pos, query_pos, self_mask, cross_mask):
                    s.out_proj.bias, layer.norm2.weight, layer.norm2.bias, c.in_proj_weight, c.in_proj_bias,
                    c.out_proj.weight, c.out_proj.bias, layer.norm3.weight, layer.norm3.bias, layer.linear1.weight,
                    layer.linear1.bias, layer.linear2.weight, layer.linear2.bias]
+    if _stack_in_c_applies(decoder, tgt, memory, query_pos, self_mask, cross_mask, params):
+        return _DecoderStackC.apply(tgt, memory.contiguous(), pos, query_pos, cfg, decoder.norm.weight,
+                                    decoder.norm.bias, *params)
     return _DecoderStack.apply(tgt, memory.contiguous(), pos, query_pos, self_mask, cross_mask, cfg,
                                decoder.norm.weight, decoder.norm.bias, *params)
