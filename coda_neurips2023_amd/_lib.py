@@ -90,6 +90,9 @@ SIGNATURES = {
     "coda_decoder_stack_bwd_ws_floats": (ctypes.c_size_t, [_c_int] * 6),
     "coda_decoder_stack_fwd_f32": (_c_int, [_P, _P]),
     "coda_decoder_stack_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    # include/coda_clip_crops.h
+    "coda_project_box_rects_f64": (_c_int, [_P] * 16 + [_c_int, _c_int, _P]),
+    "coda_crop_resize_f32": (_c_int, [_P] * 5 + [_c_int] * 6 + [_P]),
     # include/coda_eval.h
     "coda_box_point_count_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_nms_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_double, _c_int, _P]),

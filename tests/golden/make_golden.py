@@ -577,12 +577,67 @@ def golden_eval_post():
     _save("eval_post.npz", **out)
 
 
+def synthetic_camera(bsz, nbox, gen, image_size=(730, 531)):
+    """Seeded stand-ins for the per-scene entries the dataset adds for the image branch
+    (datasets/sunrgbd_anonymous_aligned_image.py:884-899): SUN RGB-D-like intrinsics / tilt, augmentation arrays."""
+    def rnd(*shape):
+        return torch.rand(*shape, generator=gen, dtype=torch.float64)
+    K = torch.zeros(bsz, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = 520 + 20 * rnd(bsz)
+    K[:, 1, 1] = 520 + 20 * rnd(bsz)
+    K[:, 0, 2] = 320 + 10 * rnd(bsz)
+    K[:, 1, 2] = 240 + 10 * rnd(bsz)
+    K[:, 2, 2] = 1
+    tilt = (rnd(bsz) - 0.5) * 0.3
+    Rtilt = torch.zeros(bsz, 3, 3, dtype=torch.float64)
+    Rtilt[:, 0, 0] = 1
+    Rtilt[:, 1, 1] = torch.cos(tilt); Rtilt[:, 1, 2] = -torch.sin(tilt)
+    Rtilt[:, 2, 1] = torch.sin(tilt); Rtilt[:, 2, 2] = torch.cos(tilt)
+    ang = (rnd(bsz) - 0.5) * 0.6
+    rot = torch.zeros(bsz, 3, 3, dtype=torch.float64)
+    rot[:, 0, 0] = torch.cos(ang); rot[:, 0, 1] = -torch.sin(ang)
+    rot[:, 1, 0] = torch.sin(ang); rot[:, 1, 1] = torch.cos(ang)
+    rot[:, 2, 2] = 1
+    flip = torch.where(rnd(bsz, 1) < 0.5, -1.0, 1.0).to(torch.float64)
+    iflip = torch.where(flip < 0, 0.0, 1.0).to(torch.float64)
+    ow = torch.full((bsz,), 640.0, dtype=torch.float64)
+    oh = torch.full((bsz,), 480.0, dtype=torch.float64)
+    return {"K": K, "Rtilt": Rtilt, "rot_array": rot, "scale_array": 0.9 + 0.2 * rnd(bsz, 1, 3), "flip_array": flip,
+            "image_flip_array": iflip, "flip_length": torch.full((bsz,), float(image_size[0]), dtype=torch.float64),
+            "ori_width": ow, "ori_height": oh, "y_offset": (image_size[0] - ow) // 2, "x_offset": (image_size[1] - oh) // 2}
+
+
+def golden_clip_crops():
+    """project_3dpoint_to_2dpoint_corners_tensor (datasets/sunrgbd_utils.py:611-635), the projection at the heart
+    of the image branch, on seeded boxes in front of / beside / behind a seeded camera, after the un-augmentation of
+    models/model_3detr.py:919-928 (replayed here with the reference's tensor expressions)."""
+    import datasets.sunrgbd_utils as RU  # the REFERENCE module
+    import utils.box_util as RB
+    gen = torch.Generator().manual_seed(23)
+    B, K = 3, 24
+    cam = synthetic_camera(B, K, gen)
+    centres = torch.stack(((torch.rand(B, K, generator=gen) - 0.5) * 6, 1.0 + torch.rand(B, K, generator=gen) * 5,
+                           (torch.rand(B, K, generator=gen) - 0.5) * 2), -1)
+    centres[:, :3, 1] = -2.0                                # behind the camera
+    sizes = torch.rand(B, K, 3, generator=gen) * 1.5 + 0.2
+    sizes[0, 5] = 0.0
+    angles = (torch.rand(B, K, generator=gen) - 0.5) * 3
+    corners = RB.get_3d_box_batch_tensor_xyz(sizes, angles, centres)        # box_corners_xyz of the model
+    g = corners.detach().clone() * cam["scale_array"].unsqueeze(1)
+    g = torch.matmul(g, cam["rot_array"].unsqueeze(1))
+    g[:, :, :, 0] = g[:, :, :, 0] * cam["flip_array"].unsqueeze(-1)
+    uv, depth = RU.project_3dpoint_to_2dpoint_corners_tensor(g.to(torch.double), K_tensor=cam["K"], Rtilt_tensor=cam["Rtilt"])
+    out = {"corners": _np(corners), "sizes": _np(sizes), "uv_raw": _np(uv), "depth": _np(depth)}
+    out.update({"cam_" + k: _np(v) for k, v in cam.items()})
+    _save("clip_crops.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post"]
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops"]
     for w in which:
         globals()["golden_" + w]()
