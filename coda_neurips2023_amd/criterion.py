@@ -318,10 +318,13 @@ class SetCriterion(nn.Module):
         res = {"loss_sem_cls_softmax_skip_none_gt_sample": sums[:, 0] / (has_object.sum() * nq + 1e-32)}
         if torch.is_tensor(targets["num_boxes_replica"]):
             # device scalars: num_boxes is clamped to >= 1 and a replica without boxes has an all-zero matched mask,
-            # i.e. zero sums -- the same zeros the branch below produces, without reading the count back
-            nb = targets["num_boxes"]
-            res.update(loss_angle_cls=sums[:, 1] / nb, loss_angle_reg=sums[:, 2] / nb, loss_center=sums[:, 3] / nb,
-                       loss_size=sums[:, 4] / nb)
+            # i.e. zero sums -- the same zeros the branch below produces, without reading the count back.  One
+            # division for the five columns (a column select per term costs four launches in its backward).
+            nb = targets["num_boxes"].to(sums.dtype).reshape(())
+            den = torch.stack((has_object.sum() * nq + 1e-32, nb, nb, nb, nb))
+            cols = (sums / den).unbind(1)
+            return dict(zip(("loss_sem_cls_softmax_skip_none_gt_sample", "loss_angle_cls", "loss_angle_reg", "loss_center",
+                             "loss_size"), cols))
         elif targets["num_boxes_replica"] > 0:
             nb = targets["num_boxes"]
             res.update(loss_angle_cls=sums[:, 1] / nb, loss_angle_reg=sums[:, 2] / nb,
@@ -589,18 +592,32 @@ class SetCriterion(nn.Module):
         for k in self.loss_functions:
             if self._live(k):
                 losses.update(getattr(self, "stacked_" + k)(outs, targets, assignments))
-        final = 0
-        for k, w in self.loss_weight_dict.items():
-            if w > 1e-32:
-                name = k.replace("_weight", "")
-                losses[name] = losses[name] * w
-                final = final + losses[name]
+        # weighted sum of the live terms (criterion.py:1138-1144, per layer): the (terms, layers) values are
+        # stacked, scaled by the weight column and summed in three launches instead of two per term (and as many
+        # again in the backward); loss_dict keeps the reference's weighted per-term values
+        names = [k.replace("_weight", "") for k, w in self.loss_weight_dict.items() if w > 1e-32]
+        if names:
+            wcol = self._weight_column(names, center.device)
+            weighted = torch.stack([losses[n] for n in names]) * wcol
+            final = weighted.sum()
+            for i, n in enumerate(names):
+                losses[n] = weighted[i]
+        else:
+            final = center.sum() * 0
         loss_dict = {}
         for name, per_layer in losses.items():
             loss_dict[name] = per_layer[nl - 1]
             for l in range(nl - 1):
                 loss_dict[f"{name}_{l}"] = per_layer[l]
-        return final.sum(), loss_dict
+        return final, loss_dict
+
+    def _weight_column(self, names, device):
+        key = (tuple(names), str(device))
+        cache = self.__dict__.setdefault("_wcol_cache", {})
+        if key not in cache:
+            cache[key] = torch.tensor([[float(self.loss_weight_dict[n + "_weight"])] for n in names],
+                                      dtype=torch.float32, device=device)
+        return cache[key]
 
     @_lib.on_tensor_device(lambda outputs, targets: targets["gt_box_present"])
     def forward(self, outputs, targets):
