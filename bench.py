@@ -366,6 +366,13 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
+    # CODA_BENCH_FORCE_DDP=1 (development check on a single GPU): a one-rank RCCL group, so that the SyncBatchNorm +
+    # DistributedDataParallel wrapping of the multi-GPU runs is exercised by the same command
+    force_ddp = world == 1 and os.environ.get("CODA_BENCH_FORCE_DDP") == "1" and not dry
+    if force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device or dry:
@@ -378,10 +385,18 @@ def main():
         torch.backends.cuda.preferred_blas_library(os.environ["CODA_BLAS"])
     mod, step_fn, desc, kind = build_workload(args.workload, dev)
     model = mod
-    if world > 1:
+    if world > 1 or force_ddp:
         # reference: SyncBatchNorm + DDP (main.py:993-996)
         model = mod if dry else torch.nn.SyncBatchNorm.convert_sync_batchnorm(mod)  # (SyncBN needs GPU modules)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if dry else [local_rank])
+        ddp_kw = {}
+        if not dry:
+            # gradients live in the all-reduce buckets (no copy in, no copy back: 252 tensors per step), two buckets
+            # of ~16 MB so that the first all-reduce overlaps the encoder's backward; CODA_DDP=default restores
+            # torch's defaults (A/B)
+            if os.environ.get("CODA_DDP", "tuned") != "default":
+                ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=int(os.environ.get("CODA_DDP_BUCKET_MB", "16")),
+                              static_graph=os.environ.get("CODA_DDP_STATIC", "0") == "1")
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if dry else [local_rank], **ddp_kw)
 
     # synthetic inputs, resident in HBM before timing; a few distinct batches cycle
     pool = []
@@ -604,7 +619,7 @@ def main():
         if dry:
             out.update(metric="dry run (control flow only)", data="none", dtype="f32")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
