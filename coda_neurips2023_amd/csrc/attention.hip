@@ -510,9 +510,13 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 //                 attending to themselves) would otherwise leave one wave per CU.
 // DB (non-QSPLIT): two single-tile stages of Q / dO in the same LDS, double buffered like the
 //                 forward kernel's K / V staging.
-template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false>
+// VLDS (with DB): the V fragments of a lane live in LDS instead of 32 registers (each lane re-reads what it wrote:
+//                 a register spill to LDS instead of to scratch memory -- the kernel was 36 VGPRs over its 256 at
+//                 two waves per SIMD, and the scratch traffic showed up as 1.6x the algorithmic HBM bytes).
+template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false, bool VLDS = false>
 __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
+  static_assert(!VLDS || (DB && !QSPLIT), "VLDS is implemented for the double-buffered long-key-sequence kernel");
   constexpr int QT = QSPLIT ? KW : (DB ? 1 : 2);  // query tiles staged per step
   static_assert(!(DB && QSPLIT), "double buffering is implemented for the long-key-sequence kernel");
   constexpr int kStageFloats = 2 * QT * kTile * LS + 2 * QT * kTile;  // Q, dO tiles + lse, delta rows
@@ -540,7 +544,9 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
 
-  float kf[HD], vf[HD];  // B operands: K[mykey][half*HD + c], V[mykey][half*HD + c]
+  float kf[HD], vf[VLDS ? 4 : HD];  // B operands: K[mykey][half*HD + c], V[mykey][half*HD + c]
+  // VLDS: this lane's V fragment, behind the two Q / dO stages (row stride LS: conflict-free ds_read_b128)
+  float *v_lane = VLDS ? s_dyn + 2 * kStageFloats + (w * kTile + l31) * LS + half * HD : nullptr;
 #pragma unroll
   for (int c = 0; c < HD; c += 4) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a;
@@ -549,7 +555,11 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
       b4 = *reinterpret_cast<const float4 *>(vbase + static_cast<size_t>(mykey) * vstride + half * HD + c);
     }
     kf[c] = a.x; kf[c + 1] = a.y; kf[c + 2] = a.z; kf[c + 3] = a.w;
-    vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
+    if (VLDS) {
+      *reinterpret_cast<float4 *>(v_lane + c) = b4;
+    } else {
+      vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
+    }
   }
   f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -616,14 +626,18 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     for (int c = 0; c < HD; c += 4) {
       const float4 qa = *reinterpret_cast<const float4 *>(tq + l31 * LS + half * HD + c);
       const float4 ga = *reinterpret_cast<const float4 *>(tdo + l31 * LS + half * HD + c);
+      float4 vv;
+      if (VLDS) vv = *reinterpret_cast<const float4 *>(v_lane + c);
+      else vv = make_float4(vf[c % (VLDS ? 4 : HD)], vf[(c + 1) % (VLDS ? 4 : HD)], vf[(c + 2) % (VLDS ? 4 : HD)],
+                            vf[(c + 3) % (VLDS ? 4 : HD)]);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kf[c], sacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vf[c], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vv.x, pacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kf[c + 1], sacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vf[c + 1], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vv.y, pacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kf[c + 2], sacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vf[c + 2], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vv.z, pacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kf[c + 3], sacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vf[c + 3], pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vv.w, pacc, 0, 0, 0);
     }
     // lane: key = mykey, register r: query q0 + crow(r, half)
     float pd[16], ds[16];
@@ -1101,11 +1115,23 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   if (p.parts & 2) {
   KernelTimer timer(2, p.l, p.s, s);
   if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
-    auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
-    const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
-    int st = set_lds(kern, lds);
-    if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+    // CODA_ATTN_VLDS=1 (D = 64): V fragments in LDS instead of registers -- no scratch spill (251 VGPRs, 0 bytes of
+    // scratch against 256 + 72 B/lane), but not faster: 648 vs 626 us standalone, 0.69 vs 0.685 ms in the step.
+    // The spill was not what holds this kernel; off by default.
+    static const bool vlds = [] { const char *e = getenv("CODA_ATTN_VLDS"); return e && atoi(e) != 0; }();
+    if (D == 64 && vlds) {
+      auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true, (D == 64)>;
+      const size_t lds = 2 * (kTileBytes + kRowBytes) + sizeof(float) * 4 * kTile * (D + 4);
+      int st = set_lds(kern, lds);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+    } else {
+      auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
+      const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
+      int st = set_lds(kern, lds);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+    }
   } else if (p.s >= 1024) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);
