@@ -93,6 +93,13 @@ SIGNATURES = {
     # include/coda_clip_crops.h
     "coda_project_box_rects_f64": (_c_int, [_P] * 16 + [_c_int, _c_int, _P]),
     "coda_crop_resize_f32": (_c_int, [_P] * 5 + [_c_int] * 6 + [_P]),
+    # include/coda_clip_tower.h
+    "coda_vit_workspace_bytes": (ctypes.c_size_t, [_P, _c_int, _c_int]),
+    "coda_vit_fwd": (_c_int, [_P, _P, _c_int, _P, _P, _P, ctypes.c_size_t, _P]),
+    "coda_vit_attention_f16": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
+    "coda_vit_quickgelu_fused": (_c_int, [_c_int]),
+    "coda_gemm_ex": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P,
+                              ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_float, _c_float, _P]),
     # include/coda_eval.h
     "coda_box_point_count_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_nms_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_double, _c_int, _P]),

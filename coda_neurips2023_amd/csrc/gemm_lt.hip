@@ -1,4 +1,5 @@
-// gemm_lt.hip -- coda_gemm_f32: fp32 hipBLASLt GEMM with per-shape cached plans (host code only).
+// gemm_lt.hip -- coda_gemm_f32 / coda_gemm_ex: hipBLASLt GEMMs (fp32, or fp16 operands with fp32 accumulation)
+// with per-shape cached plans (host code only).
 //
 // hipBLASLt is column-major.  A row-major X (r x c, row stride ld) is the column-major matrix X^T
 // (c x r, leading dimension ld), so  C = op(A) op(B)  is computed as  C^T = op(B)^T op(A)^T :
@@ -26,7 +27,8 @@ struct Plan {
   int status = CODA_OK;  // != CODA_OK: the library refused this shape (cached verdict)
 };
 
-using Key = std::tuple<int, int, int, int, int, long long, long long, long long, int>;
+// (transa, transb, m, n, k, lda, ldb, ldc, epilogue, dtype); epilogue: 0 none, 1 +bias, 2 swish(. + bias)
+using Key = std::tuple<int, int, int, int, int, long long, long long, long long, int, int>;
 
 struct State {
   std::mutex mu;
@@ -73,21 +75,24 @@ int make_plan(State &s, const Key &key, Plan &p) {
 }
 
 int make_plan_checked(State &s, const Key &key, Plan &p) {
-  const auto [transa, transb, m, n, k, lda, ldb, ldc, has_bias] = key;
+  const auto [transa, transb, m, n, k, lda, ldb, ldc, epilogue, dtype] = key;
+  const hipDataType ty = dtype == CODA_DTYPE_F16 ? HIP_R_16F : HIP_R_32F;
   LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
   // library operand 1 = B, operand 2 = A (see the header comment)
   const hipblasOperation_t op1 = transb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
   const hipblasOperation_t op2 = transa ? HIPBLAS_OP_T : HIPBLAS_OP_N;
   LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op1, sizeof(op1)));
   LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op2, sizeof(op2)));
-  if (has_bias) {
-    const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+  if (epilogue) {
+    const hipblasLtEpilogue_t epi = epilogue == 2 ? HIPBLASLT_EPILOGUE_SWISH_BIAS_EXT : HIPBLASLT_EPILOGUE_BIAS;
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+    const int32_t bias_ty = HIP_R_32F;  // bias vectors stay fp32 whatever the operand type
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_ty, sizeof(bias_ty)));
   }
   // column-major shapes as stored: B row-major (k x n) -> (n x k); transb: stored (n x k) -> (k x n)
-  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_32F, transb ? k : n, transb ? n : k, ldb));
-  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_32F, transa ? m : k, transa ? k : m, lda));
-  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, n, m, ldc));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, ty, transb ? k : n, transb ? n : k, ldb));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, ty, transa ? m : k, transa ? k : m, lda));
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, ty, n, m, ldc));
   hipblasLtMatmulHeuristicResult_t res;
   int found = 0;
   LT_CHECK(hipblasLtMatmulAlgoGetHeuristic(s.handle, p.desc, p.la, p.lb, p.lc, p.lc, s.pref, 1, &res, &found));
@@ -100,11 +105,13 @@ int make_plan_checked(State &s, const Key &key, Plan &p) {
 }  // namespace
 }  // namespace coda
 
-CODA_API int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a, long long lda,
-                           const float *b, long long ldb, float *c, long long ldc, const float *bias,
-                           int accumulate, void *stream) {
+CODA_API int coda_gemm_ex(int dtype, int epilogue, int transa, int transb, int m, int n, int k, const void *a,
+                          long long lda, const void *b, long long ldb, void *c, long long ldc, const float *bias,
+                          float alpha, float beta, void *stream) {
   using namespace coda;
   if (m < 0 || n < 0 || k < 0) return CODA_EINVAL;
+  if (dtype != CODA_DTYPE_F32 && dtype != CODA_DTYPE_F16) return CODA_EINVAL;
+  if (epilogue < 0 || epilogue > 2 || (epilogue != 0) != (bias != nullptr)) return CODA_EINVAL;
   if (m == 0 || n == 0) return CODA_OK;
   if (k == 0 || !a || !b || !c) return CODA_EINVAL;
   if (lda < (transa ? m : k) || ldb < (transb ? k : n) || ldc < n) return CODA_EINVAL;
@@ -117,7 +124,7 @@ CODA_API int coda_gemm_f32(int transa, int transb, int m, int n, int k, const fl
     LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(s.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws,
                                                    sizeof(ws)));
   }
-  const Key key{transa != 0, transb != 0, m, n, k, lda, ldb, ldc, bias != nullptr};
+  const Key key{transa != 0, transb != 0, m, n, k, lda, ldb, ldc, epilogue, dtype};
   auto it = s.plans.find(key);
   if (it == s.plans.end()) {
     Plan p;
@@ -139,8 +146,14 @@ CODA_API int coda_gemm_f32(int transa, int transb, int m, int n, int k, const fl
     ws = w->second;
   }
   if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-  const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
   LT_CHECK(hipblasLtMatmul(s.handle, p.desc, &alpha, b, p.la, a, p.lb, &beta, c, p.lc, c, p.lc, &p.algo, ws,
                            p.workspace, hs));
   return CODA_OK;
+}
+
+CODA_API int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a, long long lda,
+                           const float *b, long long ldb, float *c, long long ldc, const float *bias,
+                           int accumulate, void *stream) {
+  return coda_gemm_ex(CODA_DTYPE_F32, bias ? 1 : 0, transa, transb, m, n, k, a, lda, b, ldb, c, ldc, bias, 1.0f,
+                      accumulate ? 1.0f : 0.0f, stream);
 }

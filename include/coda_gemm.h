@@ -32,6 +32,17 @@ int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a,
                   long long lda, const float *b, long long ldb, float *c, long long ldc,
                   const float *bias, int accumulate, void *stream);
 
+/* The general form behind coda_gemm_f32 (same library, same plan cache):
+ *   C = epilogue(alpha * op(A) op(B) + beta * C [+ bias])
+ * dtype: CODA_DTYPE_F32, or CODA_DTYPE_F16 (A, B, C are IEEE half, products accumulated in fp32: the frozen CLIP
+ * image tower, include/coda_clip_tower.h).  `bias` is fp32 for either dtype.  epilogue: 0 none (bias must be
+ * NULL), 1 "+ bias", 2 "swish(. + bias)" with swish(x) = x * sigmoid(x). */
+#define CODA_DTYPE_F32 0
+#define CODA_DTYPE_F16 1
+int coda_gemm_ex(int dtype, int epilogue, int transa, int transb, int m, int n, int k, const void *a,
+                 long long lda, const void *b, long long ldb, void *c, long long ldc, const float *bias,
+                 float alpha, float beta, void *stream);
+
 /* Own fp32-MFMA kernel for the same product (csrc/gemm_nn.hip), used for the launch-sized problems of the
  * transformer stacks where the library costs ~14 us of host time per call:
  *   transb != 0:  C (m x n) [+]= A (m x k) . B^T + bias,  B (n x k)     (y = x W^T + b)

@@ -632,12 +632,46 @@ def golden_clip_crops():
     _save("clip_crops.npz", **out)
 
 
+TOWER_CASES = {  # name: (resolution, patch, width, layers, heads, out_dim, images)
+    "small": (64, 16, 128, 2, 2, 64, 3),          # 17 tokens
+    "b16_tokens": (224, 16, 128, 1, 2, 32, 2),    # 197 tokens: the ragged length of ViT-B/16
+    "patch32": (96, 32, 192, 2, 3, 48, 2),        # 10 tokens, three heads
+}
+
+
+def tower_images(name, n, res):
+    return torch.randn(n, 3, res, res, generator=torch.Generator().manual_seed(zlib_seed(name)))
+
+
+def zlib_seed(name):
+    import zlib
+    return zlib.crc32(name.encode()) & 0x7fffffff
+
+
+def golden_clip_tower():
+    """The reference's VisionTransformer (CLIP/clip/model.py:595-659) in float32 on seeded weights
+    (tests/golden/weights.py) and seeded images: class-token embedding and all-token embeddings."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_clip_model", os.path.join(REF, "CLIP", "clip", "model.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    from golden.weights import fill_deterministic
+    out = {}
+    for name, (res, patch, width, layers, heads, odim, n) in TOWER_CASES.items():
+        vit = fill_deterministic(ref.VisionTransformer(res, patch, width, layers, heads, odim), seed=5).eval()
+        with torch.no_grad():
+            cls, tok = vit(tower_images(name, n, res))
+        out[name + "_cls"], out[name + "_tokens"] = _np(cls), _np(tok)
+        out[name + "_keys"] = np.array(["%s %s" % (k, tuple(v.shape)) for k, v in sorted(vit.state_dict().items())])
+    _save("clip_tower.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops"]
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower"]
     for w in which:
         globals()["golden_" + w]()
