@@ -228,6 +228,34 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32"):
     return model, step, desc, "model"
 
 
+def run_image_tower(dev, steps, warmup):
+    """SURVEY.md 8f rank 2, measured next to the headline: the frozen CLIP image tower (ViT-B/16, fp16 like the
+    reference's) on the crops of one step -- 8 scenes x 32 proposals (models/model_3detr.py:991) -- random-init
+    weights (the checkpoint is not in this image), inputs resident in HBM.  Algorithmic flops = the GEMMs and the
+    attention products of VisionTransformer.forward; peak = dense fp16 MFMA."""
+    from coda_neurips2023_amd import clip_tower
+    crops = B_PER_GPU * 32
+    torch.manual_seed(0)
+    tower = clip_tower.convert_weights(clip_tower.ImageTower(512, 224, 12, 768, 16)).to(dev)
+    x = torch.randn(crops, 3, 224, 224, device=dev)
+    for _ in range(warmup):
+        tower.encode_image(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tower.encode_image(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    l, w, mlp = 197, 768, 3072
+    flops = crops * (12 * (2 * l * w * (4 * w + 2 * mlp) + 4 * l * l * w) + 2 * 196 * 768 * w + 2 * w * 512)
+    tf = flops / dt / 1e12
+    return {"metric": "crops/sec, CLIP ViT-B/16 image tower, fp16 (frozen, forward only)", "value": round(crops / dt, 1),
+            "unit": "crops/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f16",
+            "config": {"workload": "8 scenes x 32 crops of 224x224 (one training step's distillation crops)"},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(tf / 2500.0, 4), "traffic": None}}
+
+
 def run_extra(kind, dev, steps, warmup):
     """The other single-GPU configurations of BASELINE.json next to the headline, so that the driver's default
     command times them too: configs[1] (set abstraction only) and the one-GPU share of configs[4] (40 000-point
@@ -613,7 +641,8 @@ def main():
             # secondary lines; the headline's timed region above is untouched by them)
             ex_steps, ex_warm = max(5, min(args.steps, 10)), 3
             out["extra_configs"] = {"configs[1]_sa_only": run_extra("sa", dev, ex_steps, ex_warm),
-                                    "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm)}
+                                    "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm),
+                                    "clip_image_tower": run_image_tower(dev, ex_steps, ex_warm)}
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(kind)
         if dry:

@@ -5,7 +5,8 @@ proposals in Python: ``int(torch.min(...))`` read-backs per box, a fresh white c
 resize per crop, one tower call per scene.  Here the geometry of ALL proposals is one launch
 (``coda_project_box_rects_f64``: un-augment, project, clip, flip, 2-D extent, validity), the crops of all scenes
 one more (``coda_crop_resize_f32``: crop -> white square -> bicubic resize -> CLIP normalisation), and the frozen
-tower -- the deployment's CLIP module, its weights are not part of this package -- runs ONCE on the whole batch.
+tower -- ``clip_tower.ImageTower`` (``coda_vit_fwd``) built from the deployment's CLIP checkpoint, or any module
+with the reference's ``encode_image`` -- runs ONCE on the whole batch.
 Nothing reads device memory back.  ``RegionEmbeddingProvider`` is a drop-in ``region_embedding_provider`` for
 ``model_3detr.build_model`` (INTEGRATION.md).
 
@@ -18,7 +19,7 @@ discovery of late epochs, :992-1005 and :1087-1210, stay with the reference's co
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, clip_tower
 
 
 def _f64(t, dev, shape):
@@ -96,7 +97,10 @@ class RegionEmbeddingProvider:
         select = np.stack([self.rng.choice(pool, min(self.num, len(pool)), replace=False) for _ in range(b)])
         sel = torch.from_numpy(select.astype(np.int64)).to(dev)
         crops = crop_resize(inputs["input_image"], sel, rects, valid, self.clip_model.visual.input_resolution)
-        feats = self.clip_model.encode_image(crops.to(self.clip_model.dtype) if hasattr(self.clip_model, "dtype") else crops)
+        if isinstance(self.clip_model, clip_tower.ImageTower):  # this package's tower: float32 crops in, class embedding out
+            feats = self.clip_model.encode_image(crops)
+        else:
+            feats = self.clip_model.encode_image(crops.to(self.clip_model.dtype) if hasattr(self.clip_model, "dtype") else crops)
         if isinstance(feats, tuple):
             feats = feats[0]
         feats = feats.to(torch.float32).view(b, sel.shape[1], -1)

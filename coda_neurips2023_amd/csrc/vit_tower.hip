@@ -97,6 +97,71 @@ __global__ void ln_rows_kernel(const T *__restrict__ x, const float *__restrict_
   ln_row<T>([&](int c) { return static_cast<float>(src[c]); }, g, b, y + row * width, width, eps);
 }
 
+// The same for widths that are multiples of 256: a lane owns 4 consecutive columns per step (8- / 16-byte
+// accesses instead of one element per lane).
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec4<_Float16> { typedef _Float16 type __attribute__((ext_vector_type(4))); };
+
+template <typename T, int CNT>  // CNT = width / 256, compile-time: the row stays in registers
+__global__ void ln_rows4_kernel(const T *__restrict__ x, const float *__restrict__ g, const float *__restrict__ b,
+                                T *__restrict__ y, long long rows, float eps) {
+  typedef typename Vec4<T>::type V;
+  typedef float F4 __attribute__((ext_vector_type(4)));
+  constexpr int kMax = CNT, cnt = CNT, width = CNT * 256;
+  const long long row = blockIdx.x * 4ll + wave_id();
+  if (row >= rows) return;
+  const int lane = lane_id();
+  const T *src = x + row * width;
+  F4 v[kMax];
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < kMax; ++j)
+    if (j < cnt) {
+      const V t = *reinterpret_cast<const V *>(src + (lane + 64 * j) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[j][e] = static_cast<float>(t[e]); s += v[j][e]; }
+    }
+  const float mean = wave_sum(s) / static_cast<float>(width);
+  float q = 0.0f;
+#pragma unroll
+  for (int j = 0; j < kMax; ++j)
+    if (j < cnt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / static_cast<float>(width) + eps);
+  T *dst = y + row * width;
+#pragma unroll
+  for (int j = 0; j < kMax; ++j)
+    if (j < cnt) {
+      const int c = (lane + 64 * j) * 4;
+      const F4 gg = *reinterpret_cast<const F4 *>(g + c), bb = *reinterpret_cast<const F4 *>(b + c);
+      V t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = static_cast<T>((v[j][e] - mean) * rstd * gg[e] + bb[e]);
+      *reinterpret_cast<V *>(dst + c) = t;
+    }
+}
+
+template <typename T>
+int layer_norm_rows(const T *x, const float *g, const float *b, T *y, long long rows, int width, float eps, hipStream_t stream) {
+  const dim3 grid(static_cast<unsigned>((rows + 3) / 4));
+  clear_sticky_error();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+#define CODA_LN4(C) \
+  case C: hipLaunchKernelGGL((ln_rows4_kernel<T, C>), grid, dim3(256), 0, stream, x, g, b, y, rows, eps); break;
+  if (width % 256 == 0 && aligned) {
+    switch (width / 256) {
+      CODA_LN4(1) CODA_LN4(2) CODA_LN4(3) CODA_LN4(4) CODA_LN4(5) CODA_LN4(6) CODA_LN4(7) CODA_LN4(8)
+      default: return CODA_EINVAL;
+    }
+  } else {
+    hipLaunchKernelGGL(ln_rows_kernel<T>, grid, dim3(256), 0, stream, x, g, b, y, rows, width, eps);
+  }
+#undef CODA_LN4
+  return launch_status();
+}
+
 // fallback when the library has no swish epilogue for a shape: u = QuickGELU(u) in place (bias already added)
 template <typename T>
 __global__ void quickgelu_kernel(T *__restrict__ u, long long total) {
@@ -123,8 +188,9 @@ template <int NKT> constexpr size_t attn_lds_bytes() {
 }
 
 template <int NKT>
-__global__ __launch_bounds__(256) void vit_attention_kernel(const _Float16 *__restrict__ qkv, _Float16 *__restrict__ out,
-                                                            int n, int l, int heads) {
+__global__ __launch_bounds__(256, NKT <= 7 ? 2 : 1) void vit_attention_kernel(const _Float16 *__restrict__ qkv,
+                                                                             _Float16 *__restrict__ out, int n, int l,
+                                                                             int heads) {
   constexpr int LP = NKT * 32;
   constexpr int VP = vt_pitch_dwords<NKT>();
   extern __shared__ u32x4 smem[];
@@ -133,37 +199,62 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const _Float16 *__re
 
   const int img = blockIdx.x / heads, hd = blockIdx.x % heads;
   const int width = heads * 64;
-  const long long rs = static_cast<long long>(n) * 3 * width;  // halfs between consecutive tokens of one image
-  const _Float16 *base = qkv + static_cast<long long>(img) * 3 * width + hd * 64;
+  const uint32_t rs = static_cast<uint32_t>(n) * 3u * width;  // halfs between consecutive tokens of one image
+  const _Float16 *base = qkv + static_cast<uint32_t>(img) * 3u * width + hd * 64;  // offsets fit 32 bits (host check)
   const int tid = threadIdx.x, chunk = tid & 7;
 
+  // all global loads of the head's K and V first (one round trip), then the LDS stores
   const u32x4 zero = {0u, 0u, 0u, 0u};
-  for (int r = tid >> 3; r < LP; r += 32) {
-    const u32x4 kv = r < l ? *reinterpret_cast<const u32x4 *>(base + r * rs + width + chunk * 8) : zero;
-    *reinterpret_cast<u32x4 *>(ks + r * kKeyPitch + chunk * 8) = kv;
-  }
-  for (int rp = tid >> 3; rp < LP / 2; rp += 32) {  // two keys per thread: V^T[d][key pair] as one dword
-    const int r0 = 2 * rp;
-    const u32x4 a = r0 < l ? *reinterpret_cast<const u32x4 *>(base + r0 * rs + 2 * width + chunk * 8) : zero;
-    const u32x4 b = r0 + 1 < l ? *reinterpret_cast<const u32x4 *>(base + (r0 + 1) * rs + 2 * width + chunk * 8) : zero;
+  constexpr int NVP = (NKT + 1) / 2;  // 32-row-pair steps over LP / 2 key pairs
+  u32x4 kreg[NKT], va[NVP], vb[NVP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vt[(chunk * 8 + 2 * i) * VP + rp] = (a[i] & 0xffffu) | (b[i] << 16);
-      vt[(chunk * 8 + 2 * i + 1) * VP + rp] = (a[i] >> 16) | (b[i] & 0xffff0000u);
+  for (int i = 0; i < NKT; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    kreg[i] = r < l ? *reinterpret_cast<const u32x4 *>(base + (r * rs + width + chunk * 8)) : zero;
+  }
+#pragma unroll
+  for (int i = 0; i < NVP; ++i) {
+    const int r0 = 2 * ((tid >> 3) + 32 * i);
+    va[i] = r0 < l ? *reinterpret_cast<const u32x4 *>(base + (r0 * rs + 2 * width + chunk * 8)) : zero;
+    vb[i] = r0 + 1 < l ? *reinterpret_cast<const u32x4 *>(base + ((r0 + 1) * rs + 2 * width + chunk * 8)) : zero;
+  }
+#pragma unroll
+  for (int i = 0; i < NKT; ++i)
+    *reinterpret_cast<u32x4 *>(ks + ((tid >> 3) + 32 * i) * kKeyPitch + chunk * 8) = kreg[i];
+#pragma unroll
+  for (int i = 0; i < NVP; ++i) {  // two keys per thread: V^T[d][key pair] as one dword
+    const int rp = (tid >> 3) + 32 * i;
+    if (rp < LP / 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(chunk * 8 + 2 * e) * VP + rp] = (va[i][e] & 0xffffu) | (vb[i][e] << 16);
+        vt[(chunk * 8 + 2 * e + 1) * VP + rp] = (va[i][e] >> 16) | (vb[i][e] & 0xffff0000u);
+      }
     }
   }
   __syncthreads();
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
-  const float scale_log2 = 0.125f * 1.44269504088896340736f;  // head width 64: 1/sqrt(64), exponentials in base 2
-  for (int qt = wave_id(); qt * 32 < l; qt += 4) {
-    const int qrow = min(qt * 32 + l31, l - 1);
-    const _Float16 *qp = base + qrow * rs + half * 8;
-    h8 qf[4];
+  const float c = 0.125f * 1.44269504088896340736f;  // head width 64: 1/sqrt(64); exponentials in base 2
+  const uint32_t orow = static_cast<uint32_t>(n) * width;
+  _Float16 *obase = out + static_cast<uint32_t>(img) * width + hd * 64 + l31;
+  h8 qf[4];
+  {
+    const _Float16 *qp = base + (min(wave_id() * 32 + l31, l - 1) * rs + half * 8);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const h8 *>(qp + 16 * kk);
+  }
+  for (int qt = wave_id(); qt * 32 < l; qt += 4) {
+    h8 qn[4];  // the next tile's queries, in flight during this tile
+    {
+      const _Float16 *qp = base + (min((qt + 4) * 32 + l31, l - 1) * rs + half * 8);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) qn[kk] = *reinterpret_cast<const h8 *>(qp + 16 * kk);
+    }
 
+    // S^T = K Q^T: s[kt][4i + j] = <k[kt*32 + 8i + 4*half + j], q[l31]>
     f32x16 s[NKT];
+    float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       f32x16 acc = {};
@@ -172,31 +263,31 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const _Float16 *__re
         const h8 a = *reinterpret_cast<const h8 *>(ks + (kt * 32 + l31) * kKeyPitch + half * 8 + 16 * kk);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[kk], acc, 0, 0, 0);
       }
-      s[kt] = acc;
-    }
-    float m = -INFINITY;
+      if ((kt + 1) * 32 > l) {  // padded keys: a real (scalar) branch, taken by the last tile(s) only
+        asm volatile("" ::: "memory");
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        const float v = key < l ? s[kt][r] * scale_log2 : -INFINITY;
-        s[kt][r] = v;
-        m = fmaxf(m, v);
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3) >= l) acc[r] = -INFINITY;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r]);
+      s[kt] = acc;
+      __builtin_amdgcn_sched_barrier(0);  // one key tile's fragments at a time: the score block itself fills the registers
+    }
     m = fmaxf(m, __shfl_xor(m, 32));
+    const float mc = -m * c;
     float sum = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[kt][r] - m);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, mc));
         s[kt][r] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
 
+    // O = P V with the un-normalised probabilities (<= 1, rounded to half); rows are scaled by 1 / sum afterwards
     f32x16 o[2] = {};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -204,7 +295,7 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const _Float16 *__re
       for (int k2 = 0; k2 < 2; ++k2) {
         h8 pa;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pa[e] = static_cast<_Float16>(s[kt][8 * k2 + e] * inv);
+        for (int e = 0; e < 8; ++e) pa[e] = static_cast<_Float16>(s[kt][8 * k2 + e]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const uint32_t *vrow = vt + (l31 + 32 * db) * VP + kt * 16 + 8 * k2 + 2 * half;
@@ -212,15 +303,33 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const _Float16 *__re
           bv.w[0] = vrow[0]; bv.w[1] = vrow[1]; bv.w[2] = vrow[4]; bv.w[3] = vrow[5];
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, bv.v, o[db], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    // o[db][4i + j] belongs to query 8i + 4*half + j of the tile; its soft-max sum lives in lane (that query)
+    float inv[16];
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int r = 0; r < 16; ++r) inv[r] = __builtin_amdgcn_rcpf(__shfl(sum, 8 * (r >> 2) + 4 * half + (r & 3)));
+    _Float16 *orow_ptr = obase + static_cast<uint32_t>(qt * 32 + 4 * half) * orow;
+    if (qt * 32 + 32 <= l) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = qt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (q < l)
-          out[(static_cast<long long>(q) * n + img) * width + hd * 64 + l31 + 32 * db] = static_cast<_Float16>(o[db][r]);
+        const uint32_t off = static_cast<uint32_t>(8 * (r >> 2) + (r & 3)) * orow;
+        orow_ptr[off] = static_cast<_Float16>(o[0][r] * inv[r]);
+        orow_ptr[off + 32] = static_cast<_Float16>(o[1][r] * inv[r]);
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = 8 * (r >> 2) + 4 * half + (r & 3);
+        const uint32_t off = static_cast<uint32_t>(8 * (r >> 2) + (r & 3)) * orow;
+        if (qt * 32 + ql < l) {
+          orow_ptr[off] = static_cast<_Float16>(o[0][r] * inv[r]);
+          orow_ptr[off + 32] = static_cast<_Float16>(o[1][r] * inv[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
   }
 }
 
@@ -239,6 +348,7 @@ int launch_attention(const _Float16 *qkv, _Float16 *out, int n, int l, int heads
 }
 
 int attention_f16(const _Float16 *qkv, _Float16 *out, int n, int l, int heads, hipStream_t stream) {
+  if (static_cast<long long>(l) * n * heads * 192 >= (1ll << 31)) return CODA_ENOSPC;  // 32-bit element offsets
   if (l <= 64) return launch_attention<2>(qkv, out, n, l, heads, stream);
   if (l <= 128) return launch_attention<4>(qkv, out, n, l, heads, stream);
   if (l <= 224) return launch_attention<7>(qkv, out, n, l, heads, stream);
@@ -325,8 +435,7 @@ int run(const CodaVit *d, const Plan &p, const float *images, int n, void *cls_o
 
   for (int i = 0; i < d->nlayers; ++i) {
     const CodaVitLayer &ly = d->layers[i];
-    hipLaunchKernelGGL(ln_rows_kernel<T>, dim3(ln_blocks), dim3(256), 0, stream, x, ly.ln1_g, ly.ln1_b, h, p.rows, w, d->eps);
-    if ((st = launch_status()) != CODA_OK) return st;
+    if ((st = layer_norm_rows<T>(x, ly.ln1_g, ly.ln1_b, h, p.rows, w, d->eps, stream)) != CODA_OK) return st;
     st = coda_gemm_ex(dt, 1, 0, 1, m, 3 * w, w, h, w, ly.in_w, w, qkv, 3 * w, ly.in_b, 1.0f, 0.0f, stream);
     if (st != CODA_OK) return st;
     if constexpr (sizeof(T) == 2) {
@@ -342,8 +451,7 @@ int run(const CodaVit *d, const Plan &p, const float *images, int n, void *cls_o
     if (st != CODA_OK) return st;
     st = coda_gemm_ex(dt, 1, 0, 1, m, w, w, o, w, ly.out_w, w, x, w, ly.out_b, 1.0f, 1.0f, stream);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(ln_rows_kernel<T>, dim3(ln_blocks), dim3(256), 0, stream, x, ly.ln2_g, ly.ln2_b, h, p.rows, w, d->eps);
-    if ((st = launch_status()) != CODA_OK) return st;
+    if ((st = layer_norm_rows<T>(x, ly.ln2_g, ly.ln2_b, h, p.rows, w, d->eps, stream)) != CODA_OK) return st;
     int &swish = g_swish_ok[dt];
     float down_alpha = 1.0f;
     if (swish != 0) {
@@ -366,9 +474,7 @@ int run(const CodaVit *d, const Plan &p, const float *images, int n, void *cls_o
 
   // class-token rows are the first n rows of the sequence-first layout
   const long long post_rows = tok_out ? p.rows : n;
-  hipLaunchKernelGGL(ln_rows_kernel<T>, dim3(static_cast<int>((post_rows + 3) / 4)), dim3(256), 0, stream, x, d->ln_post_g,
-                     d->ln_post_b, h, post_rows, w, d->eps);
-  if ((st = launch_status()) != CODA_OK) return st;
+  if ((st = layer_norm_rows<T>(x, d->ln_post_g, d->ln_post_b, h, post_rows, w, d->eps, stream)) != CODA_OK) return st;
   st = coda_gemm_ex(dt, 0, 0, 0, n, d->out_dim, w, h, w, d->proj, d->out_dim, cls_out, d->out_dim, nullptr, 1.0f, 0.0f, stream);
   if (st != CODA_OK) return st;
   if (tok_out)

@@ -17,7 +17,7 @@
  * Return values and stream semantics as in coda_pointnet2.h.  A problem hipBLASLt cannot PLAN (no
  * heuristic result, unsupported leading dimension) is reported as -(3000 + hipblasStatus_t) -- the
  * verdict is cached per shape, descriptors released -- and a failure of the matmul call itself as
- * -(2000 + hipblasStatus_t).  State (handle, plans, one 32 MiB workspace per stream) is kept per device.
+ * -(2000 + hipblasStatus_t).  State (handle, plans, one workspace per stream: 32 MiB, grown up to 256 MiB if an algorithm asks for more) is kept per device.
  */
 #ifndef CODA_GEMM_H
 #define CODA_GEMM_H
@@ -42,6 +42,12 @@ int coda_gemm_f32(int transa, int transb, int m, int n, int k, const float *a,
 int coda_gemm_ex(int dtype, int epilogue, int transa, int transb, int m, int n, int k, const void *a,
                  long long lda, const void *b, long long ldb, void *c, long long ldc, const float *bias,
                  float alpha, float beta, void *stream);
+
+/* First-use timing of the library's candidate algorithms for a shape (the heuristic's first answer is not always
+ * the fastest): the candidates run on the caller's operands into a scratch output and the fastest is kept for the
+ * process.  mode 1 / 0: on / off for every dtype; -1 (default): on for CODA_DTYPE_F16, off for CODA_DTYPE_F32 (a
+ * process then always runs the same fp32 kernels).  Env CODA_GEMM_TUNE=0|1 sets the start-up value. */
+int coda_gemm_set_tuning(int mode);
 
 /* Own fp32-MFMA kernel for the same product (csrc/gemm_nn.hip), used for the launch-sized problems of the
  * transformer stacks where the library costs ~14 us of host time per call:

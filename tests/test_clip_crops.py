@@ -109,3 +109,42 @@ def test_region_embedding_provider_fills_embeddings_and_mask(dev):
     from oracle import crop_oracle as CO
     valid_o = CO.rects(G["corners"], G["sizes"], CAM)[3]
     assert not (mask.squeeze(-1).cpu().numpy() > 0)[~valid_o].any()   # skipped proposals never carry an embedding
+
+
+@pytest.mark.gpu
+def test_provider_with_this_packages_tower_matches_the_oracles(dev):
+    """crops (kernel) -> ImageTower (coda_vit_fwd, float32) against crop_oracle -> clip_tower_oracle on the same
+    selection: the image branch end to end, on a small seeded tower (64 px, two blocks)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from golden.weights import fill_deterministic
+    from coda_neurips2023_amd import clip_crops as CC, clip_tower
+    from oracle import clip_tower_oracle, crop_oracle as CO
+    tower = clip_tower.ImageTower(64, 64, 2, 128, 16)
+    fill_deterministic(tower.visual, seed=5)
+    tower = tower.to(dev)
+    b = 3
+    inputs = _gpu_inputs(dev)
+    image = torch.randint(0, 256, (b, 531, 730, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(4))
+    inputs["input_image"] = image.to(dev)
+    outputs = {"box_corners_xyz": torch.from_numpy(G["corners"]).to(dev), "size_unnormalized": torch.from_numpy(G["sizes"]).to(dev)}
+    prov = CC.RegionEmbeddingProvider(tower, distillation_box_num=6, box_pool=24, rng=np.random.RandomState(3))
+    out = prov(inputs, outputs, curr_epoch=0)
+    emb, mask = out["gt_text_correlation_embedding"].cpu().numpy(), out["gt_text_correlation_embedding_mask"].cpu().numpy()
+    rng = np.random.RandomState(3)
+    select = np.stack([rng.choice(np.arange(24), 6, replace=False) for _ in range(b)])
+    _, _, rects, valid = CO.rects(G["corners"], G["sizes"], CAM)
+    sd = {k: v.cpu().numpy() for k, v in tower.visual.state_dict().items()}
+    checked = 0
+    for i in range(b):
+        for k in select[i]:
+            if not valid[i, k]:
+                assert mask[i, k, 0] == 0 and np.abs(emb[i, k]).max() == 0
+                continue
+            crop = np.asarray(CO.crop_resize(image[i], rects[i, k], 64))
+            ref, _ = clip_tower_oracle.forward(sd, crop[None], 2, 16)
+            assert mask[i, k, 0] == 1
+            # crops may differ by one 8-bit step at a few pixels (bicubic rounding ties), the tower is float32
+            np.testing.assert_allclose(emb[i, k], ref[0], rtol=0, atol=5e-3)
+            checked += 1
+    assert checked >= 6

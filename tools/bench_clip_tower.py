@@ -2,7 +2,7 @@
 step: 8 scenes x 32 proposals = 256 crops (models/model_3detr.py:991).  Prints crops/s, ms per call and the
 matrix-core rate (algorithmic flops: GEMMs + attention products) against the dense fp16 MFMA peak.
 
-    python tools/bench_clip_tower.py [--crops 256] [--dtype fp16|fp32] [--iters 10] [--with-crops]
+    python tools/bench_clip_tower.py [--crops 256] [--dtype fp16|fp32] [--iters 10]
 """
 import argparse
 import json
@@ -29,7 +29,6 @@ def main():
     ap.add_argument("--crops", type=int, default=256)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--with-crops", action="store_true", help="time project + crop/resize in front of the tower")
     a = ap.parse_args()
     torch.manual_seed(0)
     tower = clip_tower.ImageTower(512, 224, 12, 768, 16)
