@@ -169,7 +169,24 @@ def synthetic_targets(batch, gen, ngt=64, ncls=10, max_boxes=20):
     return {k: v.to(dev) for k, v in t.items()}
 
 
-def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32"):
+def synthetic_image_inputs(bsz, dev, seed):
+    """What the dataset adds to a batch for the image branch (datasets/sunrgbd_anonymous_aligned_image.py:
+    884-899): a 730 x 530 RGB image per scene (random pixels: the tower's cost does not depend on content), a
+    SUN RGB-D-like pinhole camera, no augmentation (scale 1, no rotation, no flips)."""
+    gen = torch.Generator().manual_seed(seed)
+    f64 = dict(dtype=torch.float64)
+    eye = torch.eye(3, **f64).expand(bsz, 3, 3).contiguous()
+    kmat = torch.tensor([[529.5, 0.0, 365.0], [0.0, 529.5, 265.0], [0.0, 0.0, 1.0]], **f64).expand(bsz, 3, 3).contiguous()
+    out = {"input_image": torch.randint(0, 256, (bsz, 530, 730, 3), dtype=torch.uint8, generator=gen),
+           "K": kmat, "Rtilt": eye, "rot_array": eye.clone(), "scale_array": torch.ones(bsz, 1, 3, **f64),
+           "flip_array": torch.ones(bsz, 1, **f64), "image_flip_array": torch.ones(bsz, 1, **f64),
+           "flip_length": torch.full((bsz,), 730.0, **f64), "ori_width": torch.full((bsz,), 730.0, **f64),
+           "ori_height": torch.full((bsz,), 530.0, **f64), "y_offset": torch.zeros(bsz, **f64),
+           "x_offset": torch.zeros(bsz, **f64)}
+    return {k: v.to(dev) for k, v in out.items()}
+
+
+def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", image_branch=False):
     """configs[2] (and, with nq=512 on 40k-point scenes and bf16 MFMA attention, the one-GPU share of
     configs[4]): the training step as engine.py:144-159 runs it -- model_3detr enc(3L)+dec(8L) forward with
     dropout on (enc/dec 0.1, heads 0.3), ``criterion(outputs, batch_data_label)`` built by ``build_criterion``
@@ -193,9 +210,19 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32"):
     weak_label = torch.randint(0, ncls, (B_PER_GPU, nq), generator=gen).to(dev)
     weak_conf = (torch.rand(B_PER_GPU, nq, generator=gen) * (torch.rand(B_PER_GPU, nq, generator=gen) < 0.5)).to(dev)
 
+    regions = None
+    if image_branch:  # SURVEY.md 8f rank 2 inside the step: project + crop + frozen ViT-B/16 (fp16, random-init weights)
+        from coda_neurips2023_amd import clip_crops, clip_tower
+        tower = clip_tower.convert_weights(clip_tower.ImageTower(512, 224, 12, 768, 16)).to(dev)
+        regions = clip_crops.RegionEmbeddingProvider(tower, distillation_box_num=32, box_pool=128,
+                                                     rng=np.random.RandomState(7))
+
     def provider(inputs, outputs, curr_epoch=-1):
-        outputs["gt_text_correlation_embedding"] = img_emb
-        outputs["gt_text_correlation_embedding_mask"] = mask
+        if regions is not None:
+            outputs = regions(inputs, outputs, curr_epoch)
+        else:
+            outputs["gt_text_correlation_embedding"] = img_emb
+            outputs["gt_text_correlation_embedding_mask"] = mask
         outputs["weak_box_cate_label"] = weak_label
         outputs["weak_confidence_weight"] = weak_conf
         return outputs
@@ -266,6 +293,11 @@ def run_extra(kind, dev, steps, warmup):
     prefetch = False
     if kind == "sa":
         mod, step_fn, desc, _ = build_workload("sa", dev)
+    elif kind == "distill":
+        mod, step_fn, desc, _ = build_model_workload(dev, config_tag="configs[2] + the CLIP image branch", image_branch=True)
+        desc += ("; image branch inside the step: box projection, 8 x 32 crops, frozen ViT-B/16 image tower (fp16, "
+                 "random-init), models/model_3detr.py:902-1086")
+        prefetch = True
     else:
         attention_core.set_mfma_dtype("bf16")
         n_points = 40000
@@ -277,6 +309,8 @@ def run_extra(kind, dev, steps, warmup):
             pc, mn, mx = make_batch(B_PER_GPU, n_points, seed=4321 + i)
             pool.append({"point_clouds": torch.from_numpy(pc).to(dev), "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                          "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
+            if kind == "distill":
+                pool[-1].update(synthetic_image_inputs(B_PER_GPU, dev, seed=99 + i))
         opt = torch.optim.AdamW(mod.parameters(), lr=1e-4, fused=True)
 
         def one(i):
@@ -289,7 +323,7 @@ def run_extra(kind, dev, steps, warmup):
         for i in range(warmup):
             one(i)
         attn_ms = {}
-        if kind != "sa":
+        if kind == "model40k":
             attention_core.enable_kernel_timing(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -297,7 +331,7 @@ def run_extra(kind, dev, steps, warmup):
             one(i)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if kind != "sa":
+        if kind == "model40k":
             attn_ms = attention_core.collect_kernel_timing()
             attention_core.disable_kernel_timing()
     finally:
@@ -642,7 +676,8 @@ def main():
             ex_steps, ex_warm = max(5, min(args.steps, 10)), 3
             out["extra_configs"] = {"configs[1]_sa_only": run_extra("sa", dev, ex_steps, ex_warm),
                                     "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm),
-                                    "clip_image_tower": run_image_tower(dev, ex_steps, ex_warm)}
+                                    "clip_image_tower": run_image_tower(dev, ex_steps, ex_warm),
+                                    "configs[2]_with_image_branch": run_extra("distill", dev, ex_steps, ex_warm)}
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(kind)
         if dry:
