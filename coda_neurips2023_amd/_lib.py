@@ -44,6 +44,10 @@ SIGNATURES = {
     "coda_sa_bn_bwd_sparse_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_int, _P, _P, _P, _P]),
     "coda_sa_relu_bn_bwd_stats_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
     "coda_sa_relu_bn_bwd_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P, _P, _P]),
+    "coda_sa_bn_finalize_f32": (_c_int, [_P, ctypes.c_double, ctypes.c_double, _c_float, _P, _P, _P, _P, _P, _P, _c_int, _P]),
+    "coda_sa_bn_bwd_coef_f32": (_c_int, [_P, ctypes.c_double, _P, _P, _P, _c_int, _P, _P, _c_int, _P]),
+    "coda_sa_pool_select_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _P]),
+    "coda_sa_pool_bwd_stats_f32": (_c_int, [_P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
     # include/coda_token_ops.h
     "coda_tok_bn_stats_f32": (_c_int, [_P, _c_int, ctypes.c_longlong, _c_int, _P, _P]),
     "coda_tok_bn_finalize_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, ctypes.c_double, _c_float, _P, _P, _P]),

@@ -370,6 +370,105 @@ int nblocks(long long p) {
   return static_cast<int>(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
 }
 
+
+// ---- batch-norm bookkeeping (what used to be ~20 tiny framework kernels per layer and pass) --------------
+// sums = [sum y, sum y^2] over n rows (double).  stats = [scale, shift, mean, invstd][C] (float):
+//   mean = s1 / n, var = max(s2 / n - mean^2, 0) in double; invstd = 1 / sqrt(var + eps);
+//   scale = gamma * invstd, shift = beta - mean * scale (float, one rounding per operation);
+//   running_mean = running_mean * (1 - mom) + mom * mean, running_var likewise with the unbiased variance
+//   var * n / max(n - 1, 1) (torch.nn.BatchNorm's update), num_batches += 1.
+__global__ void bn_finalize_kernel(const double *__restrict__ sums, double n, double eps, float momentum,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   long long *__restrict__ num_batches, float *__restrict__ stats, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && num_batches) *num_batches += 1;
+  if (i >= c) return;
+  const double mean = sums[i] / n;
+  double var = sums[c + i] / n - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float mean32 = static_cast<float>(mean);
+  const float invstd = static_cast<float>(1.0 / sqrt(var + eps));
+  const float scale = __fmul_rn(gamma[i], invstd);
+  stats[i] = scale;
+  stats[c + i] = __fsub_rn(beta[i], __fmul_rn(mean32, scale));
+  stats[2 * c + i] = mean32;
+  stats[3 * c + i] = invstd;
+  if (running_mean) {
+    const float keep = 1.0f - momentum;
+    const double nm1 = n - 1.0 > 1.0 ? n - 1.0 : 1.0;
+    const float unbiased = static_cast<float>(var * (n / nm1));
+    running_mean[i] = __fadd_rn(__fmul_rn(running_mean[i], keep), __fmul_rn(momentum, mean32));
+    running_var[i] = __fadd_rn(__fmul_rn(running_var[i], keep), __fmul_rn(momentum, unbiased));
+  }
+}
+
+// sums = [sum d, sum d * xhat] (double).  dbeta / dgamma = float(sums) (may be NULL);
+// coef (may be NULL): layout 0 = [scale, shift, mean, invstd, gamma * invstd, m1, m2][C] (hidden layers),
+// layout 1 = [gamma * invstd, m1, m2, mean, invstd][C] (pooled last layer), m1 = sum d / n, m2 = sum d xhat / n
+// (n <= 0: eval mode, m1 = m2 = 0).
+__global__ void bn_bwd_coef_kernel(const double *__restrict__ sums, double n, const float *__restrict__ gamma,
+                                   const float *__restrict__ stats, float *__restrict__ coef, int layout,
+                                   float *__restrict__ dbeta, float *__restrict__ dgamma, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  if (dbeta) dbeta[i] = static_cast<float>(sums[i]);
+  if (dgamma) dgamma[i] = static_cast<float>(sums[c + i]);
+  if (!coef) return;
+  const float m1 = n > 0.0 ? static_cast<float>(sums[i] / n) : 0.0f;
+  const float m2 = n > 0.0 ? static_cast<float>(sums[c + i] / n) : 0.0f;
+  const float mean = stats[2 * c + i], invstd = stats[3 * c + i];
+  const float a = __fmul_rn(gamma[i], invstd);
+  if (layout == 0) {
+    coef[i] = stats[i]; coef[c + i] = stats[c + i]; coef[2 * c + i] = mean; coef[3 * c + i] = invstd;
+    coef[4 * c + i] = a; coef[5 * c + i] = m1; coef[6 * c + i] = m2;
+  } else {
+    coef[i] = a; coef[c + i] = m1; coef[2 * c + i] = m2; coef[3 * c + i] = mean; coef[4 * c + i] = invstd;
+  }
+}
+
+// Pooled last layer, forward: BN is monotone per channel, so the max-pool of relu(bn(y)) is relu(bn(.)) of the
+// group's max (scale >= 0) or min (scale < 0) pre-BN value.
+__global__ __launch_bounds__(kT) void pool_select_kernel(const float *__restrict__ ymax, const float *__restrict__ ymin,
+                                                         const int32_t *__restrict__ amax, const int32_t *__restrict__ amin,
+                                                         const float *__restrict__ stats, float *__restrict__ ysel,
+                                                         int32_t *__restrict__ sel, float *__restrict__ out,
+                                                         long long total, int c) {
+  for (long long i = blockIdx.x * static_cast<long long>(kT) + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * kT) {
+    const int ch = static_cast<int>(i % c);
+    const float scale = stats[ch], shift = stats[c + ch];
+    const bool pos = scale >= 0.0f;
+    const float y = pos ? ymax[i] : ymin[i];
+    ysel[i] = y;
+    sel[i] = pos ? amax[i] : amin[i];
+    out[i] = fmaxf(__fadd_rn(__fmul_rn(y, scale), shift), 0.0f);
+  }
+}
+
+// Pooled last layer, backward: d = gout where out > 0; sums = [sum d, sum d * (ysel - mean) * invstd] (double).
+__global__ __launch_bounds__(kT) void pool_bwd_stats_kernel(const float *__restrict__ gout, const float *__restrict__ out,
+                                                            const float *__restrict__ ysel, const float *__restrict__ stats,
+                                                            float *__restrict__ d, long long groups, int c,
+                                                            double *__restrict__ sums) {
+  const RowMap m = row_map(c);
+  const float4 mu = ld4(stats + 2 * c + 4 * m.cq), is = ld4(stats + 3 * c + 4 * m.cq);
+  float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+  const long long rows_pb = block_rows(groups, m.rpb);
+  const long long r0 = static_cast<long long>(blockIdx.x) * rows_pb;
+  const long long r1 = min(r0 + rows_pb, groups);
+  for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
+    const long long at = r * c + 4 * m.cq;
+    const float4 g = ld4(gout + at), o = ld4(out + at), y = ld4(ysel + at);
+    const float4 dv = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    st4(d + at, dv);
+    acc[0].x += dv.x; acc[0].y += dv.y; acc[0].z += dv.z; acc[0].w += dv.w;
+    acc[1].x += dv.x * ((y.x - mu.x) * is.x); acc[1].y += dv.y * ((y.y - mu.y) * is.y);
+    acc[1].z += dv.z * ((y.z - mu.z) * is.z); acc[1].w += dv.w * ((y.w - mu.w) * is.w);
+  }
+  block_reduce_to_global<2>(acc, m, c, sums);
+}
+
 }  // namespace
 }  // namespace coda
 
@@ -469,5 +568,58 @@ CODA_API int coda_sa_relu_bn_bwd_apply_f32(const float *da, const float *src, co
   clear_sticky_error();
   if (w1) hipLaunchKernelGGL(relu_bn_bwd_apply_kernel<true>, dim3(nblocks(p)), dim3(kT), 0, s, da, src, w1, prm, p, c, row_weight, dy, dw1);
   else hipLaunchKernelGGL(relu_bn_bwd_apply_kernel<false>, dim3(nblocks(p)), dim3(kT), 0, s, da, src, w1, prm, p, c, row_weight, dy, dw1);
+  return launch_status();
+}
+
+CODA_API int coda_sa_bn_finalize_f32(const double *sums, double n, double eps, float momentum, const float *gamma,
+                                     const float *beta, float *running_mean, float *running_var,
+                                     long long *num_batches, float *stats, int c, void *stream) {
+  using namespace coda;
+  if (c <= 0 || n <= 0.0 || !sums || !gamma || !beta || !stats) return CODA_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return CODA_EINVAL;
+  clear_sticky_error();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sums, n,
+                     eps, momentum, gamma, beta, running_mean, running_var, num_batches, stats, c);
+  return launch_status();
+}
+
+CODA_API int coda_sa_bn_bwd_coef_f32(const double *sums, double n, const float *gamma, const float *stats, float *coef,
+                                     int layout, float *dbeta, float *dgamma, int c, void *stream) {
+  using namespace coda;
+  if (c <= 0 || !sums || (layout != 0 && layout != 1)) return CODA_EINVAL;
+  if (coef && (!gamma || !stats)) return CODA_EINVAL;
+  clear_sticky_error();
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sums, n,
+                     gamma, stats, coef, layout, dbeta, dgamma, c);
+  return launch_status();
+}
+
+CODA_API int coda_sa_pool_select_f32(const float *ymax, const float *ymin, const int32_t *amax, const int32_t *amin,
+                                     const float *stats, float *ysel, int32_t *sel, float *out, long long groups,
+                                     int c, void *stream) {
+  using namespace coda;
+  if (groups < 0 || c <= 0) return CODA_EINVAL;
+  if (groups == 0) return CODA_OK;
+  if (!ymax || !ymin || !amax || !amin || !stats || !ysel || !sel || !out) return CODA_EINVAL;
+  const long long total = groups * c;
+  long long blocks = (total + kT * 4 - 1) / (kT * 4);
+  blocks = blocks > 8192 ? 8192 : blocks;
+  clear_sticky_error();
+  hipLaunchKernelGGL(pool_select_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kT), 0, static_cast<hipStream_t>(stream),
+                     ymax, ymin, amax, amin, stats, ysel, sel, out, total, c);
+  return launch_status();
+}
+
+CODA_API int coda_sa_pool_bwd_stats_f32(const float *gout, const float *out, const float *ysel, const float *stats,
+                                        float *d, long long groups, int c, double *sums, void *stream) {
+  using namespace coda;
+  if (groups < 0 || bad_c(c) || !sums) return CODA_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (groups == 0) return CODA_OK;
+  if (!gout || !out || !ysel || !stats || !d) return CODA_EINVAL;
+  clear_sticky_error();
+  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nblocks(groups)), dim3(kT), 0, s, gout, out, ysel, stats, d, groups, c, sums);
   return launch_status();
 }

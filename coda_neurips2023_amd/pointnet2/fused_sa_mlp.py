@@ -85,6 +85,23 @@ def compact_groups(idx, grouped_cl, counts=None, total=None, min_saving=0.25):
     return x, roww, goff.to(torch.int32)
 
 
+def _bwd_coef(ctx, i, sums, st, gamma, bn, training, n, layout, grads, dev):
+    """d beta / d gamma of layer i from the local sums, then (after SyncBN's all-reduce) the coefficient table of
+    the layer's backward kernel -- one launch (two with SyncBN across ranks)."""
+    c = st.shape[1]
+    coef = torch.empty((5 if layout else 7, c), dtype=torch.float32, device=dev)
+    dbeta, dgamma = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
+    grads[3 * i + 2], grads[3 * i + 1] = dbeta, dgamma
+    if training and _is_sync(bn):
+        _call("coda_sa_bn_bwd_coef_f32", _p(sums), 0.0, None, None, None, layout, _p(dbeta), _p(dgamma), c)
+        _all_reduce(sums, bn)
+        _call("coda_sa_bn_bwd_coef_f32", _p(sums), float(n), _p(gamma), _p(st), _p(coef), layout, None, None, c)
+    else:
+        _call("coda_sa_bn_bwd_coef_f32", _p(sums), float(n) if training else 0.0, _p(gamma), _p(st), _p(coef), layout,
+              _p(dbeta), _p(dgamma), c)
+    return coef
+
+
 class _FusedMlpPool(torch.autograd.Function):
     """x (P,3) grouped xyz channels-last, P = groups * nsample (or the distinct rows of
     ``compact_groups`` with ``dedup = (row_weight, group_offsets)``).  Returns (groups, C_last)."""
@@ -130,27 +147,35 @@ class _FusedMlpPool(torch.autograd.Function):
             elif training:
                 _call("coda_sa_col_stats_f32", _p(src), _p(w1), p, c, _p(roww), _p(s))
             bn = bns[i]
-            if training:
+            st = torch.empty((4, c), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
+            if training and (bn.momentum is not None or not bn.track_running_stats or bn.running_mean is None):
+                # one launch: statistics -> scale / shift and the running-statistics update
+                _all_reduce(s, bn)
+                track = bn.track_running_stats and bn.running_mean is not None
+                _call("coda_sa_bn_finalize_f32", _p(s), float(n_rows * world[i]), float(bn.eps),
+                      float(bn.momentum) if track else 0.0, _p(gammas[i].detach()), _p(betas[i].detach()),
+                      _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+                      _p(bn.num_batches_tracked) if track else None, _p(st), c)
+            elif training:  # cumulative moving average (momentum=None): the factor depends on a device counter
                 tot = _all_reduce(s.clone(), bn)
                 n = float(n_rows * world[i])
                 mean = tot[:c] / n
                 var = (tot[c:] / n - mean * mean).clamp_(min=0.0)
                 invstd = torch.rsqrt(var + bn.eps)
                 with torch.no_grad():
-                    if bn.track_running_stats and bn.running_mean is not None:
-                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                        bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32), alpha=mom)
-                        bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(torch.float32),
-                                                          alpha=mom)
-                        bn.num_batches_tracked += 1
-                mean = mean.to(torch.float32)
-                invstd = invstd.to(torch.float32)
+                    mom = 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32), alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(torch.float32), alpha=mom)
+                    bn.num_batches_tracked += 1
+                st[2], st[3] = mean.to(torch.float32), invstd.to(torch.float32)
+                st[0] = gammas[i] * st[3]
+                st[1] = betas[i] - st[2] * st[0]
             else:
-                mean = bn.running_mean
-                invstd = torch.rsqrt(bn.running_var + bn.eps)
-            scale = (gammas[i] * invstd).contiguous()
-            shift = (betas[i] - mean * scale).contiguous()
-            stats.append((mean.contiguous(), invstd.contiguous(), scale, shift))
+                st[2], st[3] = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+                st[0] = gammas[i] * st[3]
+                st[1] = betas[i] - st[2] * st[0]
+            scale, shift = st[0], st[1]
+            stats.append(st)
             saved_pre.append(pre)
             if not last:
                 act = torch.empty((p, c), dtype=torch.float32, device=dev)
@@ -159,11 +184,9 @@ class _FusedMlpPool(torch.autograd.Function):
                 cur = act
 
         ymax, ymin, amax, amin = pool
-        scale, shift = stats[-1][2], stats[-1][3]
-        pos = scale >= 0
-        ysel = torch.where(pos, ymax, ymin)      # BN is monotone per channel: pool the pre-BN values
-        sel = torch.where(pos, amax, amin)
-        out = torch.relu(ysel * scale + shift)   # (groups, C)
+        ysel, sel, out = torch.empty_like(ymax), torch.empty_like(amax), torch.empty_like(ymax)
+        _call("coda_sa_pool_select_f32", _p(ymax), _p(ymin), _p(amax), _p(amin), _p(stats[-1]), _p(ysel), _p(sel), _p(out),
+              groups, ws[-1].shape[0])             # BN is monotone per channel: pool the pre-BN values
 
         ctx.meta = (groups, nsample, bns, training, nl, world, n_rows)
         ctx.dedup = dedup
@@ -190,22 +213,11 @@ class _FusedMlpPool(torch.autograd.Function):
         # ---- last layer: max-pool + ReLU + BN backward
         i = nl - 1
         c = ws[i].shape[0]
-        mean, invstd, scale, shift = ctx.stats[i]
-        d = (gout * (out > 0)).contiguous()                      # (groups, C) at sample sel
-        xhat_sel = (ysel - mean) * invstd
-        sum_d = d.sum(0, dtype=torch.float64)
-        sum_dx = (d * xhat_sel).sum(0, dtype=torch.float64)
-        grads[3 * i + 2] = sum_d.to(torch.float32)               # d beta
-        grads[3 * i + 1] = sum_dx.to(torch.float32)              # d gamma
-        if training:
-            tot = _all_reduce(torch.cat([sum_d, sum_dx]), bns[i])
-            n = float(n_rows * world[i])
-            m1 = (tot[:c] / n).to(torch.float32)
-            m2 = (tot[c:] / n).to(torch.float32)
-        else:
-            m1 = torch.zeros(c, device=dev)
-            m2 = torch.zeros(c, device=dev)
-        coef = torch.stack([gammas[i] * invstd, m1, m2, mean, invstd]).contiguous()
+        st = ctx.stats[i]
+        d = torch.empty_like(out)                                # (groups, C) at sample sel
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        _call("coda_sa_pool_bwd_stats_f32", _p(gout.contiguous()), _p(out), _p(ysel), _p(st), _p(d), groups, c, _p(sums))
+        coef = _bwd_coef(ctx, i, sums, st, gammas[i], bns[i], training, n_rows * world[i], 1, grads, dev)
         # de-duplicated rows: the padding rows past the last group belong to no group and stay zero
         dy = (torch.zeros if roww is not None else torch.empty)((p, c), dtype=torch.float32, device=dev)
         _call("coda_sa_bn_bwd_sparse_f32", _p(pres[i]), _p(d), _p(sel.contiguous()), _p(coef), groups, nsample, c,
@@ -219,24 +231,13 @@ class _FusedMlpPool(torch.autograd.Function):
             del dy
             i -= 1
             c = ws[i].shape[0]
-            mean, invstd, scale, shift = ctx.stats[i]
+            st = ctx.stats[i]
             first = i == 0
             src = x if first else pres[i]
             w1 = ws[0].contiguous() if first else None
-            prm4 = torch.stack([scale, shift, mean, invstd]).contiguous()
             sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
-            _call("coda_sa_relu_bn_bwd_stats_f32", _p(da), _p(src), _p(w1), _p(prm4), p, c, _p(sums))
-            grads[3 * i + 2] = sums[:c].to(torch.float32)
-            grads[3 * i + 1] = sums[c:].to(torch.float32)
-            if training:
-                tot = _all_reduce(sums.clone(), bns[i])
-                n = float(n_rows * world[i])
-                m1 = (tot[:c] / n).to(torch.float32)
-                m2 = (tot[c:] / n).to(torch.float32)
-            else:
-                m1 = torch.zeros(c, device=dev)
-                m2 = torch.zeros(c, device=dev)
-            prm7 = torch.stack([scale, shift, mean, invstd, gammas[i] * invstd, m1, m2]).contiguous()
+            _call("coda_sa_relu_bn_bwd_stats_f32", _p(da), _p(src), _p(w1), _p(st), p, c, _p(sums))
+            prm7 = _bwd_coef(ctx, i, sums, st, gammas[i], bns[i], training, n_rows * world[i], 0, grads, dev)
             if first:
                 dw1 = torch.empty(3 * c, dtype=torch.float64, device=dev)
                 _call("coda_sa_relu_bn_bwd_apply_f32", _p(da), _p(src), _p(w1), _p(prm7), p, c, _p(roww), None, _p(dw1))

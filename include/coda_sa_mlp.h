@@ -64,6 +64,25 @@ int coda_sa_relu_bn_bwd_apply_f32(const float *da, const float *src, const float
                                   const float *row_weight, float *dy, double *dw1,
                                   void *stream);
 
+/* Batch-norm bookkeeping between the streaming kernels (pytorch_utils.py:8-117's BatchNorm2d in train mode):
+ * stats = [scale, shift, mean, invstd][C] from sums = [sum y, sum y^2] over n rows; running statistics updated
+ * with `momentum` (running_mean / running_var / num_batches may be NULL: no update). */
+int coda_sa_bn_finalize_f32(const double *sums, double n, double eps, float momentum, const float *gamma,
+                            const float *beta, float *running_mean, float *running_var, long long *num_batches,
+                            float *stats, int c, void *stream);
+/* sums = [sum d, sum d * xhat]: dbeta / dgamma = float(sums) (NULL: skip); coef (NULL: skip) in layout 0 =
+ * coda_sa_relu_bn_bwd_apply_f32's prm[7][C], layout 1 = coda_sa_bn_bwd_sparse_f32's coef[5][C]; n <= 0: m1 = m2 = 0. */
+int coda_sa_bn_bwd_coef_f32(const double *sums, double n, const float *gamma, const float *stats, float *coef,
+                            int layout, float *dbeta, float *dgamma, int c, void *stream);
+/* pooled last layer, forward: ysel / sel = the group's max (scale >= 0) or min pre-BN value and its row,
+ * out = relu(ysel * scale + shift); all (groups, C). */
+int coda_sa_pool_select_f32(const float *ymax, const float *ymin, const int32_t *amax, const int32_t *amin,
+                            const float *stats, float *ysel, int32_t *sel, float *out, long long groups, int c,
+                            void *stream);
+/* pooled last layer, backward: d = gout where out > 0; sums = [sum d, sum d * (ysel - mean) * invstd]. */
+int coda_sa_pool_bwd_stats_f32(const float *gout, const float *out, const float *ysel, const float *stats,
+                               float *d, long long groups, int c, double *sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
