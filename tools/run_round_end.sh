@@ -16,7 +16,12 @@ rm -rf $R/gpurun_out/final_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
   python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/final_prof_bench.json 2>/dev/null
 rm -f $R/gpurun_out/final_prof/run_kernel_trace.csv   # tens of MB; the stats file is what gets committed
+rm -rf $R/gpurun_out/final_tower_prof
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_tower_prof -o tower -- \
+  python $R/tools/bench_clip_tower.py --iters 30 > $R/gpurun_out/final_tower.json 2>/dev/null
+rm -f $R/gpurun_out/final_tower_prof/tower_kernel_trace.csv
 cd $R
+cat gpurun_out/final_tower.json
 python - <<'PY'
 import json
 for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_prof_bench"):
