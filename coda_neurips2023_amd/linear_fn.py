@@ -15,24 +15,14 @@ from . import gemm
 
 _MIN_ROWS = 4096
 _CHUNK = 2048
-_GROUPED_CHUNKS = 32
 
 
 def tn_gemm(dy, x):
     """dy (P, Co), x (P, Ci) -> dy^T x (Co, Ci), reduction over P split into chunks."""
     p = dy.shape[0]
-    if (p >= (1 << 18) and p % (_GROUPED_CHUNKS * 8) == 0 and gemm.GROUPED_TN and dy.shape[1] % 64 == 0
-            and x.shape[1] % 64 == 0 and dy.shape[1] * x.shape[1] >= 256 * 128 and dy.is_contiguous()
-            and x.is_contiguous() and dy.is_cuda and dy.dtype == torch.float32):
-        # ~10^6 grouped rows of the set-abstraction MLP into a 256 x 128 matrix: row chunks as one grouped launch
-        # of the own fp32-MFMA kernel + a small sum (505 vs 630 us for bmm + sum, tools/bench_long_tn.py)
-        rows = p // _GROUPED_CHUNKS
-        part = torch.empty((_GROUPED_CHUNKS, dy.shape[1], x.shape[1]), dtype=torch.float32, device=dy.device)
-        d = gemm.DeferredWeightGrads()
-        for i in range(_GROUPED_CHUNKS):
-            d.add(part[i], dy[i * rows:(i + 1) * rows], x[i * rows:(i + 1) * rows])
-        d.flush()
-        return part.sum(0)
+    # (row chunks of the ~10^6-row SA products as one grouped launch of the own kernel + a sum measure 505 vs 630 us
+    # stand-alone, tools/bench_long_tn.py, but 958 vs 979 scenes/s in the SA-only step -- 32 descriptor rows and
+    # slices on the host per call -- so the batched library GEMM stays)
     if p >= _MIN_ROWS and not gemm.TN_KERNEL:
         rows = _CHUNK if p % _CHUNK == 0 else 0
         if p >= (1 << 18) and p % 16384 == 0:
