@@ -59,6 +59,7 @@ class _BoxDecode(torch.autograd.Function):
         _lib.check(st, "box_decode_fwd")
         ctx.save_for_backward(center_raw, size_raw, angle_logits, angle_res_norm, dims_min, dims_max)
         ctx.mark_non_differentiable(outs[8], outs[9])
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None (the kernel takes NULL), not as zero tensors
         return outs
 
     @staticmethod

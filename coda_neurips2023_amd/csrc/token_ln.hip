@@ -259,7 +259,8 @@ __global__ __launch_bounds__(1024) void colsum_finalize_grouped_kernel(const Col
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long long rows, int c,
                                                              float *__restrict__ partials) {
   __shared__ float4 s_part[256];
-  const int tpr = c >> 2, rpb = 256 / tpr, cq = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+  // blockDim.x = tpr * rpb <= 256 (any c / 4 <= 256: c = 768 runs 192-thread blocks)
+  const int tpr = c >> 2, rpb = static_cast<int>(blockDim.x) / tpr, cq = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
   const float *xg = x + static_cast<size_t>(blockIdx.y) * rows * c;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
   long long r = static_cast<long long>(blockIdx.x) * rpb + rsub;
@@ -341,6 +342,7 @@ int ln_bwd_blocks(long long rows) {  // backward: >= 4 passes per block, one (3,
   return static_cast<int>(want < 1 ? 1 : (want > 256 ? 256 : want));
 }
 bool bad_row_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0 || (kT % (c / 4)) != 0; }
+bool bad_colsum_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0; }
 int row_blocks(long long rows, int c) {
   const int rpb = kT / (c / 4);
   const long long want = (rows + 4 * rpb - 1) / (4 * rpb);  // >= 4 passes per block
@@ -443,13 +445,13 @@ CODA_API int coda_tok_colsum_finalize_grouped_f32(const CodaColsumItem *items, i
 }
 
 CODA_API int coda_tok_colsum_blocks(long long rows, int c) {
-  if (rows < 0 || bad_row_c(c)) return CODA_EINVAL;
+  if (rows < 0 || bad_colsum_c(c)) return CODA_EINVAL;
   return row_blocks(rows, c);
 }
 
 CODA_API int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials, float *out,
                                  void *stream) {
-  if (groups <= 0 || rows < 0 || bad_row_c(c)) return CODA_EINVAL;
+  if (groups <= 0 || rows < 0 || bad_colsum_c(c)) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
     if (!out) return CODA_EINVAL;  // nothing to defer
@@ -459,7 +461,7 @@ CODA_API int coda_tok_colsum_f32(const float *x, int groups, long long rows, int
   if (!x || !partials) return CODA_EINVAL;
   const int blocks = row_blocks(rows, c);
   clear_sticky_error();
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks, groups), dim3(256), 0, s, x, rows, c, partials);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks, groups), dim3((c / 4) * (256 / (c / 4))), 0, s, x, rows, c, partials);
   if (out)
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64, groups), dim3(1024), 0, s, partials, blocks, c, out);
   return launch_status();

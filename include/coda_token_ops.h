@@ -124,7 +124,7 @@ int coda_tok_colsum_finalize_grouped_f32(const CodaColsumItem *items, int count,
 /* Column sums of x (G, rows, C) -> out (G, C) (the bias gradients of the projections):
  * per-block partials (G, blocks, C) with blocks = coda_tok_colsum_blocks(rows, c), then a
  * fixed-order reduction (two launches of one call; out == NULL: partials only, the caller reduces them later,
- * e.g. with coda_tok_colsum_finalize_grouped_f32).  C/4 must divide 256. */
+ * e.g. with coda_tok_colsum_finalize_grouped_f32).  C a multiple of 4, C <= 1024. */
 int coda_tok_colsum_blocks(long long rows, int c);
 int coda_tok_colsum_f32(const float *x, int groups, long long rows, int c, float *partials,
                         float *out, void *stream);

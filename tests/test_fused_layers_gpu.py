@@ -132,7 +132,8 @@ def test_ffn_act(dev, rows, c, p):
         _close(b.grad, h.grad.double().sum(0), "dbias", rtol=1e-5)
 
 
-@pytest.mark.parametrize("g,rows,c", [(3, 16384, 256), (1, 77, 512), (2, 2048, 128), (1, 5, 16)])
+@pytest.mark.parametrize("g,rows,c", [(3, 16384, 256), (1, 77, 512), (2, 2048, 128), (1, 5, 16), (1, 16384, 768),
+                                      (2, 333, 12), (1, 100, 1000)])
 def test_colsum_kernel(dev, g, rows, c):
     from coda_neurips2023_amd.fused_layers import _colsum_into
     x = torch.randn(g, rows, c, device=dev)
