@@ -169,11 +169,6 @@ def synthetic_targets(batch, gen, ngt=64, ncls=10, max_boxes=20):
     return {k: v.to(dev) for k, v in t.items()}
 
 
-# when the side stream starts the next batch's sampling: None = as soon as it is submitted (the host runs ahead, so
-# that is somewhere in the previous step's backward), "after_encoder" = behind this step's encoder (dev A/B)
-PREFETCH_AT = {"start": None, "encoder": "after_encoder"}[os.environ.get("CODA_PREFETCH_AT", "start")]
-
-
 def synthetic_image_inputs(bsz, dev, seed):
     """What the dataset adds to a batch for the image branch (datasets/sunrgbd_anonymous_aligned_image.py:
     884-899): a 730 x 530 RGB image per scene (random pixels: the tower's cost does not depend on content), a
@@ -482,7 +477,7 @@ def main():
         if prefetch:
             # the data pipeline knows the next batch: its furthest point sampling (8 workgroups,
             # ~3.4 ms of dependent rounds) runs on a side stream while this step computes
-            raw_model.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=PREFETCH_AT)  # batches are resident
+            raw_model.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)  # batches are resident
         opt.zero_grad(set_to_none=True)
         loss = step_fn(model, pool[i % len(pool)])
         loss.backward()

@@ -182,19 +182,7 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             return
         if not hasattr(self, "_sampling_prefetcher"):
             self._sampling_prefetcher = SamplingPrefetcher()
-        if wait_for == "after_encoder":
-            # deferred: the NEXT forward starts the side stream once its encoder has been enqueued, so that the
-            # 8-CU sampling kernel runs under the launch-sized decoder / head / loss kernels instead of taking
-            # CUs away from the chip-filling encoder attention kernels
-            self._deferred_prefetch = pc
-            return
         self._sampling_prefetcher.submit(pc, self.pre_encoder, wait_for)
-
-    def _start_deferred_prefetch(self):
-        pc = getattr(self, "_deferred_prefetch", None)
-        if pc is not None:
-            self._deferred_prefetch = None
-            self._sampling_prefetcher.submit(pc, self.pre_encoder, "current")
 
     def run_pre_encoder(self, point_clouds):
         """The set-abstraction stage alone: -> (xyz (B,M,3), features (B,C,M), inds (B,M)).  Its result
@@ -347,7 +335,6 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         ``run_pre_encoder`` on ``inputs["point_clouds"]``, when the caller ran that stage itself."""
         point_clouds = inputs["point_clouds"]
         enc_xyz, enc_features, enc_inds = self.run_encoder(point_clouds, pre_encoded)
-        self._start_deferred_prefetch()
         enc_features = self._project_encoder_features(enc_features)
         if encoder_only:
             return enc_xyz, enc_features.transpose(0, 1)
