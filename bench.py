@@ -169,6 +169,22 @@ def synthetic_targets(batch, gen, ngt=64, ncls=10, max_boxes=20):
     return {k: v.to(dev) for k, v in t.items()}
 
 
+CLIP_GRADIENT = 0.1  # main.py:52 --clip_gradient's default: engine.py:161-162 clips every step
+
+
+def make_optimizer(params, dry=False):
+    """The tail of the reference's step (engine.py:161-164): clip_grad_norm_(parameters, 0.1), AdamW.step().
+    -> (optimizer, clip function).  Default: this package's three-launch kernels (coda_neurips2023_amd.optim);
+    CODA_OPTIM=torch: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(fused=True) (dev A/B; also the dry run)."""
+    params = list(params)
+    if dry or os.environ.get("CODA_OPTIM", "coda") == "torch":
+        opt = torch.optim.AdamW(params, lr=1e-4, fused=not dry)
+        return opt, lambda: torch.nn.utils.clip_grad_norm_(params, CLIP_GRADIENT)
+    from coda_neurips2023_amd import optim
+    opt = optim.AdamW(params, lr=1e-4)
+    return opt, lambda: optim.clip_grad_norm_(params, CLIP_GRADIENT)
+
+
 def synthetic_image_inputs(bsz, dev, seed):
     """What the dataset adds to a batch for the image branch (datasets/sunrgbd_anonymous_aligned_image.py:
     884-899): a 730 x 530 RGB image per scene (random pixels: the tower's cost does not depend on content), a
@@ -311,13 +327,14 @@ def run_extra(kind, dev, steps, warmup):
                          "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
             if kind == "distill":
                 pool[-1].update(synthetic_image_inputs(B_PER_GPU, dev, seed=99 + i))
-        opt = torch.optim.AdamW(mod.parameters(), lr=1e-4, fused=True)
+        opt, clip = make_optimizer(mod.parameters())
 
         def one(i):
             if prefetch:
                 mod.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)
             opt.zero_grad(set_to_none=True)
             step_fn(mod, pool[i % len(pool)]).backward()
+            clip()
             opt.step()
 
         for i in range(warmup):
@@ -469,8 +486,7 @@ def main():
                      "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
     raw_model = model.module if hasattr(model, "module") else model
-    # fused=True: one multi-tensor kernel per parameter group instead of ~10 foreach launches
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=not dry)
+    opt, clip_gradients = make_optimizer(model.parameters(), dry)
     prefetch = args.prefetch == "on" and kind == "model"
 
     def one_step_eager(i):
@@ -481,6 +497,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = step_fn(model, pool[i % len(pool)])
         loss.backward()
+        clip_gradients()
         opt.step()
 
     graph = None  # (a hipGraph replay of the step is not available on this stack: DESIGN.md section 7)
@@ -653,7 +670,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": N_POINTS,
-                       "parallelism": f"dp{world}", "optimizer": "AdamW (fused, in timed region)",
+                       "parallelism": f"dp{world}", "optimizer": "clip_grad_norm_(0.1) + AdamW, in the timed region (engine.py:161-164)",
                        "execution": ("set-abstraction stage eager; encoder + decoder + heads + loss, forward and "
                                      "backward, replayed as one hipGraph; optimizer eager"
                                      if graph is not None else "eager"),

@@ -105,6 +105,11 @@ SIGNATURES = {
     "coda_gemm_set_tuning": (_c_int, [_c_int]),
     "coda_gemm_ex": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P,
                               ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_float, _c_float, _P]),
+    # include/coda_optim.h
+    "coda_opt_chunk_elems": (_c_int, []),
+    "coda_opt_grad_sumsq_f32": (_c_int, [_P, _P, _c_int, _P, _P]),
+    "coda_opt_grad_scale_f32": (_c_int, [_P, _P, _c_int, _P, _c_float, _P, _P]),
+    "coda_opt_adamw_f32": (_c_int, [_P, _P, _c_int, _c_float, _c_float, _c_float, _c_float, _c_float, _P]),
     # include/coda_eval.h
     "coda_box_point_count_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_nms_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_double, _c_int, _P]),

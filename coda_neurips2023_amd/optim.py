@@ -1,0 +1,153 @@
+"""Tail of the training step (engine.py:161-164): ``clip_grad_norm_`` + ``AdamW``.
+
+``clip_grad_norm_(parameters, max_norm)`` and ``AdamW(params, lr, betas, eps, weight_decay)`` have the call
+signatures and semantics of ``torch.nn.utils.clip_grad_norm_`` (norm type 2) and ``torch.optim.AdamW``
+(``amsgrad=False``, ``maximize=False``) as the reference uses them (engine.py:162, optimizer.py:35); the state
+dict has torch's layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter), so checkpoints written by either
+load into the other.  Each call is one launch per parameter group over ALL its tensors (``include/coda_optim.h``)
+instead of the framework's per-tensor / multi-tensor kernel sequences.  float32 CUDA parameters only.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class _TensorList:
+    """Device-side description of a list of parameters: the chunk map is built once, the table of pointers is
+    refreshed per call (gradients are new tensors every step)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("empty parameter list")
+        dev = self.params[0].device
+        for p in self.params:
+            if not p.is_cuda:
+                raise RuntimeError("CPU not supported")
+            if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
+                raise RuntimeError("coda optim: parameters must be contiguous float32 tensors on one device")
+        self.device = dev
+        chunk = _lib.load().coda_opt_chunk_elems()
+        counts = [-(-p.numel() // chunk) for p in self.params]
+        cmap = np.empty((sum(counts), 2), dtype=np.int32)
+        at = 0
+        for i, c in enumerate(counts):
+            cmap[at:at + c, 0] = i
+            cmap[at:at + c, 1] = np.arange(c)
+            at += c
+        self.nchunks = int(cmap.shape[0])
+        self.chunks = torch.from_numpy(cmap).to(dev)
+        # pointer tables travel host -> device without stalling the host: a ring of pinned staging buffers, each
+        # reused only after the copy that last read it has executed
+        self._ring = [torch.empty((len(self.params), 6), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._ring_np = [t.numpy() for t in self._ring]
+        self._ring_ev = [None] * len(self._ring)
+        self._turn = 0
+        self._sizes = np.array([p.numel() for p in self.params], dtype=np.int64)
+        self._tables = [torch.empty((len(self.params), 6), dtype=torch.int64, device=dev) for _ in range(4)]
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def table(self, state_ptrs=None):
+        """Device table for this call: parameter / gradient (/ state) pointers as they are now."""
+        k = self._turn
+        self._turn = (k + 1) % len(self._ring)
+        if self._ring_ev[k] is not None:
+            self._ring_ev[k].synchronize()
+        h = self._ring_np[k]
+        grads = [p.grad for p in self.params]
+        for g in grads:
+            if g is not None and (g.dtype != torch.float32 or g.is_sparse or not g.is_contiguous()):
+                raise RuntimeError("coda optim: gradients must be dense contiguous float32")
+        h[:, 0] = [p.data_ptr() for p in self.params]
+        h[:, 1] = [g.data_ptr() if g is not None else 0 for g in grads]
+        if state_ptrs is not None:
+            h[:, 2:4] = state_ptrs[0]
+            h[:, 5] = np.asarray(state_ptrs[1], dtype=np.float64).view(np.int64)  # the double's bit pattern
+        h[:, 4] = self._sizes
+        dst = self._tables[k]
+        dst.copy_(self._ring[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._ring_ev[k] = ev
+        return dst
+
+
+_LISTS = {}
+
+
+def _list_for(params):
+    key = tuple(id(p) for p in params)
+    tl = _LISTS.get(key)
+    if tl is None or any(a is not b for a, b in zip(tl.params, params)):
+        tl = _LISTS[key] = _TensorList(params)
+    return tl
+
+
+@torch.no_grad()
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
+    """-> total gradient norm (0-dim float32 tensor on the parameters' device); gradients scaled in place."""
+    if float(norm_type) != 2.0 or error_if_nonfinite:
+        raise NotImplementedError("clip_grad_norm_: norm type 2 without the non-finite check (engine.py:162)")
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return torch.tensor(0.0)
+    tl = _list_for(params)
+    lib = _lib.load()
+    total = torch.empty((), dtype=torch.float32, device=tl.device)
+    with torch.cuda.device(tl.device):
+        tab = tl.table()
+        st = lib.coda_opt_grad_sumsq_f32(tab.data_ptr(), tl.chunks.data_ptr(), tl.nchunks, tl.sumsq.data_ptr(),
+                                         _lib.current_stream_handle())
+        _lib.check(st, "coda_opt_grad_sumsq_f32")
+        st = lib.coda_opt_grad_scale_f32(tab.data_ptr(), tl.chunks.data_ptr(), tl.nchunks, tl.sumsq.data_ptr(),
+                                         float(max_norm), total.data_ptr(), _lib.current_stream_handle())
+        _lib.check(st, "coda_opt_grad_scale_f32")
+    return total
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.requires_grad]
+            if not params:
+                continue
+            steps = []
+            states = []
+            for p in params:
+                st = self.state[p]
+                if p.grad is not None:
+                    if not st:
+                        st["step"] = 0.0  # a Python number: torch.optim.AdamW converts it on load (its legacy format)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["step"] = float(st["step"]) + 1.0
+                    steps.append(st["step"])
+                    states.append((st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
+                else:
+                    steps.append(0.0)
+                    states.append((0, 0))
+            if not any(steps):
+                continue
+            tl = _list_for(params)
+            beta1, beta2 = group["betas"]
+            with torch.cuda.device(tl.device):
+                tab = tl.table((states, steps))
+                st = lib.coda_opt_adamw_f32(tab.data_ptr(), tl.chunks.data_ptr(), tl.nchunks, float(group["lr"]),
+                                            float(beta1), float(beta2), float(group["eps"]),
+                                            float(group["weight_decay"]), _lib.current_stream_handle())
+            _lib.check(st, "coda_opt_adamw_f32")
+        return loss

@@ -27,11 +27,12 @@ def main():
         pc, mn, mx = bench.make_batch(bench.B_PER_GPU, bench.N_POINTS, seed=4321 + i)
         pool.append({"point_clouds": torch.from_numpy(pc).to(dev), "point_cloud_dims_min": torch.from_numpy(mn).to(dev),
                      "point_cloud_dims_max": torch.from_numpy(mx).to(dev)})
-    opt = torch.optim.AdamW(mod.parameters(), lr=1e-4, fused=True)
+    opt, clip = bench.make_optimizer(mod.parameters())
 
     def one(i):
         opt.zero_grad(set_to_none=True)
         step_fn(mod, pool[i % 2]).backward()
+        clip()
         opt.step()
 
     for i in range(4):
