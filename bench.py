@@ -699,9 +699,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kind)
         if dry:
             out.update(metric="dry run (control flow only)", data="none", dtype="f32")
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_initialized():
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # RCCL prints its version banner to stdout here: the JSON line goes after it
+    if line is not None:
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
