@@ -122,12 +122,12 @@ def build_workload(kind, dev):
     return mod, step, desc, "sa"
 
 
-def recipe_args(nq):
+def recipe_args(nq, **model_overrides):
     """scripts/coda_sunrgbd_stage2.sh on top of main.py's defaults (main.py:154-205): the matcher costs and the
     loss weights of the recipe BASELINE.json's configs quote (both alignment terms live)."""
     from coda_neurips2023_amd.criterion import _WEIGHT_ARGS
     from coda_neurips2023_amd.model_3detr import default_args
-    ns = default_args(nqueries=nq)
+    ns = default_args(nqueries=nq, **model_overrides)
     for attr in _WEIGHT_ARGS.values():
         setattr(ns, attr, 0)
     for k, v in dict(loss_no_object_weight=0.05, loss_angle_cls_weight=0.1, loss_angle_reg_weight=0.5,
@@ -202,7 +202,7 @@ def synthetic_image_inputs(bsz, dev, seed):
     return {k: v.to(dev) for k, v in out.items()}
 
 
-def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", image_branch=False):
+def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", image_branch=False, dec_dim=256):
     """configs[2] (and, with nq=512 on 40k-point scenes and bf16 MFMA attention, the one-GPU share of
     configs[4]): the training step as engine.py:144-159 runs it -- model_3detr enc(3L)+dec(8L) forward with
     dropout on (enc/dec 0.1, heads 0.3), ``criterion(outputs, batch_data_label)`` built by ``build_criterion``
@@ -244,7 +244,7 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", imag
         return outputs
 
     cfg = HotPathDatasetConfig()
-    args = recipe_args(nq)
+    args = recipe_args(nq, dec_dim=dec_dim)
     model, _ = build_model(args, cfg, text_features_fg_norm=text, region_embedding_provider=provider)
     model.to(dev).train()
     crit = build_criterion(args, cfg)
@@ -262,7 +262,7 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", imag
         return loss
 
     desc = (f"{config_tag}: full model_3detr (SA {'40000' if nq == 512 else '20000'}->2048 r=0.2 ns=64, enc 3L d=256 "
-            f"h=4, dec 8L d=256 h=4, {nq} queries, 6 heads incl. 512-d CLIP-space head) fwd+bwd, batch=8/GPU, "
+            f"h=4, dec 8L d={dec_dim} h=4, {nq} queries, 6 heads incl. 512-d CLIP-space head) fwd+bwd, batch=8/GPU, "
             f"{'fp32 tensors, bf16 MFMA attention (fp32 accumulate/softmax)' if attn == 'bf16' else 'fp32'}, dropout on; "
             "loss = criterion(outputs, batch) of the stage-2 recipe for all 8 decoder layers: gIoU + centre + class + "
             "objectness cost matrix, Hungarian assignment (on the device), matched box terms (class CE, angle CE + "
@@ -309,6 +309,11 @@ def run_extra(kind, dev, steps, warmup):
     prefetch = False
     if kind == "sa":
         mod, step_fn, desc, _ = build_workload("sa", dev)
+    elif kind == "scripts":
+        mod, step_fn, desc, _ = build_model_workload(dev, nq=128, dec_dim=512,
+                                                     config_tag="the scripts' variant (scripts/coda_sunrgbd_stage1.sh: "
+                                                                "dec_dim 512, 128 queries; SURVEY.md 8d)")
+        prefetch = True
     elif kind == "distill":
         mod, step_fn, desc, _ = build_model_workload(dev, config_tag="configs[2] + the CLIP image branch", image_branch=True)
         desc += ("; image branch inside the step: box projection, 8 x 32 crops, frozen ViT-B/16 image tower (fp16, "
@@ -693,6 +698,7 @@ def main():
             ex_steps, ex_warm = max(5, min(args.steps, 10)), 3
             out["extra_configs"] = {"configs[1]_sa_only": run_extra("sa", dev, ex_steps, ex_warm),
                                     "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm),
+                                    "scripts_variant_dec512_128q": run_extra("scripts", dev, ex_steps, ex_warm),
                                     "clip_image_tower": run_image_tower(dev, ex_steps, ex_warm),
                                     "configs[2]_with_image_branch": run_extra("distill", dev, ex_steps, ex_warm)}
         if world == 1 and not args.no_cpu_baseline and not dry:

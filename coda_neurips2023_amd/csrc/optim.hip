@@ -19,15 +19,18 @@ __device__ __forceinline__ bool aligned16(const void *a, const void *b, const vo
            reinterpret_cast<uintptr_t>(d)) & 15) == 0;
 }
 
+// A block walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... and issues ONE double atomic at the end: with one
+// atomic per chunk the 4 000 - 12 000 same-address atomics serialised at the L2 and took 10x the read time.
 __global__ __launch_bounds__(256) void sumsq_kernel(const CodaOptTensor *__restrict__ tab, const int2 *__restrict__ chunks,
-                                                    double *__restrict__ out) {
-  const int2 ch = chunks[blockIdx.x];
-  const CodaOptTensor t = tab[ch.x];
-  const long long begin = static_cast<long long>(ch.y) * kChunk;
-  const long long end = begin + kChunk < t.n ? begin + kChunk : t.n;
+                                                    int nchunks, double *__restrict__ out) {
   float acc = 0.0f;
-  if (t.g) {
-    if (aligned16(t.g, nullptr, nullptr, nullptr)) {
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int2 ch = chunks[c];
+    const CodaOptTensor t = tab[ch.x];
+    if (!t.g) continue;
+    const long long begin = static_cast<long long>(ch.y) * kChunk;
+    const long long end = begin + kChunk < t.n ? begin + kChunk : t.n;
+    if ((reinterpret_cast<uintptr_t>(t.g) & 15) == 0) {
       for (long long i = begin + 4 * threadIdx.x; i < end; i += 1024) {
         if (i + 4 <= end) {
           const float4 v = *reinterpret_cast<const float4 *>(t.g + i);
@@ -127,7 +130,8 @@ CODA_API int coda_opt_grad_sumsq_f32(const CodaOptTensor *table, const int32_t *
   if (nchunks == 0) return CODA_OK;
   if (!table || !chunks) return CODA_EINVAL;
   clear_sticky_error();
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nchunks), dim3(256), 0, s, table, reinterpret_cast<const int2 *>(chunks), sumsq);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, table,
+                     reinterpret_cast<const int2 *>(chunks), nchunks, sumsq);
   return launch_status();
 }
 

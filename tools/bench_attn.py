@@ -50,4 +50,6 @@ for dt in (["fp32", "bf16", "bf16x3"] if which == "both" else [which]):
     for shape in [(2048, 2048), (256, 2048), (256, 256), (512, 2048), (512, 512)]:
         run(*shape, p=p)
     run(256, 2048, d=128, h=4, p=p)
+    run(128, 2048, d=128, h=4, p=p)   # the scripts' variant: dec_dim 512, 128 queries
+    run(128, 128, d=128, h=4, p=p)
 core.set_mfma_dtype("fp32")
