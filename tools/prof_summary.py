@@ -20,6 +20,9 @@ def cat(nm):
     if "coda" in nm and ("sgemm" in nm or "grouped_tn" in nm or "gemm_tn" in nm): return "own fp32-MFMA GEMMs (hip)"
     if "coda" in nm and any(k in nm for k in ("giou", "hungarian", "box_decode", "box_loss", "align_loss", "nms", "box_point")):
         return "boxes / matcher / losses (hip)"
+    if "coda" in nm and any(k in nm for k in ("adamw_kernel", "sumsq_kernel", "scale_kernel")): return "clip + AdamW (hip)"
+    if "coda" in nm and any(k in nm for k in ("vit_attention", "ln_rows", "embed_ln", "patch_gather", "crop_resize", "project_rects")):
+        return "CLIP image branch (hip)"
     if "coda" in nm: return "gather/group/interp (hip)"
     if "max_pool" in nm: return "max-pool (torch)"
     if "BatchNorm" in nm or "batch_norm" in nm: return "batch-norm (MIOpen)"
