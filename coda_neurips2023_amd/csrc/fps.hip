@@ -420,10 +420,26 @@ __device__ __forceinline__ void bucket_update(float px, float py, float pz, floa
   }
 }
 
-template <int SL, int DM>  // register slots (buckets) per wave; n <= 64 * kBucketWaves * SL
+// Two workgroups per scene (NWG = 2, n up to 2 * 20 480): each keeps one half of the Morton-ordered buckets in its
+// registers and every round the two exchange their candidates (distance, key, coordinates) through a 64-byte
+// mailbox in global memory -- three 64-bit agent-scope atomics, the last one carrying the round number with
+// release / acquire ordering.  Two mailboxes per workgroup (round parity): a workgroup can only be one round
+// ahead of its partner.  The pair is launched as blocks (scene, 0) and (scene, 1): ids s and s + b, the same XCD
+// (and L2) when b is a multiple of 8.
+struct FpsMailbox {
+  unsigned long long kk, xy, z_seq;
+  unsigned long long pad_[5];
+};
+constexpr int kFpsSpinLimit = 1 << 22;  // ~ a second of polling: a lost partner ends the wait, not the device
+
+template <int SL, int DM, int NWG = 1>  // register slots (buckets) per wave; n <= 64 * kBucketWaves * SL * NWG
 __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float *__restrict__ xyz, int n, int m,
                                                                     int log2T, float4 *__restrict__ sorted,
-                                                                    int32_t *__restrict__ idx) {
+                                                                    int32_t *__restrict__ idx,
+                                                                    FpsMailbox *__restrict__ mail) {
+  constexpr int KB = NWG == 1 ? 15 : 16;           // bits of the point index inside the tie-break key
+  constexpr int IDB = 32 - (KB + 9);               // low bits of the packed candidate left for the sender id
+  const int half = NWG == 1 ? 0 : static_cast<int>(blockIdx.y);
   __shared__ unsigned int s_hist[kMortonCells];
   __shared__ float s_red[6][kBucketWaves];
   __shared__ unsigned int s_wsum[kBucketWaves];
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
-  float4 *__restrict__ rec = sorted + static_cast<size_t>(blockIdx.x) * n;
+  float4 *__restrict__ rec = sorted + (static_cast<size_t>(half) * gridDim.x + blockIdx.x) * n;  // own copy per workgroup
   int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
 
   // ---- prologue 1: bounding box of the participating points
@@ -526,17 +542,21 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   md.maxt = -1.0f;
   md.key = 0xffffffffu;
   md.bx = md.by = md.bz = 0.0f;
+  // NWG = 2: workgroup `half` owns buckets [half * share, (half + 1) * share) of the Morton order
+  const unsigned int nbuckets = (nvalid + kWave - 1) / kWave;
+  const unsigned int share = NWG == 1 ? nbuckets : (nbuckets + 1) / 2;
 #pragma unroll
   for (int j = 0; j < SL; ++j) {
-    const unsigned int pos = (static_cast<unsigned int>(j) * kBucketWaves + w) * kWave + lane;
+    const unsigned int bucket = static_cast<unsigned int>(j) * kBucketWaves + w;
+    const unsigned int pos = (static_cast<unsigned int>(half) * share + bucket) * kWave + lane;
     float x = 0.f, y = 0.f, z = 0.f, tt = -1.0f;
     uint32_t kk = 0xffffffffu;
-    if (pos < nvalid) {
+    if (pos < nvalid && bucket < share) {
       const float4 r = rec[pos];
       x = r.x; y = r.y; z = r.z;
       const uint32_t k = __float_as_uint(r.w);
       const uint32_t kmod = k & ((1u << log2T) - 1u);
-      kk = (bitrev_low(kmod, log2T) << 15) | k;  // order: bitrev(k mod T), then k  (k < 2^15)
+      kk = (bitrev_low(kmod, log2T) << KB) | k;  // order: bitrev(k mod T), then k  (k < 2^KB)
       tt = 1e10f;  // sampling.cpp:75-77
     }
     px[j] = x; py[j] = y; pz[j] = z; t[j] = tt;
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   }
 
   out_put(s_out, 0, 0);  // :88-89
-  out_flush(s_out, 0, m, out);
+  if (half == 0) out_flush(s_out, 0, m, out);
   float cx = pts[0], cy = pts[1], cz = pts[2];
   float wv = -1.0f;           // this wave's candidate: max running distance ...
   uint32_t wk = 0xffffffffu;  // ... the key of the point holding it ...
@@ -602,23 +622,54 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
       // (distance, ~key) orders the candidates; the wave id in the low byte never decides (keys
       // are unique) and tells the readers whose coordinates to take
       const unsigned long long kk = (static_cast<unsigned long long>(__float_as_uint(wv) + 1u) << 32) |
-                                    ((static_cast<uint32_t>(~wk) & 0xffffffu) << 8) | static_cast<uint32_t>(w);
+                                    ((static_cast<uint32_t>(~wk) & ((1u << (KB + 9)) - 1u)) << IDB) |
+                                    static_cast<uint32_t>(w + kBucketWaves * half);
       s_xyz[j & 1][w] = make_float4(wx, wy, wz, 0.f);
       atomicMax(&s_slot[j % 3], kk);
     }
     __syncthreads();
-    const unsigned long long kk = s_slot[j % 3];
+    unsigned long long kk = s_slot[j % 3];
     if (tid == 0) s_slot[(j + 2) % 3] = 0ull;  // next use is two barriers away
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((kk >> 32) != 0ull) c = s_xyz[j & 1][static_cast<uint32_t>(kk) & (kBucketWaves - 1)];
+    if constexpr (NWG == 2) {
+      FpsMailbox *mine = mail + (static_cast<size_t>(blockIdx.x) * 2 + (j & 1)) * 2 + half;
+      FpsMailbox *theirs = mail + (static_cast<size_t>(blockIdx.x) * 2 + (j & 1)) * 2 + (half ^ 1);
+      if (tid == 0) {
+        __hip_atomic_store(&mine->kk, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->xy, (static_cast<unsigned long long>(__float_as_uint(c.y)) << 32) | __float_as_uint(c.x),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&mine->z_seq, (static_cast<unsigned long long>(__float_as_uint(c.z)) << 32) | static_cast<uint32_t>(j),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // every wave polls for itself (lane 0) and broadcasts: no second barrier in the round
+      unsigned long long pkk = 0ull, pxy = 0ull, pz = 0ull;
+      if (lane == 0) {
+        int spins = 0;
+        do {
+          pz = __hip_atomic_load(&theirs->z_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } while (static_cast<uint32_t>(pz) != static_cast<uint32_t>(j) && ++spins < kFpsSpinLimit);
+        pkk = __hip_atomic_load(&theirs->kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pxy = __hip_atomic_load(&theirs->xy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      pkk = __shfl(pkk, 0, kWave);
+      pxy = __shfl(pxy, 0, kWave);
+      pz = __shfl(pz, 0, kWave);
+      if (pkk > kk) {  // the partner's candidate wins (larger distance, then smaller key; keys are unique)
+        kk = pkk;
+        c = make_float4(__uint_as_float(static_cast<uint32_t>(pxy)), __uint_as_float(static_cast<uint32_t>(pxy >> 32)),
+                        __uint_as_float(static_cast<uint32_t>(pz >> 32)), 0.f);
+      }
+    }
     if ((kk >> 32) == 0ull) {  // nothing participated: reference besti = 0
       out_put(s_out, j, 0);
       cx = pts[0]; cy = pts[1]; cz = pts[2];
     } else {
       const uint32_t lo32 = static_cast<uint32_t>(kk);
-      const float4 c = s_xyz[j & 1][lo32 & 0xffu];
-      out_put(s_out, j, static_cast<int32_t>((~(lo32 >> 8)) & 0x7fffu));
+      out_put(s_out, j, static_cast<int32_t>((~(lo32 >> IDB)) & ((1u << KB) - 1u)));
       cx = c.x; cy = c.y; cz = c.z;
     }
-    out_flush(s_out, j, m, out);
+    if (half == 0) out_flush(s_out, j, m, out);
   }
 }
 
@@ -639,7 +690,9 @@ int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, 
       if (e != hipSuccess) st = static_cast<int>(e);
       else raised = true;
     }
-    if (st == CODA_OK) hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx);
+    if (st == CODA_OK)
+      hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx,
+                         static_cast<FpsMailbox *>(nullptr));
   });
   return st;
 }
@@ -651,6 +704,40 @@ int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws
   if (sl <= 24) return launch_bucket<24>(xyz, b, n, m, log2T, ws, idx, s);
   if (sl <= 32) return launch_bucket<32>(xyz, b, n, m, log2T, ws, idx, s);
   return launch_bucket<40>(xyz, b, n, m, log2T, ws, idx, s);
+}
+
+// two workgroups per scene: 20 480 < n <= 40 960
+bool bucket2_eligible(int n, int m) { return n > kBucketMaxPoints && n <= 2 * kBucketMaxPoints && m >= kBucketMinSamples; }
+size_t bucket2_mail_offset(int b, int n) { return (sizeof(float4) * 2 * static_cast<size_t>(b) * n + 255) & ~static_cast<size_t>(255); }
+size_t bucket2_workspace_bytes(int b, int n) { return bucket2_mail_offset(b, n) + sizeof(FpsMailbox) * 4 * static_cast<size_t>(b); }
+
+template <int SL>
+int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
+  constexpr size_t lds = sizeof(uint32_t) * SL * kBucketThreads;
+  FpsMailbox *mail = reinterpret_cast<FpsMailbox *>(static_cast<char *>(ws) + bucket2_mail_offset(b, n));
+  hipError_t e = hipMemsetAsync(mail, 0, sizeof(FpsMailbox) * 4 * static_cast<size_t>(b), s);  // round numbers start at 1
+  if (e != hipSuccess) return static_cast<int>(e);
+  int st = CODA_OK;
+  CODA_DISPATCH_DM(distance_mode(), {
+    auto kern = fps_bucket_kernel<SL, DM, 2>;
+    static bool raised = false;
+    if (!raised && lds + 20 * 1024 > 64 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+      if (e != hipSuccess) st = static_cast<int>(e);
+      else raised = true;
+    }
+    if (st == CODA_OK)
+      hipLaunchKernelGGL(kern, dim3(b, 2), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail);
+  });
+  return st;
+}
+
+int dispatch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
+  const int sl = ceil_div(ceil_div(ceil_div(n, 64), 2), kBucketWaves);
+  if (sl <= 24) return launch_bucket2<24>(xyz, b, n, m, log2T, ws, idx, s);
+  if (sl <= 32) return launch_bucket2<32>(xyz, b, n, m, log2T, ws, idx, s);
+  return launch_bucket2<40>(xyz, b, n, m, log2T, ws, idx, s);
 }
 
 // ---- streaming fallback: any n; running distances in LDS or in workspace -------
@@ -752,6 +839,7 @@ constexpr size_t kStreamKeyBytes = sizeof(uint2) * 2 * (kStreamThreads / kWave);
 CODA_API size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
   if (b <= 0 || n <= 0) return 0;
   if (coda::bucket_eligible(n, m)) return sizeof(float4) * static_cast<size_t>(b) * n;  // Morton-sorted records
+  if (coda::bucket2_eligible(n, m)) return coda::bucket2_workspace_bytes(b, n);  // two copies + the mailboxes
   const size_t lds_need = coda::kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
   if (n <= 1024 * 24 || lds_need <= coda::kLdsBudget) return 0;
   return sizeof(float) * static_cast<size_t>(b) * n;
@@ -774,6 +862,12 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   if (variant == 0 && bucket_eligible(n, m) && workspace &&
       workspace_bytes >= sizeof(float4) * static_cast<size_t>(b) * n && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
     const int st = dispatch_bucket(xyz, b, n, m, log2T, static_cast<float4 *>(workspace), idx, s);
+    if (st != CODA_OK) return st;
+    done = true;
+  }
+  if (!done && variant == 0 && bucket2_eligible(n, m) && workspace && workspace_bytes >= bucket2_workspace_bytes(b, n) &&
+      (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) {
+    const int st = dispatch_bucket2(xyz, b, n, m, log2T, workspace, idx, s);
     if (st != CODA_OK) return st;
     done = true;
   }

@@ -106,9 +106,22 @@ def test_fps_short_scene_golden_and_synthetic(dev, oracle, golden_ops):
     assert np.array_equal(got, oracle.furthest_point_sampling(pts, 512))
 
 
-@pytest.mark.parametrize("n,m", [(30000, 300), (50000, 200)])
+@pytest.mark.parametrize("n,m", [(20481, 130), (40000, 2048), (40960, 128)])
+def test_fps_two_workgroups_per_scene(dev, oracle, n, m):
+    """20 480 < n <= 40 960 (ScanNet-sized clouds): two cooperating workgroups per scene, candidates exchanged
+    through global mailboxes every round -- bit-exact like every other path."""
+    pc, _, _ = make_batch(2, n, seed=n + 1)
+    got = _ext.furthest_point_sampling(cu(pc, dev), m).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(pc, m))
+    dup = pc.copy()
+    dup[:, n // 2:] = dup[:, :n - n // 2]          # every point twice: ties between the two workgroups' halves
+    got = _ext.furthest_point_sampling(cu(dup, dev), min(m, 300)).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(dup, min(m, 300)))
+
+
+@pytest.mark.parametrize("n,m", [(30000, 300), (50000, 200), (30000, 100)])
 def test_fps_streaming_paths(dev, oracle, n, m):
-    """n > 24576: running distances in LDS (<= ~40000) or in the workspace."""
+    """n > 24576 with few samples, or n > 40 960: running distances in LDS (<= ~40000) or in the workspace."""
     pc, _, _ = make_batch(2, n, seed=n)
     got = _ext.furthest_point_sampling(cu(pc, dev), m).cpu().numpy()
     assert np.array_equal(got, oracle.furthest_point_sampling(pc, m))
