@@ -421,14 +421,13 @@ __device__ __forceinline__ void bucket_update(float px, float py, float pz, floa
 }
 
 // Two workgroups per scene (NWG = 2, n up to 2 * 20 480): each keeps one half of the Morton-ordered buckets in its
-// registers and every round the two exchange their candidates (distance, key, coordinates) through a 64-byte
-// mailbox in global memory -- three 64-bit agent-scope atomics, the last one carrying the round number with
-// release / acquire ordering.  Two mailboxes per workgroup (round parity): a workgroup can only be one round
-// ahead of its partner.  The pair is launched as blocks (scene, 0) and (scene, 1): ids s and s + b, the same XCD
+// registers and every round the two exchange their candidates (distance, key, round tag) through a mailbox in
+// global memory -- one relaxed 64-bit agent-scope atomic each way.  Two mailboxes per workgroup (round parity): a
+// workgroup can only be one round ahead of its partner.  The pair is launched as blocks (scene, 0) and (scene, 1): ids s and s + b, the same XCD
 // (and L2) when b is a multiple of 8.
 struct FpsMailbox {
-  unsigned long long kk, xy, z_seq;
-  unsigned long long pad_[5];
+  unsigned long long kk;
+  unsigned long long pad_[7];  // one 64-byte line per mailbox
 };
 constexpr int kFpsSpinLimit = 1 << 22;  // ~ a second of polling: a lost partner ends the wait, not the device
 
@@ -633,32 +632,27 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((kk >> 32) != 0ull) c = s_xyz[j & 1][static_cast<uint32_t>(kk) & (kBucketWaves - 1)];
     if constexpr (NWG == 2) {
+      // One relaxed 64-bit atomic per workgroup and round: [distance + 1 : 32][~key : 25][round mod 128 : 7].  No
+      // fences (an agent-scope release / acquire pair costs an L2 write-back + invalidate per round): the word is
+      // self-contained, and the winner's coordinates are re-read from the (read-only) input by its index.
+      constexpr unsigned long long kSeqMask = (1ull << IDB) - 1ull;
       FpsMailbox *mine = mail + (static_cast<size_t>(blockIdx.x) * 2 + (j & 1)) * 2 + half;
       FpsMailbox *theirs = mail + (static_cast<size_t>(blockIdx.x) * 2 + (j & 1)) * 2 + (half ^ 1);
-      if (tid == 0) {
-        __hip_atomic_store(&mine->kk, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->xy, (static_cast<unsigned long long>(__float_as_uint(c.y)) << 32) | __float_as_uint(c.x),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&mine->z_seq, (static_cast<unsigned long long>(__float_as_uint(c.z)) << 32) | static_cast<uint32_t>(j),
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      const unsigned long long seq = static_cast<unsigned long long>(j) & kSeqMask;
+      if (tid == 0) __hip_atomic_store(&mine->kk, (kk & ~kSeqMask) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // every wave polls for itself (lane 0) and broadcasts: no second barrier in the round
-      unsigned long long pkk = 0ull, pxy = 0ull, pz = 0ull;
+      unsigned long long pkk = 0ull;
       if (lane == 0) {
         int spins = 0;
         do {
-          pz = __hip_atomic_load(&theirs->z_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        } while (static_cast<uint32_t>(pz) != static_cast<uint32_t>(j) && ++spins < kFpsSpinLimit);
-        pkk = __hip_atomic_load(&theirs->kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pxy = __hip_atomic_load(&theirs->xy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pkk = __hip_atomic_load(&theirs->kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((pkk & kSeqMask) != seq && ++spins < kFpsSpinLimit);
       }
       pkk = __shfl(pkk, 0, kWave);
-      pxy = __shfl(pxy, 0, kWave);
-      pz = __shfl(pz, 0, kWave);
-      if (pkk > kk) {  // the partner's candidate wins (larger distance, then smaller key; keys are unique)
+      if ((pkk & ~kSeqMask) > (kk & ~kSeqMask)) {  // the partner's candidate wins (larger distance, then smaller key)
         kk = pkk;
-        c = make_float4(__uint_as_float(static_cast<uint32_t>(pxy)), __uint_as_float(static_cast<uint32_t>(pxy >> 32)),
-                        __uint_as_float(static_cast<uint32_t>(pz >> 32)), 0.f);
+        const uint32_t k = (~(static_cast<uint32_t>(pkk) >> IDB)) & ((1u << KB) - 1u);
+        c = make_float4(pts[k * 3], pts[k * 3 + 1], pts[k * 3 + 2], 0.f);
       }
     }
     if ((kk >> 32) == 0ull) {  // nothing participated: reference besti = 0
@@ -707,7 +701,14 @@ int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws
 }
 
 // two workgroups per scene: 20 480 < n <= 40 960
-bool bucket2_eligible(int n, int m) { return n > kBucketMaxPoints && n <= 2 * kBucketMaxPoints && m >= kBucketMinSamples; }
+// CODA_FPS_COOP_MIN=<n>: use the pair from n points on (A/B; default: only where one workgroup cannot hold the cloud)
+int bucket2_min_points() {
+  static const int v = [] { const char *e = getenv("CODA_FPS_COOP_MIN"); return e ? atoi(e) : kBucketMaxPoints + 1; }();
+  return v;
+}
+bool bucket2_eligible(int n, int m) {
+  return n >= bucket2_min_points() && n >= 2 * kBucketMinPoints && n <= 2 * kBucketMaxPoints && m >= kBucketMinSamples;
+}
 size_t bucket2_mail_offset(int b, int n) { return (sizeof(float4) * 2 * static_cast<size_t>(b) * n + 255) & ~static_cast<size_t>(255); }
 size_t bucket2_workspace_bytes(int b, int n) { return bucket2_mail_offset(b, n) + sizeof(FpsMailbox) * 4 * static_cast<size_t>(b); }
 
@@ -735,6 +736,8 @@ int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, i
 
 int dispatch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
   const int sl = ceil_div(ceil_div(ceil_div(n, 64), 2), kBucketWaves);
+  if (sl <= 8) return launch_bucket2<8>(xyz, b, n, m, log2T, ws, idx, s);
+  if (sl <= 16) return launch_bucket2<16>(xyz, b, n, m, log2T, ws, idx, s);
   if (sl <= 24) return launch_bucket2<24>(xyz, b, n, m, log2T, ws, idx, s);
   if (sl <= 32) return launch_bucket2<32>(xyz, b, n, m, log2T, ws, idx, s);
   return launch_bucket2<40>(xyz, b, n, m, log2T, ws, idx, s);
@@ -838,8 +841,8 @@ constexpr size_t kStreamKeyBytes = sizeof(uint2) * 2 * (kStreamThreads / kWave);
 
 CODA_API size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
   if (b <= 0 || n <= 0) return 0;
-  if (coda::bucket_eligible(n, m)) return sizeof(float4) * static_cast<size_t>(b) * n;  // Morton-sorted records
   if (coda::bucket2_eligible(n, m)) return coda::bucket2_workspace_bytes(b, n);  // two copies + the mailboxes
+  if (coda::bucket_eligible(n, m)) return sizeof(float4) * static_cast<size_t>(b) * n;  // Morton-sorted records
   const size_t lds_need = coda::kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
   if (n <= 1024 * 24 || lds_need <= coda::kLdsBudget) return 0;
   return sizeof(float) * static_cast<size_t>(b) * n;
@@ -859,15 +862,15 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   // 1: force the v1 register kernel, 2: never use the bucketed kernel (A/B, tests)
   static const int variant = [] { const char *e = getenv("CODA_FPS_VARIANT"); return e ? atoi(e) : 0; }();
   bool done = false;
-  if (variant == 0 && bucket_eligible(n, m) && workspace &&
-      workspace_bytes >= sizeof(float4) * static_cast<size_t>(b) * n && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
-    const int st = dispatch_bucket(xyz, b, n, m, log2T, static_cast<float4 *>(workspace), idx, s);
+  if (variant == 0 && bucket2_eligible(n, m) && workspace && workspace_bytes >= bucket2_workspace_bytes(b, n) &&
+      (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) {
+    const int st = dispatch_bucket2(xyz, b, n, m, log2T, workspace, idx, s);
     if (st != CODA_OK) return st;
     done = true;
   }
-  if (!done && variant == 0 && bucket2_eligible(n, m) && workspace && workspace_bytes >= bucket2_workspace_bytes(b, n) &&
-      (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) {
-    const int st = dispatch_bucket2(xyz, b, n, m, log2T, workspace, idx, s);
+  if (!done && variant == 0 && bucket_eligible(n, m) && workspace &&
+      workspace_bytes >= sizeof(float4) * static_cast<size_t>(b) * n && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+    const int st = dispatch_bucket(xyz, b, n, m, log2T, static_cast<float4 *>(workspace), idx, s);
     if (st != CODA_OK) return st;
     done = true;
   }
