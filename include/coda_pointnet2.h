@@ -71,10 +71,18 @@ int coda_get_distance_mode(void);
  *   the reference's 2^k-thread strided scan + LDS tree:  smallest
  *   bit-reversed (k mod T) first, then smallest k, with
  *   T = min(512, 2^floor(log2 N))  (include/cuda_utils.h:17-21).
- * The running distances live in registers (N <= 24576) or LDS (N <= ~40000);
- * only larger clouds need `workspace` (B*N floats, the reference's `tmp`
- * tensor, sampling.cpp:75-77): coda_..._workspace_bytes() returns 0 otherwise
- * and NULL/0 may be passed.                                               */
+ * Kernels by size (m >= 128 samples): 4096 <= N <= 20480: one workgroup per
+ * scene, the Morton-sorted cloud in its registers, only the buckets a new sample
+ * can reach are updated; 20480 < N <= 40960: TWO workgroups per scene, half of
+ * the buckets each, exchanging their candidate every round through a mailbox in
+ * `workspace` (one relaxed 64-bit atomic each way; the pair is co-resident on any
+ * device with more than 2*B CUs; a wait of ~2^22 polls without an answer is
+ * abandoned rather than hanging the device); otherwise the running distances live
+ * in registers (N <= 24576), LDS (N <= ~40000) or `workspace` (B*N floats, the
+ * reference's `tmp` tensor, sampling.cpp:75-77).  coda_..._workspace_bytes()
+ * gives the size the chosen kernel needs (Morton records, mailboxes, distances;
+ * 256-byte aligned); 0: NULL/0 may be passed.  Without a sufficient workspace
+ * the call falls back to the kernels that need none.                        */
 size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m);
 int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
                                      int32_t *idx, void *workspace,
