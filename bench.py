@@ -469,18 +469,27 @@ def main():
         torch.backends.cuda.preferred_blas_library(os.environ["CODA_BLAS"])
     mod, step_fn, desc, kind = build_workload(args.workload, dev)
     model = mod
+    reducer = None
     if world > 1 or force_ddp:
         # reference: SyncBatchNorm + DDP (main.py:993-996)
         model = mod if dry else torch.nn.SyncBatchNorm.convert_sync_batchnorm(mod)  # (SyncBN needs GPU modules)
-        ddp_kw = {}
-        if not dry:
-            # gradients live in the all-reduce buckets (no copy in, no copy back: 252 tensors per step), two buckets
-            # of ~16 MB so that the first all-reduce overlaps the encoder's backward; CODA_DDP=default restores
-            # torch's defaults (A/B)
-            if os.environ.get("CODA_DDP", "tuned") != "default":
+        ddp_mode = "default" if dry else os.environ.get("CODA_DDP", "flat")
+        if ddp_mode == "flat":
+            # this package's gradient synchronisation: one pack launch + ONE all-reduce of the flat 31.6 MB buffer
+            # after backward, p.grad = views of it (optim.FlatGradReducer); CODA_DDP=tuned|default: torch's
+            # DistributedDataParallel (with / without bucket views), the A/B
+            from coda_neurips2023_amd.optim import FlatGradReducer
+            reducer = FlatGradReducer(model.parameters(), broadcast=False)
+            if world > 1:
+                reducer.sync_parameters(model)
+        else:
+            ddp_kw = {}
+            if ddp_mode != "default":
+                # gradients live in the all-reduce buckets, two buckets of ~16 MB so that the first all-reduce overlaps
+                # the encoder's backward
                 ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=int(os.environ.get("CODA_DDP_BUCKET_MB", "16")),
                               static_graph=os.environ.get("CODA_DDP_STATIC", "0") == "1")
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if dry else [local_rank], **ddp_kw)
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if dry else [local_rank], **ddp_kw)
 
     # synthetic inputs, resident in HBM before timing; a few distinct batches cycle
     pool = []
@@ -502,6 +511,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = step_fn(model, pool[i % len(pool)])
         loss.backward()
+        if reducer is not None:
+            reducer.reduce()
         clip_gradients()
         opt.step()
 
@@ -675,7 +686,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": N_POINTS,
-                       "parallelism": f"dp{world}", "optimizer": "clip_grad_norm_(0.1) + AdamW, in the timed region (engine.py:161-164)",
+                       "parallelism": f"dp{world}" + ("" if world == 1 and not force_ddp else
+                                                          " (flat gradient all-reduce)" if reducer is not None else " (torch DDP)"),
+                       "optimizer": "clip_grad_norm_(0.1) + AdamW, in the timed region (engine.py:161-164)",
                        "execution": ("set-abstraction stage eager; encoder + decoder + heads + loss, forward and "
                                      "backward, replayed as one hipGraph; optimizer eager"
                                      if graph is not None else "eager"),

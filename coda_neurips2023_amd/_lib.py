@@ -109,6 +109,7 @@ SIGNATURES = {
     "coda_opt_chunk_elems": (_c_int, []),
     "coda_opt_grad_sumsq_f32": (_c_int, [_P, _P, _c_int, _P, _P]),
     "coda_opt_grad_scale_f32": (_c_int, [_P, _P, _c_int, _P, _c_float, _P, _P]),
+    "coda_opt_pack_f32": (_c_int, [_P, _P, _c_int, _c_float, _P]),
     "coda_opt_adamw_f32": (_c_int, [_P, _P, _c_int, _c_float, _c_float, _c_float, _c_float, _c_float, _P]),
     # include/coda_eval.h
     "coda_box_point_count_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),

@@ -67,6 +67,29 @@ __global__ __launch_bounds__(256) void scale_kernel(const CodaOptTensor *__restr
   for (long long i = begin + threadIdx.x; i < end; i += 256) t.g[i] = t.g[i] * coef;
 }
 
+// Gradient packing for the data-parallel all-reduce: dst (tab.p) = src (tab.g) * scale, zeros where a tensor has no
+// gradient this step.  One launch for all tensors (torch's DistributedDataParallel: one copy kernel per tensor).
+__global__ __launch_bounds__(256) void pack_kernel(const CodaOptTensor *__restrict__ tab, const int2 *__restrict__ chunks,
+                                                   float scale) {
+  const int2 ch = chunks[blockIdx.x];
+  const CodaOptTensor t = tab[ch.x];
+  const long long begin = static_cast<long long>(ch.y) * kChunk;
+  const long long end = begin + kChunk < t.n ? begin + kChunk : t.n;
+  if (t.g && aligned16(t.p, t.g, nullptr, nullptr)) {
+    for (long long i = begin + 4 * threadIdx.x; i < end; i += 1024) {
+      if (i + 4 <= end) {
+        float4 v = *reinterpret_cast<const float4 *>(t.g + i);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *reinterpret_cast<float4 *>(t.p + i) = v;
+      } else {
+        for (long long j = i; j < end; ++j) t.p[j] = t.g[j] * scale;
+      }
+    }
+  } else {
+    for (long long i = begin + threadIdx.x; i < end; i += 256) t.p[i] = t.g ? t.g[i] * scale : 0.0f;
+  }
+}
+
 struct AdamArgs { float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt; };
 struct AdamHyper { float lr, beta1, beta2, eps, weight_decay; };
 
@@ -158,5 +181,16 @@ CODA_API int coda_opt_adamw_f32(const CodaOptTensor *table, const int32_t *chunk
   clear_sticky_error();
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, static_cast<hipStream_t>(stream), table,
                      reinterpret_cast<const int2 *>(chunks), a);
+  return launch_status();
+}
+
+CODA_API int coda_opt_pack_f32(const CodaOptTensor *table, const int32_t *chunks, int nchunks, float scale, void *stream) {
+  using namespace coda;
+  if (nchunks < 0) return CODA_EINVAL;
+  if (nchunks == 0) return CODA_OK;
+  if (!table || !chunks) return CODA_EINVAL;
+  clear_sticky_error();
+  hipLaunchKernelGGL(pack_kernel, dim3(nchunks), dim3(256), 0, static_cast<hipStream_t>(stream), table,
+                     reinterpret_cast<const int2 *>(chunks), scale);
   return launch_status();
 }

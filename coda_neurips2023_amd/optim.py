@@ -48,8 +48,9 @@ class _TensorList:
         self._tables = [torch.empty((len(self.params), 6), dtype=torch.int64, device=dev) for _ in range(4)]
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    def table(self, state_ptrs=None):
-        """Device table for this call: parameter / gradient (/ state) pointers as they are now."""
+    def table(self, state_ptrs=None, dst_ptrs=None):
+        """Device table for this call: parameter / gradient (/ state) pointers as they are now (``dst_ptrs``
+        replaces the parameter column: the slices of a flat all-reduce buffer)."""
         k = self._turn
         self._turn = (k + 1) % len(self._ring)
         if self._ring_ev[k] is not None:
@@ -59,7 +60,7 @@ class _TensorList:
         for g in grads:
             if g is not None and (g.dtype != torch.float32 or g.is_sparse or not g.is_contiguous()):
                 raise RuntimeError("coda optim: gradients must be dense contiguous float32")
-        h[:, 0] = [p.data_ptr() for p in self.params]
+        h[:, 0] = dst_ptrs if dst_ptrs is not None else [p.data_ptr() for p in self.params]
         h[:, 1] = [g.data_ptr() if g is not None else 0 for g in grads]
         if state_ptrs is not None:
             h[:, 2:4] = state_ptrs[0]
@@ -151,3 +152,55 @@ class AdamW(torch.optim.Optimizer):
                                             float(group["weight_decay"]), _lib.current_stream_handle())
             _lib.check(st, "coda_opt_adamw_f32")
         return loss
+
+
+class FlatGradReducer:
+    """Data-parallel gradient averaging without per-tensor work (the reference wraps the model in
+    ``DistributedDataParallel``, main.py:993-996, which copies every gradient into its buckets with one kernel per
+    tensor -- 252 launches per step here): after ``backward`` one launch packs all gradients, pre-divided by the world
+    size, into ONE flat float32 buffer, one all-reduce (RCCL over xGMI: 31.6 MB) sums it, and every ``p.grad`` becomes
+    a view of the buffer, so ``clip_grad_norm_`` / ``AdamW`` read the reduced gradients in place -- nothing is copied
+    back.  Slices start on 16-byte boundaries.  Parameters that received no gradient contribute zeros (their
+    ``.grad`` becomes a zero view, as DDP leaves it).
+
+        reducer = FlatGradReducer(model.parameters())      # after SyncBatchNorm conversion; broadcasts rank 0's values
+        loss.backward(); reducer.reduce(); clip_grad_norm_(...); optimizer.step()
+    """
+
+    def __init__(self, parameters, process_group=None, broadcast=True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = process_group
+        self.params = [p for p in parameters if p.requires_grad]
+        self.list = _TensorList(self.params)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        offsets, at = [], 0
+        for p in self.params:
+            offsets.append(at)
+            at += -(-p.numel() // 4) * 4
+        self.flat = torch.zeros(max(at, 4), dtype=torch.float32, device=self.list.device)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, self.params)]
+        self._dst = np.array([v.data_ptr() for v in self.views], dtype=np.int64)
+        if broadcast and self.world > 1:
+            self.sync_parameters()
+
+    @torch.no_grad()
+    def sync_parameters(self, module=None):
+        """Rank 0's parameters (and, given the module, its buffers) to every rank: what DDP does at construction."""
+        tensors = list(self.params) + (list(module.buffers()) if module is not None else [])
+        for t in tensors:
+            self.dist.broadcast(t.data, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                group=self.group)
+
+    @torch.no_grad()
+    def reduce(self):
+        tl = self.list
+        with torch.cuda.device(tl.device):
+            tab = tl.table(dst_ptrs=self._dst)
+            st = _lib.load().coda_opt_pack_f32(tab.data_ptr(), tl.chunks.data_ptr(), tl.nchunks, 1.0 / self.world,
+                                               _lib.current_stream_handle())
+        _lib.check(st, "coda_opt_pack_f32")
+        if self.world > 1:
+            self.dist.all_reduce(self.flat, group=self.group)
+        for p, v in zip(self.params, self.views):
+            p.grad = v

@@ -39,6 +39,10 @@ int coda_opt_grad_sumsq_f32(const CodaOptTensor *table, const int32_t *chunks, i
                             void *stream);
 int coda_opt_grad_scale_f32(const CodaOptTensor *table, const int32_t *chunks, int nchunks, const double *sumsq,
                             float max_norm, float *total_norm, void *stream);
+/* Data-parallel gradient packing (main.py:993-996 wraps the model in DistributedDataParallel, which copies every
+ * gradient into its buckets with one kernel per tensor): p[i] = g[i] * scale for every tensor of the table (p = the
+ * tensor's slice of a flat all-reduce buffer; zeros where g == NULL), one launch. */
+int coda_opt_pack_f32(const CodaOptTensor *table, const int32_t *chunks, int nchunks, float scale, void *stream);
 int coda_opt_adamw_f32(const CodaOptTensor *table, const int32_t *chunks, int nchunks, float lr, float beta1,
                        float beta2, float eps, float weight_decay, void *stream);
 

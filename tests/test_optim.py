@@ -63,3 +63,59 @@ def test_clip_and_adamw_match_torch(dev, max_norm):
         a.grad = torch.ones_like(a)
     o_mine2.step()
     assert float(o_mine2.state[mine[0]]["step"]) == 7.0 and float(o_mine2.state[mine[7]]["step"]) == 6.0
+
+
+def _reducer_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # gloo all-reduces CUDA tensors through the host
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    params = _params(dev, seed=rank)                     # different values per rank: rank 0's must win
+    red = optim.FlatGradReducer(params)
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    params[2].grad = None                                # no gradient on this rank / step
+    red.reduce()
+    torch.save({"params": [p.detach().cpu() for p in params], "grads": [p.grad.cpu() for p in params]},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_flat_grad_reducer_two_ranks(dev, tmp_path):
+    """Two gloo ranks sharing cuda:0 (RCCL refuses two ranks per device): parameters broadcast from rank 0, gradients
+    averaged over the ranks, every p.grad a 16-byte aligned view of one flat buffer."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_reducer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{r}.pt") for r in (0, 1))
+    ref_params = _params(torch.device("cpu"), seed=0)
+    for a, b, c in zip(r0["params"], r1["params"], ref_params):
+        assert torch.equal(a, b) and torch.equal(a, c.detach())
+    for i, (a, b) in enumerate(zip(r0["grads"], r1["grads"])):
+        assert torch.equal(a, b)
+    gens = [torch.Generator().manual_seed(100 + r) for r in (0, 1)]
+    for i, a in enumerate(r0["grads"]):
+        per_rank = [torch.randn(a.shape, generator=g) for g in gens]
+        want = torch.zeros_like(a) if i == 2 else (per_rank[0] + per_rank[1]) / 2
+        assert torch.allclose(a, want, rtol=1e-6, atol=1e-7), i
+
+
+@pytest.mark.gpu
+def test_flat_grad_reducer_single_process(dev):
+    params = _params(dev)
+    red = optim.FlatGradReducer(params)
+    grads = [torch.randn_like(p) for p in params]
+    for p, g in zip(params, grads):
+        p.grad = g.clone()
+    red.reduce()
+    for p, g in zip(params, grads):
+        assert torch.equal(p.grad, g) and p.grad.data_ptr() % 16 == 0
+        assert red.flat.data_ptr() <= p.grad.data_ptr() < red.flat.data_ptr() + red.flat.numel() * 4
+    n = optim.clip_grad_norm_(params, 0.1)               # the clipping sees (and scales) the flat views
+    want = torch.sqrt(sum((g.double() ** 2).sum() for g in grads))
+    assert abs(float(n) - float(want)) < 1e-3 * float(want)
