@@ -51,10 +51,21 @@ class _TensorList:
     def table(self, state_ptrs=None, dst_ptrs=None):
         """Device table for this call: parameter / gradient (/ state) pointers as they are now (``dst_ptrs``
         replaces the parameter column: the slices of a flat all-reduce buffer)."""
-        k = self._turn
+        # a staging buffer whose last copy has executed; never wait for one (a host thread parked in an event wait
+        # wakes up late and lets the launch queue drain: measured 22.3 vs 19.3 ms per step) -- grow the ring instead
+        k = None
+        for i in range(len(self._ring)):
+            c = (self._turn + i) % len(self._ring)
+            if self._ring_ev[c] is None or self._ring_ev[c].query():
+                k = c
+                break
+        if k is None:
+            self._ring.append(torch.empty((len(self.params), 6), dtype=torch.int64).pin_memory())
+            self._ring_np.append(self._ring[-1].numpy())
+            self._ring_ev.append(None)
+            self._tables.append(torch.empty((len(self.params), 6), dtype=torch.int64, device=self.device))
+            k = len(self._ring) - 1
         self._turn = (k + 1) % len(self._ring)
-        if self._ring_ev[k] is not None:
-            self._ring_ev[k].synchronize()
         h = self._ring_np[k]
         grads = [p.grad for p in self.params]
         for g in grads:
@@ -200,7 +211,7 @@ class FlatGradReducer:
             st = _lib.load().coda_opt_pack_f32(tab.data_ptr(), tl.chunks.data_ptr(), tl.nchunks, 1.0 / self.world,
                                                _lib.current_stream_handle())
         _lib.check(st, "coda_opt_pack_f32")
-        if self.world > 1:
+        if self.dist.is_initialized():  # also on one rank: the collective is then a no-op the backend still runs
             self.dist.all_reduce(self.flat, group=self.group)
         for p, v in zip(self.params, self.views):
             p.grad = v
