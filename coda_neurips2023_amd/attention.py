@@ -16,7 +16,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import attention_core as _core
 from .linear_fn import linear as _linear

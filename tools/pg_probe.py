@@ -2,7 +2,7 @@
 how the mere existence of the communication library's streams changes the step.  Found the hardware-queue sharing
 between the sampling side stream and the compute stream (22.3 vs 18.1 ms per step; CODA_PREFETCH_PRIORITY=0
 reproduces it).      python tools/pg_probe.py plain|sync      (sync: with SyncBatchNorm conversion)"""
-import os, sys, cProfile, pstats, torch
+import os, sys, cProfile, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 import torch.distributed as dist
