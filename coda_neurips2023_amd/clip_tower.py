@@ -29,8 +29,10 @@ class LayerNorm(nn.LayerNorm):
 
 
 class QuickGELU(nn.Module):
-    def forward(self, x):
-        return x * torch.sigmoid(1.702 * x)
+    """Parameter-free marker of the ``mlp.gelu`` slot (the tower applies it as the c_fc GEMM's epilogue)."""
+
+    def forward(self, u):
+        return u / (1.0 + torch.exp(-1.702 * u))
 
 
 class ResidualAttentionBlock(nn.Module):
@@ -40,18 +42,19 @@ class ResidualAttentionBlock(nn.Module):
         super().__init__()
         if attn_mask is not None:
             raise NotImplementedError("the image tower has no attention mask (CLIP/clip/model.py:607)")
-        self.attn = nn.MultiheadAttention(d_model, n_head)
-        self.ln_1 = LayerNorm(d_model)
-        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
-                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
-        self.ln_2 = LayerNorm(d_model)
+        hidden = 4 * d_model
+        self.attn = nn.MultiheadAttention(embed_dim=d_model, num_heads=n_head)
+        self.ln_1, self.ln_2 = LayerNorm(d_model), LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, hidden)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(hidden, d_model))]))
 
 
 class Transformer(nn.Module):
     def __init__(self, width, layers, heads, attn_mask=None):
         super().__init__()
         self.width, self.layers, self.heads = width, layers, heads
-        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+        blocks = [ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)]
+        self.resblocks = nn.Sequential(*blocks)
 
 
 class _Layer(ctypes.Structure):
@@ -75,13 +78,15 @@ class VisionTransformer(nn.Module):
         super().__init__()
         self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
         self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
-        scale = width ** -0.5
-        self.class_embedding = nn.Parameter(scale * torch.randn(width))
-        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
-        self.ln_pre = LayerNorm(width)
+        tokens = (input_resolution // patch_size) ** 2 + 1
+
+        def init(*shape):  # placeholder values: the deployment loads the CLIP checkpoint over them
+            return nn.Parameter(torch.randn(*shape) / width ** 0.5)
+
+        self.class_embedding, self.positional_embedding = init(width), init(tokens, width)
+        self.ln_pre, self.ln_post = LayerNorm(width), LayerNorm(width)
         self.transformer = Transformer(width, layers, heads)
-        self.ln_post = LayerNorm(width)
-        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+        self.proj = init(width, output_dim)
         self._packed = None
         for p in self.parameters():  # frozen: inference only
             p.requires_grad_(False)
