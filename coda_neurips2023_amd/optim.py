@@ -13,6 +13,29 @@ import torch
 from . import _lib
 
 
+def chunk_map(sizes, chunk):
+    """(n_chunks, 2) int32: (tensor index, chunk index) per block -- tensor i contributes ceil(size_i / chunk) rows
+    (none for an empty tensor), in tensor order (include/coda_optim.h)."""
+    counts = [-(-int(n) // chunk) for n in sizes]
+    cmap = np.empty((sum(counts), 2), dtype=np.int32)
+    at = 0
+    for i, c in enumerate(counts):
+        cmap[at:at + c, 0] = i
+        cmap[at:at + c, 1] = np.arange(c)
+        at += c
+    return cmap
+
+
+def flat_offsets(sizes, align=4):
+    """Start of every tensor's slice in the flat all-reduce buffer (elements; slices start on `align`-element =
+    16-byte boundaries) and the buffer's total length."""
+    offsets, at = [], 0
+    for n in sizes:
+        offsets.append(at)
+        at += -(-int(n) // align) * align
+    return offsets, max(at, align)
+
+
 class _TensorList:
     """Device-side description of a list of parameters: the chunk map is built once, the table of pointers is
     refreshed per call (gradients are new tensors every step)."""
@@ -28,14 +51,7 @@ class _TensorList:
             if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
                 raise RuntimeError("coda optim: parameters must be contiguous float32 tensors on one device")
         self.device = dev
-        chunk = _lib.load().coda_opt_chunk_elems()
-        counts = [-(-p.numel() // chunk) for p in self.params]
-        cmap = np.empty((sum(counts), 2), dtype=np.int32)
-        at = 0
-        for i, c in enumerate(counts):
-            cmap[at:at + c, 0] = i
-            cmap[at:at + c, 1] = np.arange(c)
-            at += c
+        cmap = chunk_map([p.numel() for p in self.params], _lib.load().coda_opt_chunk_elems())
         self.nchunks = int(cmap.shape[0])
         self.chunks = torch.from_numpy(cmap).to(dev)
         # pointer tables travel host -> device without stalling the host: a ring of pinned staging buffers, each
@@ -185,11 +201,8 @@ class FlatGradReducer:
         self.params = [p for p in parameters if p.requires_grad]
         self.list = _TensorList(self.params)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        offsets, at = [], 0
-        for p in self.params:
-            offsets.append(at)
-            at += -(-p.numel() // 4) * 4
-        self.flat = torch.zeros(max(at, 4), dtype=torch.float32, device=self.list.device)
+        offsets, total = flat_offsets([p.numel() for p in self.params])
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.list.device)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offsets, self.params)]
         self._dst = np.array([v.data_ptr() for v in self.views], dtype=np.int64)
         if broadcast and self.world > 1:

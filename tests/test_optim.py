@@ -14,6 +14,23 @@ def _params(dev, seed=0):
     return [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in shapes]
 
 
+def test_chunk_map_and_flat_offsets_cover_every_element_once():
+    import numpy as np
+    sizes = [256 * 256, 768, 3, 0, 2048, 2049, 1, 524288]
+    cmap = optim.chunk_map(sizes, 2048)
+    assert cmap.dtype == np.int32 and cmap.shape == (sum(-(-n // 2048) for n in sizes), 2)
+    seen = {i: np.zeros(n, dtype=np.int32) for i, n in enumerate(sizes)}
+    for t, c in cmap:
+        seen[int(t)][c * 2048:min((c + 1) * 2048, sizes[t])] += 1
+    assert all((v == 1).all() for v in seen.values())
+    assert list(cmap[:, 0]) == sorted(cmap[:, 0])                       # tensor order
+    offsets, total = optim.flat_offsets(sizes)
+    assert all(o % 4 == 0 for o in offsets) and total % 4 == 0
+    ends = [o + n for o, n in zip(offsets, sizes)]
+    assert all(e <= o2 for e, o2 in zip(ends, offsets[1:])) and ends[-1] <= total
+    assert optim.flat_offsets([]) == ([], 4)
+
+
 def test_cpu_parameters_are_rejected():
     p = torch.nn.Parameter(torch.zeros(4))
     p.grad = torch.ones(4)
