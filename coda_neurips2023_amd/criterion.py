@@ -458,7 +458,7 @@ class SetCriterion(nn.Module):
             return {"loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi": fused[1]}
         emb = outputs["text_correlation_embedding"]
         emb = emb / (emb.norm(dim=-1, keepdim=True) + 1e-32)
-        text_features_clip = targets["text_features_clip"].to(torch.float32)
+        text_features_clip = targets["text_features_clip"].to(emb.dtype)  # (fp16 CLIP output -> the embedding's fp32)
         temperature_param = targets["logit_scale"]
         correlation_map = torch.matmul(emb, text_features_clip.permute(0, 2, 1)) * temperature_param
         gt_box_label, gt_box_confidence = self._alignment_labels(targets, assignments)

@@ -961,14 +961,7 @@ uint32_t drop_threshold(float p) {  // 16-bit: keep iff hash16 >= threshold; 0 =
 // steady-state launch path so that launches can be captured into hipGraphs).
 template <typename K>
 int set_lds(K kern, size_t bytes) {
-  if (bytes <= 64 * 1024) return CODA_OK;
-  static bool done = false;  // one instance per kernel type K
-  if (done) return CODA_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-  if (e != hipSuccess) return static_cast<int>(e);
-  done = true;
-  return CODA_OK;
+  return raise_dynamic_lds(kern, bytes);  // per (kernel entry point, device), common.hip.h
 }
 
 // double-buffered K/V staging of the long-sequence kernels (CODA_ATTN_DB=0: single buffer, A/B)

@@ -683,14 +683,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
 
 template <typename K>
 int raise_lds(K kern, size_t bytes) {
-  if (bytes <= 64 * 1024) return CODA_OK;
-  static bool done = false;  // one instance per kernel type
-  if (done) return CODA_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(bytes));
-  if (e != hipSuccess) return static_cast<int>(e);
-  done = true;
-  return CODA_OK;
+  return raise_dynamic_lds(kern, bytes);  // per (kernel entry point, device), common.hip.h
 }
 
 // short query / key sequences (decoder: 256 or 512 object queries) use the split variants

@@ -136,11 +136,7 @@ int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *gro
   int st = CODA_OK;
   CODA_DISPATCH_DM(distance_mode(), {
     auto kern = ball_query_scan_kernel<C, DM>;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) st = static_cast<int>(e);
-    }
+    st = raise_dynamic_lds(kern, lds);
     if (st == CODA_OK)
       hipLaunchKernelGGL(kern, grid, dim3(kBqWaves * kWave), lds, s, new_xyz, xyz, idx, grouped, n, m, r2,
                          inv_radius, nsample, normalize, b);

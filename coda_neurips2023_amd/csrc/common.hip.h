@@ -65,4 +65,24 @@ __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) 
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Opt a kernel into more than 64 KB of dynamic LDS on the CURRENT device (version.hip).  Remembered per
+// (kernel entry point, device), thread-safe, so a process that drives several GPUs raises the limit on each of
+// them and the steady-state launch path makes no runtime call.  A refused opt-in is reported as CODA_ENOSPC
+// ("does not fit"), which callers with a fallback route (matcher solver="auto") act on.
+// `static_bytes`: the kernel's static LDS, which counts against the same 64 KB default.
+int raise_dynamic_lds(const void *kernel, size_t bytes, size_t static_bytes);
+template <typename K>
+inline int raise_dynamic_lds(K kernel, size_t bytes, size_t static_bytes = 0) {
+  return raise_dynamic_lds(reinterpret_cast<const void *>(kernel), bytes, static_bytes);
+}
+// launch errors that mean "this launch configuration does not fit the device"
+inline int launch_status_nospace() {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return CODA_OK;
+  if (e == hipErrorInvalidValue || e == hipErrorInvalidConfiguration || e == hipErrorLaunchOutOfResources ||
+      e == hipErrorOutOfMemory)
+    return CODA_ENOSPC;
+  return static_cast<int>(e);
+}
+
 }  // namespace coda

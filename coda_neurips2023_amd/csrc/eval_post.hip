@@ -237,13 +237,7 @@ CODA_API int coda_nms_f32(const float *corners, const float *scores, const int32
   while (kpow2 < k) kpow2 <<= 1;
   const size_t lds = sizeof(Extent) * k + sizeof(unsigned long long) * kpow2 + kpow2;
   auto kern = nms_kernel;
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       150 * 1024);
-    if (e != hipSuccess) return static_cast<int>(e);
-    raised = true;
-  }
+  if (int st = raise_dynamic_lds(kern, lds); st != CODA_OK) return st;
   clear_sticky_error();
   hipLaunchKernelGGL(kern, dim3(b), dim3(kNmsThreads), lds, static_cast<hipStream_t>(stream), corners, scores, classes,
                      nonempty, keep, k, kpow2, mode, nms_iou, old_type);

@@ -677,13 +677,7 @@ int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, 
   int st = CODA_OK;
   CODA_DISPATCH_DM(distance_mode(), {
     auto kern = fps_bucket_kernel<SL, DM>;
-    static bool raised = false;  // per (SL, DM): static + dynamic LDS exceeds the 64 KB default
-    if (!raised && lds + 20 * 1024 > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-      if (e != hipSuccess) st = static_cast<int>(e);
-      else raised = true;
-    }
+    st = raise_dynamic_lds(kern, lds, 20 * 1024);  // static + dynamic LDS exceeds the 64 KB default
     if (st == CODA_OK)
       hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx,
                          static_cast<FpsMailbox *>(nullptr));
@@ -721,13 +715,7 @@ int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, i
   int st = CODA_OK;
   CODA_DISPATCH_DM(distance_mode(), {
     auto kern = fps_bucket_kernel<SL, DM, 2>;
-    static bool raised = false;
-    if (!raised && lds + 20 * 1024 > 64 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds));
-      if (e != hipSuccess) st = static_cast<int>(e);
-      else raised = true;
-    }
+    st = raise_dynamic_lds(kern, lds, 20 * 1024);
     if (st == CODA_OK)
       hipLaunchKernelGGL(kern, dim3(b, 2), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail);
   });
@@ -884,11 +872,10 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
     CODA_DISPATCH_DM(distance_mode(), {
       auto kern = fps_stream_kernel<kStreamThreads, DM>;
       if (in_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_need));
-        if (e != hipSuccess) st = static_cast<int>(e);
-        else hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), lds_need, s, xyz, n, m, log2T,
-                                static_cast<float *>(nullptr), idx);
+        st = raise_dynamic_lds(kern, lds_need);
+        if (st == CODA_OK)
+          hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), lds_need, s, xyz, n, m, log2T,
+                             static_cast<float *>(nullptr), idx);
       } else {
         hipLaunchKernelGGL(kern, dim3(b), dim3(kStreamThreads), kStreamKeyBytes, s, xyz, n, m, log2T,
                            static_cast<float *>(workspace), idx);

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
   __shared__ int s_insr[kMaxRows];
   __shared__ Best s_best[kHungThreads / kWave];
   __shared__ Best s_pick;
+  __shared__ int s_invalid;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const int prob = blockIdx.x;
@@ -59,15 +60,22 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
     s_row4col[j] = -1;
   }
   if (n == 0) return;  // block-uniform
+  if (tid == 0) s_invalid = 0;
+  __syncthreads();
+  bool bad = false;
   for (int e = tid; e < m * n; e += kHungThreads) {  // cost^T into LDS: s_cost[i][j]
     const int j = e / n, i = e % n;
     float v = c[static_cast<size_t>(j) * ngt + i];
-    // a diverged model can hand in NaN / inf costs (scipy raises on them): keep every cost finite so that the search
-    // below always finds a column and terminates; the assignment of such a problem is arbitrary but valid
+    // A diverged model hands in NaN / inf costs.  scipy.optimize.linear_sum_assignment raises ValueError on them
+    // ("matrix contains invalid numeric entries"), which stops the reference's training; a kernel cannot raise, so the
+    // search runs on clamped costs (it always finds a column and terminates) and the problem is POISONED below: its
+    // matched mask becomes NaN, the loss of the step becomes NaN, and engine.py:155-157 stops the run.
+    bad |= !(fabsf(v) <= FLT_MAX);
     if (!(v == v)) v = FLT_MAX;
     v = fminf(fmaxf(v, -FLT_MAX), FLT_MAX);
     s_cost[i * m + j] = v;
   }
+  if (bad) s_invalid = 1;
   if (tid < n) {
     s_u[tid] = 0.0;
     s_col4row[tid] = -1;
@@ -152,6 +160,10 @@ __global__ __launch_bounds__(kHungThreads) void hungarian_kernel(const float *__
       mask[j] = 1.0f;
     }
   }
+  if (s_invalid) {  // block-uniform (written before the first barrier of the search)
+    __syncthreads();
+    for (int j = tid; j < m; j += kHungThreads) mask[j] = __builtin_nanf("");
+  }
 }
 
 }  // namespace
@@ -166,15 +178,9 @@ CODA_API int coda_hungarian_f32(const float *cost, const int64_t *nactual, int64
   const size_t lds = static_cast<size_t>(nq) * (8 + 8 + 4 + 4 + 4) + sizeof(float) * static_cast<size_t>(nq) * ngt;
   if (nq > 1024 || ngt > kMaxRows || nq < ngt || lds > 150 * 1024) return CODA_ENOSPC;
   auto kern = hungarian_kernel;
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       150 * 1024);
-    if (e != hipSuccess) return static_cast<int>(e);
-    raised = true;
-  }
+  if (int st = raise_dynamic_lds(kern, lds); st != CODA_OK) return st;  // CODA_ENOSPC: solver="auto" takes the host route
   clear_sticky_error();
   hipLaunchKernelGGL(kern, dim3(nprob), dim3(kHungThreads), lds, static_cast<hipStream_t>(stream), cost, nactual,
                      per_prop_gt_inds, matched_mask, nq, ngt);
-  return launch_status();
+  return launch_status_nospace();
 }

@@ -3,6 +3,9 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace coda {
 namespace {
@@ -21,6 +24,36 @@ int distance_mode() {
     g_distance_mode.store(m, std::memory_order_relaxed);
   }
   return m;
+}
+}  // namespace coda
+
+namespace coda {
+int raise_dynamic_lds(const void *kernel, size_t bytes, size_t static_bytes) {
+  if (bytes + static_bytes <= 64 * 1024) return CODA_OK;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = -1;
+  }
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> raised;
+  const auto key = std::make_pair(kernel, dev);
+  if (dev >= 0) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = raised.find(key);
+    if (it != raised.end() && it->second >= bytes) return CODA_OK;
+  }
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return CODA_ENOSPC;
+  }
+  if (dev >= 0) {
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &slot = raised[key];
+    if (slot < bytes) slot = bytes;
+  }
+  return CODA_OK;
 }
 }  // namespace coda
 

@@ -337,11 +337,7 @@ template <int NKT>
 int launch_attention(const _Float16 *qkv, _Float16 *out, int n, int l, int heads, hipStream_t stream) {
   auto kern = vit_attention_kernel<NKT>;
   constexpr size_t lds = attn_lds_bytes<NKT>();
-  if (lds > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-  }
+  if (int st = raise_dynamic_lds(kern, lds); st != CODA_OK) return st;
   clear_sticky_error();
   hipLaunchKernelGGL(kern, dim3(n * heads), dim3(256), lds, stream, qkv, out, n, l, heads);
   return launch_status();

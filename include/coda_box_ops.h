@@ -106,7 +106,10 @@ int coda_matcher_cost_f32(const float *corners1, const float *corners2, const in
  *   per_prop_gt_inds (nprob, nq) int64: GT index of a matched proposal, 0 otherwise (criterion.py:72-74, 80);
  *   matched_mask (nprob, nq) float32: 1 for matched proposals (:75-77, 81).
  * The optimum is unique unless costs tie exactly; under exact ties the total cost equals scipy's while the
- * chosen proposals may differ.  Limits: nq <= 1024, ngt <= 128, (nq * ngt * 4 + nq * 24) bytes of LDS <= 160 KiB;
+ * chosen proposals may differ (scipy prefers the lowest row index of its formulation, this kernel the lowest
+ * proposal index among equal reduced costs).  Non-finite costs (NaN, +-inf: a diverged model): scipy raises
+ * ValueError; here the problem's matched_mask is written as NaN for every proposal, which makes the step's loss
+ * NaN, the condition engine.py:155-157 stops on.  Limits: nq <= 1024, ngt <= 128, (nq * ngt * 4 + nq * 24) bytes of LDS <= 160 KiB;
  * CODA_ENOSPC otherwise (callers fall back to the host solver). */
 int coda_hungarian_f32(const float *cost, const int64_t *nactual, int64_t *per_prop_gt_inds, float *matched_mask,
                        int nprob, int nq, int ngt, void *stream);

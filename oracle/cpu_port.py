@@ -38,12 +38,68 @@ def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, retur
     return torch.from_numpy(out)
 
 
+class _AnyDtypeExt:
+    """The nine operators for tensors of any floating dtype -- the float64 JUDGE of the full-size parity tests
+    (tests/test_full_step_gpu.py): index-producing operators run the C oracle on the float32 image of their input
+    (the clouds ARE float32 data, so the cast back is lossless and the indices are the float32 path's), gathers and
+    their adjoints are plain torch indexing in the tensor's own dtype."""
+
+    def __init__(self):
+        self._f32 = O.TorchExt()
+
+    def furthest_point_sampling(self, points, nsamples):
+        return self._f32.furthest_point_sampling(points.detach().float(), nsamples)
+
+    def ball_query(self, new_xyz, xyz, radius, nsample):
+        return self._f32.ball_query(new_xyz.detach().float(), xyz.detach().float(), radius, nsample)
+
+    def three_nn(self, unknowns, knows):
+        d, i = self._f32.three_nn(unknowns.detach().float(), knows.detach().float())
+        return d.to(unknowns.dtype), i
+
+    @staticmethod
+    def gather_points(points, idx):                       # (B,C,N), (B,M) -> (B,C,M)
+        return torch.gather(points, 2, idx.long().unsqueeze(1).expand(-1, points.shape[1], -1))
+
+    @staticmethod
+    def gather_points_grad(grad_out, idx, n):             # (B,C,M) -> (B,C,n)
+        out = grad_out.new_zeros(grad_out.shape[0], grad_out.shape[1], n)
+        return out.scatter_add_(2, idx.long().unsqueeze(1).expand(-1, grad_out.shape[1], -1), grad_out)
+
+    @staticmethod
+    def group_points(points, idx):                        # (B,C,N), (B,M,S) -> (B,C,M,S)
+        b, c, _ = points.shape
+        flat = idx.long().reshape(b, 1, -1).expand(-1, c, -1)
+        return torch.gather(points, 2, flat).view(b, c, idx.shape[1], idx.shape[2])
+
+    @staticmethod
+    def group_points_grad(grad_out, idx, n):              # (B,C,M,S) -> (B,C,n)
+        b, c = grad_out.shape[:2]
+        out = grad_out.new_zeros(b, c, n)
+        return out.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), grad_out.reshape(b, c, -1))
+
+    @staticmethod
+    def three_interpolate(points, idx, weight):           # (B,C,m), (B,n,3), (B,n,3) -> (B,C,n)
+        b, c, _ = points.shape
+        g = torch.gather(points, 2, idx.long().reshape(b, 1, -1).expand(-1, c, -1)).view(b, c, idx.shape[1], 3)
+        return (g * weight.to(points.dtype).unsqueeze(1)).sum(-1)
+
+    @staticmethod
+    def three_interpolate_grad(grad_out, idx, weight, m):  # (B,C,n) -> (B,C,m)
+        b, c, n = grad_out.shape
+        contrib = (grad_out.unsqueeze(-1) * weight.to(grad_out.dtype).unsqueeze(1)).reshape(b, c, n * 3)
+        out = grad_out.new_zeros(b, c, m)
+        return out.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), contrib)
+
+
 @contextlib.contextmanager
-def patched():
+def patched(any_dtype=False):
+    """``any_dtype=True``: operators that follow the tensors' dtype (``_AnyDtypeExt``), for a float64 run of the
+    same module graph as the judge between two float32 evaluations."""
     from coda_neurips2023_amd import attention_core
     from coda_neurips2023_amd.pointnet2 import _ext
 
-    ext = O.TorchExt()
+    ext = _AnyDtypeExt() if any_dtype else O.TorchExt()
     names = ["gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
              "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
              "group_points_grad"]

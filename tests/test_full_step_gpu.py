@@ -1,0 +1,229 @@
+"""Whole training step at the BASELINE.json sizes, forward + criterion + backward, GPU path against the CPU port.
+
+One step of engine.py:144-159 -- ``model(batch)`` -> ``criterion(outputs, batch)`` (cost matrix, Hungarian
+assignment of all 8 decoder layers, matched box terms, CLIP-space alignment terms, criterion.py:1162-1216) ->
+``backward`` -- on 8 scenes, with dropout 0 so both sides are deterministic, for the three per-GPU shares the
+configs of BASELINE.json name:
+
+* ``configs[2]``     20 000 points, 256 queries, d_dec 256, fp32, stage-2 loss set (both alignment terms);
+* ``configs[3]``     the stage-1 recipe of scripts/coda_sunrgbd_stage1.sh:7-27 at its own shape: d_dec 512
+                     (head width 128), 128 queries, L1 alignment term only;
+* ``configs[4]``     40 000 points, 512 queries, bf16-MFMA attention (``set_mfma_dtype("bf16")``).
+
+Checker: the CPU port (oracle/cpu_port.py: the same host-side module graph with the C oracle ops and plain torch
+attention in the kernel seams, C gIoU, scipy assignment = the reference's host route), run twice: in float32 (what
+the reference's own PyTorch layers compute) and in float64 (the JUDGE between the two float32 evaluations: some
+gradient tensors -- the query projection behind 8 decoder layers, biases in front of a batch norm whose true
+gradient is zero -- differ between ANY two float32 evaluation orders by more than 1e-3).  Compared: FPS indices
+(bit-exact), every loss term, the 64 (layer, scene) assignments, and per-parameter gradients in the relative L2
+norm.  Tolerances are stated at each assert.  The CPU side takes a few GB of host memory and a few minutes on the
+GPU box's host cores."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(__file__))
+from golden.weights import fill_deterministic  # noqa: E402
+
+import bench  # noqa: E402  (recipe_args / synthetic_targets: the step bench.py times)
+from coda_neurips2023_amd import attention_core  # noqa: E402
+from coda_neurips2023_amd.criterion import build_criterion  # noqa: E402
+from coda_neurips2023_amd.dataset_config import HotPathDatasetConfig  # noqa: E402
+from coda_neurips2023_amd.model_3detr import build_model  # noqa: E402
+from coda_neurips2023_amd.synthetic_scenes import make_batch  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+B = 8
+
+CASES = {
+    # name: (points, queries, dec_dim, stage, attention dtype on the GPU side)
+    "configs2_20k_256q_fp32": (20000, 256, 256, 2, "fp32"),
+    "configs3_stage1_dec512_128q": (20000, 128, 512, 1, "fp32"),
+    "configs4_40k_512q_bf16": (40000, 512, 256, 2, "bf16"),
+}
+# Tolerances (relative).  fp32: the north-star 1e-3.  Gradients are compared in the L2 norm per parameter
+# tensor; the set-abstraction MLP's weight gradients are sums over 1 048 576 grouped rows in which a few hundred
+# ReLU / max-pool decisions sit within fp32 rounding of a flip between ANY two evaluation orders
+# (tests/test_full_size_gpu.py, tools/diag_sa_grad.py), and everything upstream of a flipped decision inherits
+# it: those tensors are held at 5e-3.  bf16 attention: 8 significand bits in Q/K/V/P (tests/
+# test_attention_bf16_gpu.py states 2e-2 max / 1e-2 L2 for the core alone); the whole step is held at 3e-2.
+TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3), "bf16": dict(loss=3e-2, grad=3e-2, grad_sa=3e-2)}
+
+
+def _build(dev, nq, dec_dim, stage, provider_tensors):
+    args = bench.recipe_args(nq, dec_dim=dec_dim, enc_dropout=0.0, dec_dropout=0.0, mlp_dropout=0.0)
+    if stage == 1:  # scripts/coda_sunrgbd_stage1.sh: L1 alignment only
+        args.loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi_weight = 0
+    cfg = HotPathDatasetConfig()
+    text, img_emb, mask, weak_label, weak_conf = (t.to(dev) for t in provider_tensors)
+
+    def provider(inputs, outputs, curr_epoch=-1):
+        outputs["gt_text_correlation_embedding"] = img_emb
+        outputs["gt_text_correlation_embedding_mask"] = mask
+        outputs["weak_box_cate_label"] = weak_label
+        outputs["weak_confidence_weight"] = weak_conf
+        return outputs
+
+    model, _ = build_model(args, cfg, text_features_fg_norm=text, region_embedding_provider=provider)
+    crit = build_criterion(args, cfg)
+    if dev.type == "cpu":
+        from oracle import cpu_port
+        crit.giou_fn = cpu_port.generalized_box3d_iou
+    return model, crit.to(dev)
+
+
+def _step(model, crit, batch):
+    """-> (loss, loss_dict, assignments dict of the 8 x B problems)."""
+    captured = {}
+    solve = crit.matcher.solve
+
+    def spy(final_cost, nactual_gt):
+        res = solve(final_cost, nactual_gt)
+        captured["inds"] = res["per_prop_gt_inds"].detach().cpu()
+        captured["mask"] = res["proposal_matched_mask"].detach().cpu()
+        captured["cost"] = final_cost.detach().cpu()
+        return res
+
+    crit.matcher.solve = spy
+    hook = model.pre_encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("sa_inds", o[2].detach().cpu()))
+    try:
+        pred = model(batch, curr_epoch=0)
+        loss, loss_dict = crit(pred, batch)
+        loss.backward()
+    finally:
+        crit.matcher.solve = solve
+        hook.remove()
+    return loss, loss_dict, captured, pred
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_whole_step_forward_criterion_backward(dev, case):
+    from oracle import cpu_port
+    npts, nq, dec_dim, stage, attn = CASES[case]
+    tol = TOL[attn]
+    gen = torch.Generator().manual_seed(11)
+    ncls = 10
+    tensors = (F.normalize(torch.randn(ncls, 512, generator=gen), dim=-1),
+               F.normalize(torch.randn(B, nq, 512, generator=gen), dim=-1),
+               (torch.rand(B, nq, 1, generator=gen) < 0.25).float(),
+               torch.randint(0, ncls, (B, nq), generator=gen),
+               torch.rand(B, nq, generator=gen) * (torch.rand(B, nq, generator=gen) < 0.5))
+    cpu = torch.device("cpu")
+    ref_model, ref_crit = _build(cpu, nq, dec_dim, stage, tensors)
+    fill_deterministic(ref_model, seed=23)
+    gpu_model, gpu_crit = _build(dev, nq, dec_dim, stage, tensors)
+    gpu_model.load_state_dict(ref_model.state_dict())
+    gpu_model.to(dev).train()
+    ref_model.train()
+
+    pc, mn, mx = make_batch(B, npts, seed=555)
+    cpu_batch = {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
+                 "point_cloud_dims_max": torch.from_numpy(mx)}
+    cpu_batch.update(bench.synthetic_targets(cpu_batch, torch.Generator().manual_seed(2)))
+    gpu_batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with cpu_port.patched():
+        r_loss, r_dict, r_cap, r_pred = _step(ref_model, ref_crit, cpu_batch)
+    if attn == "bf16":
+        attention_core.set_mfma_dtype("bf16")
+    try:
+        g_loss, g_dict, g_cap, g_pred = _step(gpu_model, gpu_crit, gpu_batch)
+        torch.cuda.synchronize()
+    finally:
+        attention_core.set_mfma_dtype("fp32")
+
+    # ---- furthest point sampling of the set-abstraction stage (20 000 / 40 000 -> 2048): bit-exact ----------------
+    assert torch.equal(g_cap["sa_inds"], r_cap["sa_inds"]), "FPS indices of the pre-encoder differ from the oracle's"
+
+    # ---- loss terms ------------------------------------------------------------------------------------------
+    rel = abs(float(g_loss) - float(r_loss)) / abs(float(r_loss))
+    print(f"{case}: loss gpu {float(g_loss):.6f} cpu {float(r_loss):.6f} rel {rel:.2e}")
+    assert rel < tol["loss"], f"total loss {rel:.3e}"
+    assert set(g_dict) == set(r_dict)
+    worst = 0.0
+    for k, rv in r_dict.items():
+        rv, gv = float(rv), float(g_dict[k])
+        # terms are compared relative to the size of the total per-layer loss, so that a term whose value is
+        # ~0 (e.g. a zero-weighted one) does not turn round-off into a relative error
+        e = abs(gv - rv) / max(abs(rv), 1e-3 * abs(float(r_loss)))
+        worst = max(worst, e)
+        if k.startswith("loss_cardinality"):
+            # logged only: mean |#predicted objects - #GT| over the scenes; one arg-max within round-off of a tie moves
+            # it by 1/B
+            assert abs(gv - rv) <= 2.0 / B + 1e-6, f"{k}: gpu {gv} cpu {rv}"
+            continue
+        assert e < tol["loss"], f"{k}: gpu {gv} cpu {rv}"
+    if stage == 1:
+        assert not any(k.startswith("loss_feat_seen") for k in g_dict)
+
+    # ---- assignments of the 8 layers x 8 scenes ------------------------------------------------------------------
+    nprob = r_cap["inds"].shape[0]
+    assert nprob == 8 * B
+    r_pairs = r_cap["inds"] * (r_cap["mask"] > 0) - (r_cap["mask"] == 0).long()     # -1 = unmatched proposal
+    g_pairs = g_cap["inds"] * (g_cap["mask"] > 0) - (g_cap["mask"] == 0).long()
+    same = (r_pairs == g_pairs).all(dim=1)
+    n_same = int(same.sum())
+    print(f"{case}: identical assignments in {n_same} of {nprob} problems; worst loss-term rel err {worst:.2e}")
+    # Where the two sides disagree they must both be optimal for the CPU side's cost matrix up to the cost's own
+    # round-off (the two cost matrices differ in the last bits: a tie within that noise may be broken either way).
+    cost = r_cap["cost"].double()
+    for p in torch.nonzero(~same).flatten().tolist():
+        rows_r = torch.nonzero(r_pairs[p] >= 0).flatten()
+        rows_g = torch.nonzero(g_pairs[p] >= 0).flatten()
+        assert rows_r.numel() == rows_g.numel(), f"problem {p}: different match counts"
+        c_r = cost[p, rows_r, r_pairs[p, rows_r]].sum()
+        c_g = cost[p, rows_g, g_pairs[p, rows_g]].sum()
+        assert abs(float(c_g - c_r)) <= tol["loss"] * abs(float(c_r)) + 1e-6, \
+            f"problem {p}: GPU assignment is not optimal for the reference costs ({float(c_g)} vs {float(c_r)})"
+    if attn == "fp32":
+        assert n_same == nprob, f"assignments differ in {nprob - n_same} of {nprob} problems"
+    else:
+        assert n_same >= nprob * 3 // 4, f"assignments differ in {nprob - n_same} of {nprob} problems"
+
+    # ---- gradients: per-parameter relative L2 against the float64 judge --------------------------------------------
+    t64 = tuple(t.double() if t.dtype.is_floating_point else t for t in tensors)
+    j_model, j_crit = _build(cpu, nq, dec_dim, stage, t64)
+    j_model.load_state_dict(ref_model.state_dict())
+    j_model.double().train()
+    j_crit.double()
+    j_batch = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in cpu_batch.items()
+               if k not in ("nactual_gt", "num_boxes", "num_boxes_replica")}
+    with cpu_port.patched(any_dtype=True):
+        j_loss, _, j_cap, _ = _step(j_model, j_crit, j_batch)
+    j_pairs = j_cap["inds"] * (j_cap["mask"] > 0) - (j_cap["mask"] == 0).long()
+    print(f"{case}: float64 judge loss {float(j_loss):.6f}; its assignments equal the float32 port's in "
+          f"{int((j_pairs == r_pairs).all(dim=1).sum())} and the GPU's in {int((j_pairs == g_pairs).all(dim=1).sum())} "
+          f"of {nprob} problems")
+    judge = {n: p.grad for n, p in j_model.named_parameters()}
+    ref_params = dict(ref_model.named_parameters())
+    scale = max(float(g.norm()) for g in judge.values() if g is not None)
+    report, failed = [], []
+    for name, p in gpu_model.named_parameters():
+        j = judge[name]
+        assert (p.grad is None) == (j is None), name
+        if j is None:
+            continue
+        g = p.grad.detach().double().cpu()
+        r = ref_params[name].grad.double()
+        if float(j.norm()) < 1e-6 * scale:
+            # true gradient zero (a bias in front of a batch-statistics norm): both float32 sides hold round-off
+            assert float(g.norm()) < 1e-3 * scale, f"grad {name}: {float(g.norm()):.3e} where the judge has ~0"
+            continue
+        e_gpu = float((g - j).norm() / j.norm())
+        e_cpu = float((r - j).norm() / j.norm())
+        report.append((e_gpu, e_cpu, name))
+        # limit: the stated tolerance, or -- where plain torch float32 on the host does not reach it either -- 1.5x
+        # that evaluation's own distance to the judge
+        lim = max(tol["grad_sa"] if name.startswith("pre_encoder.") else tol["grad"], 1.5 * e_cpu)
+        if not e_gpu < lim:
+            failed.append(f"{name}: rel L2 {e_gpu:.3e} (limit {lim:.1e}; torch-CPU float32 {e_cpu:.1e})")
+    report.sort(reverse=True)
+    over = [r for r in report if r[0] >= (tol["grad_sa"] if r[2].startswith("pre_encoder.") else tol["grad"])]
+    print(f"{case}: {len(report)} gradient tensors vs the float64 judge; {len(over)} above the stated tolerance "
+          f"(allowed only where torch-CPU float32 is as far); worst (gpu / torch-cpu-f32): "
+          + ", ".join(f"{n} {a:.1e}/{b:.1e}" for a, b, n in report[:10]))
+    assert not failed, "gradients: " + "; ".join(failed)

@@ -157,9 +157,11 @@ def test_criterion_same_loss_with_and_without_the_fused_matcher_front(rotated):
         assert torch.allclose(ga[k], gb[k], rtol=1e-5, atol=1e-7), k
 
 
-def test_non_finite_costs_terminate_with_a_valid_assignment():
-    """A diverged model hands the matcher NaN / inf costs (scipy raises ValueError there); the device solver must
-    neither hang nor index out of range: every real GT box still gets a distinct proposal."""
+def test_non_finite_costs_terminate_and_poison_the_problem():
+    """A diverged model hands the matcher NaN / inf costs.  scipy raises ValueError there (and the reference's run
+    dies); the device solver must neither hang nor index out of range, and it marks the problem: the matched mask
+    of a problem with a non-finite cost is NaN everywhere, so the step's loss is NaN and engine.py:155-157 stops
+    the run.  Problems with finite costs in the same launch are solved as usual."""
     gen = torch.Generator().manual_seed(3)
     nprob, nq, ngt = 6, 128, 16
     outputs, cost = _outputs(nprob, nq, ngt, gen)
@@ -174,9 +176,12 @@ def test_non_finite_costs_terminate_with_a_valid_assignment():
     got = Matcher(0, 0, 0, 1, solver="device")(outputs, targets)
     torch.cuda.synchronize()
     inds, mask = got["per_prop_gt_inds"].cpu().numpy(), got["proposal_matched_mask"].cpu().numpy()
-    for b in range(nprob):
+    for b in range(4):
+        assert np.isnan(mask[b]).all(), f"problem {b} holds non-finite costs: its mask must be poisoned"
+        assert ((inds[b] >= 0) & (inds[b] < ngt)).all()
+    for b in (4, 5):
         rows = np.nonzero(mask[b])[0]
-        assert len(rows) == int(nactual[b])
+        assert np.isfinite(mask[b]).all() and len(rows) == int(nactual[b])
         assert sorted(inds[b, rows].tolist()) == list(range(int(nactual[b])))
     # the untouched problem is still solved optimally
     r, col = linear_sum_assignment(cost[4, :, :7].numpy().astype(np.float64))
