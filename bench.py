@@ -480,9 +480,13 @@ def main():
             # executed): 444 scenes/s against 425 under DistributedDataParallel with bucket views (CODA_DDP=tuned) and
             # torch's defaults (CODA_DDP=default)
             from coda_neurips2023_amd.optim import FlatGradReducer
-            reducer = FlatGradReducer(model.parameters(), broadcast=False)
+            # two segments: heads + decoder (81 % of the bytes) are packed and all-reduced from a backward hook as
+            # soon as the decoder node's gradients have landed, i.e. under the projection / encoder / set-abstraction
+            # backward; the rest after backward.  CODA_DDP_OVERLAP=0: both after backward (A/B)
+            reducer = FlatGradReducer(model, broadcast=False, early=("mlp_heads.", "decoder."),
+                                      overlap=os.environ.get("CODA_DDP_OVERLAP", "1") != "0")
             if world > 1:
-                reducer.sync_parameters(model)
+                reducer.sync_parameters(model)  # rank 0's parameters AND buffers, like DDP's constructor
         else:
             ddp_kw = {}
             if ddp_mode != "default":

@@ -153,8 +153,8 @@ def test_whole_step_forward_criterion_backward(dev, case):
         worst = max(worst, e)
         if k.startswith("loss_cardinality"):
             # logged only: mean |#predicted objects - #GT| over the scenes; one arg-max within round-off of a tie moves
-            # it by 1/B
-            assert abs(gv - rv) <= 2.0 / B + 1e-6, f"{k}: gpu {gv} cpu {rv}"
+            # it by 1/B (bf16 attention: more near-ties flip, held at the loss tolerance)
+            assert abs(gv - rv) <= max(2.0 / B, tol["loss"] * abs(rv)) + 1e-6, f"{k}: gpu {gv} cpu {rv}"
             continue
         assert e < tol["loss"], f"{k}: gpu {gv} cpu {rv}"
     if stage == 1:
@@ -168,17 +168,29 @@ def test_whole_step_forward_criterion_backward(dev, case):
     same = (r_pairs == g_pairs).all(dim=1)
     n_same = int(same.sum())
     print(f"{case}: identical assignments in {n_same} of {nprob} problems; worst loss-term rel err {worst:.2e}")
-    # Where the two sides disagree they must both be optimal for the CPU side's cost matrix up to the cost's own
-    # round-off (the two cost matrices differ in the last bits: a tie within that noise may be broken either way).
-    cost = r_cap["cost"].double()
+    # Where the two sides disagree (bf16 attention only: fp32 must agree everywhere): the GPU's assignment must be
+    # optimal for the GPU's OWN cost matrix (scipy on it: the solver did its job), and the two cost matrices must
+    # agree within the stated tolerance -- then C(A_gpu) - C(A_cpu) <= 2 n max|dC| on either matrix, checked too.
+    from scipy.optimize import linear_sum_assignment
+    cost, gcost = r_cap["cost"].double(), g_cap["cost"].double()
+    nact = cpu_batch["gt_box_present"].sum(1).long().repeat(8)
+    dmax = max(float((cost[p, :, :int(nact[p])] - gcost[p, :, :int(nact[p])]).abs().max()) for p in range(nprob)
+               if int(nact[p]) > 0)
+    cmax = float(cost.abs().max())
+    print(f"{case}: cost matrices differ by at most {dmax:.2e} (|cost| up to {cmax:.2f})")
+    assert dmax <= tol["loss"] * cmax, f"cost matrices differ by {dmax:.3e}"
     for p in torch.nonzero(~same).flatten().tolist():
+        n = int(nact[p])
         rows_r = torch.nonzero(r_pairs[p] >= 0).flatten()
         rows_g = torch.nonzero(g_pairs[p] >= 0).flatten()
-        assert rows_r.numel() == rows_g.numel(), f"problem {p}: different match counts"
-        c_r = cost[p, rows_r, r_pairs[p, rows_r]].sum()
-        c_g = cost[p, rows_g, g_pairs[p, rows_g]].sum()
-        assert abs(float(c_g - c_r)) <= tol["loss"] * abs(float(c_r)) + 1e-6, \
-            f"problem {p}: GPU assignment is not optimal for the reference costs ({float(c_g)} vs {float(c_r)})"
+        assert rows_r.numel() == rows_g.numel() == n, f"problem {p}: different match counts"
+        opt_r, opt_c = linear_sum_assignment(gcost[p, :, :n].numpy())
+        own = float(gcost[p, rows_g, g_pairs[p, rows_g]].sum())
+        assert abs(own - float(gcost[p, opt_r, opt_c].sum())) <= 1e-5 * max(1.0, abs(own)), \
+            f"problem {p}: the device solver's assignment is not optimal for its own costs"
+        c_r = float(cost[p, rows_r, r_pairs[p, rows_r]].sum())
+        c_g = float(cost[p, rows_g, g_pairs[p, rows_g]].sum())
+        assert c_g - c_r <= 2 * n * dmax + 1e-6, f"problem {p}: {c_g} vs {c_r} with max|dC| {dmax}"
     if attn == "fp32":
         assert n_same == nprob, f"assignments differ in {nprob - n_same} of {nprob} problems"
     else:
