@@ -97,6 +97,10 @@ SIGNATURES = {
     # include/coda_clip_crops.h
     "coda_project_box_rects_f64": (_c_int, [_P] * 16 + [_c_int, _c_int, _P]),
     "coda_crop_resize_f32": (_c_int, [_P] * 5 + [_c_int] * 6 + [_P]),
+    # include/coda_clip_labels.h
+    "coda_clip_weak_labels_f32": (_c_int, [_P, ctypes.c_longlong, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
+                                           _c_int, _P]),
+    "coda_pseudo_box_filter_f32": (_c_int, [_P] * 6 + [_c_float] * 3 + [_P, _P, _c_int, _c_int, _c_int, _P]),
     # include/coda_clip_tower.h
     "coda_vit_workspace_bytes": (ctypes.c_size_t, [_P, _c_int, _c_int]),
     "coda_vit_fwd": (_c_int, [_P, _P, _c_int, _P, _P, _P, ctypes.c_size_t, _P]),

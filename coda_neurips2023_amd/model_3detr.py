@@ -10,13 +10,13 @@ decoder call (:1784-1792), ``get_box_predictions`` (:1634-1740),
 output dictionary keys and every ``state_dict`` key of the trunk are the
 reference's, so ``main.py`` / ``engine.py`` can call it unchanged.
 
-Out of scope here (SURVEY.md 8f "next"): the CLIP towers and the image-crop
-distillation branch (``get_predicted_box_clip_embedding*``, :902-1632), which
-need weights that are not available.  Their PRODUCTS enter the hot path through
-two seams: ``text_features_fg_norm`` (the normalised text embeddings, computed
-once at init in the reference, :339-342) and ``region_embedding_provider`` (a
-callable that adds ``gt_text_correlation_embedding(_mask)`` etc. to the output
-dictionary like the crop branch does, :1102-1103).
+The CLIP side enters through two seams: ``text_features_fg_norm`` (and
+``superset_text_features_fg_norm``: the normalised text embeddings, computed once
+at init in the reference, :339-360 -- the text tower runs once at start-up and is
+the deployment's) and ``region_embedding_provider``, the image-crop distillation
+branch (``get_predicted_box_clip_embedding*``, :902-1632): ``clip_crops.
+RegionEmbeddingProvider`` implements both of the reference's methods on the
+device; any callable with its signature can stand in (tests, ``bench.py``).
 """
 import math
 
@@ -83,7 +83,8 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
                  if_keep_box=False, if_select_box_by_objectness=False, keep_objectness=0.5,
                  online_nms_update_novel_label=False, online_nms_update_accumulate_novel_label=False,
                  online_nms_update_accumulate_epoch=10, distillation_box_num=32, args=None,
-                 text_features_fg_norm=None, region_embedding_provider=None, clip_model=None, logit_scale=None):
+                 text_features_fg_norm=None, region_embedding_provider=None, clip_model=None, logit_scale=None,
+                 superset_text_features_fg_norm=None):
         super().__init__()
         self.if_with_fake_classes = if_with_fake_classes
         self.num_cls_predict = num_cls_predict
@@ -97,7 +98,11 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         self.keep_objectness = keep_objectness
         self.distillation_box_num = distillation_box_num
         self.eval_layer_id = getattr(args, "eval_layer_id", -1) if args is not None else -1
-        self.if_clip_superset = False
+        # --if_clip_superset (models/model_3detr.py:282-360): the training prompts are a larger class list (LVIS-derived,
+        # 232 / 1201 entries) whose normalised embeddings the caller hands in like `text_features_fg_norm`
+        self.if_clip_superset = bool(getattr(args, "if_clip_superset", False)) and superset_text_features_fg_norm is not None
+        self.online_nms_update_save_novel_label_clip_driven_with_cate_confidence = bool(
+            getattr(args, "online_nms_update_save_novel_label_clip_driven_with_cate_confidence", False))  # :437
 
         # The CLIP towers themselves are outside the hot path (weights are not redistributable here):
         # the constructor takes their PRODUCTS -- the normalised prompt embeddings, the frozen
@@ -127,6 +132,9 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
                 self.logit_scale = nn.Parameter(torch.ones([]) * value, requires_grad=False)
         else:
             self.text_features_fg_norm = None
+        if superset_text_features_fg_norm is not None:
+            self.register_buffer("superset_text_features_fg_norm", superset_text_features_fg_norm.to(torch.float32),
+                                 persistent=False)
 
         self.encoder_to_decoder_projection = GenericMLP(
             input_dim=256, hidden_dims=[512, 512], output_dim=decoder_dim, norm_fn_name="bn1d",
@@ -353,12 +361,18 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         outputs = box_predictions["outputs"]
         outputs["logit_scale"] = torch.clip(self.logit_scale.exp(), min=None, max=100)
         bsz = point_clouds.shape[0]
-        if (not if_real_test) and (not if_cmp_class) and (not if_test):
-            outputs["text_features_clip"] = self.text_features_fg_norm[:self.train_range_max, :] \
-                .unsqueeze(0).repeat(bsz, 1, 1)
-            if self.region_embedding_provider is not None:
-                box_predictions["outputs"] = self.region_embedding_provider(inputs, outputs,
-                                                                            curr_epoch=curr_epoch)
+        if (not if_real_test) and (not if_cmp_class) and (not if_test):  # :1799-1817
+            prompts = self.superset_text_features_fg_norm if self.if_clip_superset \
+                else self.text_features_fg_norm[:self.train_range_max, :]
+            outputs["text_features_clip"] = prompts.unsqueeze(0).repeat(bsz, 1, 1)
+            provider = self.region_embedding_provider
+            if provider is not None:
+                if getattr(provider, "stage2", self.online_nms_update_save_novel_label_clip_driven_with_cate_confidence):
+                    outputs["maybe_novel_text_features_clip"] = self.superset_text_features_fg_norm \
+                        if self.if_clip_superset else self.text_features_fg_norm[:self.test_range_max, :]
+                if hasattr(provider, "if_keep_box"):
+                    provider.if_keep_box = self.if_keep_box   # main.py:356 sets it on the model at epoch boundaries
+                box_predictions["outputs"] = provider(inputs, outputs, curr_epoch=curr_epoch)
         if if_real_test:
             outputs["text_features_clip"] = self.text_features_fg_norm.unsqueeze(0).repeat(bsz, 1, 1)
             box_predictions, _, _ = self.get_class_scores(box_predictions)

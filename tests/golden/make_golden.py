@@ -666,12 +666,101 @@ def golden_clip_tower():
     _save("clip_tower.npz", **out)
 
 
+def nms_restated(boxes, scores, iou_threshold):
+    """torchvision.ops.nms (0.9.1, the version README.md:43 names; the package is not in this image): greedy
+    suppression in descending score order, IoU = inter / (a1 + a2 - inter) on (x1,y1,x2,y2) float32 boxes without a
+    +1, suppress when IoU > threshold; returns the kept indices in that order.  Equal scores: lower index first
+    (torchvision's sort is not stable; the fixture inputs only tie on discarded boxes)."""
+    boxes = boxes.detach().to(torch.float32)
+    order = sorted(range(boxes.shape[0]), key=lambda j: (-float(scores[j]), j))
+    x1, y1, x2, y2 = boxes.unbind(1)
+    areas = (x2 - x1) * (y2 - y1)
+    dead, keep = set(), []
+    for a, i in enumerate(order):
+        if i in dead:
+            continue
+        keep.append(i)
+        for j in order[a + 1:]:
+            if j in dead:
+                continue
+            w = torch.clamp(torch.minimum(x2[i], x2[j]) - torch.maximum(x1[i], x1[j]), min=0)
+            h = torch.clamp(torch.minimum(y2[i], y2[j]) - torch.maximum(y1[i], y1[j]), min=0)
+            inter = w * h
+            if float(inter / (areas[i] + areas[j] - inter)) > iou_threshold:
+                dead.add(j)
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+def golden_region_branch():
+    """The reference's two image-branch methods (models/model_3detr.py:902-1210 and :1212-1632) run END TO END on
+    seeded inputs (tests/golden/region_inputs.py) with a seeded stand-in image tower: selection (random /
+    objectness-driven), crops, embedding scatter + mask, novel-box discovery into the ground truth, CLIP weak labels,
+    and the stage-2 pseudo-label mining (2-D NMS, 3-D IoU against the ground truth, objectness / CLIP thresholds, the
+    .npy rows).  Stand-ins for what this image lacks: torchvision's ``Resize`` / ``nms`` and CLIP's tensor transform
+    (restated: oracle/crop_oracle.py, nms_restated above)."""
+    import tempfile
+    import types as T
+    import models.model_3detr as M
+    import datasets.sunrgbd_utils as RU
+    import utils.box_util as RB
+    from golden import region_inputs as R
+    from oracle import crop_oracle as CO
+    cls = M.Model3DETRPredictedBoxDistillationHead
+    sys.modules["torchvision.ops"].nms = nms_restated
+    sys.modules["torchvision"].ops = sys.modules["torchvision.ops"]
+
+    def resize(img):  # torchvision 0.9.1 Resize(224, BICUBIC) on a square uint8 (3,E,E) tensor
+        y = torch.nn.functional.interpolate(img.unsqueeze(0).float(), size=(224, 224), mode="bicubic", align_corners=False)
+        return y.clamp(0, 255).round()[0].to(torch.uint8)
+
+    def preprocess(x):  # CLIP/clip/clip.py:95-101 on (n,3,224,224): resize / crop are identities at this size
+        x = x / 255.0
+        return (x - torch.tensor(CO.MEAN).view(1, 3, 1, 1)) / torch.tensor(CO.STD).view(1, 3, 1, 1)
+
+    out = {}
+    for name, (method, epoch, flags) in R.CASES.items():
+        inputs, outputs, tower_w = R.build(RB.get_3d_box_batch_tensor_xyz, RB.get_3d_box_batch_tensor)
+        text = outputs.pop("text_features_all")
+        ncls = R.NTEXT if (name.startswith("stage1_objectness") or name.startswith("stage2")) else R.NSEEN
+        outputs["text_features_clip"] = text[:ncls].unsqueeze(0).repeat(R.B, 1, 1)   # (stage 2: the superset, :1800-1802)
+        outputs["maybe_novel_text_features_clip"] = text
+        me = T.SimpleNamespace(device="cpu", dataset_util=RU, box_idx_list=np.arange(128, dtype=np.int8),
+                               resize=resize, preprocess_for_tensor=preprocess, clip_model=R.StandInTower(tower_w),
+                               if_select_box_by_objectness=False, if_keep_box=False, if_clip_weak_labels=False,
+                               if_accumulate_former_pseudo_labels=False, **R.MODEL_FLAGS)
+        for k, v in flags.items():
+            setattr(me, k, v)
+        me.cal_iou = T.MethodType(cls.cal_iou, me)
+        tmp = tempfile.mkdtemp()
+        inputs["pseudo_box_path"] = [os.path.join(tmp, f"scene{b}.npy") for b in range(R.B)]
+        if flags.get("if_accumulate_former_pseudo_labels"):
+            np.save(inputs["pseudo_box_path"][0], np.zeros((0, 10)))
+            np.save(inputs["pseudo_box_path"][1], np.zeros((0, 10)))
+            np.save(inputs["pseudo_box_path"][2], np.arange(10, dtype=np.float64)[None])
+        np.random.seed(2024)
+        with torch.no_grad():
+            res = getattr(cls, method)(me, inputs, outputs, curr_epoch=epoch)
+        out[f"{name}/emb"] = _np(res["gt_text_correlation_embedding"])
+        out[f"{name}/mask"] = _np(res["gt_text_correlation_embedding_mask"])
+        if "weak_box_cate_label" in res:  # (the stage-2 method adds no weak entries without if_clip_weak_labels, :1614)
+            out[f"{name}/weak_label"] = _np(res["weak_box_cate_label"])
+            out[f"{name}/weak_conf"] = _np(res["weak_confidence_weight"])
+        for k in R.GT_KEYS:
+            out[f"{name}/{k}"] = _np(inputs[k])
+        for b, path in enumerate(inputs["pseudo_box_path"]):
+            out[f"{name}/pseudo{b}"] = np.load(path) if os.path.exists(path) else np.zeros((0, 10))
+        print(name, "masked", int(res["gt_text_correlation_embedding_mask"].sum()), "gt now",
+              [int(x) for x in inputs["gt_box_present"].sum(1)], "pseudo rows",
+              [out[f"{name}/pseudo{b}"].shape[0] for b in range(R.B)], "weak conf>0", int((res["weak_confidence_weight"] > 0).sum()) if "weak_confidence_weight" in res else None)
+    _save("region_branch.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower"]
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch"]
     for w in which:
         globals()["golden_" + w]()
