@@ -301,6 +301,209 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   }
 }
 
+// Split-key forward WITHOUT LDS staging (round 3).  In the split-key decomposition every K / V tile is used by exactly
+// one wave, so staging it through LDS buys no reuse -- it only costs the wave 32 VMEM issues + 32 ds_write_b128 per
+// tile, a barrier per stage whose skew nothing hides (one wave per SIMD), and the LDS round trip in front of the
+// MFMAs.  Here the fragments go from L2 straight into registers in the layout the MFMAs consume:
+//   K (A operand of S^T = K Q^T):   lane (key = l31, half) reads the D/2 consecutive floats of its key row
+//                                    -> D/8 float4 loads, each key row's two cache lines consumed completely;
+//   V (A operand of O^T = V^T P^T): for accumulator row r the lanes of a half read key row crow(r, half) at
+//                                    columns NT*l31.. -> 16 loads of NT floats, 256 B contiguous per half-wave.
+// Two register sets: the loads of a wave's NEXT tile are issued before the MFMAs of the current one (a tile is
+// ~2.5 us of work: any L2 / HBM latency is covered), no barrier anywhere in the key loop.  LDS is used for the
+// final merge of the QW partial soft-max states only (26 KB), so the waves of a workgroup never wait for each other.
+template <int D, int QW, bool GEN>
+__global__ __launch_bounds__(QW * kWave, (QW >= 8 && D == 64) ? 2 : 1) void mha_fwd_direct_kernel(MhaParams p) {
+  constexpr int HD = D / 2, NT = D / 32;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  const int lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = th.tile * kTile;
+  const int myq = q0 + l31;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float qf[HD];
+  const float qscale = p.scale * kLog2e;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (myq < p.l) t = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
+    qf[c] = t.x * qscale; qf[c + 1] = t.y * qscale; qf[c + 2] = t.z * qscale; qf[c + 3] = t.w * qscale;
+  }
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
+
+  struct Frag {
+    float4 k[HD / 4];
+    float v[16][NT];
+  };
+  auto load = [&](Frag &f, int s0) {
+    const int krow = s0 + l31;
+    const bool kin = !GEN || krow < p.s;
+    const float *kp = kbase + static_cast<size_t>(kin ? krow : 0) * kstride + half * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const float4 t = *reinterpret_cast<const float4 *>(kp + 4 * c);
+      f.k[c] = kin ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int vrow = s0 + crow(r, half);
+      const bool vin = !GEN || vrow < p.s;
+      const float *vp = vbase + static_cast<size_t>(vin ? vrow : 0) * vstride + NT * l31;
+      if (NT == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(vp);
+        f.v[r][0] = vin ? t.x : 0.f; f.v[r][1] = vin ? t.y : 0.f;
+      } else {
+        const float4 t = *reinterpret_cast<const float4 *>(vp);
+        f.v[r][0] = vin ? t.x : 0.f; f.v[r][1] = vin ? t.y : 0.f; f.v[r][2 % NT] = vin ? t.z : 0.f; f.v[r][3 % NT] = vin ? t.w : 0.f;
+      }
+    }
+  };
+  auto compute = [&](const Frag &f, int s0) {
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kf = f.k[c / 4];
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c + 1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c + 2], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c + 3], sacc, 0, 0, 0);
+    }
+    float pr[16];
+    float tmax = -INFINITY;
+    if (!GEN) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pr[r] = sacc[r];
+        tmax = fmaxf(tmax, pr[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + crow(r, half);
+        bool dead = key >= p.s;
+        if (p.mask && !dead && myq < p.l) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
+        pr[r] = dead ? -INFINITY : sacc[r];
+        tmax = fmaxf(tmax, pr[r]);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    if (__ballot(m_new != m) != 0ull) {  // lazy rescale (see mha_fwd_kernel)
+      const float alpha = fast_exp2(m - m_safe);
+      lsum *= alpha;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m = m_new;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = fast_exp2(pr[r] - m_safe);
+      rs += pr[r];
+    }
+    lsum += rs;
+    if (use_drop) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
+        pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] : 0.f;
+        pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.v[r][t], pr[r], o[t], 0, 0, 0);
+    }
+  };
+
+  const int ntile = (p.s + kTile - 1) / kTile;
+  if (q0 < p.l) {  // wave-uniform (all waves of a workgroup share the query tile)
+    Frag fa, fb;
+    int t = w;
+    if (t < ntile) load(fa, t * kTile);
+    while (t < ntile) {
+      if (t + QW < ntile) load(fb, (t + QW) * kTile);
+      compute(fa, t * kTile);
+      t += QW;
+      if (t >= ntile) break;
+      if (t + QW < ntile) load(fa, (t + QW) * kTile);
+      compute(fb, t * kTile);
+      t += QW;
+    }
+  }
+
+  lsum += __shfl_xor(lsum, 32);
+  if (QW > 1) {  // merge the per-wave partial soft-max states: slot layout [wave-1][NT*16 + 2][64 lanes]
+    float *slot = s_dyn + static_cast<size_t>(w > 0 ? w - 1 : 0) * (NT * 16 + 2) * kWave;
+    if (w > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * kWave + lane] = o[t][r];
+      slot[(NT * 16) * kWave + lane] = m;
+      slot[(NT * 16 + 1) * kWave + lane] = lsum;
+    }
+    __syncthreads();
+    if (w > 0) return;
+    float m_all = m;
+    for (int ww = 1; ww < QW; ++ww) m_all = fmaxf(m_all, s_dyn[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
+    const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
+    const float f0 = fast_exp2(m - m_ref);
+    lsum *= f0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= f0;
+    for (int ww = 1; ww < QW; ++ww) {
+      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
+      const float fw = fast_exp2(sl[(NT * 16) * kWave + lane] - m_ref);
+      lsum += sl[(NT * 16 + 1) * kWave + lane] * fw;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] += sl[(t * 16 + r) * kWave + lane] * fw;
+    }
+    m = m_all;
+  }
+  if (myq < p.l) {
+    const float inv = lsum > 0.f ? p.inv_keep / lsum : 0.f;
+    float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dv = NT * crow(r, half);
+      if (NT == 2) {
+        *reinterpret_cast<float2 *>(orow + dv) = make_float2(o[0][r] * inv, o[1][r] * inv);
+      } else {
+        *reinterpret_cast<float4 *>(orow + dv) =
+            make_float4(o[0][r] * inv, o[1][r] * inv, o[2 % NT][r] * inv, o[3 % NT][r] * inv);
+      }
+    }
+    if (half == 0) p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m * kLn2 + __logf(lsum) : -INFINITY;
+  }
+}
+
 // Long-sequence forward with the S tile of the NEXT key block already in flight: a wave issues the 32 MFMAs of
 // S_{t+1} = K_{t+1} Q^T before it starts the soft-max arithmetic of S_t, so its own VALU work (exp2, dropout hash,
 // rescale) runs under MFMAs of its own instead of leaving the matrix pipe to the other wave of the SIMD only.
@@ -971,6 +1174,11 @@ bool split_double_buffered() {
   static const bool on = [] { const char *e = getenv("CODA_ATTN_SPLIT_DB"); return !e || atoi(e) != 0; }();
   return on;
 }
+// split-key kernels without LDS staging (CODA_ATTN_DIRECT = 0 off | 4 | 8 waves per workgroup; default 4)
+int split_direct() {
+  static const int v = [] { const char *e = getenv("CODA_ATTN_DIRECT"); return e ? atoi(e) : 4; }();
+  return v;
+}
 // ---- optional per-kernel HIP-event timing (coda_mha_timing_*) -----------------------------------
 struct TimingRecord {
   int kind, l, s;
@@ -1051,7 +1259,21 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
     }
   } else {
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
-    if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
+    const int direct = split_direct();
+    if (direct) {  // K / V fragments straight from L2 into registers, no staging (mha_fwd_direct_kernel)
+      constexpr size_t mlds4 = sizeof(float) * 3 * (D / 32 * 16 + 2) * kWave, mlds8 = sizeof(float) * 7 * (D / 32 * 16 + 2) * kWave;
+      if (direct == 8 && D == 64) {
+        auto kern = mha_fwd_direct_kernel<D, 8, GEN>;
+        int st = set_lds(kern, mlds8);
+        if (st != CODA_OK) return st;
+        hipLaunchKernelGGL(kern, grid, dim3(8 * kWave), mlds8, s, p);
+      } else {
+        auto kern = mha_fwd_direct_kernel<D, 4, GEN>;
+        int st = set_lds(kern, mlds4);
+        if (st != CODA_OK) return st;
+        hipLaunchKernelGGL(kern, grid, dim3(4 * kWave), mlds4, s, p);
+      }
+    } else if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
       auto kern = mha_fwd_kernel<D, 4, true, GEN, true>;  // 4 waves, 2 x 4 tile pairs
       int st = set_lds(kern, 8 * kTileBytes);
       if (st != CODA_OK) return st;

@@ -19,14 +19,31 @@
 //    centred / normalised (B,3,M,S) tensor directly.
 #include "common.hip.h"
 
+#include <atomic>
+#include <cstdlib>
+
 namespace coda {
 
 // ball_query_grid.hip
 int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b, int n,
                     int m, float radius, int nsample, int normalize, void *workspace, hipStream_t s);
 size_t ball_query_grid_workspace(int b, int n, int nsample);
+// ball_query_tile.hip
+bool ball_query_tile_applies(int n, int m, int nsample);
+int ball_query_tile(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b, int n, int m, float radius,
+                    int nsample, int normalize, hipStream_t s);
 
 namespace {
+std::atomic<int> g_bq_route{-1};
+int ball_query_route() {
+  int r = g_bq_route.load(std::memory_order_relaxed);
+  if (r < 0) {  // first use: CODA_BQ = auto | grid | scan | tile
+    const char *e = getenv("CODA_BQ");
+    r = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0)));
+    g_bq_route.store(r, std::memory_order_relaxed);
+  }
+  return r;
+}
 
 constexpr int kBqWaves = 4;  // waves per workgroup
 
@@ -147,9 +164,16 @@ int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *gro
 int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b,
                         int n, int m, float radius, int nsample, int normalize, void *workspace,
                         size_t workspace_bytes, hipStream_t s) {
+  // 0 auto (grid when the caller provided its workspace, else scan) | 1 grid | 2 scan | 3 tile (one launch,
+  // LDS-resident tiles: exact and workspace-free, but measured 2.4x slower than the grid pair -- DESIGN.md section 7)
+  const int route = ball_query_route();
+  if (route == 3 && radius > 0.0f && ball_query_tile_applies(n, m, nsample)) {
+    const int st = ball_query_tile(new_xyz, xyz, idx, grouped, b, n, m, radius, nsample, normalize, s);
+    if (st != CODA_ENOSPC) return st;
+  }
   // cell-binned search when the caller provided the workspace it was told to provide
   const size_t need = ball_query_grid_workspace(b, n, nsample);
-  if (workspace && need > 0 && workspace_bytes >= need && radius > 0.0f)
+  if (route != 2 && workspace && need > 0 && workspace_bytes >= need && radius > 0.0f)
     return ball_query_grid(new_xyz, xyz, idx, grouped, b, n, m, radius, nsample, normalize, workspace, s);
   // LDS rows: waves * C * nsample * 4 B must fit the 160 KiB CU.
   const size_t per_centre = sizeof(int32_t) * kBqWaves * static_cast<size_t>(nsample);
@@ -164,6 +188,12 @@ int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, fl
 
 }  // namespace
 }  // namespace coda
+
+CODA_API int coda_set_ball_query_route(int route) {
+  if (route < 0 || route > 3) return CODA_EINVAL;
+  coda::g_bq_route.store(route, std::memory_order_relaxed);
+  return CODA_OK;
+}
 
 CODA_API size_t coda_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
   (void)m;

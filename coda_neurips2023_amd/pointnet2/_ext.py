@@ -132,12 +132,34 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+_ROUTES = {"auto": 0, "grid": 1, "scan": 2, "tile": 3}
+
+
+class _ball_query_route:
+    """``algorithm``: "auto" (the cell table in a workspace where it applies, else the scan) | "grid" | "scan" (brute
+    force) | "tile" (one launch, no workspace: include/coda_pointnet2.h).  All give identical results; the non-default
+    ones exist for the parity tests and A/B timing, and switch the library's process-wide route for the duration
+    of the call."""
+
+    def __init__(self, lib, algorithm):
+        if algorithm not in _ROUTES:
+            raise ValueError(f"unknown ball_query algorithm {algorithm!r}")
+        self.lib, self.route = lib, _ROUTES[algorithm]
+
+    def __enter__(self):
+        if self.route:
+            self.lib.coda_set_ball_query_route(self.route)
+
+    def __exit__(self, *exc):
+        if self.route:
+            self.lib.coda_set_ball_query_route(0)
+
+
 def _ball_query_workspace(lib, b, n, m, nsample, device, algorithm):
-    """Workspace of the cell-binned search; ``algorithm='scan'`` passes none, which makes the
-    C ABI fall back to the brute-force scan kernel (same results, used by the parity tests)."""
-    if algorithm not in ("auto", "scan", "grid"):
+    """Workspace of the cell-binned search ("auto" / "grid"); "scan" and "tile" need none."""
+    if algorithm not in _ROUTES:
         raise ValueError(f"unknown ball_query algorithm {algorithm!r}")
-    ws_bytes = 0 if algorithm == "scan" else lib.coda_ball_query_workspace_bytes(b, n, m, nsample)
+    ws_bytes = 0 if algorithm in ("scan", "tile") else lib.coda_ball_query_workspace_bytes(b, n, m, nsample)
     if algorithm == "grid" and ws_bytes == 0:
         raise RuntimeError("grid ball_query not applicable to this shape (n < 1024 or nsample > 128)")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device) if ws_bytes else None
@@ -156,7 +178,7 @@ def ball_query(new_xyz, xyz, radius, nsample, algorithm="auto"):
     m = new_xyz.size(1)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
-    with torch.cuda.device(new_xyz.device), _timed("ball_query"):
+    with torch.cuda.device(new_xyz.device), _ball_query_route(lib, algorithm), _timed("ball_query"):
         st = lib.coda_ball_query_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), b, n, m, float(radius),
                                      int(nsample), _ptr(ws), ws_bytes, _stream())
     _lib.check(st, "ball_query")
@@ -280,7 +302,7 @@ def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz, algorithm=
     shape = (b, m, nsample, 3) if channels_last else (b, 3, m, nsample)
     grouped = torch.empty(shape, dtype=torch.float32, device=new_xyz.device)
     ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
-    with torch.cuda.device(new_xyz.device), _timed("query_and_group_xyz"):
+    with torch.cuda.device(new_xyz.device), _ball_query_route(lib, algorithm), _timed("query_and_group_xyz"):
         st = lib.coda_query_and_group_xyz_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(grouped),
                                               b, n, m, float(radius), int(nsample),
                                               (1 if normalize_xyz else 0) | (2 if channels_last else 0),

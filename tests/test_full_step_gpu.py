@@ -75,13 +75,17 @@ def _build(dev, nq, dec_dim, stage, provider_tensors):
     return model, crit.to(dev)
 
 
-def _step(model, crit, batch):
-    """-> (loss, loss_dict, assignments dict of the 8 x B problems)."""
+def _step(model, crit, batch, forced=None):
+    """-> (loss, loss_dict, assignments dict of the 8 x B problems).  ``forced``: (inds, mask) to use INSTEAD of the
+    solver's result (the costs are still captured)."""
     captured = {}
     solve = crit.matcher.solve
 
     def spy(final_cost, nactual_gt):
         res = solve(final_cost, nactual_gt)
+        if forced is not None:
+            res = {"assignments": None, "per_prop_gt_inds": forced[0].to(final_cost.device),
+                   "proposal_matched_mask": forced[1].to(final_cost.device)}
         captured["inds"] = res["per_prop_gt_inds"].detach().cpu()
         captured["mask"] = res["proposal_matched_mask"].detach().cpu()
         captured["cost"] = final_cost.detach().cpu()
@@ -194,6 +198,19 @@ def test_whole_step_forward_criterion_backward(dev, case):
         assert n_same >= nprob * 3 // 4, f"assignments differ in {nprob - n_same} of {nprob} problems"
 
     # ---- gradients: per-parameter relative L2 against the float64 judge --------------------------------------------
+    if n_same != nprob:
+        # (bf16 only) a different assignment moves whole matched-box terms from one proposal to another: to compare
+        # ARITHMETIC, the GPU step is repeated with the reference's assignments (the matcher itself was checked above)
+        gpu_model.zero_grad(set_to_none=True)
+        attention_core.set_mfma_dtype(attn)
+        try:
+            g_loss, g_dict, _, g_pred = _step(gpu_model, gpu_crit, gpu_batch, forced=(r_cap["inds"], r_cap["mask"]))
+            torch.cuda.synchronize()
+        finally:
+            attention_core.set_mfma_dtype("fp32")
+        rel = abs(float(g_loss) - float(r_loss)) / abs(float(r_loss))
+        print(f"{case}: with the reference's assignments: loss gpu {float(g_loss):.6f} rel {rel:.2e}")
+        assert rel < tol["loss"]
     t64 = tuple(t.double() if t.dtype.is_floating_point else t for t in tensors)
     j_model, j_crit = _build(cpu, nq, dec_dim, stage, t64)
     j_model.load_state_dict(ref_model.state_dict())

@@ -49,13 +49,31 @@ def main():
     if "bq" in which:
         nbytes = 8 * (12 * 20000 + 12 * 2048 + 4 * 2048 * 64)
         gbytes = 8 * 3126016
-        for alg in ("scan", "grid"):
+        for alg in ("scan", "grid", "tile"):
             med, mn = timeit(lambda: _ext.ball_query(new_xyz, xyz, 0.2, 64, algorithm=alg))
             print(f"ball_query {alg}: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
                   f"({nbytes / med / 1e6:.1f} GB/s algorithmic)")
             med, mn = timeit(lambda: _ext.query_and_group_xyz(new_xyz, xyz, 0.2, 64, True, algorithm=alg))
             print(f"query_and_group_xyz {alg}: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
                   f"({gbytes / med / 1e6:.1f} GB/s algorithmic, bq+group bytes)")
+            med, mn = timeit(lambda: _ext.query_and_group_xyz(new_xyz, xyz, 0.2, 64, True, algorithm=alg, channels_last=True))
+            print(f"query_and_group_xyz {alg} channels-last: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
+                  f"({gbytes / med / 1e6:.1f} GB/s)")
+        # the 8-GPU global batch on one GPU (64 scenes) and a ScanNet-sized cloud: where the operator becomes bandwidth-bound
+        pcs = [make_batch(8, 20000, seed=2000 + i)[0] for i in range(8)]
+        xyz64 = torch.from_numpy(np.concatenate(pcs)).to(dev)
+        inds64 = _ext.furthest_point_sampling(xyz64, 2048)
+        new64 = torch.gather(xyz64, 1, inds64.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        for alg in ("grid", "tile"):
+            med, mn = timeit(lambda: _ext.query_and_group_xyz(new64, xyz64, 0.2, 64, True, algorithm=alg, channels_last=True))
+            print(f"query_and_group_xyz {alg} B=64: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
+                  f"({8 * gbytes / med / 1e6:.1f} GB/s = {8 * gbytes / med / 1e6 / 8000:.3f} of 8 TB/s)")
+        pc40, _, _ = make_batch(8, 40000, seed=77)
+        xyz40 = torch.from_numpy(pc40).to(dev)
+        new40 = torch.gather(xyz40, 1, _ext.furthest_point_sampling(xyz40, 2048).long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        for alg in ("grid", "tile"):
+            med, mn = timeit(lambda: _ext.query_and_group_xyz(new40, xyz40, 0.2, 64, True, algorithm=alg, channels_last=True))
+            print(f"query_and_group_xyz {alg} N=40000: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us")
     if "group" in which:
         idx = _ext.ball_query(new_xyz, xyz, 0.2, 64)
         xyz_t = xyz.transpose(1, 2).contiguous()
