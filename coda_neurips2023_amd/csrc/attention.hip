@@ -1152,6 +1152,203 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
   }
 }
 
+// Split-key dQ WITHOUT LDS staging (see mha_fwd_direct_kernel): a wave's K / V tiles are its own, so their
+// fragments are loaded from L2 straight into the three register layouts the MFMAs consume -- K rows (A operand of
+// S^T = K Q^T), V rows (A operand of dP^T = V dO^T), K columns (B operand of dQ = dS K) -- one tile ahead of the
+// MFMAs; LDS only for the final sum of the QW partial dQ.
+template <int D, int QW, bool GEN>
+__global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_direct_kernel(MhaBwdParams p) {
+  constexpr int HD = D / 2, NT = D / 32;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  const int lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = th.tile * kTile;
+  const int myq = q0 + l31;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float qf[HD], gf[HD];
+  const float qscale = p.scale * kLog2e;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), g = a;
+    if (myq < p.l) {
+      a = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
+      g = *reinterpret_cast<const float4 *>(p.dout + static_cast<size_t>(myq) * rstride + head_off + half * HD + c);
+    }
+    qf[c] = a.x * qscale; qf[c + 1] = a.y * qscale; qf[c + 2] = a.z * qscale; qf[c + 3] = a.w * qscale;
+    gf[c] = g.x; gf[c + 1] = g.y; gf[c + 2] = g.z; gf[c + 3] = g.w;
+  }
+  float lse = 0.f, delta = 0.f;
+  if (myq < p.l) {
+    lse = p.lse[static_cast<size_t>(bh) * p.l + myq] * kLog2e;  // log2 units
+    delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
+  }
+  const float lse_eff = (myq < p.l && lse != -INFINITY) ? lse : INFINITY;
+  f32x16 dq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+
+  struct Frag {
+    float4 k[HD / 4], v[HD / 4];  // rows l31 of the tile, half `half` of the head dimension
+    float kc[16][NT];             // K[crow(r, half)][NT * l31 ..]
+  };
+  auto load_kv = [&](Frag &f, int s0) {
+    const int row = s0 + l31;
+    const bool in = !GEN || row < p.s;
+    const float *kp = kbase + static_cast<size_t>(in ? row : 0) * kstride + half * HD;
+    const float *vp = vbase + static_cast<size_t>(in ? row : 0) * vstride + half * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4 *>(kp + 4 * c), b = *reinterpret_cast<const float4 *>(vp + 4 * c);
+      f.k[c] = in ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+      f.v[c] = in ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto load_kc = [&](Frag &f, int s0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = s0 + crow(r, half);
+      const bool kin = !GEN || krow < p.s;
+      const float *cp = kbase + static_cast<size_t>(kin ? krow : 0) * kstride + NT * l31;
+      if (NT == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(cp);
+        f.kc[r][0] = kin ? t.x : 0.f; f.kc[r][1] = kin ? t.y : 0.f;
+      } else {
+        const float4 t = *reinterpret_cast<const float4 *>(cp);
+        f.kc[r][0] = kin ? t.x : 0.f; f.kc[r][1] = kin ? t.y : 0.f; f.kc[r][2 % NT] = kin ? t.z : 0.f; f.kc[r][3 % NT] = kin ? t.w : 0.f;
+      }
+    }
+  };
+  float ds[16];
+  auto scores = [&](const Frag &f, int s0) {
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 ka = f.k[c / 4], va = f.v[c / 4];
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qf[c], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, gf[c], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qf[c + 1], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, gf[c + 1], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qf[c + 2], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, gf[c + 2], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qf[c + 3], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, gf[c + 3], pacc, 0, 0, 0);
+    }
+    if (!GEN) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float keep0 = 1.f, keep1 = 1.f;
+        if (use_drop) {
+          const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
+          keep0 = drop_keep_lo(hsh, p.thresh16) ? p.inv_keep : 0.f;
+          keep1 = drop_keep_hi(hsh, p.thresh16) ? p.inv_keep : 0.f;
+        }
+        const float prob0 = fast_exp2(sacc[r] - lse_eff);
+        const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
+        ds[r] = prob0 * (pacc[r] * keep0 - delta);  // * scale: once, on the dQ rows
+        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + crow(r, half);
+        bool dead = key >= p.s || myq >= p.l;
+        if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + myq) * p.s + key] != 0;
+        const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] - lse);
+        float keep = 1.f;
+        if (use_drop) keep = drop_keep(drop_hash(dconst, myq, p.s, key), key, p.thresh16) ? p.inv_keep : 0.f;
+        ds[r] = prob * (pacc[r] * keep - delta);
+      }
+    }
+  };
+  auto accumulate = [&](const Frag &f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], f.kc[r][t], dq[t], 0, 0, 0);
+    }
+  };
+
+  const int ntile = (p.s + kTile - 1) / kTile;
+  const bool wave_active = q0 < p.l;
+  if (wave_active && D <= 64) {  // two register sets: the whole next tile in flight during this tile's MFMAs
+    Frag fa, fb;
+    int t = w;
+    if (t < ntile) { load_kv(fa, t * kTile); load_kc(fa, t * kTile); }
+    while (t < ntile) {
+      if (t + QW < ntile) { load_kv(fb, (t + QW) * kTile); load_kc(fb, (t + QW) * kTile); }
+      scores(fa, t * kTile);
+      accumulate(fa);
+      t += QW;
+      if (t >= ntile) break;
+      if (t + QW < ntile) { load_kv(fa, (t + QW) * kTile); load_kc(fa, (t + QW) * kTile); }
+      scores(fb, t * kTile);
+      accumulate(fb);
+      t += QW;
+    }
+  } else if (wave_active) {
+    // head width 128: 192 registers per fragment set -- one set, phased: the K columns of the CURRENT tile load
+    // under its S / dP MFMAs (128 of them), the K / V rows of the NEXT tile under its dQ MFMAs (64) + soft-max
+    Frag f;
+    int t = w;
+    if (t < ntile) load_kv(f, t * kTile);
+    while (t < ntile) {
+      load_kc(f, t * kTile);
+      scores(f, t * kTile);
+      if (t + QW < ntile) load_kv(f, (t + QW) * kTile);
+      accumulate(f);
+      t += QW;
+    }
+  }
+  if (QW > 1) {  // sum the per-wave partial dQ through LDS: [wave-1][NT*16][64 lanes]
+    if (w > 0) {
+      float *slot = s_dyn + static_cast<size_t>(w - 1) * (NT * 16) * kWave;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * kWave + lane] = dq[t][r];
+    }
+    __syncthreads();
+    if (w > 0) return;
+    for (int ww = 1; ww < QW; ++ww) {
+      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16) * kWave;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[t][r] += sl[(t * 16 + r) * kWave + lane];
+    }
+  }
+  if (wave_active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + crow(r, half);
+      if (qq < p.l) {
+        float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + NT * l31;
+        if (NT == 2) {
+          *reinterpret_cast<float2 *>(row) = make_float2(dq[0][r] * p.scale, dq[1][r] * p.scale);
+        } else {
+          *reinterpret_cast<float4 *>(row) = make_float4(dq[0][r] * p.scale, dq[1][r] * p.scale, dq[2 % NT][r] * p.scale,
+                                                          dq[3 % NT][r] * p.scale);
+        }
+      }
+    }
+  }
+}
+
 uint32_t drop_threshold(float p) {  // 16-bit: keep iff hash16 >= threshold; 0 = dropout off
   if (!(p > 0.f)) return 0u;
   double t = static_cast<double>(p) * 65536.0 + 0.5;
@@ -1374,7 +1571,17 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else {
-    if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
+    // K / V fragments straight from L2 into registers (mha_bwd_dq_direct_kernel): head width 128 only -- 250 -> 133 us
+    // on 256 x 2048; at width 64 the LDS-staged kernel below is the faster one (83 vs 93 us: 32 narrow VMEM
+    // instructions per tile against 16 wide ones + LDS reads).  CODA_ATTN_DIRECT_DQ=1 forces it (A/B)
+    static const bool force_dq = [] { const char *e = getenv("CODA_ATTN_DIRECT_DQ"); return e && atoi(e) != 0; }();
+    if (split_direct() && (D > 64 || force_dq)) {
+      constexpr size_t mlds = sizeof(float) * 3 * (D / 32 * 16) * kWave;
+      auto kern = mha_bwd_dq_direct_kernel<D, 4, GEN>;
+      int st = set_lds(kern, mlds);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(4 * kWave), mlds, s, p);
+    } else if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
       auto kern = mha_bwd_dq_kernel<D, 4, true, GEN, true>;
       int st = set_lds(kern, 8 * kTileBytes);
       if (st != CODA_OK) return st;
