@@ -8,6 +8,11 @@ threshold.  Here the two filters are HIP kernels (csrc/eval_post.hip: ``coda_box
 ``coda_nms_f32``) on the tensors where the model left them; one device->host copy of the survivors' rows builds
 the same list-of-tuples the reference's ``APCalculator.accumulate`` / ``eval_det`` consume, in the same order.
 Function names, arguments and the config dictionary are the reference's.
+
+``APCalculator`` (:1054-1808: ``step_meter`` / ``step`` / ``accumulate`` / ``compute_metrics`` / ``metrics_to_str``)
+accumulates those lists and turns them into the mAP / AR tables through ``eval_det`` (eval_det.py: every 3-D IoU of
+a class in one launch).  ``merge_across_ranks`` is this package's alternative to gathering every rank's inputs
+before ``step_meter`` (dist_utils.py).
 """
 import numpy as np
 import torch
@@ -117,3 +122,146 @@ def parse_predictions_obb(predicted_boxes, sem_cls_probs, objectness_probs, poin
                      objectness_probs.unsqueeze(-1)], dim=-1)
     mask = prediction_mask(predicted_boxes, sem_cls_probs, objectness_probs, point_cloud, config_dict)
     return _lists(mask, predicted_boxes, sem_cls_probs, objectness_probs, config_dict, obb=obb)
+
+
+class APCalculator(object):
+    """utils/ap_calculator.py:1054-1808, the entry points engine.py's evaluate loops use."""
+
+    def __init__(self, dataset_config, ap_iou_thresh=[0.25, 0.5], class2type_map=None, exact_eval=True, args=None,
+                 ap_config_dict=None, reset_nms_iou=None):
+        self.ap_iou_thresh = ap_iou_thresh
+        if ap_config_dict is None:
+            ap_config_dict = get_ap_config_dict(dataset_config=dataset_config, remove_empty_box=exact_eval)
+        self.ap_config_dict = ap_config_dict
+        self.class2type_map = class2type_map
+        self.args = args
+        self.dataset_config = dataset_config
+        self.reset()
+        self.reset_nms_iou = reset_nms_iou
+
+    def reset(self):
+        self.gt_map_cls = {}    # {scan id: [(class, corners)]}
+        self.pred_map_cls = {}  # {scan id: [(class, corners, score)]}
+        self.point_clouds = {}
+        self.scan_cnt = 0
+
+    def make_gt_list(self, gt_box_corners, gt_box_sem_cls_labels, gt_box_present):
+        return [[(gt_box_sem_cls_labels[i, j].item(), gt_box_corners[i, j]) for j in range(gt_box_corners.shape[1])
+                 if gt_box_present[i, j] == 1] for i in range(gt_box_corners.shape[0])]
+
+    def step_meter(self, outputs, targets):
+        if "outputs" in outputs:
+            outputs = outputs["outputs"]
+        self.step(predicted_box_corners=outputs["box_corners"], sem_cls_probs=outputs["sem_cls_prob"],
+                  objectness_probs=outputs["objectness_prob"], point_cloud=targets["point_clouds"],
+                  gt_box_corners=targets["gt_box_corners"], gt_box_sem_cls_labels=targets["gt_box_sem_cls_label"],
+                  gt_box_present=targets["gt_box_present"])
+
+    def step(self, predicted_box_corners, sem_cls_probs, objectness_probs, point_cloud, gt_box_corners,
+             gt_box_sem_cls_labels, gt_box_present):
+        batch_gt_map_cls = self.make_gt_list(gt_box_corners.cpu().detach().numpy(),
+                                             gt_box_sem_cls_labels.cpu().detach().numpy(),
+                                             gt_box_present.cpu().detach().numpy())
+        batch_pred_map_cls = parse_predictions(predicted_box_corners, sem_cls_probs, objectness_probs, point_cloud,
+                                               self.ap_config_dict)
+        self.accumulate(batch_pred_map_cls, batch_gt_map_cls)
+
+    def accumulate(self, batch_pred_map_cls, batch_gt_map_cls):
+        assert len(batch_pred_map_cls) == len(batch_gt_map_cls)
+        for pred, gt in zip(batch_pred_map_cls, batch_gt_map_cls):
+            self.gt_map_cls[self.scan_cnt] = gt
+            self.pred_map_cls[self.scan_cnt] = pred
+            self.scan_cnt += 1
+
+    def merge_across_ranks(self):
+        """Every rank ends up with all ranks' accumulated scans (rank-major scan ids).  Call once before
+        ``compute_metrics`` when each rank stepped on its own scenes only."""
+        from . import dist_utils
+        if not dist_utils.is_distributed():
+            return
+        import torch.distributed as dist
+        mine = [(self.pred_map_cls[i], self.gt_map_cls[i]) for i in range(self.scan_cnt)]
+        everyone = [None] * dist_utils.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        self.reset()
+        for part in everyone:
+            for pred, gt in part:
+                self.pred_map_cls[self.scan_cnt], self.gt_map_cls[self.scan_cnt] = pred, gt
+                self.scan_cnt += 1
+
+    def _groups(self, count):
+        """Index sets of the frequent / common / base / novel class groups (:1577-1590)."""
+        scannet = self.args is not None and getattr(self.args, "dataset_name", "").find("scannet") != -1
+        if not scannet or count < 21:
+            return slice(0, 4), slice(4, 10), slice(0, 10), slice(10, None)
+        seen, novel = self.dataset_config.seen_idx_list, self.dataset_config.novel_idx_list
+        return seen, seen, seen, novel
+
+    def compute_metrics(self, get_iou_func=None):
+        from collections import OrderedDict
+        from .eval_det import eval_det
+        overall_ret = OrderedDict()
+        for ap_iou_thresh in self.ap_iou_thresh:
+            ret = OrderedDict()
+            rec, prec, ap = eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=ap_iou_thresh,
+                                     get_iou_func=get_iou_func)
+            name = (lambda key: self.class2type_map[key]) if self.class2type_map else str
+            for key in sorted(ap.keys()):
+                ret["%s Average Precision" % name(key)] = ap[key]
+            ap_vals = np.array(list(ap.values()), dtype=np.float32)
+            ap_vals[np.isnan(ap_vals)] = 0
+            many = ap_vals.shape[0] > 2
+            fre, common, base, novel = self._groups(ap_vals.shape[0])
+            ret["mAP"] = ap_vals.mean()
+            if many:
+                ret["mAP_fre"], ret["mAP_common"] = ap_vals[fre].mean(), ap_vals[common].mean()
+                ret["mAP_base"], ret["mAP_novel"] = ap_vals[base].mean(), ap_vals[novel].mean()
+            prec_list, rec_list = [], []
+            for key in sorted(prec.keys()):
+                last = prec[key][-1] if len(prec[key]) else 0
+                ret["%s Prec" % name(key)] = last
+                prec_list.append(last)
+            for key in sorted(ap.keys()):
+                last = rec[key][-1] if len(rec[key]) else 0
+                ret["%s Recall" % name(key)] = last
+                rec_list.append(last)
+            for label, values in (("Prec", np.array(prec_list)), ("AR", np.array(rec_list))):
+                if many:
+                    ret[label + "_fre"], ret[label + "_common"] = np.mean(values[fre]), np.mean(values[common])
+                    ret[label + "_base"], ret[label + "_novel"] = np.mean(values[base]), np.mean(values[novel])
+                ret[label] = np.mean(values)
+            overall_ret[ap_iou_thresh] = ret
+        return overall_ret
+
+    def __str__(self):
+        return self.metrics_to_str(self.compute_metrics())
+
+    def metrics_to_str(self, overall_ret, per_class=True):
+        blocks = {"mAP": [], "AR": [], "Prec": []}
+        per_class_metrics = []
+        for t in self.ap_iou_thresh:
+            ret = overall_ret[t]
+            for label in ("mAP", "AR", "Prec"):
+                blocks[label].append(f"{label}{t:.2f}: {ret[label] * 100:.2f}\n")
+                if label + "_fre" in ret:
+                    for group in ("fre", "common", "base", "novel"):
+                        tail = "\n\n" if group == "novel" else "\n"
+                        blocks[label].append(f"{label}_{group}{t:.2f}: {ret[f'{label}_{group}'] * 100:.2f}{tail}")
+            if per_class:
+                per_class_metrics.append("-" * 5)
+                per_class_metrics.append(f"IOU Thresh={t}")
+                for x in ret.keys():
+                    if x in ("mAP", "AR") or x.endswith(("fre", "common", "base", "novel")):
+                        continue
+                    per_class_metrics.append(f"{x}: {ret[x] * 100:.2f}")
+        ap_str = "".join(blocks["mAP"]) + "\n" + "".join(blocks["AR"]) + "\n" + "".join(blocks["Prec"]) + "\n"
+        if per_class:
+            ap_str += "\n" + "\n".join(per_class_metrics)
+        return ap_str
+
+    def metrics_to_dict(self, overall_ret):
+        out = {}
+        for t in self.ap_iou_thresh:
+            out[f"mAP_{t}"] = overall_ret[t]["mAP"] * 100
+            out[f"AR_{t}"] = overall_ret[t]["AR"] * 100
+        return out

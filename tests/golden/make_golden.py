@@ -755,12 +755,35 @@ def golden_region_branch():
     _save("region_branch.npz", **out)
 
 
+def golden_eval_det():
+    """The reference's APCalculator.accumulate / compute_metrics / metrics_to_str (utils/ap_calculator.py:1491-1803)
+    over utils/eval_det.eval_det with its own box3d_iou (numpy clip + scipy ConvexHull), on the seeded detection lists
+    of tests/golden/eval_inputs.py: every metric of both IoU thresholds, and the printed table."""
+    import types as T
+    from utils.ap_calculator import APCalculator
+    from golden import eval_inputs as E
+    cfg = T.SimpleNamespace(num_semcls=E.NCLS)
+    calc = APCalculator(dataset_config=cfg, ap_iou_thresh=[0.25, 0.5], class2type_map=None, exact_eval=False,
+                        args=T.SimpleNamespace(dataset_name="sunrgbd"))
+    for pred, gt in E.build():
+        calc.accumulate(pred, gt)
+    ret = calc.compute_metrics()
+    out = {}
+    for t, d in ret.items():
+        out[f"keys_{t}"] = np.array(list(d.keys()))
+        out[f"vals_{t}"] = np.array([float(v) for v in d.values()], dtype=np.float64)
+    out["table"] = np.array(calc.metrics_to_str(ret))
+    out["dict"] = np.array([calc.metrics_to_dict(ret)[k] for k in sorted(calc.metrics_to_dict(ret))])
+    print("mAP", {t: float(d["mAP"]) for t, d in ret.items()}, "classes", sum(k.endswith("Average Precision") for k in ret[0.25]))
+    _save("eval_det.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch"]
+    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det"]
     for w in which:
         globals()["golden_" + w]()
