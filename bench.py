@@ -172,12 +172,12 @@ def synthetic_targets(batch, gen, ngt=64, ncls=10, max_boxes=20):
 CLIP_GRADIENT = 0.1  # main.py:52 --clip_gradient's default: engine.py:161-162 clips every step
 
 
-def make_optimizer(params, dry=False):
+def make_optimizer(params, dry=False, force_torch=False):
     """The tail of the reference's step (engine.py:161-164): clip_grad_norm_(parameters, 0.1), AdamW.step().
     -> (optimizer, clip function).  Default: this package's three-launch kernels (coda_neurips2023_amd.optim);
     CODA_OPTIM=torch: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(fused=True) (dev A/B; also the dry run)."""
     params = list(params)
-    if dry or os.environ.get("CODA_OPTIM", "coda") == "torch":
+    if dry or force_torch or os.environ.get("CODA_OPTIM", "coda") == "torch":
         opt = torch.optim.AdamW(params, lr=1e-4, fused=not dry)
         return opt, lambda: torch.nn.utils.clip_grad_norm_(params, CLIP_GRADIENT)
     from coda_neurips2023_amd import optim
@@ -595,6 +595,35 @@ def main():
         ev = (timing if store is None else store).get(name, [])
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
 
+    # The same step as an UNCHANGED engine.py would run it: no `prefetch_sampling` call (the
+    # sampling runs in line and the padded group copies are not de-duplicated), torch.nn.utils.clip_grad_norm_ +
+    # torch.optim.AdamW(fused=True) instead of this package's three-launch tail.  Single process only (with several
+    # ranks every rank would have to run it in lockstep); `steps` more steps right after the headline's.
+    unchanged = None
+    if world == 1 and kind == "model" and not dry:
+        opt2, clip2 = make_optimizer(model.parameters(), force_torch=True)
+
+        def plain_step(i):
+            opt2.zero_grad(set_to_none=True)
+            step_fn(model, pool[i % len(pool)]).backward()
+            clip2()
+            opt2.step()
+
+        for i in range(3):
+            plain_step(i)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            plain_step(i)
+        sync()
+        dt2 = time.perf_counter() - t1
+        unchanged = {"value": round(B_PER_GPU * args.steps / dt2, 3), "unit": "scenes/s",
+                     "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                     "what": "the same step through the reference's unchanged call sequence (engine.py:136-164): "
+                             "model(batch) / criterion / backward / torch clip_grad_norm_ + torch AdamW(fused), no "
+                             "sampling prefetch, no group de-duplication"}
+        del opt2
+
     alone = {}
     if rank == 0 and prefetch:
         # with the sampling prefetch the operator ran on a side stream, competing with the step's own
@@ -708,6 +737,8 @@ def main():
                      "gc_passes": gc_stat["n"], "gc_ms_per_step": round(gc_stat["ms"] / args.steps, 4)},
             "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
         }
+        if unchanged is not None:
+            out["value_unchanged_caller"] = unchanged
         if others:
             out["roofline_others"] = others
         if world == 1 and not dry and not args.no_extras and kind == "model" and args.workload != "model40k":

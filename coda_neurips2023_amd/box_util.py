@@ -97,6 +97,12 @@ def get_3d_box_batch_tensor(box_size, angle, center):
 ROTATED_K2_LIMIT = -1
 
 
+def _vols_mode(flag):
+    """0: gIoU; 1: intersection volumes as generalized_box3d_iou_tensor computes them (with its axis-aligned pre-test);
+    2 ("exact"): intersection volumes of every pair, the evaluation's box3d_iou."""
+    return 2 if flag == "exact" else int(bool(flag))
+
+
 def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, return_inter_vols_only=False,
                           needs_grad=False):
     """corners1 (B,K1,8,3), corners2 (B,K2,8,3), nums_k2 (B) -> (B,K1,K2) gIoU (utils/box_util.py:861-875).
@@ -120,11 +126,11 @@ def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, retur
             flag = rotated_boxes.reshape(-1)[:1].to(device=c1.device, dtype=torch.uint8)
             st = _lib.load().coda_generalized_box3d_iou_devflag_f32(
                 c1.data_ptr(), c2.data_ptr(), nums_ptr, out.data_ptr(), b, k1, k2, flag.data_ptr(),
-                int(bool(return_inter_vols_only)), int(ROTATED_K2_LIMIT), _lib.current_stream_handle())
+                _vols_mode(return_inter_vols_only), int(ROTATED_K2_LIMIT), _lib.current_stream_handle())
         else:
             st = _lib.load().coda_generalized_box3d_iou_f32(c1.data_ptr(), c2.data_ptr(), nums_ptr,
                                                             out.data_ptr(), b, k1, k2, int(bool(rotated_boxes)),
-                                                            int(bool(return_inter_vols_only)), int(ROTATED_K2_LIMIT),
+                                                            _vols_mode(return_inter_vols_only), int(ROTATED_K2_LIMIT),
                                                             _lib.current_stream_handle())
     _lib.check(st, "generalized_box3d_iou")
     return out

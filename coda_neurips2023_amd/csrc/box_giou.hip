@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void giou_kernel(const float *__restrict__ cor
   float area = fmaxf(rbx - ltx, 0.0f) * fmaxf(rby - lty, 0.0f);
   if (!real) area = 0.0f;  // :692-694
   if (rotated) {
-    const bool visit = real && area != 0.0f && (k2_limit < 0 || k2 < k2_limit);
+    // vols_only == 2: the evaluation's box3d_iou (utils/box_util.py:156-183) clips EVERY pair; the matcher's
+    // generalized_box3d_iou_tensor first tests corners 1 / 3 of the two quadrilaterals as if they were axis-aligned
+    // extents (:688-694) and skips the pairs that test rejects -- reproduced for the matcher, not wanted here
+    const bool visit = real && (vols_only == 2 || (area != 0.0f && (k2_limit < 0 || k2 < k2_limit)));
     area = visit ? clipped_area(r1, r2) : 0.0f;
   }
   const float inter_vol = area * height;

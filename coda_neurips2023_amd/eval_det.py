@@ -5,8 +5,8 @@ Mirror of utils/eval_det.py (``voc_ap`` :23-54, ``eval_det_cls`` :66-162, ``eval
 confidence, same precision / recall / AP definitions.  What the reference spends its evaluation time on is the 3-D
 IoU of every (detection, ground-truth box of that scan and class) pair -- ``utils/box_util.box3d_iou`` (:156-183): a
 Python Sutherland-Hodgman clip + ``scipy.spatial.ConvexHull`` per pair.  Here, per class, ALL pairs are one launch
-of the gIoU kernel's intersection pass (``coda_generalized_box3d_iou_f32`` with ``inter_vols_only``,
-include/coda_box_ops.h) on scans padded to a common size; the marking loop then reads the matrix.  Passing
+of the gIoU kernel's intersection pass (``coda_generalized_box3d_iou_f32`` with ``inter_vols_only = 2``: every
+pair clipped, include/coda_box_ops.h) on scans padded to a common size; the marking loop then reads the matrix.  Passing
 ``get_iou_func`` (e.g. the reference's ``get_iou_obb``) selects the reference's per-pair host route instead."""
 import numpy as np
 import torch
@@ -56,7 +56,7 @@ def scan_ious(dets, gts, device=None):
         c2[i, :g.shape[0]] = g
     nums = torch.tensor([g.shape[0] for g in gts], dtype=torch.int64, device=dev)
     inter = box_util.generalized_box3d_iou(torch.from_numpy(c1).to(dev), torch.from_numpy(c2).to(dev), nums,
-                                           rotated_boxes=True, return_inter_vols_only=True).double().cpu().numpy()
+                                           rotated_boxes=True, return_inter_vols_only="exact").double().cpu().numpy()
     v1, v2 = box3d_vol(c1.astype(np.float64)), box3d_vol(c2.astype(np.float64))
     for i, (d, g) in enumerate(zip(dets, gts)):
         n, m = d.shape[0], g.shape[0]

@@ -19,7 +19,9 @@
  *                         overlap of rect[1] / rect[3] is non-zero, :716-717]
  *                       : that axis-aligned overlap                                    :688-691
  *     giou    = iou - (1 - union / enclosing)  for well-formed pairs, else 0           :733-738
- *   inter_vols_only != 0 returns area * height instead (:729-731).
+ *   inter_vols_only != 0 returns area * height instead (:729-731); the value 2 additionally skips the reference's
+ *   axis-aligned pre-test of the two quadrilaterals (:688-694), i.e. EVERY pair is clipped: the intersection volume
+ *   of utils/box_util.py:156-183 (box3d_iou), which the evaluation's eval_det uses.
  *   rotated_k2_limit: < 0 = none.  The reference's Cython fast path (utils/box_intersection.pyx:
  *   181, `K2 = rect2.shape[2]`) only visits GT columns k2 < 4 when boxes are rotated; pass 4 to
  *   reproduce a deployment that built the Cython module.
