@@ -268,10 +268,13 @@ class RegionEmbeddingProvider:
             if self.stage2 and (not if_test) and curr_epoch % self.save_epoch == 0:
                 self._mine_pseudo_labels(inputs, outputs, rects, valid)
             select, slot = self._select(outputs, b, k, curr_epoch)
-            sel = torch.from_numpy(select).to(dev)
+            # one pinned, non-blocking host -> device copy for both arrays: a pageable copy would park the host
+            # until the GPU has drained everything enqueued so far (the whole forward pass)
+            staged = torch.from_numpy(np.stack((select, slot.astype(np.int64)))).pin_memory().to(dev, non_blocking=True)
+            sel, slot_dev = staged[0], staged[1].bool()
             crops = crop_resize(inputs["input_image"], sel, rects, valid, self._resolution())
             feats = self._encode(crops).view(b, sel.shape[1], -1)
-            keep = torch.gather(valid, 1, sel).bool() & torch.from_numpy(slot).to(dev)     # (B,S)
+            keep = torch.gather(valid, 1, sel).bool() & slot_dev     # (B,S)
             keepf = keep.to(torch.float32).unsqueeze(-1)
             # padded slots (index 0, keep 0) and skipped proposals must not touch a real entry: they go to a trash row
             emb = torch.zeros((b, k + 1, feats.shape[-1]), dtype=torch.float32, device=dev)

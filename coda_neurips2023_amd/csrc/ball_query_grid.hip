@@ -31,6 +31,8 @@
 //   one 256-B row (+ the centred / normalised xyz of the fused QueryAndGroup path).
 #include "common.hip.h"
 
+#include <cstdlib>
+
 namespace coda {
 
 constexpr int kGridX = 32, kGridY = 32, kGridZ = 16;   // cells per axis of the torus (powers of two)
@@ -150,6 +152,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float *
   if (G > 0) {
 #pragma unroll
     for (int i = 0; i < GG; ++i) count_quad(q[i], tid + i * kBuildThreads);
+    // groups beyond the resident ones (a cloud larger than G * 2048 points) are read again in each pass
+    for (int g = tid + GG * kBuildThreads; g < ngroups; g += kBuildThreads) count_quad(load_quad(pts, g, n, vec != 0), g);
   } else {
     for (int g = tid; g < ngroups; g += kBuildThreads) count_quad(load_quad(pts, g, n, vec != 0), g);
   }
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float *
       for (int e = 0; e < 12; ++e) asm volatile("" : "+v"(q[i].v[e]));
       scatter_quad(q[i], tid + i * kBuildThreads);
     }
+    for (int g = tid + GG * kBuildThreads; g < ngroups; g += kBuildThreads) scatter_quad(load_quad(pts, g, n, vec != 0), g);
   } else {
     for (int g = tid; g < ngroups; g += kBuildThreads) scatter_quad(load_quad(pts, g, n, vec != 0), g);
   }
@@ -364,9 +369,17 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
   const int vec = (n % 4 == 0 && (reinterpret_cast<uintptr_t>(xyz) & 15) == 0) ? 1 : 0;
   const int per = ceil_div(ceil_div(n, 4), kBuildThreads);  // groups of four points per thread
   const dim3 bgrid(b * kSlabs);
-  if (per <= 2) hipLaunchKernelGGL(grid_build_kernel<2>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
-  else if (per <= 6) hipLaunchKernelGGL(grid_build_kernel<6>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
-  else if (per <= kKeepMax) hipLaunchKernelGGL(grid_build_kernel<kKeepMax>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
+  // G = quads a thread keeps in registers across the count and the scatter pass.  Round 2 kept 12 for a cloud of
+  // 20 000 points (10 needed): that instantiation spills (164 B of scratch per lane = 5.4 MB of HBM traffic per call
+  // at B = 8 -- what the PMC table of profiles/r02_pmc_ball_query.md showed as "partial-line writes").  G = 8 is the
+  // largest spill-free one; the groups beyond it are read again from L2 in the second pass.
+  // CODA_BQ_KEEP=0|2|6|8|12 forces an instantiation (A/B).
+  static const int force = [] { const char *e = getenv("CODA_BQ_KEEP"); return e ? atoi(e) : -1; }();
+  const int keep = force >= 0 ? force : (per <= 2 ? 2 : (per <= 6 ? 6 : 8));
+  if (keep == 2) hipLaunchKernelGGL(grid_build_kernel<2>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
+  else if (keep == 6) hipLaunchKernelGGL(grid_build_kernel<6>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
+  else if (keep == 8) hipLaunchKernelGGL(grid_build_kernel<8>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
+  else if (keep == 12) hipLaunchKernelGGL(grid_build_kernel<kKeepMax>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
   else hipLaunchKernelGGL(grid_build_kernel<0>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
   const float r2 = radius * radius;
   CODA_DISPATCH_DM(distance_mode(),

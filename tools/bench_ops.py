@@ -46,10 +46,16 @@ def main():
                   f"median {med:.3f} ms  min {mn:.3f} ms  ({med / 2047 * 1e3:.3f} us/round)")
         med, mn = timeit(lambda: _ext.furthest_point_sampling(new_xyz, 256))
         print(f"fps 2048->256 B=8: median {med:.4f} ms  min {mn:.4f} ms ({med / 255 * 1e3:.3f} us/round)")
+    if "bqonly" in which:   # the operator alone (PMC passes): the default route, fused group, channels-last
+        for _ in range(40):
+            _ext.query_and_group_xyz(new_xyz, xyz, 0.2, 64, True, channels_last=True)
+        torch.cuda.synchronize()
     if "bq" in which:
         nbytes = 8 * (12 * 20000 + 12 * 2048 + 4 * 2048 * 64)
         gbytes = 8 * 3126016
         for alg in ("scan", "grid", "tile"):
+            if alg == "scan" and "quick" in which:
+                continue
             med, mn = timeit(lambda: _ext.ball_query(new_xyz, xyz, 0.2, 64, algorithm=alg))
             print(f"ball_query {alg}: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
                   f"({nbytes / med / 1e6:.1f} GB/s algorithmic)")
