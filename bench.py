@@ -658,9 +658,9 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
             # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate
-            # rocprofv3 --pmc passes of tools/bench_ops.py: profiles/r02_pmc_ball_query.md (not collected in this run)
-            "traffic": 35683584,
-            "traffic_source": "profiles/r02_pmc_ball_query.md",
+            # rocprofv3 --pmc passes of tools/bench_ops.py: profiles/r03_pmc_ball_query.md (not collected in this run)
+            "traffic": 25585664,
+            "traffic_source": "profiles/r03_pmc_ball_query.md",
             "bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
             # same operator, same inputs, GPU otherwise idle (only reported when the timed region ran it

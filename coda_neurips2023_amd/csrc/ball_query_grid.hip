@@ -299,26 +299,43 @@ __global__ __launch_bounds__(kQueryWaves *kWave) void grid_query_kernel(
 
   const uint64_t below = (1ull << lane) - 1ull;
   int nhits = 0;
-  for (int t0 = 0; t0 < total; t0 += kWave) {
-    const int t = t0 + lane;
-    int src = -1;
+  // Candidates are fetched kUn x 64 at a time: the record gathers of a whole batch (random 16-byte reads, an L2 round
+  // trip each) are in flight together instead of one dependent round trip per 64 candidates -- a ball has 130-300
+  // candidates, so most centres need ONE batch.  The range search is shared by the batch's kUn positions.
+  constexpr int kUn = 4;
+  for (int t0 = 0; t0 < total; t0 += kWave * kUn) {
+    int src[kUn];
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) src[u] = -1;
     for (int r = 0; r < nranges; ++r) {
       const int r_incl = __builtin_amdgcn_readlane(incl, r);
       const int r_len = __builtin_amdgcn_readlane(len, r);
-      const int r_start = __builtin_amdgcn_readlane(start, r);
-      if (src < 0 && t < r_incl) src = r_start + (t - (r_incl - r_len));
+      const int r_first = __builtin_amdgcn_readlane(start, r) - (r_incl - r_len);
+#pragma unroll
+      for (int u = 0; u < kUn; ++u) {
+        const int t = t0 + u * kWave + lane;
+        if (src[u] < 0 && t < r_incl) src[u] = r_first + t;
+      }
     }
-    const bool valid = t < total;
-    float4 p = make_float4(0, 0, 0, 0);
-    if (valid) p = records[src];
-    const float d2 = sqdist3<DM>(__fsub_rn(cx, p.x), __fsub_rn(cy, p.y), __fsub_rn(cz, p.z));
-    const bool hit = valid && d2 < r2;  // same fp32 expression as the scan: ball_query_gpu.cu:34-36
-    const uint64_t mask = __ballot(hit);
-    const int add = __popcll(mask);
-    if (add) {
-      if (nhits + add > kHitCap) nhits = rank_and_keep(buf, nhits, nsample, lane);
-      if (hit) buf[nhits + __popcll(mask & below)] = p;
-      nhits += add;
+    float4 p[kUn];
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      const bool valid = t0 + u * kWave + lane < total;
+      p[u] = valid ? records[src[u]] : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      if (t0 + u * kWave >= total) break;  // wave-uniform
+      const bool valid = t0 + u * kWave + lane < total;
+      const float d2 = sqdist3<DM>(__fsub_rn(cx, p[u].x), __fsub_rn(cy, p[u].y), __fsub_rn(cz, p[u].z));
+      const bool hit = valid && d2 < r2;  // same fp32 expression as the scan: ball_query_gpu.cu:34-36
+      const uint64_t mask = __ballot(hit);
+      const int add = __popcll(mask);
+      if (add) {
+        if (nhits + add > kHitCap) nhits = rank_and_keep(buf, nhits, nsample, lane);
+        if (hit) buf[nhits + __popcll(mask & below)] = p[u];
+        nhits += add;
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
