@@ -92,6 +92,21 @@ class VisionTransformer(nn.Module):
             p.requires_grad_(False)
 
     # ---- weights as the C driver wants them: matrices in the compute type, vectors in float32 -------------------
+    def refresh(self):
+        """Drop the converted weight copies: the next call converts again.  The cache below is keyed on (pointer,
+        version counter, dtype) of every parameter, which ``load_state_dict`` / ``.to()`` / in-place tensor ops
+        change; a write through ``p.data`` (``p.data.copy_(...)``, as some checkpoint loaders do) changes neither, so
+        such loaders call this afterwards.  ``load_state_dict`` and ``_apply`` (``.to()`` / ``.half()`` / ``.cuda()``) do."""
+        self._packed = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
     def _pack(self):
         params = list(self.parameters())
         stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in params)

@@ -120,3 +120,19 @@ def test_vit_b16_shape_runs_and_is_deterministic():
     assert torch.equal(a, b)
     half = tower.encode_image(x[:4])      # images are independent units
     assert float((half.float() - a[:4].float()).abs().max()) < 2e-2
+
+
+def test_converted_weight_cache_is_dropped_when_weights_change():
+    """The C driver's converted weight copies must not outlive the weights: load_state_dict and .to() / .half() drop
+    them, refresh() is the hook for loaders that write through p.data (which changes neither pointer nor version)."""
+    from coda_neurips2023_amd import clip_tower
+    vit = clip_tower.VisionTransformer(32, 16, 64, 1, 2, 16)
+    vit._packed = ("stamp", "copies")
+    vit.load_state_dict(vit.state_dict())
+    assert vit._packed is None
+    vit._packed = ("stamp", "copies")
+    vit.half()
+    assert vit._packed is None
+    vit._packed = ("stamp", "copies")
+    vit.refresh()
+    assert vit._packed is None
