@@ -49,8 +49,12 @@ CASES = {
 # ReLU / max-pool decisions sit within fp32 rounding of a flip between ANY two evaluation orders
 # (tests/test_full_size_gpu.py, tools/diag_sa_grad.py), and everything upstream of a flipped decision inherits
 # it: those tensors are held at 5e-3.  bf16 attention: 8 significand bits in Q/K/V/P (tests/
-# test_attention_bf16_gpu.py states 2e-2 max / 1e-2 L2 for the core alone); the whole step is held at 3e-2.
-TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3), "bf16": dict(loss=3e-2, grad=3e-2, grad_sa=3e-2)}
+# test_attention_bf16_gpu.py states 2e-2 max / 1e-2 L2 for the core alone).  Through 3 encoder + 8 decoder layers and
+# the batch-statistics norms of the heads that becomes, measured on MI355X with the reference's assignments forced:
+# loss 4e-6, loss terms up to 1.2e-2, gradient tensors up to 7.6e-2 in the relative L2 norm (centre head; most
+# between 2e-2 and 6e-2).  Held at: loss / loss terms 3e-2, gradients 1e-1 -- a bound that still catches a wrong
+# sign, scale or missing term, which is what a whole-step test of a reduced-precision mode can establish.
+TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3), "bf16": dict(loss=3e-2, grad=1e-1, grad_sa=1e-1)}
 
 
 def _build(dev, nq, dec_dim, stage, provider_tensors):
