@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace coda {
 namespace {
@@ -391,32 +392,65 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 struct BucketMeta {  // lane j: bucket in slot j of this wave
   float lox, loy, loz, hix, hiy, hiz;  // bounding box
   float maxt;                          // largest running distance in the bucket
-  uint32_t key;                        // tie-break key of the point holding it ...
-  float bx, by, bz;                    // ... and its coordinates
 };
 __device__ __forceinline__ float readlane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// Update the points of one bucket against the new sample and refresh its cached maximum.
-template <int DM>
-__device__ __forceinline__ void bucket_update(float px, float py, float pz, float &t, const uint32_t *s_keys,
-                                              int slot, float cx, float cy, float cz, BucketMeta &md) {
-  const uint32_t key = s_keys[slot * kBucketThreads + threadIdx.x];  // issued early, used after the max
-  // opaque copy: keeps the compiler from hoisting the distance arithmetic of ALL buckets out of
-  // the loop over the active ones (it is loop-invariant there, and pruning it is the point)
-  asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
-  const float d = sqdist3<DM>(__fsub_rn(px, cx), __fsub_rn(py, cy), __fsub_rn(pz, cz));
-  asm volatile("v_min_f32 %0, %1, %0" : "+v"(t) : "v"(d));  // in place; lanes without a point keep -1
-  const float wmax = wave_max_f32(t);
-  const uint32_t cand = (t == wmax) ? key : 0xffffffffu;
-  const uint32_t wkey = wave_min_u32(cand);
-  const int owner = __builtin_ctzll(__ballot(cand == wkey));  // keys are unique; all-empty buckets never get here
-  const float ox = readlane_f(px, owner), oy = readlane_f(py, owner), oz = readlane_f(pz, owner);
-  if (lane_id() == slot) {
-    md.maxt = wmax;
-    md.key = wkey;
-    md.bx = ox; md.by = oy; md.bz = oz;
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+// SL floats per lane with WAVE-UNIFORM dynamic indexing.  The storage is one or two ext-vector register tuples
+// (32 / 16 / 8 / 4 wide), which the backend indexes with s_set_gpr_idx (three instructions per access) -- a C array
+// indexed through a switch is turned into a tree of flow blocks with a register copy per slot and level (measured:
+// 966 clocks per bucket update, tools/fps_prof.py, of which the arithmetic is < 300).
+template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
+template <int SL>
+struct Slots {
+  static constexpr int A = SL >= 32 ? 32 : SL >= 16 ? 16 : SL >= 8 ? 8 : 4;
+  static constexpr int B = SL - A;  // 0, 4, 8 or 16
+  static_assert(B == 0 || B == 4 || B == 8 || B == 16, "slot counts: 4, 8, 12, 16, 20, 24, 32, 36, 40, 48");
+  // a tuple of <= 8 registers is indexed with a compare / select chain per element by the backend, wider ones with
+  // s_set_gpr_idx: the second tuple is 16 wide where the register budget allows it (8 waves: 256 per lane)
+  static constexpr int BW = B == 0 ? 4 : (B == 8 && A == 32) ? 16 : B;
+  typename FVec<A>::type a;
+  typename FVec<BW>::type b;
+  template <int J> __device__ __forceinline__ void put(float v) {
+    if constexpr (J < A) a[J] = v;
+    else b[J - A] = v;
+  }
+};
+
+// One bucket (register `i` of the tuples) against the new sample: running distances, then the bucket's new maximum.
+// The holder of the maximum (tie-break key, coordinates) is NOT resolved here: only the wave's best bucket needs
+// it, once per round.
+template <int DM, class V>
+__device__ __forceinline__ float bucket_touch(const V &px, const V &py, const V &pz, V &t, int i, float cx, float cy,
+                                              float cz) {
+  const float d = sqdist3<DM>(__fsub_rn(px[i], cx), __fsub_rn(py[i], cy), __fsub_rn(pz[i], cz));
+  float tt = t[i];
+  asm volatile("v_min_f32 %0, %1, %0" : "+v"(tt) : "v"(d));  // lanes without a point keep -1
+  t[i] = tt;
+  return wave_max_f32(tt);
+}
+
+// The points of bucket `i` holding the distance wv: smallest key (keys are unique) and, if it beats wk, its owner.
+template <class V>
+__device__ __forceinline__ void bucket_resolve(const V &px, const V &py, const V &pz, const V &t, int i, uint32_t key,
+                                               float wv, uint32_t &wk, float &wx, float &wy, float &wz) {
+  const uint32_t cand = (t[i] == wv) ? key : 0xffffffffu;
+  const uint32_t k = wave_min_u32(cand);
+  if (k < wk) {
+    wk = k;
+    const int owner = __builtin_ctzll(__ballot(cand == k));
+    wx = readlane_f(px[i], owner);
+    wy = readlane_f(py[i], owner);
+    wz = readlane_f(pz[i], owner);
   }
 }
 
@@ -431,21 +465,49 @@ struct FpsMailbox {
 };
 constexpr int kFpsSpinLimit = 1 << 22;  // ~ a second of polling: a lost partner ends the wait, not the device
 
-template <int SL, int DM, int NWG = 1>  // register slots (buckets) per wave; n <= 64 * kBucketWaves * SL * NWG
-__global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float *__restrict__ xyz, int n, int m,
-                                                                    int log2T, float4 *__restrict__ sorted,
-                                                                    int32_t *__restrict__ idx,
-                                                                    FpsMailbox *__restrict__ mail) {
+// -DCODA_FPS_PROF (tools/fps_prof.py builds a private copy of this file with it): shader-clock sums of the phases
+// of a round per (scene, wave), read back with coda_fps_prof_read.  Compiles to nothing in the library.
+#ifdef CODA_FPS_PROF
+__device__ unsigned long long g_fps_prof[64][16][8];
+#define FPS_PROF_DECL unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter()
+#define FPS_PROF_MARK(i)                                              \
+  do {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();     \
+    prof_[i] += now_ - prof_t_;                                       \
+    prof_t_ = now_;                                                   \
+  } while (0)
+#define FPS_PROF_COUNT(i, v) prof_[i] += (v)
+#define FPS_PROF_STORE                                                                        \
+  do {                                                                                        \
+    if (lane == 0 && blockIdx.x < 64)                                                         \
+      for (int q_ = 0; q_ < 8; ++q_) g_fps_prof[blockIdx.x][w + W * half][q_] = prof_[q_]; \
+  } while (0)
+#else
+#define FPS_PROF_DECL
+#define FPS_PROF_MARK(i)
+#define FPS_PROF_COUNT(i, v)
+#define FPS_PROF_STORE
+#endif
+
+// template parameters: SL register slots (buckets) per wave, distance mode, workgroups per scene, waves per workgroup;
+// n <= 64 * W * SL * NWG
+template <int SL, int DM, int NWG = 1, int W = kBucketWaves>
+__global__ __launch_bounds__(64 * W) void fps_bucket_kernel(const float *__restrict__ xyz, int n, int m, int log2T,
+                                                            float4 *__restrict__ sorted, int32_t *__restrict__ idx,
+                                                            FpsMailbox *__restrict__ mail) {
+  constexpr int TH = 64 * W;                       // threads
+  constexpr int PER = kMortonCells / TH;           // histogram counters per thread in the scan
   constexpr int KB = NWG == 1 ? 15 : 16;           // bits of the point index inside the tie-break key
   constexpr int IDB = 32 - (KB + 9);               // low bits of the packed candidate left for the sender id
+  static_assert(W * NWG <= (1 << IDB), "sender id bits");
   const int half = NWG == 1 ? 0 : static_cast<int>(blockIdx.y);
   __shared__ unsigned int s_hist[kMortonCells];
-  __shared__ float s_red[6][kBucketWaves];
-  __shared__ unsigned int s_wsum[kBucketWaves];
+  __shared__ float s_red[6][W];
+  __shared__ unsigned int s_wsum[W];
   __shared__ unsigned long long s_slot[3];
-  __shared__ float4 s_xyz[2][kBucketWaves];  // per-wave candidate coordinates, round parity
+  __shared__ float4 s_xyz[2][W];  // per-wave candidate coordinates, round parity
   __shared__ int32_t s_out[kOutRing];
-  extern __shared__ uint32_t s_keys[];  // [SL][512]: tie-break key of the point in (slot, thread)
+  extern __shared__ uint32_t s_keys[];  // [SL][TH]: tie-break key of the point in (slot, thread)
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
@@ -454,7 +516,7 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
 
   // ---- prologue 1: bounding box of the participating points
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k = tid; k < n; k += kBucketThreads) {
+  for (int k = tid; k < n; k += TH) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
     if (!fps_skipped<DM>(x, y, z)) {
       lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
@@ -470,13 +532,13 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
       s_red[a][w] = lo[a];
       s_red[3 + a][w] = hi[a];
     }
-  for (int c = tid; c < kMortonCells; c += kBucketThreads) s_hist[c] = 0u;
+  for (int c = tid; c < kMortonCells; c += TH) s_hist[c] = 0u;
   if (tid < 3) s_slot[tid] = 0ull;
   __syncthreads();
   float inv[3];
   for (int a = 0; a < 3; ++a) {
     float l = s_red[a][0], h = s_red[3 + a][0];
-    for (int q = 1; q < kBucketWaves; ++q) {
+    for (int q = 1; q < W; ++q) {
       l = fminf(l, s_red[a][q]);
       h = fmaxf(h, s_red[3 + a][q]);
     }
@@ -491,16 +553,16 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   };
 
   // ---- prologue 2: counting sort by Morton cell into `rec` (x, y, z, index)
-  for (int k = tid; k < n; k += kBucketThreads) {
+  for (int k = tid; k < n; k += TH) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
     if (!fps_skipped<DM>(x, y, z)) atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
   }
   __syncthreads();
-  {  // exclusive scan of the 4096 counters: 8 per thread
-    unsigned int v[8], sum = 0u;
+  {  // exclusive scan of the 4096 counters: PER per thread
+    unsigned int v[PER], sum = 0u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      v[q] = s_hist[tid * 8 + q];
+    for (int q = 0; q < PER; ++q) {
+      v[q] = s_hist[tid * PER + q];
       sum += v[q];
     }
     unsigned int incl = sum;
@@ -515,15 +577,15 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
     for (int q = 0; q < w; ++q) base += s_wsum[q];
     unsigned int run = base + incl - sum;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      s_hist[tid * 8 + q] = run;
+    for (int q = 0; q < PER; ++q) {
+      s_hist[tid * PER + q] = run;
       run += v[q];
     }
   }
   __syncthreads();
   unsigned int nvalid = 0u;
-  for (int q = 0; q < kBucketWaves; ++q) nvalid += s_wsum[q];
-  for (int k = tid; k < n; k += kBucketThreads) {
+  for (int q = 0; q < W; ++q) nvalid += s_wsum[q];
+  for (int k = tid; k < n; k += TH) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
     if (!fps_skipped<DM>(x, y, z)) {
       const unsigned int pos = atomicAdd(&s_hist[cell_of(x, y, z)], 1u);
@@ -533,20 +595,18 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   __threadfence_block();
   __syncthreads();
 
-  // ---- prologue 3: buckets into registers; bucket b -> wave b % 8, slot b / 8
-  float px[SL], py[SL], pz[SL], t[SL];
+  // ---- prologue 3: buckets into registers; bucket b -> wave b % W, slot b / W
+  Slots<SL> px, py, pz, t;
   BucketMeta md;
   md.lox = md.loy = md.loz = INFINITY;
   md.hix = md.hiy = md.hiz = -INFINITY;
   md.maxt = -1.0f;
-  md.key = 0xffffffffu;
-  md.bx = md.by = md.bz = 0.0f;
   // NWG = 2: workgroup `half` owns buckets [half * share, (half + 1) * share) of the Morton order
   const unsigned int nbuckets = (nvalid + kWave - 1) / kWave;
   const unsigned int share = NWG == 1 ? nbuckets : (nbuckets + 1) / 2;
-#pragma unroll
-  for (int j = 0; j < SL; ++j) {
-    const unsigned int bucket = static_cast<unsigned int>(j) * kBucketWaves + w;
+  auto load_slot = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const unsigned int bucket = static_cast<unsigned int>(j) * W + w;
     const unsigned int pos = (static_cast<unsigned int>(half) * share + bucket) * kWave + lane;
     float x = 0.f, y = 0.f, z = 0.f, tt = -1.0f;
     uint32_t kk = 0xffffffffu;
@@ -558,8 +618,8 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
       kk = (bitrev_low(kmod, log2T) << KB) | k;  // order: bitrev(k mod T), then k  (k < 2^KB)
       tt = 1e10f;  // sampling.cpp:75-77
     }
-    px[j] = x; py[j] = y; pz[j] = z; t[j] = tt;
-    s_keys[j * kBucketThreads + tid] = kk;
+    px.template put<j>(x); py.template put<j>(y); pz.template put<j>(z); t.template put<j>(tt);
+    s_keys[j * TH + tid] = kk;
     const bool has = tt >= 0.0f;
     const float bl0 = wave_reduce_min(has ? x : INFINITY), bl1 = wave_reduce_min(has ? y : INFINITY),
                 bl2 = wave_reduce_min(has ? z : INFINITY);
@@ -571,7 +631,8 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
       md.hix = bh0; md.hiy = bh1; md.hiz = bh2;
       md.maxt = bt;
     }
-  }
+  };
+  static_for<SL>(load_slot);
 
   out_put(s_out, 0, 0);  // :88-89
   if (half == 0) out_flush(s_out, 0, m, out);
@@ -579,58 +640,81 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
   float wv = -1.0f;           // this wave's candidate: max running distance ...
   uint32_t wk = 0xffffffffu;  // ... the key of the point holding it ...
   float wx = 0.f, wy = 0.f, wz = 0.f;  // ... and its coordinates
+  int r3 = 1;                 // j % 3
+  int wslot = -1;             // the slot of the wave's candidate (-1: none yet)
 
+  FPS_PROF_DECL;
   for (int j = 1; j < m; ++j) {
     // lane s: can bucket s change?  LB = |clamp(c, box) - c|^2 with the rounding of sqdist3
-    const float qx = fminf(fmaxf(cx, md.lox), md.hix), qy = fminf(fmaxf(cy, md.loy), md.hiy),
-                qz = fminf(fmaxf(cz, md.loz), md.hiz);
+    // (v_med3_f32 = the clamp in one instruction; an empty slot's box is (+inf, -inf): the median is c itself, LB = 0,
+    // and 0 < maxt = -1 is false)
+    const float qx = __builtin_amdgcn_fmed3f(cx, md.lox, md.hix), qy = __builtin_amdgcn_fmed3f(cy, md.loy, md.hiy),
+                qz = __builtin_amdgcn_fmed3f(cz, md.loz, md.hiz);
     const float lb = sqdist3<DM>(__fsub_rn(qx, cx), __fsub_rn(qy, cy), __fsub_rn(qz, cz));
     unsigned long long mask = __ballot(lane < SL && lb < md.maxt);
+    const unsigned long long touched = mask;
+    FPS_PROF_MARK(0);
+    FPS_PROF_COUNT(6, __builtin_popcountll(mask));
+    FPS_PROF_COUNT(7, mask != 0ull);
     if (mask != 0ull) {
-      while (mask != 0ull) {
+      do {
         const int sl = __builtin_ctzll(mask);
         mask &= mask - 1ull;
-        switch (sl) {
-#define CODA_FPS_CASE(J)                                                                   \
-  case J:                                                                                  \
-    if (J < SL) bucket_update<DM>(px[J < SL ? J : 0], py[J < SL ? J : 0], pz[J < SL ? J : 0],  \
-                              t[J < SL ? J : 0], s_keys, J, cx, cy, cz, md);                \
-    break;
-          CODA_FPS_CASE(0) CODA_FPS_CASE(1) CODA_FPS_CASE(2) CODA_FPS_CASE(3) CODA_FPS_CASE(4)
-          CODA_FPS_CASE(5) CODA_FPS_CASE(6) CODA_FPS_CASE(7) CODA_FPS_CASE(8) CODA_FPS_CASE(9)
-          CODA_FPS_CASE(10) CODA_FPS_CASE(11) CODA_FPS_CASE(12) CODA_FPS_CASE(13) CODA_FPS_CASE(14)
-          CODA_FPS_CASE(15) CODA_FPS_CASE(16) CODA_FPS_CASE(17) CODA_FPS_CASE(18) CODA_FPS_CASE(19)
-          CODA_FPS_CASE(20) CODA_FPS_CASE(21) CODA_FPS_CASE(22) CODA_FPS_CASE(23) CODA_FPS_CASE(24)
-          CODA_FPS_CASE(25) CODA_FPS_CASE(26) CODA_FPS_CASE(27) CODA_FPS_CASE(28) CODA_FPS_CASE(29)
-          CODA_FPS_CASE(30) CODA_FPS_CASE(31) CODA_FPS_CASE(32) CODA_FPS_CASE(33) CODA_FPS_CASE(34)
-          CODA_FPS_CASE(35) CODA_FPS_CASE(36) CODA_FPS_CASE(37) CODA_FPS_CASE(38) CODA_FPS_CASE(39)
-#undef CODA_FPS_CASE
-          default: break;
-        }
-      }
-      // the wave's candidate over its bucket maxima (lanes >= SL hold -1)
-      wv = wave_max_f32(md.maxt);
-      const uint32_t cand = (md.maxt == wv) ? md.key : 0xffffffffu;
-      wk = wave_min_u32(cand);
-      const int owner = __builtin_ctzll(__ballot(cand == wk) | (1ull << 63));
-      wx = readlane_f(md.bx, owner);
-      wy = readlane_f(md.by, owner);
-      wz = readlane_f(md.bz, owner);
+        float wmax;
+        if (Slots<SL>::B == 0 || sl < Slots<SL>::A) wmax = bucket_touch<DM>(px.a, py.a, pz.a, t.a, sl, cx, cy, cz);
+        else wmax = bucket_touch<DM>(px.b, py.b, pz.b, t.b, sl - Slots<SL>::A, cx, cy, cz);
+        if (lane == sl) md.maxt = wmax;
+      } while (mask != 0ull);
+      FPS_PROF_MARK(1);
     }
+    // Running distances only decrease, so the wave's candidate stands unless its own bucket was touched (it always is
+    // when the candidate won the previous round: that bucket contains the new sample).
+    if (touched != 0ull && (wslot < 0 || ((touched >> wslot) & 1ull) != 0ull)) {
+      // the wave's candidate: the largest bucket maximum (lanes >= SL hold -1), and among the points holding it --
+      // possibly in several buckets -- the one with the smallest key
+      wv = wave_max_f32(md.maxt);
+      wk = 0xffffffffu;
+      wslot = -1;
+      if (wv >= 0.0f) {
+        unsigned long long tie = __ballot(md.maxt == wv);
+        do {
+          const int sl = __builtin_ctzll(tie);
+          tie &= tie - 1ull;
+          const uint32_t key = s_keys[sl * TH + tid];
+          const uint32_t before = wk;
+          if (Slots<SL>::B == 0 || sl < Slots<SL>::A) bucket_resolve(px.a, py.a, pz.a, t.a, sl, key, wv, wk, wx, wy, wz);
+          else bucket_resolve(px.b, py.b, pz.b, t.b, sl - Slots<SL>::A, key, wv, wk, wx, wy, wz);
+          if (wk != before) wslot = sl;
+        } while (tie != 0ull);
+      }
+      FPS_PROF_MARK(2);
+    }
+    // ---- exchange: lane 0 of every wave posts its coordinates and raises the round's 64-bit maximum
+    // (distance, ~key, sender) with one LDS atomic; behind the barrier every wave reads the maximum and -- in the same
+    // LDS round trip, lane l fetching wave (l mod W)'s coordinates -- picks the sender's by readlane.  (A barrier-free
+    // variant, records with round tags polled by every wave, measured slower: 2.56 vs 2.32 ms -- the polling waves take
+    // issue slots from the wave everybody is waiting for.)
     if (lane == 0 && wv >= 0.0f) {
-      // (distance, ~key) orders the candidates; the wave id in the low byte never decides (keys
-      // are unique) and tells the readers whose coordinates to take
+      // the sender id in the low bits never decides (keys are unique) and tells the readers whose coordinates to take
       const unsigned long long kk = (static_cast<unsigned long long>(__float_as_uint(wv) + 1u) << 32) |
                                     ((static_cast<uint32_t>(~wk) & ((1u << (KB + 9)) - 1u)) << IDB) |
-                                    static_cast<uint32_t>(w + kBucketWaves * half);
+                                    static_cast<uint32_t>(w + W * half);
       s_xyz[j & 1][w] = make_float4(wx, wy, wz, 0.f);
-      atomicMax(&s_slot[j % 3], kk);
+      atomicMax(&s_slot[r3], kk);
     }
+    FPS_PROF_MARK(3);
     __syncthreads();
-    unsigned long long kk = s_slot[j % 3];
-    if (tid == 0) s_slot[(j + 2) % 3] = 0ull;  // next use is two barriers away
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((kk >> 32) != 0ull) c = s_xyz[j & 1][static_cast<uint32_t>(kk) & (kBucketWaves - 1)];
+    FPS_PROF_MARK(4);
+    unsigned long long kk = s_slot[r3];
+    const float4 cl = s_xyz[j & 1][lane & (W - 1)];
+    const int r3n = r3 == 2 ? 0 : r3 + 1;
+    if (tid == 0) s_slot[r3n == 2 ? 0 : r3n + 1] = 0ull;  // (j + 2) % 3: next use is two barriers away
+    r3 = r3n;
+    // (the builtin returns int: without the casts the low word would be sign-extended over the high one)
+    kk = (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(kk >> 32)))) << 32) |
+         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(kk)));
+    const int wwin = static_cast<int>(static_cast<uint32_t>(kk) & (W - 1));
+    float4 c = make_float4(readlane_f(cl.x, wwin), readlane_f(cl.y, wwin), readlane_f(cl.z, wwin), 0.f);
     if constexpr (NWG == 2) {
       // One relaxed 64-bit atomic per workgroup and round: [distance + 1 : 32][~key : 25][round mod 128 : 7].  No
       // fences (an agent-scope release / acquire pair costs an L2 write-back + invalidate per round): the word is
@@ -664,28 +748,46 @@ __global__ __launch_bounds__(kBucketThreads) void fps_bucket_kernel(const float 
       cx = c.x; cy = c.y; cz = c.z;
     }
     if (half == 0) out_flush(s_out, j, m, out);
+#ifdef CODA_FPS_PROF
+    asm volatile("" ::"v"(cx), "v"(cy), "v"(cz));
+#endif
+    FPS_PROF_MARK(5);
   }
+  FPS_PROF_STORE;
 }
 
 constexpr int kBucketMinPoints = 4096, kBucketMaxPoints = 64 * kBucketWaves * 40, kBucketMinSamples = 128;
 
 bool bucket_eligible(int n, int m) { return n >= kBucketMinPoints && n <= kBucketMaxPoints && m >= kBucketMinSamples; }
 
-template <int SL>
+template <int SL, int W = kBucketWaves>
 int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
-  constexpr size_t lds = sizeof(uint32_t) * SL * kBucketThreads;
+  constexpr size_t lds = sizeof(uint32_t) * SL * 64 * W;
   int st = CODA_OK;
   CODA_DISPATCH_DM(distance_mode(), {
-    auto kern = fps_bucket_kernel<SL, DM>;
+    auto kern = fps_bucket_kernel<SL, DM, 1, W>;
     st = raise_dynamic_lds(kern, lds, 20 * 1024);  // static + dynamic LDS exceeds the 64 KB default
     if (st == CODA_OK)
-      hipLaunchKernelGGL(kern, dim3(b), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, ws, idx,
+      hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, xyz, n, m, log2T, ws, idx,
                          static_cast<FpsMailbox *>(nullptr));
   });
   return st;
 }
 
+// CODA_FPS_WAVES=16: sixteen waves with half the slots each (A/B; 4 waves per SIMD leave 128 registers per lane)
+int bucket_waves() {
+  static const int v = [] { const char *e = getenv("CODA_FPS_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();
+  return v;
+}
+
 int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
+  if (bucket_waves() == 16) {
+    const int sl = ceil_div(n, 64 * 16);
+    if (sl <= 8) return launch_bucket<8, 16>(xyz, b, n, m, log2T, ws, idx, s);
+    if (sl <= 12) return launch_bucket<12, 16>(xyz, b, n, m, log2T, ws, idx, s);
+    if (sl <= 16) return launch_bucket<16, 16>(xyz, b, n, m, log2T, ws, idx, s);
+    return launch_bucket<20, 16>(xyz, b, n, m, log2T, ws, idx, s);
+  }
   const int sl = ceil_div(n, 64 * kBucketWaves);
   if (sl <= 8) return launch_bucket<8>(xyz, b, n, m, log2T, ws, idx, s);
   if (sl <= 16) return launch_bucket<16>(xyz, b, n, m, log2T, ws, idx, s);
@@ -885,3 +987,9 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   }
   return launch_status();
 }
+
+#ifdef CODA_FPS_PROF
+CODA_API int coda_fps_prof_read(unsigned long long *host) {
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(coda::g_fps_prof), sizeof(coda::g_fps_prof)));
+}
+#endif
