@@ -30,6 +30,7 @@ SIGNATURES = {
     "coda_gather_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_gather_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_set_ball_query_route": (_c_int, [_c_int]),
+    "coda_set_fps_waves": (_c_int, [_c_int]),
     "coda_ball_query_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "coda_ball_query_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _P, _c_size_t, _P]),
     "coda_group_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),

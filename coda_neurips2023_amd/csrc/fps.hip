@@ -21,6 +21,7 @@
 //    T = min(512, 2^floor(log2 N)) (include/cuda_utils.h:17-21).
 #include "common.hip.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -774,9 +775,17 @@ int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, 
   return st;
 }
 
-// CODA_FPS_WAVES=16: sixteen waves with half the slots each (A/B; 4 waves per SIMD leave 128 registers per lane)
+// Waves per workgroup of the bucketed kernels: 16 (default; 4 per SIMD, 128 registers per lane, at most 20 slots) or 8
+// (40 slots).  More waves spread the buckets a round touches -- a dozen, spatially clustered -- over more issue
+// ports: 2.02 vs 2.16 ms for 8 x 20 000 -> 2048.  coda_set_fps_waves() / CODA_FPS_WAVES select (A/B, tests).
+std::atomic<int> g_fps_waves{-1};
 int bucket_waves() {
-  static const int v = [] { const char *e = getenv("CODA_FPS_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();
+  int v = g_fps_waves.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv("CODA_FPS_WAVES");
+    v = e && atoi(e) == 8 ? 8 : 16;
+    g_fps_waves.store(v, std::memory_order_relaxed);
+  }
   return v;
 }
 
@@ -808,24 +817,32 @@ bool bucket2_eligible(int n, int m) {
 size_t bucket2_mail_offset(int b, int n) { return (sizeof(float4) * 2 * static_cast<size_t>(b) * n + 255) & ~static_cast<size_t>(255); }
 size_t bucket2_workspace_bytes(int b, int n) { return bucket2_mail_offset(b, n) + sizeof(FpsMailbox) * 4 * static_cast<size_t>(b); }
 
-template <int SL>
+template <int SL, int W = kBucketWaves>
 int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
-  constexpr size_t lds = sizeof(uint32_t) * SL * kBucketThreads;
+  constexpr size_t lds = sizeof(uint32_t) * SL * 64 * W;
   FpsMailbox *mail = reinterpret_cast<FpsMailbox *>(static_cast<char *>(ws) + bucket2_mail_offset(b, n));
   hipError_t e = hipMemsetAsync(mail, 0, sizeof(FpsMailbox) * 4 * static_cast<size_t>(b), s);  // round numbers start at 1
   if (e != hipSuccess) return static_cast<int>(e);
   int st = CODA_OK;
   CODA_DISPATCH_DM(distance_mode(), {
-    auto kern = fps_bucket_kernel<SL, DM, 2>;
+    auto kern = fps_bucket_kernel<SL, DM, 2, W>;
     st = raise_dynamic_lds(kern, lds, 20 * 1024);
     if (st == CODA_OK)
-      hipLaunchKernelGGL(kern, dim3(b, 2), dim3(kBucketThreads), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail);
+      hipLaunchKernelGGL(kern, dim3(b, 2), dim3(64 * W), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail);
   });
   return st;
 }
 
 int dispatch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
-  const int sl = ceil_div(ceil_div(ceil_div(n, 64), 2), kBucketWaves);
+  const int share = ceil_div(ceil_div(n, 64), 2);  // buckets per workgroup
+  if (bucket_waves() == 16) {
+    const int sl = ceil_div(share, 16);
+    if (sl <= 8) return launch_bucket2<8, 16>(xyz, b, n, m, log2T, ws, idx, s);
+    if (sl <= 12) return launch_bucket2<12, 16>(xyz, b, n, m, log2T, ws, idx, s);
+    if (sl <= 16) return launch_bucket2<16, 16>(xyz, b, n, m, log2T, ws, idx, s);
+    return launch_bucket2<20, 16>(xyz, b, n, m, log2T, ws, idx, s);
+  }
+  const int sl = ceil_div(share, kBucketWaves);
   if (sl <= 8) return launch_bucket2<8>(xyz, b, n, m, log2T, ws, idx, s);
   if (sl <= 16) return launch_bucket2<16>(xyz, b, n, m, log2T, ws, idx, s);
   if (sl <= 24) return launch_bucket2<24>(xyz, b, n, m, log2T, ws, idx, s);
@@ -986,6 +1003,12 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
     if (st != CODA_OK) return st;
   }
   return launch_status();
+}
+
+CODA_API int coda_set_fps_waves(int waves) {
+  if (waves != 0 && waves != 8 && waves != 16) return CODA_EINVAL;
+  coda::g_fps_waves.store(waves == 0 ? 16 : waves, std::memory_order_relaxed);
+  return CODA_OK;
 }
 
 #ifdef CODA_FPS_PROF

@@ -81,6 +81,11 @@ def _ptr(t):
     return t.data_ptr() if t is not None and t.numel() > 0 else None
 
 
+def set_fps_waves(waves=0):
+    """Waves per workgroup of the bucketed FPS kernels: 0 (default = 16), 8 or 16.  Process-wide; same indices."""
+    _lib.check(_lib.load().coda_set_fps_waves(int(waves)), "coda_set_fps_waves")
+
+
 def furthest_point_sampling(points, nsamples):
     """(B,N,3) f32 -> (B,nsamples) i32.  sampling.cpp:67-88."""
     _check_contiguous(points, "points")

@@ -55,10 +55,18 @@ def test_fps_tie_rule_with_duplicates(dev, oracle, n):
     assert np.array_equal(got, oracle.furthest_point_sampling(x, 80))
 
 
+@pytest.fixture(params=[16, 8], ids=["w16", "w8"])
+def fps_waves(request):
+    """Both workgroup shapes of the bucketed FPS kernels (16 waves x <= 20 slots, 8 waves x <= 40 slots)."""
+    _ext.set_fps_waves(request.param)
+    yield request.param
+    _ext.set_fps_waves(0)
+
+
 @pytest.mark.parametrize("n,m,kind", [(4096, 128, "normal"), (4097, 300, "dup"), (9000, 256, "plane"),
                                       (20000, 512, "dup"), (20480, 200, "normal"), (20000, 300, "skip"),
                                       (6000, 150, "same"), (20000, 2048, "line")])
-def test_fps_bucketed_kernel_bit_exact(dev, oracle, n, m, kind):
+def test_fps_bucketed_kernel_bit_exact(dev, oracle, fps_waves, n, m, kind):
     """n in [4096, 20480], m >= 128: the Morton-bucketed kernel with bounding-box pruning must
     select exactly the exhaustive scan's indices, including ties between duplicated points,
     degenerate extents and points inside the skip radius."""
@@ -107,7 +115,7 @@ def test_fps_short_scene_golden_and_synthetic(dev, oracle, golden_ops):
 
 
 @pytest.mark.parametrize("n,m", [(20481, 130), (40000, 2048), (40960, 128)])
-def test_fps_two_workgroups_per_scene(dev, oracle, n, m):
+def test_fps_two_workgroups_per_scene(dev, oracle, fps_waves, n, m):
     """20 480 < n <= 40 960 (ScanNet-sized clouds): two cooperating workgroups per scene, candidates exchanged
     through global mailboxes every round -- bit-exact like every other path."""
     pc, _, _ = make_batch(2, n, seed=n + 1)
@@ -127,7 +135,7 @@ def test_fps_streaming_paths(dev, oracle, n, m):
     assert np.array_equal(got, oracle.furthest_point_sampling(pc, m))
 
 
-def test_fps_full_size_bit_exact(dev, oracle):
+def test_fps_full_size_bit_exact(dev, oracle, fps_waves):
     """BASELINE shape: B=8, N=20000 -> 2048, then 2048 -> 256 (query sampling)."""
     pc, _, _ = make_batch(8, 20000, seed=1234)
     got = _ext.furthest_point_sampling(cu(pc, dev), 2048).cpu().numpy()

@@ -44,6 +44,12 @@ def main():
             med, mn = timeit(lambda: _ext.furthest_point_sampling(x, 2048), reps=10)
             print(f"fps 20000->2048 B={b:3d} variant={os.environ.get('CODA_FPS_VARIANT', '0')}: "
                   f"median {med:.3f} ms  min {mn:.3f} ms  ({med / 2047 * 1e3:.3f} us/round)")
+        if "quick" not in which:
+            pc40, _, _ = make_batch(8, 40000, seed=77)
+            x40 = torch.from_numpy(pc40).to(dev)
+            med, mn = timeit(lambda: _ext.furthest_point_sampling(x40, 2048), reps=10)
+            print(f"fps 40000->2048 B=8 (two workgroups per scene): median {med:.3f} ms  min {mn:.3f} ms  "
+                  f"({med / 2047 * 1e3:.3f} us/round)")
         med, mn = timeit(lambda: _ext.furthest_point_sampling(new_xyz, 256))
         print(f"fps 2048->256 B=8: median {med:.4f} ms  min {mn:.4f} ms ({med / 255 * 1e3:.3f} us/round)")
     if "bqonly" in which:   # the operator alone (PMC passes): the default route, fused group, channels-last
