@@ -621,7 +621,7 @@ def main():
                      "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                      "what": "the same step through the reference's unchanged call sequence (engine.py:136-164): "
                              "model(batch) / criterion / backward / torch clip_grad_norm_ + torch AdamW(fused), no "
-                             "sampling prefetch, no group de-duplication"}
+                             "sampling prefetch (the set-abstraction module waits for its distinct-row count itself)"}
         del opt2
 
     alone = {}

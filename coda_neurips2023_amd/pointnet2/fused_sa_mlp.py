@@ -251,9 +251,11 @@ class _FusedMlpPool(torch.autograd.Function):
 def fused_mlp_pool(x_cl, groups, nsample, mlp_module, idx=None, counts=None, total=None):
     """x_cl (P,3) float32 cuda grouped xyz (P = groups*nsample rows); mlp_module: the
     reference-shaped SharedMLP; idx: the ball-query indices (B,M,S) the rows came from.
-    Padded copies inside a group are computed once (``compact_groups``) when the distinct-row
-    count is already on the host (``counts`` / ``total`` from a prefetched preparation) or when
-    ``CODA_SA_DEDUP=1`` accepts a synchronisation for it; ``CODA_SA_DEDUP=0`` never de-duplicates.
+    Padded copies inside a group are computed once (``compact_groups``).  The distinct-row count has to be on
+    the host for that: a prefetched preparation brings it along (``counts`` / ``total``); otherwise the call
+    waits for it -- one synchronisation at the very start of the step, where the host is far ahead of the
+    device anyway (the unchanged caller's step: 407 vs 376 scenes/s).  ``CODA_SA_DEDUP=nosync`` only
+    de-duplicates with a prefetched count, ``CODA_SA_DEDUP=0`` never.
     -> (groups, C_last)."""
     layers = list(mlp_module.children())
     bns = [layer.bn.bn for layer in layers]
@@ -263,7 +265,7 @@ def fused_mlp_pool(x_cl, groups, nsample, mlp_module, idx=None, counts=None, tot
     training = bns[0].training
     dedup = None
     mode = os.environ.get("CODA_SA_DEDUP", "auto")
-    if idx is not None and mode != "0" and (total is not None or mode == "1"):
+    if idx is not None and mode != "0" and (total is not None or mode != "nosync"):
         compact = compact_groups(idx, x_cl, counts, total)
         if compact is not None:
             x_cl, roww, goff = compact
