@@ -19,6 +19,7 @@ RegionEmbeddingProvider`` implements both of the reference's methods on the
 device; any callable with its signature can stand in (tests, ``bench.py``).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -165,7 +166,12 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             for name, width in widths.items())
 
     def get_query_embeddings(self, encoder_xyz, point_cloud_dims):
-        query_inds = furthest_point_sample(encoder_xyz, self.num_queries).long()
+        ahead = getattr(self, "_queries_ahead", None)
+        self._queries_ahead = None
+        if ahead is not None and ahead[0] is encoder_xyz and ahead[1].shape[1] == self.num_queries:
+            query_inds = ahead[1].long()  # sampled next to the pre-encoder's own sampling (prefetch_sampling)
+        else:
+            query_inds = furthest_point_sample(encoder_xyz, self.num_queries).long()
         query_xyz = torch.gather(encoder_xyz, 1, query_inds.unsqueeze(-1).expand(-1, -1, 3))
         pos_embed = self.pos_embedding(query_xyz, input_range=point_cloud_dims)
         if self.query_projection.tokens_supported():
@@ -190,7 +196,14 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             return
         if not hasattr(self, "_sampling_prefetcher"):
             self._sampling_prefetcher = SamplingPrefetcher()
-        self._sampling_prefetcher.submit(pc, self.pre_encoder, wait_for)
+        after = None
+        if type(self.encoder).__name__ == "TransformerEncoder" and os.environ.get("CODA_PREFETCH_QUERIES", "1") != "0":
+            # an encoder that hands its xyz through unchanged: the object queries are a sampling of the
+            # pre-encoder's centres, known before the encoder runs -- 140 us of one-workgroup-per-scene work that
+            # would otherwise sit in line between encoder and decoder
+            def after(prepared):
+                prepared["query_inds"] = furthest_point_sample(prepared["new_xyz"], self.num_queries)
+        self._sampling_prefetcher.submit(pc, self.pre_encoder, wait_for, after=after)
 
     def run_pre_encoder(self, point_clouds):
         """The set-abstraction stage alone: -> (xyz (B,M,3), features (B,C,M), inds (B,M)).  Its result
@@ -201,6 +214,8 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         if hasattr(self, "_sampling_prefetcher"):
             prepared = self._sampling_prefetcher.take(point_clouds)
         if prepared is not None:
+            if "query_inds" in prepared:
+                self._queries_ahead = (prepared["new_xyz"], prepared["query_inds"])
             return self.pre_encoder(prepared["xyz"], features, prepared=prepared)
         return self.pre_encoder(xyz, features)
 

@@ -71,7 +71,9 @@ class SamplingPrefetcher:
         self._max = max_pending
         self.wait_for_counts = wait_for_counts
 
-    def submit(self, point_clouds, module, wait_for="current"):
+    def submit(self, point_clouds, module, wait_for="current", after=None):
+        """``after(prepared)``: more work for the side stream that only needs the prepared front (it may add
+        entries to the dict), run before the completion event is recorded."""
         dev = point_clouds.device
         if self._stream is None or self._stream.device != dev:
             # A HIGH-PRIORITY stream: it gets a hardware queue of its own.  Streams of equal priority are dealt onto a
@@ -90,6 +92,8 @@ class SamplingPrefetcher:
             prepared = module.prepare(xyz)
             if prepared is None:
                 return False
+            if after is not None:
+                after(prepared)
             done = torch.cuda.Event()
             done.record(self._stream)
         self._pending.append((point_clouds, point_clouds._version, prepared, done))

@@ -126,7 +126,17 @@ def test_prefetched_sampling_gives_identical_outputs(dev):
         ref = model(inputs)["outputs"]
         model.prefetch_sampling(inputs)
         assert len(model._sampling_prefetcher._pending) == 1
-        got = model(inputs)["outputs"]
+        # the object queries were sampled ahead as well (the tiny model's encoder hands its xyz through)
+        assert "query_inds" in model._sampling_prefetcher._pending[0][2]
+        import coda_neurips2023_amd.model_3detr as m3
+        calls = []
+        real = m3.furthest_point_sample
+        m3.furthest_point_sample = lambda *a, **k: (calls.append(a[1]), real(*a, **k))[1]
+        try:
+            got = model(inputs)["outputs"]
+        finally:
+            m3.furthest_point_sample = real
+        assert calls == []  # no in-line query sampling
         assert len(model._sampling_prefetcher._pending) == 0  # consumed
         for k in ["center_normalized", "sem_cls_logits", "box_corners"]:
             # same indices and groups; the shared MLP may run on de-duplicated rows (summation order)
