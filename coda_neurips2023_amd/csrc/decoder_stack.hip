@@ -111,11 +111,12 @@ CODA_API size_t coda_decoder_stack_ws_floats(int nl, int nq, int bsz, int e, int
 
 CODA_API int coda_decoder_stack_fwd_f32(const CodaDecoderStack *a, void *stream) {
   if (!a || bad_dims(a->nl, a->nq, a->bsz, a->e, a->nheads, a->ffn) || a->ns <= 0) return CODA_EINVAL;
+  if (a->ld_kv != 0 && (a->ld_kv < a->nl * a->e || a->ld_kv % 4 != 0)) return CODA_EINVAL;
   if (!a->tgt || !a->query_pos || !a->k_all || !a->v_all || !a->norm_g || !a->norm_b || !a->params || !a->outs || !a->ws)
     return CODA_EINVAL;
   const Dims d = dims_of(a->nl, a->nq, a->bsz, a->e, a->ns, a->nheads, a->ffn);
   const LayerWs lw = layer_ws(d);
-  const int R = static_cast<int>(d.R), E = d.e, F = d.f, hd = E / d.h, ld_kv = d.nl * E;
+  const int R = static_cast<int>(d.R), E = d.e, F = d.f, hd = E / d.h, ld_kv = a->ld_kv > 0 ? a->ld_kv : d.nl * E;
   const float scale = 1.0f / sqrtf(static_cast<float>(hd));
   float *tmp = a->ws + lw.total * d.nl;
   float *a1 = tmp, *a2 = tmp + up4(d.RE), *o = tmp + 2 * up4(d.RE), *y2 = tmp + 3 * up4(d.RE);
@@ -195,13 +196,14 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
                                         float *dk_all, float *dv_all, float *const *grads, float *sums, float *bwd_ws,
                                         void *stream) {
   if (!a || bad_dims(a->nl, a->nq, a->bsz, a->e, a->nheads, a->ffn) || a->ns <= 0) return CODA_EINVAL;
+  if (a->ld_kv != 0 && (a->ld_kv < a->nl * a->e || a->ld_kv % 4 != 0)) return CODA_EINVAL;
   if (!a->tgt || !a->query_pos || !a->k_all || !a->v_all || !a->norm_g || !a->params || !a->ws || !dstack || !d_tgt ||
       !d_query_pos || !dk_all || !dv_all || !grads || !sums || !bwd_ws)
     return CODA_EINVAL;
   const Dims d = dims_of(a->nl, a->nq, a->bsz, a->e, a->ns, a->nheads, a->ffn);
   const LayerWs lw = layer_ws(d);
   const LayerBwd lb = layer_bwd(d);
-  const int R = static_cast<int>(d.R), E = d.e, F = d.f, hd = E / d.h, ld_kv = d.nl * E;
+  const int R = static_cast<int>(d.R), E = d.e, F = d.f, hd = E / d.h, ld_kv = a->ld_kv > 0 ? a->ld_kv : d.nl * E;
   const float scale = 1.0f / sqrtf(static_cast<float>(hd));
   const int bl = coda_tok_add_ln_bwd_blocks(R, E), bf = coda_tok_bias_relu_dropout_bwd_blocks(R, F),
             bc = coda_tok_colsum_blocks(R, E);

@@ -246,6 +246,17 @@ def _colsum_vec(x2):
     return out
 
 
+# Row padding of the packed (tokens, nl * E) key / value buffers: with 8 layers of width 256 the rows of a layer's
+# column slice are exactly 8 KB apart and land on a fraction of the memory channels (cross-attention dK/dV: 120 us on
+# such slices, 96 us with 64 more floats per row, tools/probe_attn_layout.py).  CODA_KV_PAD=0 switches it off (A/B).
+_KV_PAD = int(os.environ.get("CODA_KV_PAD", "64"))
+
+
+def _kv_buffer(rows, cols, dev):
+    """(rows, cols) float32 view with a row stride of cols + _KV_PAD."""
+    return torch.empty((rows, cols + _KV_PAD), dtype=torch.float32, device=dev)[:, :cols]
+
+
 class _DecoderStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tgt, memory, pos, query_pos, self_mask, cross_mask, cfg, norm_g, norm_b, *params):
@@ -265,9 +276,9 @@ class _DecoderStack(torch.autograd.Function):
         wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
         bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
         bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
-        k_all = gemm.linear(mp2, wk_all, bk_all)                   # (S*B, nl*E)
-        v_all = gemm.linear(mem2, wv_all, bv_all)
-        ld_kv = nl * e
+        k_all = gemm.linear(mp2, wk_all, bk_all, out=_kv_buffer(mp2.shape[0], nl * e, dev))   # (S*B, nl*E)
+        v_all = gemm.linear(mem2, wv_all, bv_all, out=_kv_buffer(mp2.shape[0], nl * e, dev))
+        ld_kv = k_all.stride(0)
         scale = 1.0 / (d ** 0.5)
         mask_ptr = cross_mask.data_ptr() if cross_mask is not None else None
 
@@ -319,11 +330,11 @@ class _DecoderStack(torch.autograd.Function):
         dev = dstack.device
         lib = _lib.load()
         d = e // nheads
-        ld_kv = nl * e
+        ld_kv = k_all.stride(0)
         mask_ptr = ctx.cross_mask.data_ptr() if ctx.cross_mask is not None else None
         dstack = dstack.contiguous()
-        dk_all = torch.empty_like(k_all)
-        dv_all = torch.empty_like(v_all)
+        dk_all = _kv_buffer(k_all.shape[0], k_all.shape[1], dev)
+        dv_all = _kv_buffer(k_all.shape[0], k_all.shape[1], dev)
         din2_all = torch.empty((nl, 3 * e, e), dtype=torch.float32, device=dev)   # cross in_proj weight grads
         dib2_all = torch.empty((nl, 3 * e), dtype=torch.float32, device=dev)
         dnorm_g, dnorm_b = [], []                                                  # decoder norm: per-layer parts
@@ -426,7 +437,8 @@ class _StackArgs(ctypes.Structure):
                 ("p_ffn", ctypes.c_float), ("p3", ctypes.c_float), ("seed", ctypes.c_uint64),
                 ("tgt", ctypes.c_void_p), ("query_pos", ctypes.c_void_p), ("k_all", ctypes.c_void_p),
                 ("v_all", ctypes.c_void_p), ("norm_g", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
-                ("params", ctypes.c_void_p), ("outs", ctypes.c_void_p), ("ws", ctypes.c_void_p)]
+                ("params", ctypes.c_void_p), ("outs", ctypes.c_void_p), ("ws", ctypes.c_void_p),
+                ("ld_kv", ctypes.c_int)]
 
 
 def _ptr_table(tensors):
@@ -452,8 +464,8 @@ class _DecoderStackC(torch.autograd.Function):
         wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
         bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
         bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
-        k_all = gemm.linear(mp2, wk_all, bk_all)
-        v_all = gemm.linear(mem2, wv_all, bv_all)
+        k_all = gemm.linear(mp2, wk_all, bk_all, out=_kv_buffer(mp2.shape[0], nl * e, dev))
+        v_all = gemm.linear(mem2, wv_all, bv_all, out=_kv_buffer(mp2.shape[0], nl * e, dev))
         ws = torch.empty(lib.coda_decoder_stack_ws_floats(nl, nq, bsz, e, nheads, ffn), dtype=torch.float32, device=dev)
         outs = torch.empty((nl, nq, bsz, e), dtype=torch.float32, device=dev)
         tgt, query_pos = tgt.contiguous(), query_pos.contiguous()
@@ -461,7 +473,7 @@ class _DecoderStackC(torch.autograd.Function):
         table = _ptr_table(params)
         args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
                           query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
-                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr())
+                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr(), k_all.stride(0))
         _lib.check(lib.coda_decoder_stack_fwd_f32(ctypes.byref(args), _lib.current_stream_handle()), "decoder_stack_fwd")
         ctx.args = (nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, pos is not None)
         ctx.save_for_backward(tgt, query_pos, mem2, mp2, k_all, v_all, wk_all, wv_all, ws, norm_g, norm_b, *params)
@@ -478,7 +490,8 @@ class _DecoderStackC(torch.autograd.Function):
         lib = _lib.load()
         f32 = dict(dtype=torch.float32, device=dev)
         dstack = dstack.contiguous()
-        dk_all, dv_all = torch.empty_like(k_all), torch.empty_like(v_all)
+        dk_all = _kv_buffer(k_all.shape[0], k_all.shape[1], dev)
+        dv_all = _kv_buffer(k_all.shape[0], k_all.shape[1], dev)
         d_tgt = torch.empty((nq, bsz, e), **f32)
         d_qpos = torch.empty((nq, bsz, e), **f32)
         sums = torch.empty((nl, 4, 3 * e), **f32)
@@ -503,7 +516,7 @@ class _DecoderStackC(torch.autograd.Function):
         table = _ptr_table(params)
         args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
                           query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
-                          ctypes.addressof(table), None, ws.data_ptr())
+                          ctypes.addressof(table), None, ws.data_ptr(), k_all.stride(0))
         _lib.check(lib.coda_decoder_stack_bwd_f32(ctypes.byref(args), dstack.data_ptr(), d_tgt.data_ptr(), d_qpos.data_ptr(),
                                                   dk_all.data_ptr(), dv_all.data_ptr(), ctypes.addressof(gtable),
                                                   sums.data_ptr(), bws.data_ptr(), _lib.current_stream_handle()),

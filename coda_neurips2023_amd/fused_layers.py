@@ -37,7 +37,7 @@ def _colsum_into(out, x3, defer=None):
     """out (G*C) <- column sums of x3 (G, rows, C).  With a collector (gemm.DeferredWeightGrads) only the
     per-block partials are produced now; the reduction joins the collector's grouped launch."""
     g, rows, c = x3.shape
-    if c % 4 or c > 1024:
+    if c % 4 or c > 1024 or not x3.is_contiguous():  # (the padded key / value gradient buffers come here as views)
         torch.sum(x3, 1, out=out.view(g, c))
         return
     blocks = _lib.load().coda_tok_colsum_blocks(rows, c)

@@ -27,9 +27,9 @@ def tn_gemm(dy, x):
         rows = _CHUNK if p % _CHUNK == 0 else 0
         if p >= (1 << 18) and p % 16384 == 0:
             rows = 16384
-        if rows and dy.is_contiguous() and x.is_contiguous():
+        if rows and dy.stride(1) == 1 and x.stride(1) == 1:  # (padded row strides are fine: the chunks are views)
             nc = p // rows
-            return torch.bmm(dy.view(nc, rows, -1).transpose(1, 2), x.view(nc, rows, -1)).sum(0)
+            return torch.bmm(dy.unflatten(0, (nc, rows)).transpose(1, 2), x.unflatten(0, (nc, rows))).sum(0)
     return gemm.mm_tn(dy, x)  # (falls back to torch.mm for anything but 2-D fp32 CUDA operands)
 
 

@@ -19,8 +19,12 @@
  * multihead_attn.in_proj_weight, multihead_attn.in_proj_bias, multihead_attn.out_proj.weight,
  * multihead_attn.out_proj.bias, norm3.weight, norm3.bias, linear1.weight (F,E), linear1.bias, linear2.weight (E,F),
  * linear2.bias.  k_all / v_all: the memory's key / value projections of ALL layers, (ns * bsz, nl * E) (layer l =
- * columns l*E ..), computed by the caller (two large GEMMs).  Dropout: counter-based, op seeds are derived from
- * `seed`; the backward must be given the forward's value.
+ * columns l*E ..), computed by the caller (two large GEMMs), with a row stride of `ld_kv` floats (0: nl * E; a
+ * multiple of 4).  A stride of nl * E + 64 is worth using: with 8 layers of width 256 the rows of a layer's slice
+ * are 8 KB apart and land on a fraction of the memory channels -- the cross-attention dK/dV kernel takes 120 us on
+ * such slices and 96 us with the padded stride (tools/probe_attn_layout.py).  dk_all / dv_all of the backward use the
+ * same stride.  Dropout: counter-based, op seeds are derived from `seed`; the backward must be given the forward's
+ * value.
  */
 #ifndef CODA_STACK_H
 #define CODA_STACK_H
@@ -43,6 +47,7 @@ typedef struct CodaDecoderStack {
   const float *const *params;   /* HOST array of nl * 18 device pointers */
   float *outs;             /* (nl, nq, bsz, E): decoder-normed output of every layer */
   float *ws;               /* saved activations: coda_decoder_stack_ws_floats() floats, written by fwd, read by bwd */
+  int ld_kv;               /* row stride of k_all / v_all / dk_all / dv_all in floats (0: nl * E) */
 } CodaDecoderStack;
 
 /* floats of `ws` / of the backward's scratch for these dimensions (0 on invalid dimensions) */
@@ -52,7 +57,7 @@ size_t coda_decoder_stack_bwd_ws_floats(int nl, int nq, int bsz, int e, int nhea
 int coda_decoder_stack_fwd_f32(const CodaDecoderStack *d, void *stream);
 
 /* dstack (nl, nq, bsz, E): gradient of `outs`.  Outputs: d_tgt (nq,bsz,E), d_query_pos (nq,bsz,E), dk_all / dv_all
- * (ns*bsz, nl*E: layer l's columns), grads: HOST array of nl * 18 device pointers in the order of `params` for the
+ * (ns*bsz, nl*E: layer l's columns, row stride ld_kv), grads: HOST array of nl * 18 device pointers in the order of `params` for the
  * MATRIX-shaped gradients and the projection biases -- entries 2, 3, 4, 8, 9, 10, 14, 15, 16 (of
  * multihead_attn.in_proj_weight / bias only the query rows [0, E) are written: the key / value rows follow from
  * dk_all / dv_all on the caller's side); the other entries are ignored.  The LayerNorm and output-bias gradients

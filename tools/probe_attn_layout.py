@@ -17,6 +17,9 @@ q = torch.randn(L, B, H, D, device=dev, requires_grad=True)
 go = torch.randn(L, B, H, D, device=dev)
 k_all = torch.randn(S, B, NL * H * D, device=dev)
 v_all = torch.randn(S, B, NL * H * D, device=dev)
+PAD = int(os.environ.get("PAD", "64"))   # floats of row padding for the third layout
+k_pad = torch.randn(S, B, NL * H * D + PAD, device=dev)[..., :NL * H * D]
+v_pad = torch.randn(S, B, NL * H * D + PAD, device=dev)[..., :NL * H * D]
 flush = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
 
 
@@ -24,7 +27,10 @@ def run(strided, cold, reps=16):
     core.enable_kernel_timing(0)
     for r in range(reps + 2):
         layer = r % NL
-        if strided:
+        if strided == 2:
+            k = k_pad.unflatten(2, (NL, H, D))[:, :, layer].detach().requires_grad_(True)
+            v = v_pad.unflatten(2, (NL, H, D))[:, :, layer].detach().requires_grad_(True)
+        elif strided:
             k = k_all.view(S, B, NL, H, D)[:, :, layer].detach().requires_grad_(True)
             v = v_all.view(S, B, NL, H, D)[:, :, layer].detach().requires_grad_(True)
         else:
@@ -38,13 +44,13 @@ def run(strided, cold, reps=16):
         out.backward(go)
     rec = core.collect_kernel_timing()
     core.disable_kernel_timing()
-    line = f"{'packed slice' if strided else 'contiguous  '} {'cold' if cold else 'warm'}:"
+    line = f"{['contiguous  ', 'packed slice', 'padded slice'][int(strided)]} {'cold' if cold else 'warm'}:"
     for kind in ("fwd", "dkv", "dq"):
         ms = sorted(rec[(kind, L, S)][2:])
         line += f"  {kind} {1e3 * ms[len(ms) // 2]:6.1f} us"
     print(line)
 
 
-for strided in (False, True):
+for strided in (0, 1, 2):
     for cold in (False, True):
         run(strided, cold)
