@@ -15,6 +15,7 @@ cd /tmp
 rm -rf $R/gpurun_out/final_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
   python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/final_prof_bench.json 2>/dev/null
+python $R/tools/trace_by_grid.py $R/gpurun_out/final_prof/run_kernel_trace.csv > $R/gpurun_out/final_prof/attention_by_grid.csv
 rm -f $R/gpurun_out/final_prof/run_kernel_trace.csv   # tens of MB; the stats file is what gets committed
 rm -rf $R/gpurun_out/final_tower_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_tower_prof -o tower -- \
