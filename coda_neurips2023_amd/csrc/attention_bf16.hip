@@ -687,7 +687,13 @@ int raise_lds(K kern, size_t bytes) {
 }
 
 // short query / key sequences (decoder: 256 or 512 object queries) use the split variants
-constexpr int kSplitBelow = 1024;
+// Query (key, for dK/dV) counts from which a wave owns its own 32 rows and the workgroup's waves share the staged
+// tiles; below, the waves share 32 rows and split the other sequence.  CODA_ATTN_BF16_SPLIT_BELOW overrides (A/B).
+inline int split_below() {
+  static const int v = [] { const char *e = getenv("CODA_ATTN_BF16_SPLIT_BELOW"); return e ? atoi(e) : 1024; }();
+  return v;
+}
+#define kSplitBelow split_below()
 
 // Which problems the three-piece (NS = 3) kernels take; the others stay with the fp32-MFMA kernels of
 // attention.hip (same fp32-level arithmetic either way, so the two can be mixed inside one backward).
@@ -730,7 +736,8 @@ template <int D, bool GEN, int NS>
 int dkv_launch(const MhaBwdParams &p, hipStream_t s) {
   using L = Lay<D>;
   int st;
-  if (p.s >= kSplitBelow) {
+  // (from 512 keys on: 512 x 512, the self-attention of a 512-query decoder, 60 -> 52 us)
+  if (p.s >= kSplitBelow / 2) {
     constexpr int QT = NS == 3 ? 1 : 2;
     const size_t lds = static_cast<size_t>(QT) * NS * (2 * L::ROWB + 2 * L::TRB) + sizeof(float) * 2 * kTile * QT;
     auto kern = mha_bwd_dkv_bf16_kernel<D, false, GEN, NS>;

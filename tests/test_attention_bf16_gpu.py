@@ -41,6 +41,7 @@ def l2(a, b):
     (128, 128, 2, 4, 128, True, True),
     (1024, 1024, 1, 2, 128, True, False),
     (96, 64, 3, 4, 64, False, False),       # 12 batch*heads: plain grid
+    (300, 700, 2, 2, 64, False, True),      # 512 <= keys < 1024: dK/dV with the keys owned per wave, ragged + mask
 ])
 def test_bf16_forward_backward_match_fp32_reference(dev, l, s, b, h, d, packed, masked):
     leaves, q, k, v = make_qkv(dev, l, s, b, h, d, packed, seed=l + s)
