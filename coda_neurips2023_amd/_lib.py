@@ -50,6 +50,8 @@ SIGNATURES = {
     "coda_sa_bn_bwd_coef_f32": (_c_int, [_P, ctypes.c_double, _P, _P, _P, _c_int, _P, _P, _c_int, _P]),
     "coda_sa_pool_select_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _P]),
     "coda_sa_pool_bwd_stats_f32": (_c_int, [_P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
+    "coda_sa_compact_groups_f32": (_c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, ctypes.c_longlong,
+                                             ctypes.c_longlong, _P]),
     # include/coda_token_ops.h
     "coda_tok_bn_stats_f32": (_c_int, [_P, _c_int, ctypes.c_longlong, _c_int, _P, _P]),
     "coda_tok_bn_finalize_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, ctypes.c_double, _c_float, _P, _P, _P]),
@@ -72,6 +74,7 @@ SIGNATURES = {
                                                     _P, _P]),
     "coda_tok_bias_relu_dropout_bwd_blocks": (_c_int, [ctypes.c_longlong, _c_int]),
     "coda_tok_bias_relu_dropout_bwd_f32": (_c_int, [_P, _P, ctypes.c_longlong, _c_int, _c_float, _P, _P, _P, _P]),
+    "coda_fourier_pos_embed_f32": (_c_int, [_P, _P, _P, _P, _c_int, _P, _c_int, _c_int, _c_int, _P]),
     # include/coda_align_loss.h
     "coda_align_loss_fwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P, _P,
                                          _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),

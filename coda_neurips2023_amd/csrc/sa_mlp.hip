@@ -469,6 +469,35 @@ __global__ __launch_bounds__(kT) void pool_bwd_stats_kernel(const float *__restr
   block_reduce_to_global<2>(acc, m, c, sums);
 }
 
+// one thread per (group, slot) and, behind them, per padding row
+__global__ __launch_bounds__(256) void compact_groups_kernel(const float *__restrict__ grouped, const int64_t *__restrict__ cnt,
+                                                             const int64_t *__restrict__ goff, float *__restrict__ x,
+                                                             float *__restrict__ roww, int32_t *__restrict__ goff32,
+                                                             long long groups, int s_len, long long total,
+                                                             long long rows_padded) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long slots = groups * s_len;
+  if (i < slots) {
+    const long long g = i / s_len;
+    const int j = static_cast<int>(i - g * s_len);
+    const long long c = cnt[g], base = goff[g];
+    if (j < c) {
+      const float *src = grouped + i * 3;
+      float *dst = x + (base + j) * 3;
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+      roww[base + j] = j == 0 ? static_cast<float>(s_len - c + 1) : 1.0f;
+    }
+    if (j == 0) goff32[g] = static_cast<int32_t>(base);
+    if (i == 0) goff32[groups] = static_cast<int32_t>(total);
+  } else {
+    const long long r = total + (i - slots);
+    if (r < rows_padded) {
+      x[r * 3] = 0.f; x[r * 3 + 1] = 0.f; x[r * 3 + 2] = 0.f;
+      roww[r] = 0.f;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace coda
 
@@ -621,5 +650,22 @@ CODA_API int coda_sa_pool_bwd_stats_f32(const float *gout, const float *out, con
   if (!gout || !out || !ysel || !stats || !d) return CODA_EINVAL;
   clear_sticky_error();
   hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nblocks(groups)), dim3(kT), 0, s, gout, out, ysel, stats, d, groups, c, sums);
+  return launch_status();
+}
+
+CODA_API int coda_sa_compact_groups_f32(const float *grouped, const int64_t *cnt, const int64_t *goff, float *x,
+                                        float *row_weight, int32_t *goff32, long long groups, int s_len, long long total,
+                                        long long rows_padded, void *stream) {
+  using namespace coda;
+  if (groups < 0 || s_len <= 0 || total < 0 || rows_padded < total || total > groups * s_len) return CODA_EINVAL;
+  if (!goff32 || (groups > 0 && (!grouped || !cnt || !goff)) || (rows_padded > 0 && (!x || !row_weight))) return CODA_EINVAL;
+  const long long work = groups * s_len + (rows_padded - total);
+  clear_sticky_error();
+  if (work == 0) {  // no groups: only the terminating offset
+    return static_cast<int>(hipMemsetAsync(goff32, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+  }
+  hipLaunchKernelGGL(compact_groups_kernel, dim3(static_cast<unsigned>((work + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), grouped, cnt, goff, x, row_weight, goff32, groups, s_len, total,
+                     rows_padded);
   return launch_status();
 }

@@ -75,14 +75,14 @@ def compact_groups(idx, grouped_cl, counts=None, total=None, min_saving=0.25):
     if total > (1.0 - min_saving) * g * s:
         return None
     pp = -(-total // 2048) * 2048
-    grp = torch.repeat_interleave(torch.arange(g, device=dev), cnt, output_size=total)
-    src = grp * s + (torch.arange(total, device=dev) - goff[grp])
-    x = torch.zeros((pp, 3), dtype=torch.float32, device=dev)
-    x[:total] = grouped_cl.reshape(-1, 3)[src]
-    roww = torch.zeros(pp, dtype=torch.float32, device=dev)
-    roww[:total] = 1.0
-    roww[goff[:-1]] = (s - cnt + 1).to(torch.float32)
-    return x, roww, goff.to(torch.int32)
+    # one launch (coda_sa_compact_groups_f32): a group's distinct rows are its first cnt slots
+    x = torch.empty((pp, 3), dtype=torch.float32, device=dev)
+    roww = torch.empty(pp, dtype=torch.float32, device=dev)
+    goff32 = torch.empty(g + 1, dtype=torch.int32, device=dev)
+    src = grouped_cl if grouped_cl.is_contiguous() else grouped_cl.contiguous()
+    _call("coda_sa_compact_groups_f32", _p(src), _p(cnt.contiguous()), _p(goff), _p(x), _p(roww), _p(goff32), g, s, total,
+          pp)
+    return x, roww, goff32
 
 
 def _bwd_coef(ctx, i, sums, st, gamma, bn, training, n, layout, grads, dev):

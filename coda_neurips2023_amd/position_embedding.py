@@ -66,6 +66,25 @@ class PositionEmbeddingCoordsSine(nn.Module):
         half = self.gauss_B.shape[1] if num_channels is None else num_channels // 2
         if half <= 0 or half > self.gauss_B.shape[1] or (num_channels is not None and num_channels % 2):
             raise ValueError("num_channels must be even and at most 2 * gauss_B.shape[1]")
+        if (xyz.is_cuda and xyz.dtype == torch.float32 and xyz.shape[-1] == 3 and self.gauss_B.dtype == torch.float32
+                and self.gauss_B.is_cuda and not torch.is_grad_enabled()):
+            # one launch instead of eight (csrc/pos_embed.hip, include/coda_token_ops.h part 3)
+            from . import _lib
+            b, n = xyz.shape[0], xyz.shape[1]
+            pts = xyz.contiguous()
+            lo = hi = None
+            if self.normalize:
+                lo = input_range[0].to(torch.float32).reshape(b, 3).contiguous()
+                hi = input_range[1].to(torch.float32).reshape(b, 3).contiguous()
+            gauss = self.gauss_B if self.gauss_B.stride(1) == 1 else self.gauss_B.contiguous()
+            out = torch.empty((b, n, 2 * half), dtype=torch.float32, device=xyz.device)
+            with torch.cuda.device(xyz.device):
+                st = _lib.load().coda_fourier_pos_embed_f32(pts.data_ptr(), lo.data_ptr() if lo is not None else None,
+                                                            hi.data_ptr() if hi is not None else None, gauss.data_ptr(),
+                                                            gauss.stride(0), out.data_ptr(), b, n, half,
+                                                            _lib.current_stream_handle())
+            _lib.check(st, "coda_fourier_pos_embed_f32")
+            return out.transpose(1, 2)
         phase = (self._unit(xyz, input_range) * (2 * math.pi)).reshape(-1, xyz.shape[-1]) @ self.gauss_B[:, :half]
         phase = phase.view(xyz.shape[0], xyz.shape[1], half)
         return torch.cat((phase.sin(), phase.cos()), dim=2).transpose(1, 2)

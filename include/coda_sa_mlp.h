@@ -83,6 +83,18 @@ int coda_sa_pool_select_f32(const float *ymax, const float *ymin, const int32_t 
 int coda_sa_pool_bwd_stats_f32(const float *gout, const float *out, const float *ysel, const float *stats,
                                float *d, long long groups, int c, double *sums, void *stream);
 
+/* De-duplicated groups of a ball query in one launch: ball_query pads a group with copies of its FIRST hit behind its
+ * distinct hits (ball_query_gpu.cu:35-48), so group g's distinct rows are its first cnt[g] slots.
+ *   grouped (groups, s_len, 3) float32 (channels-last grouped xyz), cnt (groups) int64, goff (groups + 1) int64 =
+ *   exclusive prefix sum of cnt (goff[groups] = total).
+ *   x (rows_padded, 3): row goff[g] + j = grouped[g][j] for j < cnt[g]; rows >= total are zero.
+ *   row_weight (rows_padded): s_len - cnt[g] + 1 for the first row of a group (it stands for the copies), 1 for the
+ *   other distinct rows, 0 for the padding.  goff32 (groups + 1) int32 = goff.
+ * rows_padded >= total (the caller rounds it up to the GEMM's row granularity). */
+int coda_sa_compact_groups_f32(const float *grouped, const int64_t *cnt, const int64_t *goff, float *x,
+                               float *row_weight, int32_t *goff32, long long groups, int s_len, long long total,
+                               long long rows_padded, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,15 @@ int coda_tok_bias_relu_dropout_bwd_f32(const float *da, const float *a, long lon
                                        float dropout_p, float *dz, float *partials, float *dbias,
                                        void *stream);
 
+/* Part 3, the Fourier coordinate embedding of the decoder (models/position_embedding.py:97-130) in one launch:
+ *   u = (xyz - range_lo[b]) / (range_hi[b] - range_lo[b])   (skipped when the range pointers are NULL)
+ *   phase = (u * 2*pi) @ gauss[:, :half]                     (gauss (3, >= half) row-major, row stride ld_gauss)
+ *   out[b][i][0:half] = sin(phase), out[b][i][half:2*half] = cos(phase)
+ * xyz (b, n, 3), range_lo / range_hi (b, 3), out (b, n, 2*half) float32 -- the reference returns its transpose
+ * (b, 2*half, n) as a view of exactly this buffer.  One rounding per operation, products summed left to right. */
+int coda_fourier_pos_embed_f32(const float *xyz, const float *range_lo, const float *range_hi, const float *gauss,
+                               int ld_gauss, float *out, int b, int n, int half, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
