@@ -428,6 +428,11 @@ def cpu_baseline(kind):
                       f"OpenMP over scenes) + torch-CPU layers on {cores} threads"}
 
 
+def _tuned_gemms():
+    from coda_neurips2023_amd import tuning
+    return tuning.is_on()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -728,7 +733,9 @@ def main():
                                      if graph is not None else "eager"),
                        "sampling": ("FPS + ball query of batch i+1 run on a side stream during step i (once per "
                                     "step, inside the timed region); padded group copies are computed once"
-                                    if prefetch else "in line")},
+                                    if prefetch else "in line"),
+                       "library_gemms": ("kernel per shape from the shipped look-up table (tuning.py, TunableOp without "
+                                         "run-time tuning)" if _tuned_gemms() else "library heuristics")},
             "roofline": roofline,
             # host side of the timed region on rank 0: time until the last step was enqueued (close to the wall
             # time when the host is the bottleneck -- or when the GPU is and the launch queue fills up) and what

@@ -42,6 +42,9 @@ def _all_reduce(t, bn):
     return t
 
 
+_ROW_PAD = max(2048, int(os.environ.get("CODA_SA_ROW_PAD", "16384")) // 2048 * 2048)
+
+
 def count_distinct_rows(idx):
     """idx (B,M,S) int32 ball-query indices -> (cnt (G,), goff (G+1,) int64, total (1,) int64):
     distinct rows per group, their exclusive prefix sum and the overall count.  ball_query fills
@@ -61,7 +64,7 @@ def compact_groups(idx, grouped_cl, counts=None, total=None, min_saving=0.25):
     idx (B,M,S) int32, grouped_cl (B,M,S,3).  Identical rows stay identical through the whole
     shared MLP, so only the distinct rows of a group need to be computed.  Returns
     ``(x (Pp,3), row_weight (Pp,), group_offsets (G+1,) int32)`` with Pp the number of distinct
-    rows rounded up to a multiple of 2048 (zero rows of weight 0), or None when fewer than
+    rows rounded up to a multiple of ``_ROW_PAD`` (zero rows of weight 0), or None when fewer than
     ``min_saving`` of the rows are copies.  The row count sizes the GEMMs, so it must be known
     on the host: pass ``counts`` / ``total`` from an earlier ``count_distinct_rows`` whose
     result has already been copied back (the sampling prefetcher does), otherwise this call
@@ -74,7 +77,9 @@ def compact_groups(idx, grouped_cl, counts=None, total=None, min_saving=0.25):
         total = int(tot.item())
     if total > (1.0 - min_saving) * g * s:
         return None
-    pp = -(-total // 2048) * 2048
+    # rows rounded up to _ROW_PAD (zero rows of weight 0): the row count is data-dependent, and a coarse grid keeps
+    # the set of GEMM shapes small enough for a table of tuned library kernels (tuning.py) at 2.5 % more rows
+    pp = -(-total // _ROW_PAD) * _ROW_PAD
     # one launch (coda_sa_compact_groups_f32): a group's distinct rows are its first cnt slots
     x = torch.empty((pp, 3), dtype=torch.float32, device=dev)
     roww = torch.empty(pp, dtype=torch.float32, device=dev)
