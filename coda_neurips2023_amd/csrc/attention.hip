@@ -959,6 +959,26 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   }
 }
 
+// delta = rowsum(dO * O) of this lane's query inside the dQ kernel (fuse_delta): the lane holds its half of the dO row
+// already; the other half comes from lane ^ 32.  Written once per query for the dK/dV kernel that runs behind this one
+// -- a launch (6.5 us, 19 per step) less than the stand-alone mha_delta_kernel.
+template <int HD>
+__device__ __forceinline__ float row_delta(const MhaBwdParams &p, const float (&gf)[HD], int myq, int bh, size_t rstride,
+                                           size_t head_off, int half, bool writer) {
+  float acc = 0.f;
+  if (myq < p.l) {
+    const float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off + half * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 o = *reinterpret_cast<const float4 *>(orow + c);
+      acc += o.x * gf[c] + o.y * gf[c + 1] + o.z * gf[c + 2] + o.w * gf[c + 3];
+    }
+  }
+  acc += __shfl_xor(acc, 32, kWave);
+  if (writer && half == 0 && myq < p.l) p.delta[static_cast<size_t>(bh) * p.l + myq] = acc;
+  return acc;
+}
+
 // dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
 // the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
 template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
@@ -1004,8 +1024,9 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
   float lse = 0.f, delta = 0.f;
   if (myq < p.l) {
     lse = p.lse[static_cast<size_t>(bh) * p.l + myq] * kLog2e;  // log2 units
-    delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
+    if (!p.fuse_delta) delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
   }
+  if (p.fuse_delta) delta = row_delta<HD>(p, gf, myq, bh, rstride, head_off, half, !SPLIT || w == 0);
   // rows past the end or without any admissible key: exp2(x - inf) = 0 without a per-element test
   const float lse_eff = (myq < p.l && lse != -INFINITY) ? lse : INFINITY;
   f32x16 dq[NT];
@@ -1191,8 +1212,9 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_direct_kernel(MhaBwdPar
   float lse = 0.f, delta = 0.f;
   if (myq < p.l) {
     lse = p.lse[static_cast<size_t>(bh) * p.l + myq] * kLog2e;  // log2 units
-    delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
+    if (!p.fuse_delta) delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
   }
+  if (p.fuse_delta) delta = row_delta<HD>(p, gf, myq, bh, rstride, head_off, half, w == 0);
   const float lse_eff = (myq < p.l && lse != -INFINITY) ? lse : INFINITY;
   f32x16 dq[NT];
 #pragma unroll
@@ -1524,7 +1546,8 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   // double-buffered Q / dO staging pays on long query sequences (encoder: -5 %); with 256 queries
   // (decoder memory) there are only 8 stages and the prologue eats the gain
-  if (p.parts & 2) {
+  auto run_dkv = [&]() -> int {
+  if (!(p.parts & 2)) return CODA_OK;
   KernelTimer timer(2, p.l, p.s, s);
   if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
     // CODA_ATTN_VLDS=1 (D = 64): V fragments in LDS instead of registers -- no scratch spill (251 VGPRs, 0 bytes of
@@ -1557,8 +1580,10 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     if (st != CODA_OK) return st;
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
-  }
-  if (!(p.parts & 4)) return launch_status();
+  return CODA_OK;
+  };
+  auto run_dq = [&]() -> int {
+  if (!(p.parts & 4)) return CODA_OK;
   KernelTimer timer(3, p.l, p.s, s);
   if (p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN, true>;
@@ -1593,14 +1618,23 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
       hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
     }
   }
-  return launch_status();
+  return CODA_OK;
+  };
+  // fuse_delta: the dQ kernel writes delta, so it runs first
+  int st = p.fuse_delta ? run_dq() : run_dkv();
+  if (st != CODA_OK) return st;
+  st = p.fuse_delta ? run_dkv() : run_dq();
+  return st != CODA_OK ? st : launch_status();
 }
 
 template <int D>
 int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   clear_sticky_error();
   const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
-  if (p.parts & 1) {
+  // The whole backward with the fp32-MFMA kernels: delta is formed inside the dQ kernel (CODA_ATTN_FUSE_DELTA=0: A/B)
+  static const bool fuse_ok = [] { const char *e = getenv("CODA_ATTN_FUSE_DELTA"); return !e || atoi(e) != 0; }();
+  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7;
+  if ((p.parts & 1) && !fuse) {
     KernelTimer timer(1, p.l, p.s, s);
     hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
   }
@@ -1619,6 +1653,7 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   }
   MhaBwdParams rest = p;  // what the fp32-MFMA kernels still have to do
   rest.parts = p.parts & ~1;
+  rest.fuse_delta = fuse ? 1 : 0;
   if (mfma_dtype() == 2) {
     int st = CODA_OK;
     if ((p.parts & 2) && mha_x3_takes_dkv(p, D)) {

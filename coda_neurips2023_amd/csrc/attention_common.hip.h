@@ -89,6 +89,7 @@ struct MhaBwdParams {
   uint32_t thresh16, seed;
   const uint64_t *seed_dev;
   int parts = 7;  // which launches a backward call issues: 1 = delta, 2 = dK/dV, 4 = dQ (host-side only)
+  int fuse_delta = 0;  // 1: the dQ kernel forms delta = rowsum(dO * O) itself and writes it for the dK/dV kernel behind it
 };
 
 

@@ -34,6 +34,8 @@ def run(l, s, b=8, h=4, d=64, p=0.1, reps=20):
     core.disable_kernel_timing()
     line = f"L={l:5d} S={s:5d} d={d:3d} p={p}:"
     for kind in ("fwd", "delta", "dkv", "dq"):
+        if (kind, l, s) not in rec:   # delta: formed inside the dQ kernel on the fp32 path
+            continue
         ms = sorted(rec[(kind, l, s)])
         med = ms[len(ms) // 2]
         line += f"  {kind} {1e3 * med:7.1f} us"
