@@ -149,9 +149,17 @@ CODA_API int coda_decoder_stack_fwd_f32(const CodaDecoderStack *a, void *stream)
     CODA_TRY(coda_tok_add_ln_fwd_f32(a2, ob2, W + lw.s2, nullptr, g3, b3n, R, E, a->eps, a->p2, op_seed(a->seed, l, 3), nullptr,
                                      W + lw.s3, W + lw.y3, nullptr, W + lw.mean3, W + lw.rstd3, stream));
     // 6. feed-forward: h = drop(relu(y3 W1^T + fb1)), o = h W2^T
-    CODA_TRY(linear(R, F, E, W + lw.y3, w1, E, nullptr, W + lw.h, F, stream));
-    CODA_TRY(coda_tok_bias_relu_dropout_fwd_f32(W + lw.h, fb1, R, F, a->p_ffn, op_seed(a->seed, l, 4), nullptr, W + lw.h,
-                                                stream));
+    {  // one launch where the own kernel takes the shape (bias + ReLU + dropout in its epilogue), else two
+      const int st = coda_sgemm_relu_dropout_f32(1, R, F, E, W + lw.y3, E, w1, E, W + lw.h, F, fb1, a->p_ffn,
+                                                 op_seed(a->seed, l, 4), stream);
+      if (st == CODA_ENOSPC) {
+        CODA_TRY(linear(R, F, E, W + lw.y3, w1, E, nullptr, W + lw.h, F, stream));
+        CODA_TRY(coda_tok_bias_relu_dropout_fwd_f32(W + lw.h, fb1, R, F, a->p_ffn, op_seed(a->seed, l, 4), nullptr, W + lw.h,
+                                                    stream));
+      } else {
+        CODA_TRY(st);
+      }
+    }
     CODA_TRY(linear(R, E, F, W + lw.h, w2, F, nullptr, o, E, stream));
     // 7. s4 = s3 + drop(o + fb2); the layer's output = decoder.norm(s4)
     CODA_TRY(coda_tok_add_ln_fwd_f32(o, fb2, W + lw.s3, nullptr, a->norm_g, a->norm_b, R, E, a->eps, a->p3,

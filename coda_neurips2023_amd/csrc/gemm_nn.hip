@@ -16,6 +16,7 @@
 // cycles and SIMD, so the 4-8 LDS reads per 16 instructions hide completely; the kernel is MFMA-issue bound.
 #include "coda_gemm.h"
 #include "common.hip.h"
+#include "dropout.hip.h"
 
 namespace coda {
 namespace {
@@ -109,12 +110,20 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_kernel(const float *__restri
 // issue K/2 dependent MFMAs back to back (8 us).  Here a workgroup owns a 32 x 32 tile of C and its four waves
 // split K: 512 workgroups, 32 MFMAs per wave, operands straight from global memory into registers (a lane reads 64
 // contiguous bytes of its row; no LDS staging, no barrier in the loop), partial tiles summed through LDS.
-template <bool BT>
+// EPI = 1: C = dropout(relu(A . op(B) + bias)) -- the feed-forward's first layer with the element-wise pass that
+// followed it (token_ln.hip: bias_relu_dropout_fwd_kernel) in the epilogue; same counter hash of (seed, row * n + col),
+// so the masks are those of the stand-alone kernel.
+struct ReluDrop {
+  uint32_t thresh24, seed;
+  float inv_keep;
+  int n;
+};
+template <bool BT, int EPI = 0>
 __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *__restrict__ a, long long lda,
                                                                  const float *__restrict__ b, long long ldb,
                                                                  float *__restrict__ c, long long ldc,
                                                                  const float *__restrict__ bias, int n_tiles, int k,
-                                                                 int accumulate) {
+                                                                 int accumulate, ReluDrop epi = ReluDrop{0u, 0u, 1.f, 0}) {
   __shared__ float s_part[3][16][kWave];
   const int lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
@@ -159,6 +168,13 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
     float *p = c + static_cast<size_t>(m0 + crow_nn(r, half)) * ldc + col;
     float v = ((acc[r] + s_part[0][r][lane]) + (s_part[1][r][lane] + s_part[2][r][lane])) + bval;
     if (accumulate) v += *p;
+    if (EPI == 1) {
+      v = fmaxf(v, 0.f);
+      if (epi.thresh24) {
+        const uint32_t idx = static_cast<uint32_t>(m0 + crow_nn(r, half)) * static_cast<uint32_t>(epi.n) + static_cast<uint32_t>(col);
+        v = keep_elem(epi.seed, idx, epi.thresh24) ? v * epi.inv_keep : 0.f;
+      }
+    }
     *p = v;
   }
 }
@@ -190,5 +206,26 @@ CODA_API int coda_sgemm_f32(int transb, int m, int n, int k, const float *a, lon
   const dim3 grid(static_cast<unsigned>((m / kTile) * n_tiles));
   if (transb) hipLaunchKernelGGL(sgemm_kernel<true>, grid, dim3(kThreadsNN), 0, s, a, lda, b, ldb, c, ldc, bias, n_tiles, k, accumulate);
   else hipLaunchKernelGGL(sgemm_kernel<false>, grid, dim3(kThreadsNN), 0, s, a, lda, b, ldb, c, ldc, bias, n_tiles, k, accumulate);
+  return launch_status();
+}
+
+CODA_API int coda_sgemm_relu_dropout_f32(int transb, int m, int n, int k, const float *a, long long lda, const float *b,
+                                         long long ldb, float *c, long long ldc, const float *bias, float dropout_p,
+                                         uint64_t seed, void *stream) {
+  using namespace coda;
+  if (m < 0 || n < 0 || k < 0 || !(dropout_p >= 0.f) || dropout_p >= 1.f) return CODA_EINVAL;
+  if (m == 0 || n == 0) return CODA_OK;
+  if (!a || !b || !c) return CODA_EINVAL;
+  // the launch-sized split-K kernel only (a wave-0 epilogue owns whole sums there); anything else: separate passes
+  if (m % 64 || n % 64 || k % 128 || (lda | ldb) % 4 || ldc != n || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 ||
+      static_cast<long long>(m) * n > 2048ll * 1024)
+    return CODA_ENOSPC;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_sticky_error();
+  ReluDrop epi{drop_thresh24(dropout_p), static_cast<uint32_t>(seed ^ (seed >> 32)), 1.0f / (1.0f - dropout_p), n};
+  const int nt = n / 32;
+  const dim3 sgrid(static_cast<unsigned>((m / 32) * nt));
+  if (transb) hipLaunchKernelGGL((sgemm_splitk_kernel<true, 1>), sgrid, dim3(kThreadsNN), 0, s, a, lda, b, ldb, c, ldc, bias, nt, k, 0, epi);
+  else hipLaunchKernelGGL((sgemm_splitk_kernel<false, 1>), sgrid, dim3(kThreadsNN), 0, s, a, lda, b, ldb, c, ldc, bias, nt, k, 0, epi);
   return launch_status();
 }

@@ -57,6 +57,14 @@ int coda_gemm_set_tuning(int mode);
  * aligned; any other problem returns CODA_ENOSPC ("not this kernel's shape": use coda_gemm_f32). */
 int coda_sgemm_f32(int transb, int m, int n, int k, const float *a, long long lda, const float *b,
                    long long ldb, float *c, long long ldc, const float *bias, int accumulate, void *stream);
+/* The same product with the transformer feed-forward's element-wise pass in the epilogue:
+ *   C = dropout(relu(A . op(B) + bias)),  keep decisions = the counter hash of (seed, row * n + col) that
+ *   coda_tok_bias_relu_dropout_fwd_f32 uses, so C equals that call on the plain product.
+ * Launch-sized problems only (m * n <= 2048 * 1024, m, n multiples of 64, k a multiple of 128, ldc == n);
+ * CODA_ENOSPC otherwise: run the two passes. */
+int coda_sgemm_relu_dropout_f32(int transb, int m, int n, int k, const float *a, long long lda, const float *b,
+                                long long ldb, float *c, long long ldc, const float *bias, float dropout_p,
+                                uint64_t seed, void *stream);
 
 /* Opt-in (CODA_TN_KERNEL=1 or gemm.mm_tn(..., kernel=True); parity-tested on MI355X, tests/test_gemm_gpu.py):
  * out (co x ci, row stride ldout) [+]= dy^T x with dy (rows x co, row stride lddy), x (rows x ci, row stride

@@ -121,6 +121,34 @@ def test_own_sgemm_kernels(dev, m, n, k, transb):
     assert st == _lib.CODA_ENOSPC
 
 
+@pytest.mark.parametrize("m,n,k,p", [(2048, 256, 256, 0.1), (2048, 256, 256, 0.0), (1024, 512, 512, 0.3), (64, 64, 128, 0.5)])
+def test_sgemm_with_relu_dropout_epilogue_equals_the_two_passes(dev, m, n, k, p):
+    """coda_sgemm_relu_dropout_f32 = coda_sgemm_f32 followed by coda_tok_bias_relu_dropout_fwd_f32 with the same seed,
+    element for element (same sums, same keep decisions); shapes outside the launch-sized kernel are refused."""
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(dev)
+    w = torch.randn(n, k, generator=g).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    seed = 0x1234567890ABCDEF
+    fused = torch.empty(m, n, device=dev)
+    st = lib.coda_sgemm_relu_dropout_f32(1, m, n, k, a.data_ptr(), k, w.data_ptr(), k, fused.data_ptr(), n, bias.data_ptr(),
+                                         p, seed, _lib.current_stream_handle())
+    assert st == 0, st
+    two = torch.empty(m, n, device=dev)
+    assert lib.coda_sgemm_f32(1, m, n, k, a.data_ptr(), k, w.data_ptr(), k, two.data_ptr(), n, None, 0,
+                              _lib.current_stream_handle()) == 0
+    assert lib.coda_tok_bias_relu_dropout_fwd_f32(two.data_ptr(), bias.data_ptr(), m, n, p, seed, None, two.data_ptr(),
+                                                  _lib.current_stream_handle()) == 0
+    assert torch.equal(fused, two)
+    kept = float((fused != 0).float().mean())
+    assert abs(kept - 0.5 * (1 - p)) < 0.05          # relu halves, dropout keeps 1 - p
+    st = lib.coda_sgemm_relu_dropout_f32(1, 16384, 256, 256, a.data_ptr(), k, w.data_ptr(), k, fused.data_ptr(), 256,
+                                         None, p, seed, _lib.current_stream_handle())
+    assert st == _lib.CODA_ENOSPC
+
+
 def test_grouped_weight_gradients(dev):
     """coda_grouped_gemm_tn_f32 through gemm.DeferredWeightGrads: many dy^T x products in one launch -- mixed
     shapes, slices of packed buffers as operands and outputs, more problems than one launch carries, shapes the
