@@ -194,11 +194,14 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m, tmax);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    // lazy rescale: once the running row maxima have settled no lane changes its maximum and the
-    // accumulators (AGPRs: a rescale costs a read-modify-write of all of them) are left alone
-    if (__ballot(m_new != m) != 0ull) {
-      const float alpha = fast_exp2(m - m_safe);
+    // Lazy rescale with slack: the reference point m of the exponentials only moves when some row's maximum has
+    // outgrown it by more than kMaxSlack (log2 units) -- the probabilities of a tile are then at most 2^kMaxSlack
+    // instead of 1, which changes nothing in out = o / lsum and lse = m + log lsum, and the accumulators (a rescale
+    // is a read-modify-write of all of them: 160 of the ~730 non-MFMA instructions of a tile) are left alone after
+    // the first tiles instead of in the ~30 % of the tiles in which no row at all changes its maximum.
+    if (__ballot(m_new > m + kMaxSlack) != 0ull) {
+      const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m - m_to);
       lsum *= alpha;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       m = m_new;
     }
+    const float m_safe = (m == -INFINITY) ? 0.f : m;
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -406,9 +410,9 @@ __global__ __launch_bounds__(QW * kWave, (QW >= 8 && D == 64) ? 2 : 1) void mha_
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m, tmax);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    if (__ballot(m_new != m) != 0ull) {  // lazy rescale (see mha_fwd_kernel)
-      const float alpha = fast_exp2(m - m_safe);
+    if (__ballot(m_new > m + kMaxSlack) != 0ull) {  // lazy rescale with slack (see mha_fwd_kernel)
+      const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m - m_to);
       lsum *= alpha;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(QW * kWave, (QW >= 8 && D == 64) ? 2 : 1) void mha_
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       m = m_new;
     }
+    const float m_safe = (m == -INFINITY) ? 0.f : m;
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -582,9 +587,9 @@ __global__ __launch_bounds__(256) void mha_fwd_pipe_kernel(MhaParams p) {
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m, tmax);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    if (__ballot(m_new != m) != 0ull) {  // lazy rescale (see mha_fwd_kernel)
-      const float alpha = fast_exp2(m - m_safe);
+    if (__ballot(m_new > m + kMaxSlack) != 0ull) {  // lazy rescale with slack (see mha_fwd_kernel)
+      const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = fast_exp2(m - m_to);
       lsum *= alpha;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(256) void mha_fwd_pipe_kernel(MhaParams p) {
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       m = m_new;
     }
+    const float m_safe = (m == -INFINITY) ? 0.f : m;
     f32x16 s_next = sacc;
     if (next_k) s_next = qk(next_k);  // wave-uniform
     float rs = 0.f;

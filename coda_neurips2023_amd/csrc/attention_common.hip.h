@@ -9,6 +9,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 32;  // keys (or queries) per MFMA tile
 constexpr float kLog2e = 1.4426950408889634f;
+// forward kernels: how far (log2 units) a row maximum may outgrow the reference point of its exponentials before the
+// accumulators are rescaled (probabilities stay <= 2^8; see mha_fwd_kernel)
+constexpr float kMaxSlack = 8.0f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
