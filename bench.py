@@ -63,7 +63,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_m
 ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6}
 # HBM bytes per launch of the 2048x2048 dK/dV kernel from PMC: FETCH_SIZE 55 374 KB x 2 (gfx950 correction) +
 # WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
-ATTN_DKV_TRAFFIC = 93_743_104 + 45_474_816  # FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r02_pmc_attention_hbm.md
+ATTN_DKV_TRAFFIC = 94_247_117 + 45_362_074  # FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r03_pmc_attention_hbm.md
 
 
 def parse():
@@ -700,7 +700,7 @@ def main():
                                   "`steps` eagerly enqueued steps of the same workload right after it")
             # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes), not collected in this run
             roofline["traffic"] = ATTN_DKV_TRAFFIC
-            roofline["traffic_source"] = "profiles/r02_pmc_attention_hbm.md (PMC, separate FETCH_SIZE / WRITE_SIZE passes)"
+            roofline["traffic_source"] = "profiles/r03_pmc_attention_hbm.md (PMC, separate FETCH_SIZE / WRITE_SIZE passes)"
             t_bwd = sum(sum(attn_ms[(k, 2048, 2048)]) / len(attn_ms[(k, 2048, 2048)])
                         for k in ("delta", "dkv", "dq") if (k, 2048, 2048) in attn_ms)
             # SURVEY 8d's count for the whole backward with recomputation: 12 * Lq * Lk * d over delta + dK/dV + dQ
