@@ -853,15 +853,27 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     const float sscale = p.scale * kLog2e;
     constexpr bool plain = !GEN;  // no mask, L and S multiples of the tile
     if (plain) {
+      // One hash word decides a PAIR of adjacent keys (drop_hash ignores the key's low bit), and here adjacent keys are
+      // adjacent lanes: lane parity `par` computes the word of query crow(r) + par of every register pair (r, r + 1)
+      // and gets the other one from its neighbour with a DPP swap -- 8 hashes per tile and lane instead of 16, the
+      // same words as before.
+      const int par = l31 & 1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; r += 2) {
+        float keep0 = 1.f, keep1 = 1.f;
+        if (use_drop) {
+          const uint32_t mine = drop_hash(dconst, q0 + crow(r, half) + par, p.s, mykey);
+          const uint32_t other = __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+          keep0 = drop_keep(par ? other : mine, mykey, p.thresh16) ? p.inv_keep : 0.f;
+          keep1 = drop_keep(par ? mine : other, mykey, p.thresh16) ? p.inv_keep : 0.f;
+        }
         const int qi = crow(r, half);
-        const float prob = fast_exp2(sacc[r] * sscale - t_lse[qi]);  // one fma; lse = -inf cannot occur here
-        float keep = 1.f;
-        if (use_drop)
-          keep = drop_keep(drop_hash(dconst, q0 + qi, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
-        pd[r] = prob * keep;
-        ds[r] = prob * (pacc[r] * keep - t_delta[qi]);  // * scale: once, on the dK rows
+        const float prob0 = fast_exp2(sacc[r] * sscale - t_lse[qi]);  // one fma; lse = -inf cannot occur here
+        const float prob1 = fast_exp2(sacc[r + 1] * sscale - t_lse[qi + 1]);
+        pd[r] = prob0 * keep0;
+        pd[r + 1] = prob1 * keep1;
+        ds[r] = prob0 * (pacc[r] * keep0 - t_delta[qi]);  // * scale: once, on the dK rows
+        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - t_delta[qi + 1]);
       }
     } else {
 #pragma unroll
