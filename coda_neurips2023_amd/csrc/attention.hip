@@ -868,12 +868,12 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
           keep1 = drop_keep(par ? mine : other, mykey, p.thresh16) ? p.inv_keep : 0.f;
         }
         const int qi = crow(r, half);
-        const float prob0 = fast_exp2(sacc[r] * sscale - t_lse[qi]);  // one fma; lse = -inf cannot occur here
-        const float prob1 = fast_exp2(sacc[r + 1] * sscale - t_lse[qi + 1]);
+        const float prob0 = fast_exp2(__fmaf_rn(sacc[r], sscale, -t_lse[qi]));  // one fma; lse = -inf cannot occur here
+        const float prob1 = fast_exp2(__fmaf_rn(sacc[r + 1], sscale, -t_lse[qi + 1]));
         pd[r] = prob0 * keep0;
         pd[r + 1] = prob1 * keep1;
-        ds[r] = prob0 * (pacc[r] * keep0 - t_delta[qi]);  // * scale: once, on the dK rows
-        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - t_delta[qi + 1]);
+        ds[r] = prob0 * __fmaf_rn(pacc[r], keep0, -t_delta[qi]);  // * scale: once, on the dK rows
+        ds[r + 1] = prob1 * __fmaf_rn(pacc[r + 1], keep1, -t_delta[qi + 1]);
       }
     } else {
 #pragma unroll
@@ -882,11 +882,11 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
         bool dead = qq >= p.l || mykey >= p.s;
         if (p.mask && !dead) dead = p.mask[(static_cast<size_t>(bh) * p.l + qq) * p.s + mykey] != 0;
         const float lse = t_lse[qi];
-        float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] * sscale - lse);
+        float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(__fmaf_rn(sacc[r], sscale, -lse));
         float keep = 1.f;
         if (use_drop) keep = drop_keep(drop_hash(dconst, qq, p.s, mykey), mykey, p.thresh16) ? p.inv_keep : 0.f;
         pd[r] = prob * keep;
-        ds[r] = prob * (pacc[r] * keep - t_delta[qi]);  // * scale: once, on the dK rows
+        ds[r] = prob * __fmaf_rn(pacc[r], keep, -t_delta[qi]);  // * scale: once, on the dK rows
       }
     }
     // dV^T? no: dV[key][dv] += sum_q Pd[q][key] dO[q][dv]  (A = Pd^T: lane = key, k = query)
@@ -1114,8 +1114,8 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
         }
         const float prob0 = fast_exp2(sacc[r] - lse_eff);
         const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
-        ds[r] = prob0 * (pacc[r] * keep0 - delta);  // * scale: once, on the dQ rows
-        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta);
+        ds[r] = prob0 * __fmaf_rn(pacc[r], keep0, -delta);  // * scale: once, on the dQ rows
+        ds[r + 1] = prob1 * __fmaf_rn(pacc[r + 1], keep1, -delta);
       }
     } else {
 #pragma unroll
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
         const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] - lse);
         float keep = 1.f;
         if (use_drop) keep = drop_keep(drop_hash(dconst, myq, p.s, key), key, p.thresh16) ? p.inv_keep : 0.f;
-        ds[r] = prob * (pacc[r] * keep - delta);
+        ds[r] = prob * __fmaf_rn(pacc[r], keep, -delta);
       }
     }
     // dQ[q][d] += sum_key dS[q][key] K[key][d]   (A = dS: lane = query, k = key)
@@ -1299,8 +1299,8 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_direct_kernel(MhaBwdPar
         }
         const float prob0 = fast_exp2(sacc[r] - lse_eff);
         const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
-        ds[r] = prob0 * (pacc[r] * keep0 - delta);  // * scale: once, on the dQ rows
-        ds[r + 1] = prob1 * (pacc[r + 1] * keep1 - delta);
+        ds[r] = prob0 * __fmaf_rn(pacc[r], keep0, -delta);  // * scale: once, on the dQ rows
+        ds[r + 1] = prob1 * __fmaf_rn(pacc[r + 1], keep1, -delta);
       }
     } else {
 #pragma unroll
@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_direct_kernel(MhaBwdPar
         const float prob = (dead || lse == -INFINITY) ? 0.f : fast_exp2(sacc[r] - lse);
         float keep = 1.f;
         if (use_drop) keep = drop_keep(drop_hash(dconst, myq, p.s, key), key, p.thresh16) ? p.inv_keep : 0.f;
-        ds[r] = prob * (pacc[r] * keep - delta);
+        ds[r] = prob * __fmaf_rn(pacc[r], keep, -delta);
       }
     }
   };
