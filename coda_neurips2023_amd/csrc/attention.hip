@@ -867,13 +867,16 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
           keep0 = drop_keep(par ? other : mine, mykey, p.thresh16) ? p.inv_keep : 0.f;
           keep1 = drop_keep(par ? mine : other, mykey, p.thresh16) ? p.inv_keep : 0.f;
         }
+        // the pair's arithmetic as packed fp32 operations (v_pk_fma_f32 / v_pk_mul_f32: two elements per instruction)
         const int qi = crow(r, half);
-        const float prob0 = fast_exp2(__fmaf_rn(sacc[r], sscale, -t_lse[qi]));  // one fma; lse = -inf cannot occur here
-        const float prob1 = fast_exp2(__fmaf_rn(sacc[r + 1], sscale, -t_lse[qi + 1]));
-        pd[r] = prob0 * keep0;
-        pd[r + 1] = prob1 * keep1;
-        ds[r] = prob0 * __fmaf_rn(pacc[r], keep0, -t_delta[qi]);  // * scale: once, on the dK rows
-        ds[r + 1] = prob1 * __fmaf_rn(pacc[r + 1], keep1, -t_delta[qi + 1]);
+        const f32x2 lse2 = {t_lse[qi], t_lse[qi + 1]}, del2 = {t_delta[qi], t_delta[qi + 1]};
+        const f32x2 keep2 = {keep0, keep1}, s2 = {sacc[r], sacc[r + 1]}, dp2 = {pacc[r], pacc[r + 1]};
+        const f32x2 arg = __builtin_elementwise_fma(s2, f32x2{sscale, sscale}, -lse2);  // lse = -inf cannot occur here
+        const f32x2 prob = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+        const f32x2 pdv = prob * keep2;
+        const f32x2 dsv = prob * __builtin_elementwise_fma(dp2, keep2, -del2);  // * scale: once, on the dK rows
+        pd[r] = pdv[0]; pd[r + 1] = pdv[1];
+        ds[r] = dsv[0]; ds[r + 1] = dsv[1];
       }
     } else {
 #pragma unroll
@@ -1112,10 +1115,11 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
           keep0 = drop_keep_lo(hsh, p.thresh16) ? p.inv_keep : 0.f;
           keep1 = drop_keep_hi(hsh, p.thresh16) ? p.inv_keep : 0.f;
         }
-        const float prob0 = fast_exp2(sacc[r] - lse_eff);
-        const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
-        ds[r] = prob0 * __fmaf_rn(pacc[r], keep0, -delta);  // * scale: once, on the dQ rows
-        ds[r + 1] = prob1 * __fmaf_rn(pacc[r + 1], keep1, -delta);
+        const f32x2 arg = f32x2{sacc[r], sacc[r + 1]} - f32x2{lse_eff, lse_eff};  // packed fp32 (v_pk_*)
+        const f32x2 prob = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+        const f32x2 dsv = prob * __builtin_elementwise_fma(f32x2{pacc[r], pacc[r + 1]}, f32x2{keep0, keep1},
+                                                            f32x2{-delta, -delta});  // * scale: once, on the dQ rows
+        ds[r] = dsv[0]; ds[r + 1] = dsv[1];
       }
     } else {
 #pragma unroll
@@ -1297,10 +1301,11 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_direct_kernel(MhaBwdPar
           keep0 = drop_keep_lo(hsh, p.thresh16) ? p.inv_keep : 0.f;
           keep1 = drop_keep_hi(hsh, p.thresh16) ? p.inv_keep : 0.f;
         }
-        const float prob0 = fast_exp2(sacc[r] - lse_eff);
-        const float prob1 = fast_exp2(sacc[r + 1] - lse_eff);
-        ds[r] = prob0 * __fmaf_rn(pacc[r], keep0, -delta);  // * scale: once, on the dQ rows
-        ds[r + 1] = prob1 * __fmaf_rn(pacc[r + 1], keep1, -delta);
+        const f32x2 arg = f32x2{sacc[r], sacc[r + 1]} - f32x2{lse_eff, lse_eff};  // packed fp32 (v_pk_*)
+        const f32x2 prob = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+        const f32x2 dsv = prob * __builtin_elementwise_fma(f32x2{pacc[r], pacc[r + 1]}, f32x2{keep0, keep1},
+                                                            f32x2{-delta, -delta});  // * scale: once, on the dQ rows
+        ds[r] = dsv[0]; ds[r + 1] = dsv[1];
       }
     } else {
 #pragma unroll

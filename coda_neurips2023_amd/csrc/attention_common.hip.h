@@ -6,6 +6,7 @@
 namespace coda {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTile = 32;  // keys (or queries) per MFMA tile
 constexpr float kLog2e = 1.4426950408889634f;
