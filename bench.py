@@ -449,6 +449,8 @@ def main():
         dev = torch.device("cpu")
     else:
         torch.cuda.set_device(local_rank)
+        from coda_neurips2023_amd import tuning
+        tuning.enable_tuned_gemms()  # also for the workloads that never call build_model (configs[1])
         dev = torch.device("cuda", local_rank)
 
     def sync():
