@@ -80,6 +80,8 @@ def compact_groups(idx, grouped_cl, counts=None, total=None, min_saving=0.25):
     # rows rounded up to _ROW_PAD (zero rows of weight 0): the row count is data-dependent, and a coarse grid keeps
     # the set of GEMM shapes small enough for a table of tuned library kernels (tuning.py) at 2.5 % more rows
     pp = -(-total // _ROW_PAD) * _ROW_PAD
+    if pp >= g * s:  # small inputs: the padded compact form would not be smaller than the padded groups themselves
+        return None
     # one launch (coda_sa_compact_groups_f32): a group's distinct rows are its first cnt slots
     x = torch.empty((pp, 3), dtype=torch.float32, device=dev)
     roww = torch.empty(pp, dtype=torch.float32, device=dev)
