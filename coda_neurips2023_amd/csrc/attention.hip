@@ -210,13 +210,15 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       m = m_new;
     }
     const float m_safe = (m == -INFINITY) ? 0.f : m;
-    float rs = 0.f;
+    f32x2 rs2 = {0.f, 0.f};  // pairs: the subtraction and the row sum as packed fp32 operations
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pr[r] = fast_exp2(pr[r] - m_safe);
-      rs += pr[r];
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 arg = f32x2{pr[r], pr[r + 1]} - f32x2{m_safe, m_safe};
+      pr[r] = fast_exp2(arg[0]);
+      pr[r + 1] = fast_exp2(arg[1]);
+      rs2 += f32x2{pr[r], pr[r + 1]};
     }
-    lsum += rs;
+    lsum += rs2[0] + rs2[1];
     if (use_drop) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {  // keys crow(r), crow(r)+1: one aligned pair
@@ -421,13 +423,15 @@ __global__ __launch_bounds__(QW * kWave, (QW >= 8 && D == 64) ? 2 : 1) void mha_
       m = m_new;
     }
     const float m_safe = (m == -INFINITY) ? 0.f : m;
-    float rs = 0.f;
+    f32x2 rs2 = {0.f, 0.f};  // pairs: the subtraction and the row sum as packed fp32 operations
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pr[r] = fast_exp2(pr[r] - m_safe);
-      rs += pr[r];
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 arg = f32x2{pr[r], pr[r + 1]} - f32x2{m_safe, m_safe};
+      pr[r] = fast_exp2(arg[0]);
+      pr[r + 1] = fast_exp2(arg[1]);
+      rs2 += f32x2{pr[r], pr[r + 1]};
     }
-    lsum += rs;
+    lsum += rs2[0] + rs2[1];
     if (use_drop) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -600,13 +604,15 @@ __global__ __launch_bounds__(256) void mha_fwd_pipe_kernel(MhaParams p) {
     const float m_safe = (m == -INFINITY) ? 0.f : m;
     f32x16 s_next = sacc;
     if (next_k) s_next = qk(next_k);  // wave-uniform
-    float rs = 0.f;
+    f32x2 rs2 = {0.f, 0.f};  // pairs: the subtraction and the row sum as packed fp32 operations
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pr[r] = fast_exp2(pr[r] - m_safe);
-      rs += pr[r];
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 arg = f32x2{pr[r], pr[r + 1]} - f32x2{m_safe, m_safe};
+      pr[r] = fast_exp2(arg[0]);
+      pr[r + 1] = fast_exp2(arg[1]);
+      rs2 += f32x2{pr[r], pr[r + 1]};
     }
-    lsum += rs;
+    lsum += rs2[0] + rs2[1];
     if (use_drop) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
