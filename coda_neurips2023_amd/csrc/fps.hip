@@ -787,18 +787,20 @@ int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, 
   return st;
 }
 
-// Waves per workgroup of the bucketed kernels: 16 (default; 4 per SIMD, 128 registers per lane, at most 20 slots) or 8
-// (40 slots).  More waves spread the buckets a round touches -- a dozen, spatially clustered -- over more issue
-// ports: 2.02 vs 2.16 ms for 8 x 20 000 -> 2048.  coda_set_fps_waves() / CODA_FPS_WAVES select (A/B, tests).
+// Waves per workgroup of the bucketed kernels: 16 (4 per SIMD, 128 registers per lane, at most 20 slots) or 8 (40
+// slots).  More waves spread the buckets a round touches -- a dozen, spatially clustered -- over more issue ports:
+// 2.02 vs 2.16 ms for 8 x 20 000 -> 2048 with one workgroup per scene (default 16); with two workgroups per scene the
+// round is dominated by the mailbox round trip and 8 waves are slightly ahead (3.58 vs 3.64 ms for 8 x 40 000: default
+// 8).  coda_set_fps_waves() / CODA_FPS_WAVES force one shape for both (A/B, tests).
 std::atomic<int> g_fps_waves{-1};
-int bucket_waves() {
+int bucket_waves(int workgroups_per_scene = 1) {
   int v = g_fps_waves.load(std::memory_order_relaxed);
   if (v < 0) {
     const char *e = getenv("CODA_FPS_WAVES");
-    v = e && atoi(e) == 8 ? 8 : 16;
+    v = !e ? 0 : (atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0));
     g_fps_waves.store(v, std::memory_order_relaxed);
   }
-  return v;
+  return v != 0 ? v : (workgroups_per_scene == 2 ? 8 : 16);
 }
 
 int dispatch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, int32_t *idx, hipStream_t s) {
@@ -847,7 +849,7 @@ int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, i
 
 int dispatch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
   const int share = ceil_div(ceil_div(n, 64), 2);  // buckets per workgroup
-  if (bucket_waves() == 16) {
+  if (bucket_waves(2) == 16) {
     const int sl = ceil_div(share, 16);
     if (sl <= 8) return launch_bucket2<8, 16>(xyz, b, n, m, log2T, ws, idx, s);
     if (sl <= 12) return launch_bucket2<12, 16>(xyz, b, n, m, log2T, ws, idx, s);
@@ -1019,7 +1021,7 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
 
 CODA_API int coda_set_fps_waves(int waves) {
   if (waves != 0 && waves != 8 && waves != 16) return CODA_EINVAL;
-  coda::g_fps_waves.store(waves == 0 ? 16 : waves, std::memory_order_relaxed);
+  coda::g_fps_waves.store(waves, std::memory_order_relaxed);
   return CODA_OK;
 }
 

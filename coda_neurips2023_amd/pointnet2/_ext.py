@@ -82,7 +82,8 @@ def _ptr(t):
 
 
 def set_fps_waves(waves=0):
-    """Waves per workgroup of the bucketed FPS kernels: 0 (default = 16), 8 or 16.  Process-wide; same indices."""
+    """Waves per workgroup of the bucketed FPS kernels: 0 (default: 16, or 8 with two workgroups per scene), 8 or 16.
+    Process-wide; same indices."""
     _lib.check(_lib.load().coda_set_fps_waves(int(waves)), "coda_set_fps_waves")
 
 

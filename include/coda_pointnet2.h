@@ -84,7 +84,8 @@ int coda_get_distance_mode(void);
  * 256-byte aligned); 0: NULL/0 may be passed.  Without a sufficient workspace
  * the call falls back to the kernels that need none.
  * coda_set_fps_waves(0 default | 8 | 16): waves per workgroup of the bucketed
- * kernels (process-wide; same indices either way; CODA_FPS_WAVES presets it).  */
+ * kernels (process-wide; same indices either way; CODA_FPS_WAVES presets it;
+ * default: 16 with one workgroup per scene, 8 with two).                      */
 int coda_set_fps_waves(int waves);
 size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m);
 int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
