@@ -30,6 +30,7 @@ DDP gradient all-reduce (+ SyncBatchNorm statistics), as in the reference
 import argparse
 import gc
 import json
+import math
 import os
 import sys
 import time
@@ -90,10 +91,11 @@ def build_dry_workload(dev):
     mod = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(),
                               torch.nn.Linear(16, 1)).to(dev).train()
 
-    def step(model, batch, pre_encoded=None):
+    def step(model, batch, pre_encoded=None, with_dict=False):
         if dist.is_initialized():  # stands in for the SyncBatchNorm statistics exchange of the forward pass
             dist.all_reduce(torch.ones(32))
-        return model(batch["point_clouds"].reshape(-1, 3)).square().mean()
+        loss = model(batch["point_clouds"].reshape(-1, 3)).square().mean()
+        return (loss, {"loss_toy": loss.detach(), "loss_toy_0": loss.detach() * 2}) if with_dict else loss
 
     return mod, step, "dry run of bench.py's control flow (toy CPU module, no kernels, numbers meaningless)", "dry"
 
@@ -254,12 +256,12 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", imag
     crit = crit.to(dev)
     tgt_gen = torch.Generator().manual_seed(2)
 
-    def step(m, batch, pre_encoded=None):
+    def step(m, batch, pre_encoded=None, with_dict=False):
         if "gt_box_present" not in batch:  # ground truth travels with the batch (engine.py:137-148); made once
             batch.update(synthetic_targets(batch, tgt_gen))
         pred = m(batch, curr_epoch=0, pre_encoded=pre_encoded) if pre_encoded is not None else m(batch, curr_epoch=0)
-        loss, _ = crit(pred, batch)
-        return loss
+        loss, loss_dict = crit(pred, batch)
+        return (loss, loss_dict) if with_dict else loss
 
     desc = (f"{config_tag}: full model_3detr (SA {'40000' if nq == 512 else '20000'}->2048 r=0.2 ns=64, enc 3L d=256 "
             f"h=4, dec 8L d={dec_dim} h=4, {nq} queries, 6 heads incl. 512-d CLIP-space head) fwd+bwd, batch=8/GPU, "
@@ -428,6 +430,49 @@ def cpu_baseline(kind):
                       f"OpenMP over scenes) + torch-CPU layers on {cores} threads"}
 
 
+class DeferredFiniteCheck:
+    """engine.py:155-157 stops the training on a non-finite loss with ``loss_reduced.item()``: a device-to-host
+    read-back that parks the host until the whole forward pass has executed, every step.  The headline loop keeps the
+    check but defers it by one step: the loss goes to pinned host memory asynchronously and the PREVIOUS step's value
+    (long complete) is examined -- the run still stops, one step later, and the host never waits.  (The unchanged
+    caller's leg below keeps the reference's blocking form.)"""
+
+    def __init__(self, dev):
+        self.host = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.events = [None, None]
+        self.turn = 0
+
+    def push(self, loss):
+        prev = self.turn ^ 1
+        if self.events[prev] is not None:
+            self.events[prev].synchronize()  # recorded a whole step ago
+            if not math.isfinite(float(self.host[prev][0])):
+                print("Loss in not finite. Training will be stopped.", file=sys.stderr)
+                sys.exit(1)
+        self.host[self.turn].copy_(loss.detach().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.turn] = ev
+        self.turn = prev
+
+
+def reference_loss_sync(loss, loss_dict):
+    """engine.py:152-157, verbatim in effect: the loss averaged over the ranks, the loss dictionary reduced, and the
+    blocking finite check on the host."""
+    from coda_neurips2023_amd.dist_utils import all_reduce_average, reduce_dict
+    loss_reduced = all_reduce_average(loss)
+    loss_dict_reduced = reduce_dict(loss_dict)
+    if not math.isfinite(loss_reduced.item()):
+        print("Loss in not finite. Training will be stopped.", file=sys.stderr)
+        sys.exit(1)
+    return loss_reduced, loss_dict_reduced
+
+
+def make_batch_t(bsz, n, seed, dev):
+    pc, _, _ = make_batch(bsz, n, seed=seed)
+    return torch.from_numpy(pc).to(dev)[..., :3].contiguous()
+
+
 def _tuned_gemms():
     from coda_neurips2023_amd import tuning
     return tuning.is_on()
@@ -515,6 +560,8 @@ def main():
     opt, clip_gradients = make_optimizer(model.parameters(), dry)
     prefetch = args.prefetch == "on" and kind == "model"
 
+    finite = DeferredFiniteCheck(dev) if not dry else None
+
     def one_step_eager(i):
         if prefetch:
             # the data pipeline knows the next batch: its furthest point sampling (8 workgroups,
@@ -522,6 +569,8 @@ def main():
             raw_model.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)  # batches are resident
         opt.zero_grad(set_to_none=True)
         loss = step_fn(model, pool[i % len(pool)])
+        if finite is not None:
+            finite.push(loss)  # engine.py:155-157's exit on a non-finite loss, one step late and without a host stall
         loss.backward()
         if reducer is not None:
             reducer.reduce()
@@ -602,34 +651,89 @@ def main():
         ev = (timing if store is None else store).get(name, [])
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev) if ev else None
 
-    # The same step as an UNCHANGED engine.py would run it: no `prefetch_sampling` call (the
-    # sampling runs in line and the padded group copies are not de-duplicated), torch.nn.utils.clip_grad_norm_ +
-    # torch.optim.AdamW(fused=True) instead of this package's three-launch tail.  Single process only (with several
-    # ranks every rank would have to run it in lockstep); `steps` more steps right after the headline's.
+    # The same step as an UNCHANGED engine.py runs it (engine.py:136-164, main.py:993-996): no `prefetch_sampling` call,
+    # the loss averaged over the ranks + reduce_dict + the BLOCKING `.item()` finite check of engine.py:152-157 between
+    # forward and backward, torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW instead of this package's three-launch
+    # tail, and with several ranks the reference's own wrap: SyncBatchNorm.convert_sync_batchnorm +
+    # DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False).  Every rank runs it in
+    # lockstep, `steps` steps right after the headline's, same barrier + synchronize bracket, max over ranks.
     unchanged = None
-    if world == 1 and kind == "model" and not dry:
-        opt2, clip2 = make_optimizer(model.parameters(), force_torch=True)
+    if kind in ("model", "dry"):
+        model_u = model
+        if reducer is not None:
+            reducer.remove_hooks()
+            model.zero_grad(set_to_none=True)  # the gradients were views of the reducer's flat buffer
+        if world > 1 and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            model_u = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if dry else [local_rank],
+                                                                find_unused_parameters=False)
+        opt2, clip2 = make_optimizer(model_u.parameters(), dry=dry, force_torch=True)
 
         def plain_step(i):
-            opt2.zero_grad(set_to_none=True)
-            step_fn(model, pool[i % len(pool)]).backward()
+            opt2.zero_grad()
+            loss, loss_dict = step_fn(model_u, pool[i % len(pool)], with_dict=True)
+            reference_loss_sync(loss, loss_dict)
+            loss.backward()
             clip2()
             opt2.step()
 
         for i in range(3):
             plain_step(i)
+        if world > 1:
+            dist.barrier()
         sync()
         t1 = time.perf_counter()
         for i in range(args.steps):
             plain_step(i)
         sync()
+        if world > 1:
+            dist.barrier()
+        sync()
         dt2 = time.perf_counter() - t1
-        unchanged = {"value": round(B_PER_GPU * args.steps / dt2, 3), "unit": "scenes/s",
+        if world > 1:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        unchanged = {"value": round(world * B_PER_GPU * args.steps / dt2, 3), "unit": "scenes/s",
                      "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                      "what": "the same step through the reference's unchanged call sequence (engine.py:136-164): "
-                             "model(batch) / criterion / backward / torch clip_grad_norm_ + torch AdamW(fused), no "
-                             "sampling prefetch (the set-abstraction module waits for its distinct-row count itself)"}
+                             "model(batch) / criterion / all_reduce_average(loss) + reduce_dict(loss_dict) + the "
+                             "blocking loss.item() finite check / backward / torch clip_grad_norm_ + torch AdamW, no "
+                             "sampling prefetch" + (", SyncBatchNorm + torch DistributedDataParallel (main.py:993-996)"
+                                                    if world > 1 else "")}
         del opt2
+
+    # Multi-GPU diagnostics (rank 0 reports, every rank takes part): the collectives of a step timed in isolation with
+    # HIP events -- the two segments of the flat gradient all-reduce and one SyncBatchNorm statistics all-reduce --
+    # so that the first scaling run shows where a shortfall comes from.
+    comm = None
+    if world > 1 or force_ddp:
+        def timed_allreduce(t, reps):
+            if not dry:
+                torch.cuda.synchronize()
+            if dist.get_world_size() > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dist.all_reduce(t)
+            if not dry:
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()}
+        reps = 10
+        if reducer is not None:
+            names = ["early", "late"] if len(reducer.segments) == 2 else [str(k) for k in range(len(reducer.segments))]
+            comm["allreduce_ms"] = {n: round(timed_allreduce(seg.flat, reps), 4) for n, seg in zip(names, reducer.segments)}
+            comm["allreduce_bytes"] = {n: seg.flat.numel() * 4 for n, seg in zip(names, reducer.segments)}
+        else:
+            flat = torch.zeros(sum(p.numel() for p in raw_model.parameters() if p.requires_grad), device=dev)
+            comm["allreduce_ms"] = {"all": round(timed_allreduce(flat, reps), 4)}
+            comm["allreduce_bytes"] = {"all": flat.numel() * 4}
+        small = torch.zeros(512, dtype=torch.float64, device=dev)  # [sum, sum of squares] of a 256-channel layer
+        one = timed_allreduce(small, 50)
+        comm["syncbn_allreduce_ms_each"] = round(one, 4)
+        comm["syncbn_collectives_per_step"] = 16  # 8 BatchNorm layers x (forward statistics + backward sums)
+        comm["syncbn_ms"] = round(16 * one, 4)
 
     alone = {}
     if rank == 0 and prefetch:
@@ -645,6 +749,32 @@ def main():
                 _ext.query_and_group_xyz(new_xyz, xyz, RADIUS, NSAMPLE, True, channels_last=True)
         torch.cuda.synchronize()
         _ext.disable_kernel_timing()
+
+    # the same operator with the GLOBAL batch on one GPU (64 scenes): at 8 scenes the 25 MB of a call are 5 us of HBM
+    # time, below two launch latencies, so the bandwidth fraction at B = 8 measures launch-sized kernels; B = 64 is
+    # the size at which the operator can be judged against the HBM roofline at all
+    bq64 = None
+    if rank == 0 and world == 1 and kind == "model" and not dry and not args.no_extras:
+        with torch.no_grad():
+            big = torch.cat([make_batch_t(B_PER_GPU, N_POINTS, 777 + j, dev) for j in range(8)], 0)
+            inds = _ext.furthest_point_sampling(big, M_CENTRES)
+            new_big = torch.gather(big, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            t64 = _ext.enable_kernel_timing(["query_and_group_xyz"])
+            for _ in range(3 + args.steps):
+                torch.cuda.synchronize()
+                _ext.query_and_group_xyz(new_big, big, RADIUS, NSAMPLE, True, channels_last=True)
+            torch.cuda.synchronize()
+            _ext.disable_kernel_timing()
+        ev = t64.get("query_and_group_xyz", [])[3:]
+        if ev:
+            ms64 = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            by = BQ_GROUP_BYTES_PER_SCENE * 64
+            bq64 = {"kernel": "grid_build_kernel + grid_query_kernel, B = 64 scenes in one call (the global batch on one "
+                              "GPU), GPU otherwise idle",
+                    "timing": "HIP events around each call", "bound": "hbm", "achieved": round(by / (ms64 * 1e-3) / 1e9, 3),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "traffic": None, "bytes_per_launch": by, "avg_launch_ms": round(ms64, 5)}
+        del big, new_big
 
     if rank == 0:
         bq_ms = avg_ms("query_and_group_xyz") or avg_ms("ball_query")
@@ -712,7 +842,21 @@ def main():
             for key in sorted(attn_ms_all, key=lambda k: (-k[1] * k[2], k[0])):
                 if key[0] != "delta" and key != dom:
                     others.append(attn_entry(key, attn_ms_all[key], note))
+            # the six decoder-shaped kernels together (north_star: >= 50 % of the MFMA peak on decoder attention):
+            # sum of the flops of one launch of each / sum of their event-timed durations
+            dec_keys = [k for k in attn_ms_all if k[0] != "delta" and k[1] == 256 and k[2] in (256, 2048)]
+            if dec_keys:
+                fl = sum(ATTN_FLOPS[k[0]] * k[1] * k[2] * 256 * B_PER_GPU for k in dec_keys)
+                ms = sum(sum(attn_ms_all[k]) / len(attn_ms_all[k]) for k in dec_keys)
+                others.append({"kernel": "decoder_aggregate: cross-attention (256 x 2048) and self-attention (256 x 256) "
+                                         "forward + dQ + dK/dV, one launch of each",
+                               "timing": note, "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
+                               "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "flops": fl, "sum_launch_ms": round(ms, 5), "kernels": len(dec_keys)})
             others.append(bq_roofline)
+            if bq64 is not None:
+                others.append(bq64)
         out = {
             "metric": "scenes/sec fwd+bwd (20k pts, 256 queries)",
             "value": round(world * B_PER_GPU * args.steps / dt, 3),
@@ -747,7 +891,11 @@ def main():
             "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
         }
         if unchanged is not None:
+            out["value_unchanged"] = unchanged["value"]
+            out["ms_per_step_unchanged"] = unchanged["ms_per_step"]
             out["value_unchanged_caller"] = unchanged
+        if comm is not None:
+            out["comm"] = comm
         if others:
             out["roofline_others"] = others
         if world == 1 and not dry and not args.no_extras and kind == "model" and args.workload != "model40k":

@@ -52,6 +52,19 @@ SIGNATURES = {
     "coda_sa_pool_bwd_stats_f32": (_c_int, [_P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
     "coda_sa_compact_groups_f32": (_c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, ctypes.c_longlong,
                                              ctypes.c_longlong, _P]),
+    # MFMA pipeline (csrc/sa_mfma.hip)
+    "coda_sa_mfma_blocks": (_c_int, []),
+    "coda_sa_mfma_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
+    "coda_sa_pack_groups_f32": (_c_int, [_P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, ctypes.c_longlong, _c_int, _P]),
+    "coda_sa_l1_sums_f32": (_c_int, [_P, _P, _P, _c_int, _P]),
+    "coda_sa_mfma_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_int, _c_int, _P, _P, _P, _P,
+                                      _P, _P, _P, _P, _c_int, _P]),
+    "coda_sa_pool_finish_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_int, _P]),
+    "coda_sa_mfma_bwd_dx_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int,
+                                         _c_int, _c_int, _P, _P, _c_int, _P]),
+    "coda_sa_mfma_bwd_dw_f32": (_c_int, [_P, _P, _P, _P, _P, _c_int, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int,
+                                         _c_int, _c_int, _P, _P, _c_int, _P]),
+    "coda_sa_l1_bwd_f32": (_c_int, [_P, _P, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _c_int, _P]),
     # include/coda_token_ops.h
     "coda_tok_bn_stats_f32": (_c_int, [_P, _c_int, ctypes.c_longlong, _c_int, _P, _P]),
     "coda_tok_bn_finalize_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, ctypes.c_double, _c_float, _P, _P, _P]),

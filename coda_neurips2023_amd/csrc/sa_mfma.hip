@@ -1,0 +1,1030 @@
+// sa_mfma.hip -- the set-abstraction shared MLP as hand-written fp32-MFMA GEMMs (gfx950).
+//
+// Reference: SharedMLP([3, 64, 128, 256], bn=True) = per layer 1x1 Conv2d (no bias) -> BatchNorm2d -> ReLU, then
+// F.max_pool2d over nsample (third_party_pointnet2/pointnet2/pytorch_utils.py:8-33, pointnet2_modules.py:247-253).
+// Here the activations are channels-last rows (one row per distinct neighbour of a ball-query group, see
+// include/coda_sa_mlp.h) and every 1x1 convolution is a GEMM on v_mfma_f32_32x32x2_f32 with the work around it
+// fused in:
+//
+//   sa_fwd_kernel<CIN, COUT, FIRST, POOL>      y_out = relu(bn(y_in)) W^T
+//       prologue  FIRST: y_in = x . w1^T recomputed from the grouped xyz (layer 1 never exists in memory)
+//                 else : y_in read once; BN + ReLU of the layer below applied while the tile is staged into LDS
+//       epilogue  per-channel sum / sum of squares (weighted by the row multiplicity) for this layer's batch
+//                 statistics; POOL: running max of sign(gamma) * y per (group, channel) with its row index
+//   sa_bwd_dx_kernel<CIN, COUT, LAST, FIRST>   dmid_in = relu'(.) (dy W)
+//       prologue  dy = BN backward of the upstream gradient formed from y_out while the tile is staged; LAST: the
+//                 upstream gradient is the pooled one (d, sel) -- the sparse tensor is never materialised
+//       epilogue  ReLU mask of the layer below and that layer's BN-backward sums; FIRST: also sum dmid_in * x_j,
+//                 from which layer 1's weight gradient follows in closed form (sa_l1_bwd_kernel)
+//   sa_bwd_dw_kernel<CIN, COUT, LAST, FIRST>   dW = dy^T relu(bn(y_in)), K = the rows; per-workgroup partial tiles
+//                                              in registers over the whole row range, fixed-order reduction
+//
+// Tiling.  A workgroup = 4 waves, one per SIMD (up to 512 VGPRs per lane), persistent over a contiguous range of
+// 64-row sub-tiles.  fp32 MFMA runs at the vector rate (64 cycles per 32x32x2), so operand delivery is cheap: the
+// stationary operand (the weights) lives in REGISTERS in MFMA fragment layout for the whole kernel, the moving
+// operand goes through one LDS tile, the next sub-tile's global loads are in flight (registers) under the MFMAs
+// of the current one.  MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 31][k = lane >> 5],
+// B[k = lane >> 5][j = lane & 31], D: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#include "coda_sa_mlp.h"
+#include "common.hip.h"
+
+#include <mutex>
+
+namespace coda {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kT = 256;     // threads per workgroup: 4 waves, one per SIMD
+constexpr int kRows = 64;   // rows of a sub-tile
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ i32x4 ldg4i(const int32_t *p) { return *reinterpret_cast<const i32x4 *>(p); }
+
+// y1[c] = x . w1[c] with one rounding per operation, the same expression as csrc/sa_mlp.hip's conv3()
+__device__ __forceinline__ float dot3w(float x0, float x1, float x2, float w0, float w1, float w2) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(x0, w0), __fmul_rn(x1, w1)), __fmul_rn(x2, w2));
+}
+__device__ __forceinline__ float bn_act(float y, float scale, float shift) {
+  return fmaxf(__fadd_rn(__fmul_rn(y, scale), shift), 0.0f);
+}
+
+// The workgroup's range of sub-tiles: the packed rows split evenly, in whole sub-tiles, over the grid.
+struct Range {
+  long long total;       // packed rows
+  long long sub0, sub1;  // sub-tiles [sub0, sub1) of 64 rows
+  long long per;         // sub-tiles per workgroup
+};
+__device__ __forceinline__ Range wg_range(const int32_t *__restrict__ goff, long long groups) {
+  Range r;
+  r.total = goff[groups];
+  const long long nsub = (r.total + kRows - 1) / kRows;
+  r.per = (nsub + gridDim.x - 1) / gridDim.x;
+  r.sub0 = static_cast<long long>(blockIdx.x) * r.per;
+  if (r.sub0 > nsub) r.sub0 = nsub;
+  r.sub1 = r.sub0 + r.per < nsub ? r.sub0 + r.per : nsub;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// packing of the ball-query groups (no host read-back): count -> scan -> scatter (+ xyz moments)
+// ---------------------------------------------------------------------------------------------------------------
+// one wave per group: distinct rows = slot 0 + the slots whose index differs from slot 0's (ball_query pads with
+// copies of the first hit, ball_query_gpu.cu:35-48; real hits are distinct ascending indices)
+__global__ __launch_bounds__(kT) void pack_count_kernel(const int32_t *__restrict__ idx, int32_t *__restrict__ cnt,
+                                                        long long groups, int s_len, int dedup) {
+  const long long g = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const int lane = threadIdx.x & 63;
+  if (!dedup) {
+    if (lane == 0) cnt[g] = s_len;
+    return;
+  }
+  const int32_t *row = idx + g * s_len;
+  const int32_t first = row[0];
+  int n = 0;
+  for (int j = lane; j < s_len; j += 64) n += (j == 0 || row[j] != first) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if (lane == 0) cnt[g] = n;
+}
+
+// one workgroup: exclusive scan of the counts -> group_offsets; zeroes the moments and the caller's accumulators
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t *__restrict__ cnt, int32_t *__restrict__ goff,
+                                                         long long groups, double *__restrict__ moments,
+                                                         double *__restrict__ zero, int nzero) {
+  __shared__ int s_part[1024];
+  const int t = threadIdx.x;
+  for (int i = t; i < 10; i += 1024) moments[i] = 0.0;
+  for (int i = t; i < nzero; i += 1024) zero[i] = 0.0;
+  const long long per = (groups + 1023) / 1024;
+  const long long g0 = t * per, g1 = g0 + per < groups ? g0 + per : groups;
+  int sum = 0;
+  for (long long g = g0; g < g1; ++g) sum += cnt[g];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = t >= o ? s_part[t - o] : 0;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  int run = s_part[t] - sum;
+  for (long long g = g0; g < g1; ++g) {
+    goff[g] = run;
+    run += cnt[g];
+  }
+  if (t == 1023) goff[groups] = s_part[1023];
+}
+
+// one thread per (group, slot): row group_offsets[g] + j <- grouped[g][j] for j < cnt[g]
+__global__ __launch_bounds__(kT) void pack_scatter_kernel(const float *__restrict__ grouped, const int32_t *__restrict__ cnt,
+                                                          const int32_t *__restrict__ goff, float *__restrict__ x,
+                                                          float *__restrict__ roww, int32_t *__restrict__ grow,
+                                                          double *__restrict__ moments, long long groups, int s_len) {
+  __shared__ float s_m[10][kT / 64];
+  const long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x;
+  float m[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) m[k] = 0.0f;
+  if (i < groups * s_len) {
+    const long long g = i / s_len;
+    const int j = static_cast<int>(i - g * s_len);
+    const int c = cnt[g];
+    if (j < c) {
+      const long long r = static_cast<long long>(goff[g]) + j;
+      const float *src = grouped + i * 3;
+      const float x0 = src[0], x1 = src[1], x2 = src[2];
+      const float w = j == 0 ? static_cast<float>(s_len - c + 1) : 1.0f;
+      x[r * 3] = x0; x[r * 3 + 1] = x1; x[r * 3 + 2] = x2;
+      roww[r] = w;
+      grow[r] = static_cast<int32_t>((g << 6) | j);  // group and row-in-group (s_len <= 64) in one word
+      m[0] = w; m[1] = w * x0; m[2] = w * x1; m[3] = w * x2;
+      m[4] = w * x0 * x0; m[5] = w * x0 * x1; m[6] = w * x0 * x2;
+      m[7] = w * x1 * x1; m[8] = w * x1 * x2; m[9] = w * x2 * x2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    float v = m[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s_m[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    double v = 0.0;
+    for (int q = 0; q < kT / 64; ++q) v += static_cast<double>(s_m[threadIdx.x][q]);
+    atomicAdd(moments + threadIdx.x, v);
+  }
+}
+
+// layer 1's batch statistics from the moments: y1 = x . w1[c] is linear in x
+__global__ void l1_sums_kernel(const double *__restrict__ mom, const float *__restrict__ w1, double *__restrict__ sums, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double a = w1[3 * i], b = w1[3 * i + 1], d = w1[3 * i + 2];
+  sums[i] = a * mom[1] + b * mom[2] + d * mom[3];
+  sums[c + i] = a * a * mom[4] + b * b * mom[7] + d * d * mom[9] + 2.0 * (a * b * mom[5] + a * d * mom[6] + b * d * mom[8]);
+}
+
+// layer 1 backward in closed form (include/coda_sa_mlp.h): with dy1 = a (d1 - w (m1 + xhat m2)),
+//   dW1[c][j] = sum_p dy1 x_j = a (T_j - m1 X_j - m2 invstd ((W1[c] . XX[:, j]) - mean X_j))
+__global__ void l1_bwd_kernel(const double *__restrict__ s5, const double *__restrict__ sbn, double n,
+                              const float *__restrict__ gamma, const float *__restrict__ stats,
+                              const double *__restrict__ mom, const float *__restrict__ w1, float *__restrict__ dw1,
+                              float *__restrict__ dbeta, float *__restrict__ dgamma, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  if (dbeta) dbeta[i] = static_cast<float>(s5[i]);
+  if (dgamma) dgamma[i] = static_cast<float>(s5[c + i]);
+  if (!dw1) return;
+  const double mean = stats[2 * c + i], invstd = stats[3 * c + i];
+  const double a = static_cast<double>(__fmul_rn(gamma[i], stats[3 * c + i]));
+  const double m1 = n > 0.0 ? sbn[i] / n : 0.0, m2 = n > 0.0 ? sbn[c + i] / n : 0.0;
+  const double wa = w1[3 * i], wb = w1[3 * i + 1], wc = w1[3 * i + 2];
+  const double xx[3][3] = {{mom[4], mom[5], mom[6]}, {mom[5], mom[7], mom[8]}, {mom[6], mom[8], mom[9]}};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double wxx = wa * xx[0][j] + wb * xx[1][j] + wc * xx[2][j];
+    const double t = s5[(2 + j) * c + i];
+    dw1[3 * i + j] = static_cast<float>(a * (t - m1 * mom[1 + j] - m2 * invstd * (wxx - mean * mom[1 + j])));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+  const float *src, *w1, *st_in, *w, *roww;
+  const int32_t *goff, *grow;
+  long long groups;
+  float *y_out;
+  double *sums;
+  const float *gamma;
+  float *ysel;
+  int32_t *sel;
+  float *part_y;
+  int32_t *part_sel, *part_gid;
+};
+
+template <int CIN, int COUT, bool FIRST, bool POOL>
+__global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
+  static_assert(COUT % 128 == 0 && CIN % 32 == 0, "tile shape");
+  static_assert(!POOL || COUT == kT, "pooling scan: one thread per channel");
+  constexpr int CBW = COUT / 128;    // 32-column blocks per wave
+  constexpr int KK = CIN / 2;        // MFMA k-steps
+  constexpr int SA = CIN + 4;        // LDS row stride of the A tile (floats): b128 fragment reads conflict-free
+  constexpr int SY = kRows + 4;      // LDS stride of the [channel][row] pooling tile
+  constexpr int QPR = CIN / 4;       // float4 per input row
+  constexpr int RPP = kT / QPR;      // rows per staging pass
+  constexpr int NPASS = kRows / RPP;
+  extern __shared__ float lds[];
+  float *s_a = lds;                                  // [64][SA], column k at (k & 1) * CIN/2 + (k >> 1)
+  float *s_w = s_a + kRows * SA;                     // [64] row multiplicity (0: row not valid)
+  int *s_grow = reinterpret_cast<int *>(s_w + kRows);  // [64] group of the row
+  float *s_y = reinterpret_cast<float *>(s_grow + kRows);  // POOL: [COUT][SY]
+  float *s_w1 = POOL ? s_y + COUT * SY : s_y;        // FIRST: [CIN][4] = w1[k][0..2], 0 ; then [CIN][2] scale, shift
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const Range rg = wg_range(a.goff, a.groups);
+  const int b = blockIdx.x;
+  if (POOL && tid == 0) a.part_gid[b] = -1;
+  if (rg.sub0 >= rg.sub1) return;
+
+  // stationary operand: W^T fragments, B[k = 2 kk + h][j = column] = w[column][2 kk + h]
+  const int cbase = wv * (COUT / 4);
+  float wreg[CBW][KK];
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) wreg[cb][kk] = a.w[static_cast<size_t>(cbase + 32 * cb + l31) * CIN + 2 * kk + h];
+
+  if (FIRST) {
+    for (int k = tid; k < CIN; k += kT) {
+      s_w1[4 * k] = a.w1[3 * k]; s_w1[4 * k + 1] = a.w1[3 * k + 1]; s_w1[4 * k + 2] = a.w1[3 * k + 2]; s_w1[4 * k + 3] = 0.f;
+      s_w1[4 * CIN + 2 * k] = a.st_in[k]; s_w1[4 * CIN + 2 * k + 1] = a.st_in[CIN + k];
+    }
+  }
+  // staging roles
+  const int cq = tid % QPR, r0 = tid / QPR;       // non-FIRST: this thread's channel quad and first row
+  f32x4 sc4 = {0, 0, 0, 0}, sh4 = {0, 0, 0, 0};
+  if (!FIRST) { sc4 = ldg4(a.st_in + 4 * cq); sh4 = ldg4(a.st_in + CIN + 4 * cq); }
+  const int frow = tid >> 2, fpart = tid & 3;     // FIRST: row and quarter of the channels
+
+  f32x4 pre[FIRST ? 1 : NPASS];
+  float px0 = 0.f, px1 = 0.f, px2 = 0.f;
+  float pw = 0.f;
+  int pg = 0;
+  auto prefetch = [&](long long sub) {
+    const long long s0 = sub * kRows;
+    if (FIRST) {
+      const long long r = s0 + frow;
+      const bool ok = r < rg.total;
+      px0 = ok ? a.src[r * 3] : 0.f; px1 = ok ? a.src[r * 3 + 1] : 0.f; px2 = ok ? a.src[r * 3 + 2] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPASS; ++j) {
+        const long long r = s0 + r0 + RPP * j;
+        pre[j] = r < rg.total ? ldg4(a.src + r * CIN + 4 * cq) : f32x4{0, 0, 0, 0};
+      }
+    }
+    if (tid < kRows) {
+      const long long r = s0 + tid;
+      pw = r < rg.total ? a.roww[r] : 0.f;
+      pg = r < rg.total ? a.grow[r] : -1;
+    }
+  };
+
+  float st_s[CBW][2] = {}, st_q[CBW][2] = {};  // per-lane partial statistics of its column(s)
+  // pooling state of this thread's channel
+  const float sg = POOL ? (a.gamma[tid % COUT] >= 0.0f ? 1.0f : -1.0f) : 1.0f;
+  int cur_g = -1, arg = 0;
+  bool tail = false;  // the current group began in the previous workgroup
+  float best = -INFINITY;
+  const long long row_first = rg.sub0 * kRows;
+  auto flush = [&]() {
+    const float yv = best * sg;
+    if (tail) {  // this workgroup holds the group's tail only
+      a.part_y[static_cast<size_t>(b) * COUT + tid] = yv;
+      a.part_sel[static_cast<size_t>(b) * COUT + tid] = arg;
+      if (tid == 0) a.part_gid[b] = cur_g;
+    } else {
+      a.ysel[static_cast<size_t>(cur_g) * COUT + tid] = yv;
+      a.sel[static_cast<size_t>(cur_g) * COUT + tid] = arg;
+    }
+  };
+
+  prefetch(rg.sub0);
+  for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
+    const long long s0 = sub * kRows;
+    __syncthreads();  // the previous sub-tile's fragment reads / pooling scan are done
+    if (FIRST) {
+      const bool ok = s0 + frow < rg.total;
+#pragma unroll
+      for (int i = 0; i < CIN / 4; i += 4) {
+        const int k0 = fpart * (CIN / 4) + i;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 wk = *reinterpret_cast<const f32x4 *>(s_w1 + 4 * (k0 + u));
+          const f32x2 ss = *reinterpret_cast<const f32x2 *>(s_w1 + 4 * CIN + 2 * (k0 + u));
+          v[u] = ok ? bn_act(dot3w(px0, px1, px2, wk[0], wk[1], wk[2]), ss[0], ss[1]) : 0.f;
+        }
+        *reinterpret_cast<f32x2 *>(s_a + frow * SA + (k0 >> 1)) = f32x2{v[0], v[2]};
+        *reinterpret_cast<f32x2 *>(s_a + frow * SA + CIN / 2 + (k0 >> 1)) = f32x2{v[1], v[3]};
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPASS; ++j) {
+        const int row = r0 + RPP * j;
+        const bool ok = s0 + row < rg.total;
+        const f32x4 y = pre[j];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ok ? bn_act(y[u], sc4[u], sh4[u]) : 0.f;
+        *reinterpret_cast<f32x2 *>(s_a + row * SA + 2 * cq) = f32x2{v[0], v[2]};
+        *reinterpret_cast<f32x2 *>(s_a + row * SA + CIN / 2 + 2 * cq) = f32x2{v[1], v[3]};
+      }
+    }
+    if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
+    __syncthreads();
+    if (sub + 1 < rg.sub1) prefetch(sub + 1);
+
+    f32x16 acc[2][CBW];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.f;
+#pragma unroll
+    for (int kq = 0; kq < KK / 4; ++kq) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_a + l31 * SA + h * (CIN / 2) + 4 * kq);
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(s_a + (32 + l31) * SA + h * (CIN / 2) + 4 * kq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+          acc[0][cb] = mfma(a0[i], wreg[cb][4 * kq + i], acc[0][cb]);
+          acc[1][cb] = mfma(a1[i], wreg[cb][4 * kq + i], acc[1][cb]);
+        }
+    }
+
+    // ---- epilogue: statistics, store, pooling tile
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rowq = 32 * rb + 8 * q + 4 * h;  // rows rowq .. rowq + 3 <-> registers 4 q .. 4 q + 3
+        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_w + rowq);
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+          const int col = cbase + 32 * cb + l31;
+          f32x4 y4;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) y4[u] = acc[rb][cb][4 * q + u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float wy = w4[u] * y4[u];
+            st_s[cb][u & 1] += wy;
+            st_q[cb][u & 1] = fmaf(wy, y4[u], st_q[cb][u & 1]);
+          }
+          if (a.y_out) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const long long r = s0 + rowq + u;
+              if (r < rg.total) a.y_out[r * COUT + col] = y4[u];
+            }
+          }
+          if (POOL) *reinterpret_cast<f32x4 *>(s_y + col * SY + rowq) = y4;
+        }
+      }
+    }
+    if (POOL) {
+      __syncthreads();
+      const long long left = rg.total - s0;
+      const int nvalid = left < kRows ? static_cast<int>(left) : kRows;
+      const float *col = s_y + tid * SY;
+      for (int r4 = 0; r4 < nvalid; r4 += 4) {
+        const f32x4 y4 = *reinterpret_cast<const f32x4 *>(col + r4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r4 + u;
+          if (r < nvalid) {
+            const int packed = s_grow[r];  // (group << 6) | row-in-group
+            const int g = packed >> 6, rin = packed & 63;
+            if (g != cur_g) {  // uniform over the workgroup
+              if (cur_g >= 0) flush();
+              cur_g = g;
+              tail = s0 + r - rin < row_first;
+              best = -INFINITY;
+              arg = rin;
+            }
+            const float v = y4[u] * sg;
+            if (v > best) { best = v; arg = rin; }
+          }
+        }
+      }
+    }
+  }
+  if (POOL && cur_g >= 0) flush();
+
+  // statistics: the two half-waves hold the two row halves of a column
+#pragma unroll
+  for (int cb = 0; cb < CBW; ++cb) {
+    float s = st_s[cb][0] + st_s[cb][1], q = st_q[cb][0] + st_q[cb][1];
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (h == 0) {
+      const int col = cbase + 32 * cb + l31;
+      atomicAdd(a.sums + col, static_cast<double>(s));
+      atomicAdd(a.sums + COUT + col, static_cast<double>(q));
+    }
+  }
+}
+
+// merge the partial pools of the groups that straddle two workgroups, then out = relu(bn(ysel))
+__global__ __launch_bounds__(kT) void pool_finish_kernel(float *__restrict__ ysel, int32_t *__restrict__ sel,
+                                                         const float *__restrict__ part_y, const int32_t *__restrict__ part_sel,
+                                                         const int32_t *__restrict__ part_gid, const int32_t *__restrict__ goff,
+                                                         const float *__restrict__ gamma, const float *__restrict__ stats,
+                                                         float *__restrict__ out, long long groups, int c, int nblk) {
+  const long long total = goff[groups];
+  const long long nsub = (total + kRows - 1) / kRows;
+  const long long per = (nsub + nblk - 1) / nblk;
+  for (long long i = blockIdx.x * static_cast<long long>(kT) + threadIdx.x; i < groups * c;
+       i += static_cast<long long>(gridDim.x) * kT) {
+    const long long g = i / c;
+    const int ch = static_cast<int>(i - g * c);
+    float y = ysel[i];
+    int s = sel[i];
+    const long long first = goff[g], last = static_cast<long long>(goff[g + 1]) - 1;
+    const long long b0 = (first / kRows) / per, b1 = (last / kRows) / per;
+    if (b1 != b0 && part_gid[b1] == static_cast<int32_t>(g)) {
+      const float sg = gamma[ch] >= 0.0f ? 1.0f : -1.0f;
+      const float y2 = part_y[b1 * c + ch];
+      if (y2 * sg > y * sg) {  // strict: on ties the head part (lower rows) wins
+        y = y2;
+        s = part_sel[b1 * c + ch];
+      }
+      ysel[i] = y;
+      sel[i] = s;
+    }
+    out[i] = fmaxf(__fadd_rn(__fmul_rn(y, stats[ch]), stats[c + ch]), 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const float *y_out, *dmid, *d;
+  const int32_t *sel;
+  const float *ca, *cm1, *cm2, *cmean, *cinv;  // per output channel: a = gamma invstd, m1, m2, mean, invstd
+  const float *w;                              // (COUT, CIN)
+  const float *src_in, *w1, *st_in;            // input activations: y_in (rows, CIN) or x (rows, 3) + w1
+  const float *roww;
+  const int32_t *goff, *grow;
+  long long groups;
+  float *dmid_in;
+  double *sums_in;
+  float *partials;
+};
+
+// dy of one float4 of a row: the op order of csrc/sa_mlp.hip's bn_bwd_sparse / relu_bn_bwd_apply kernels
+__device__ __forceinline__ f32x4 dy4(f32x4 y, f32x4 dsel, float w, f32x4 ca, f32x4 m1, f32x4 m2, f32x4 mu, f32x4 is) {
+  f32x4 o;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) o[u] = ca[u] * (dsel[u] - w * (m1[u] + (y[u] - mu[u]) * is[u] * m2[u]));
+  return o;
+}
+
+// Staging of the dy tile, shared by the dx and the dw kernel.  Thread = (channel quad cq, rows r0 + RPP j).
+// LAST: the upstream gradient is the pooled one; a wave owns whole rows (COUT == 256), so the group of a row is
+// wave-uniform.  The (d, sel) quads of the groups of the wave's first and last row of the NEXT sub-tile are
+// prefetched with the tile; a row of a third group in between reads them directly.
+template <int COUT, bool LAST>
+struct DyStage {
+  static constexpr int QPR = COUT / 4;
+  static constexpr int RPP = kT / QPR;
+  static constexpr int NPASS = kRows / RPP;
+  f32x4 py[NPASS];
+  f32x4 pd[LAST ? 1 : NPASS];
+  f32x4 ca, m1, m2, mu, is;
+  int cq, r0;
+  // LAST: prefetched (d, sel) of two groups; nA / nB: their ids one sub-tile further ahead (so that the (d, sel)
+  // loads of a prefetch never wait for an id load issued in the same prefetch), -2 = not loaded yet
+  int nA = -2, nB = -2;
+  int gA = -1, gB = -1;
+  f32x4 dA = {0, 0, 0, 0}, dB = {0, 0, 0, 0};
+  i32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
+
+  __device__ __forceinline__ void init(const BwdArgs &a) {
+    cq = threadIdx.x % QPR;
+    r0 = threadIdx.x / QPR;
+    ca = ldg4(a.ca + 4 * cq); m1 = ldg4(a.cm1 + 4 * cq); m2 = ldg4(a.cm2 + 4 * cq);
+    mu = ldg4(a.cmean + 4 * cq); is = ldg4(a.cinv + 4 * cq);
+  }
+  __device__ __forceinline__ void prefetch(const BwdArgs &a, long long s0, long long total) {
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+      const long long r = s0 + r0 + RPP * j;
+      const bool ok = r < total;
+      py[j] = ok ? ldg4(a.y_out + r * COUT + 4 * cq) : f32x4{0, 0, 0, 0};
+      if (!LAST) pd[j] = ok ? ldg4(a.dmid + r * COUT + 4 * cq) : f32x4{0, 0, 0, 0};
+    }
+    if (LAST) {
+      const long long ra = s0 + r0, rb = s0 + r0 + RPP * (NPASS - 1);
+      if (nA == -2) {  // first sub-tile of the workgroup
+        nA = ra < total ? a.grow[ra] >> 6 : -1;
+        nB = rb < total ? a.grow[rb] >> 6 : -1;
+      }
+      gA = nA;
+      gB = nB < 0 ? nA : nB;
+      nA = ra + kRows < total ? a.grow[ra + kRows] >> 6 : -1;
+      nB = rb + kRows < total ? a.grow[rb + kRows] >> 6 : -1;
+      if (gA >= 0) { dA = ldg4(a.d + static_cast<size_t>(gA) * COUT + 4 * cq); sA = ldg4i(a.sel + static_cast<size_t>(gA) * COUT + 4 * cq); }
+      if (gB >= 0) { dB = ldg4(a.d + static_cast<size_t>(gB) * COUT + 4 * cq); sB = ldg4i(a.sel + static_cast<size_t>(gB) * COUT + 4 * cq); }
+    }
+  }
+  // dy of pass j (row r0 + RPP j of the sub-tile at s0); zero for rows past the end
+  __device__ __forceinline__ f32x4 value(const BwdArgs &a, int j, long long s0, long long total, const float *s_w,
+                                         const int *s_grow) {
+    const int row = r0 + RPP * j;
+    if (s0 + row >= total) return f32x4{0, 0, 0, 0};
+    f32x4 dsel;
+    if (LAST) {
+      const int packed = s_grow[row];
+      const int g = packed >> 6, rin = packed & 63;
+      f32x4 dg;
+      i32x4 sg;
+      if (g == gA) { dg = dA; sg = sA; }
+      else if (g == gB) { dg = dB; sg = sB; }
+      else { dg = ldg4(a.d + static_cast<size_t>(g) * COUT + 4 * cq); sg = ldg4i(a.sel + static_cast<size_t>(g) * COUT + 4 * cq); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dsel[u] = rin == sg[u] ? dg[u] : 0.f;
+    } else {
+      dsel = pd[j];
+    }
+    return dy4(py[j], dsel, s_w[row], ca, m1, m2, mu, is);
+  }
+};
+
+template <int CIN, int COUT, bool LAST, bool FIRST>
+__global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
+  static_assert(!LAST || COUT == 256, "pooled layer: a wave stages whole rows");
+  static_assert(CIN == 64 || CIN == 128, "wave tiling");
+  constexpr int WN = CIN / 32;       // waves along the output columns (one 32-column block each)
+  constexpr int WM = 4 / WN;         // waves along the rows
+  constexpr int RBW = 2 / WM;        // 32-row blocks per wave
+  constexpr int KK = COUT / 2;       // MFMA k-steps (contraction over the output channels of the layer)
+  constexpr int SD = COUT + 4;
+  extern __shared__ float lds[];
+  float *s_dy = lds;                                 // [64][SD], channel c at (c & 1) * COUT/2 + (c >> 1)
+  float *s_w = s_dy + kRows * SD;                    // [64]
+  int *s_grow = reinterpret_cast<int *>(s_w + kRows);  // [64]
+  float *s_x = reinterpret_cast<float *>(s_grow + kRows);  // FIRST: [64][4] grouped xyz of the rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wn = wv / WM, wm = wv % WM;
+  const Range rg = wg_range(a.goff, a.groups);
+  const int kcol = 32 * wn + l31;  // this lane's input channel (column of dA)
+
+  float acc_s = 0.f, acc_x = 0.f, acc_t0 = 0.f, acc_t1 = 0.f, acc_t2 = 0.f;
+  if (rg.sub0 < rg.sub1) {
+    // stationary operand: B[k = c = 2 cc + h][j = input channel] = w[c][kcol]
+    float wreg[KK];
+#pragma unroll
+    for (int cc = 0; cc < KK; ++cc) wreg[cc] = a.w[static_cast<size_t>(2 * cc + h) * CIN + kcol];
+    // the layer below, for the epilogue: scale, shift, mean, invstd of this lane's input channel
+    const float e_sc = a.st_in[kcol], e_sh = a.st_in[CIN + kcol], e_mu = a.st_in[2 * CIN + kcol], e_is = a.st_in[3 * CIN + kcol];
+    float e_w0 = 0.f, e_w1 = 0.f, e_w2 = 0.f;
+    if (FIRST) { e_w0 = a.w1[3 * kcol]; e_w1 = a.w1[3 * kcol + 1]; e_w2 = a.w1[3 * kcol + 2]; }
+
+    DyStage<COUT, LAST> st;
+    st.init(a);
+    float pw = 0.f, px[3] = {0.f, 0.f, 0.f};
+    int pg = 0;
+    auto prefetch = [&](long long sub) {
+      const long long s0 = sub * kRows;
+      st.prefetch(a, s0, rg.total);
+      if (tid < kRows) {
+        const long long r = s0 + tid;
+        const bool ok = r < rg.total;
+        pw = ok ? a.roww[r] : 0.f;
+        pg = ok ? a.grow[r] : -1;
+        if (FIRST) {
+          px[0] = ok ? a.src_in[r * 3] : 0.f; px[1] = ok ? a.src_in[r * 3 + 1] : 0.f; px[2] = ok ? a.src_in[r * 3 + 2] : 0.f;
+        }
+      }
+    };
+    prefetch(rg.sub0);
+    for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
+      const long long s0 = sub * kRows;
+      __syncthreads();
+      if (tid < kRows) {
+        s_w[tid] = pw; s_grow[tid] = pg;
+        if (FIRST) { s_x[4 * tid] = px[0]; s_x[4 * tid + 1] = px[1]; s_x[4 * tid + 2] = px[2]; s_x[4 * tid + 3] = 0.f; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
+        const f32x4 v = st.value(a, j, s0, rg.total, s_w, s_grow);
+        const int row = st.r0 + DyStage<COUT, LAST>::RPP * j;
+        *reinterpret_cast<f32x2 *>(s_dy + row * SD + 2 * st.cq) = f32x2{v[0], v[2]};
+        *reinterpret_cast<f32x2 *>(s_dy + row * SD + COUT / 2 + 2 * st.cq) = f32x2{v[1], v[3]};
+      }
+      __syncthreads();
+      if (sub + 1 < rg.sub1) prefetch(sub + 1);
+
+      // y_in of this lane's accumulator elements (epilogue), in flight under the MFMAs
+      float yin[RBW][16];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = 32 * (wm * RBW + rb) + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (FIRST) {
+            const f32x4 xr = *reinterpret_cast<const f32x4 *>(s_x + 4 * row);
+            yin[rb][e] = dot3w(xr[0], xr[1], xr[2], e_w0, e_w1, e_w2);
+          } else {
+            const long long r = s0 + row;
+            yin[rb][e] = r < rg.total ? a.src_in[r * CIN + kcol] : 0.f;
+          }
+        }
+
+      f32x16 acc[RBW];
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
+#pragma unroll
+      for (int kq = 0; kq < KK / 4; ++kq) {
+        f32x4 av[RBW];
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb)
+          av[rb] = *reinterpret_cast<const f32x4 *>(s_dy + (32 * (wm * RBW + rb) + l31) * SD + h * (COUT / 2) + 4 * kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int rb = 0; rb < RBW; ++rb) acc[rb] = mfma(av[rb][i], wreg[4 * kq + i], acc[rb]);
+      }
+
+      // ---- epilogue: ReLU mask of the layer below, its BN-backward sums, store
+#pragma unroll
+      for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = 32 * (wm * RBW + rb) + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const long long r = s0 + row;
+          const float y = yin[rb][e];
+          const bool on = __fadd_rn(__fmul_rn(y, e_sc), e_sh) > 0.0f && r < rg.total;
+          const float dm = on ? acc[rb][e] : 0.f;
+          acc_s += dm;
+          acc_x = fmaf(dm, (y - e_mu) * e_is, acc_x);
+          if (FIRST) {
+            const f32x4 xr = *reinterpret_cast<const f32x4 *>(s_x + 4 * row);
+            acc_t0 = fmaf(dm, xr[0], acc_t0); acc_t1 = fmaf(dm, xr[1], acc_t1); acc_t2 = fmaf(dm, xr[2], acc_t2);
+          } else if (r < rg.total) {
+            a.dmid_in[r * CIN + kcol] = dm;
+          }
+        }
+    }
+  }
+  // sums of this lane's input channel: the two half-waves hold different rows
+  acc_s += __shfl_xor(acc_s, 32);
+  acc_x += __shfl_xor(acc_x, 32);
+  if (FIRST) { acc_t0 += __shfl_xor(acc_t0, 32); acc_t1 += __shfl_xor(acc_t1, 32); acc_t2 += __shfl_xor(acc_t2, 32); }
+  if (h == 0 && rg.sub0 < rg.sub1) {
+    atomicAdd(a.sums_in + kcol, static_cast<double>(acc_s));
+    atomicAdd(a.sums_in + CIN + kcol, static_cast<double>(acc_x));
+    if (FIRST) {
+      atomicAdd(a.sums_in + 2 * CIN + kcol, static_cast<double>(acc_t0));
+      atomicAdd(a.sums_in + 3 * CIN + kcol, static_cast<double>(acc_t1));
+      atomicAdd(a.sums_in + 4 * CIN + kcol, static_cast<double>(acc_t2));
+    }
+  }
+}
+
+template <int CIN, int COUT, bool LAST, bool FIRST>
+__global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
+  static_assert(!LAST || COUT == 256, "pooled layer: a wave stages whole rows");
+  constexpr int IB = COUT / 32, JB = CIN / 32;
+  static_assert(IB % 4 == 0, "wave tiling");
+  constexpr int IBW = IB / 4;        // 32-row blocks of dW per wave (all JB column blocks)
+  constexpr int SD = COUT;           // dy tile [64][COUT], natural layout
+  constexpr int SA = CIN;            // act tile [64][CIN]
+  constexpr int QPA = CIN / 4, RPA = kT / QPA, NPA = kRows / RPA;
+  extern __shared__ float lds[];
+  float *s_dy = lds;
+  float *s_a = s_dy + kRows * SD;
+  float *s_w = s_a + kRows * SA;
+  int *s_grow = reinterpret_cast<int *>(s_w + kRows);
+  float *s_w1 = reinterpret_cast<float *>(s_grow + kRows);  // FIRST: [CIN][4] w1, [CIN][2] scale / shift
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const Range rg = wg_range(a.goff, a.groups);
+
+  f32x16 acc[IBW][JB];
+#pragma unroll
+  for (int ib = 0; ib < IBW; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ib][jb][e] = 0.f;
+
+  if (rg.sub0 < rg.sub1) {
+    if (FIRST) {
+      for (int k = tid; k < CIN; k += kT) {
+        s_w1[4 * k] = a.w1[3 * k]; s_w1[4 * k + 1] = a.w1[3 * k + 1]; s_w1[4 * k + 2] = a.w1[3 * k + 2]; s_w1[4 * k + 3] = 0.f;
+        s_w1[4 * CIN + 2 * k] = a.st_in[k]; s_w1[4 * CIN + 2 * k + 1] = a.st_in[CIN + k];
+      }
+    }
+    DyStage<COUT, LAST> st;
+    st.init(a);
+    const int aq = tid % QPA, ar0 = tid / QPA;
+    f32x4 sc4 = {0, 0, 0, 0}, sh4 = {0, 0, 0, 0};
+    if (!FIRST) { sc4 = ldg4(a.st_in + 4 * aq); sh4 = ldg4(a.st_in + CIN + 4 * aq); }
+    const int frow = tid >> 2, fpart = tid & 3;
+    f32x4 pa[FIRST ? 1 : NPA];
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f, pw = 0.f;
+    int pg = 0;
+    auto prefetch = [&](long long sub) {
+      const long long s0 = sub * kRows;
+      st.prefetch(a, s0, rg.total);
+      if (FIRST) {
+        const long long r = s0 + frow;
+        const bool ok = r < rg.total;
+        px0 = ok ? a.src_in[r * 3] : 0.f; px1 = ok ? a.src_in[r * 3 + 1] : 0.f; px2 = ok ? a.src_in[r * 3 + 2] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+          const long long r = s0 + ar0 + RPA * j;
+          pa[j] = r < rg.total ? ldg4(a.src_in + r * CIN + 4 * aq) : f32x4{0, 0, 0, 0};
+        }
+      }
+      if (tid < kRows) {
+        const long long r = s0 + tid;
+        pw = r < rg.total ? a.roww[r] : 0.f;
+        pg = r < rg.total ? a.grow[r] : -1;
+      }
+    };
+    prefetch(rg.sub0);
+    for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
+      const long long s0 = sub * kRows;
+      __syncthreads();
+      if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
+      // activations of the layer below
+      if (FIRST) {
+        const bool ok = s0 + frow < rg.total;
+#pragma unroll
+        for (int i = 0; i < CIN / 4; i += 4) {
+          const int k0 = fpart * (CIN / 4) + i;
+          f32x4 v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 wk = *reinterpret_cast<const f32x4 *>(s_w1 + 4 * (k0 + u));
+            const f32x2 ss = *reinterpret_cast<const f32x2 *>(s_w1 + 4 * CIN + 2 * (k0 + u));
+            v[u] = ok ? bn_act(dot3w(px0, px1, px2, wk[0], wk[1], wk[2]), ss[0], ss[1]) : 0.f;
+          }
+          *reinterpret_cast<f32x4 *>(s_a + frow * SA + k0) = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+          const int row = ar0 + RPA * j;
+          const bool ok = s0 + row < rg.total;
+          f32x4 v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = ok ? bn_act(pa[j][u], sc4[u], sh4[u]) : 0.f;
+          *reinterpret_cast<f32x4 *>(s_a + row * SA + 4 * aq) = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
+        const f32x4 v = st.value(a, j, s0, rg.total, s_w, s_grow);
+        const int row = st.r0 + DyStage<COUT, LAST>::RPP * j;
+        *reinterpret_cast<f32x4 *>(s_dy + row * SD + 4 * st.cq) = v;
+      }
+      __syncthreads();
+      if (sub + 1 < rg.sub1) prefetch(sub + 1);
+
+      // dW[c][k] += sum_rows dy[row][c] act[row][k]: A[i = c][k = row], B[k = row][j = k-channel]
+#pragma unroll 4
+      for (int kk = 0; kk < kRows / 2; ++kk) {
+        float af[IBW], bf[JB];
+#pragma unroll
+        for (int ib = 0; ib < IBW; ++ib) af[ib] = s_dy[(2 * kk + h) * SD + 32 * (IBW * wv + ib) + l31];
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) bf[jb] = s_a[(2 * kk + h) * SA + 32 * jb + l31];
+#pragma unroll
+        for (int ib = 0; ib < IBW; ++ib)
+#pragma unroll
+          for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = mfma(af[ib], bf[jb], acc[ib][jb]);
+      }
+    }
+  }
+  // this workgroup's partial tile (zeros when it had no rows)
+  float *out = a.partials + static_cast<size_t>(blockIdx.x) * COUT * CIN;
+#pragma unroll
+  for (int ib = 0; ib < IBW; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = 32 * (IBW * wv + ib) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        out[static_cast<size_t>(c) * CIN + 32 * jb + l31] = acc[ib][jb][e];
+      }
+}
+
+// dw[i] = sum over the workgroups' partial tiles, in workgroup order (deterministic)
+__global__ __launch_bounds__(kT) void dw_reduce_kernel(const float *__restrict__ partials, float *__restrict__ dw, int n, int nblk) {
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partials[static_cast<size_t>(b) * n + i];
+  dw[i] = s;
+}
+
+int device_cus() {
+  static std::mutex mu;
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
+template <int CIN, int COUT, bool FIRST, bool POOL>
+int launch_fwd(const FwdArgs &a, int nblk, hipStream_t s) {
+  size_t lds = sizeof(float) * (kRows * (CIN + 4) + 2 * kRows);
+  if (POOL) lds += sizeof(float) * COUT * (kRows + 4);
+  if (FIRST) lds += sizeof(float) * 6 * CIN;
+  auto kern = sa_fwd_kernel<CIN, COUT, FIRST, POOL>;
+  int st = raise_dynamic_lds(kern, lds);
+  if (st != CODA_OK) return st;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(kT), lds, s, a);
+  return launch_status();
+}
+template <int CIN, int COUT, bool LAST, bool FIRST>
+int launch_dx(const BwdArgs &a, int nblk, hipStream_t s) {
+  size_t lds = sizeof(float) * (kRows * (COUT + 4) + 2 * kRows + (FIRST ? 4 * kRows : 0));
+  auto kern = sa_bwd_dx_kernel<CIN, COUT, LAST, FIRST>;
+  int st = raise_dynamic_lds(kern, lds);
+  if (st != CODA_OK) return st;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(kT), lds, s, a);
+  return launch_status();
+}
+template <int CIN, int COUT, bool LAST, bool FIRST>
+int launch_dw(const BwdArgs &a, int nblk, hipStream_t s) {
+  size_t lds = sizeof(float) * (kRows * COUT + kRows * CIN + 2 * kRows + (FIRST ? 6 * CIN : 0));
+  auto kern = sa_bwd_dw_kernel<CIN, COUT, LAST, FIRST>;
+  int st = raise_dynamic_lds(kern, lds);
+  if (st != CODA_OK) return st;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(kT), lds, s, a);
+  return launch_status();
+}
+
+bool fill_coef(BwdArgs &a, const float *coef, int layout, int cout) {
+  if (!coef) return false;
+  if (layout == 1) {  // [a, m1, m2, mean, invstd]
+    a.ca = coef; a.cm1 = coef + cout; a.cm2 = coef + 2 * cout; a.cmean = coef + 3 * cout; a.cinv = coef + 4 * cout;
+  } else if (layout == 0) {  // [scale, shift, mean, invstd, a, m1, m2]
+    a.cmean = coef + 2 * cout; a.cinv = coef + 3 * cout; a.ca = coef + 4 * cout; a.cm1 = coef + 5 * cout; a.cm2 = coef + 6 * cout;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+}  // namespace coda
+
+using namespace coda;
+
+CODA_API int coda_sa_mfma_blocks(void) { return device_cus(); }
+
+CODA_API int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len) {
+  return c1 == 64 && c2 == 128 && c3 == 256 && s_len >= 1 && s_len <= kRows ? 1 : 0;
+}
+
+CODA_API int coda_sa_pack_groups_f32(const float *grouped, const int32_t *idx, int dedup, float *x, float *row_weight,
+                                     int32_t *group_offsets, int32_t *row_group, double *moments, int32_t *counts,
+                                     double *zero, int nzero, long long groups, int s_len, void *stream) {
+  if (groups < 0 || s_len <= 0 || nzero < 0 || groups * s_len > 0x7fffffffLL) return CODA_EINVAL;
+  if (!group_offsets || !moments || (nzero > 0 && !zero)) return CODA_EINVAL;
+  if (groups > 0 && (!grouped || !idx || !x || !row_weight || !row_group || !counts)) return CODA_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_sticky_error();
+  if (groups > 0)
+    hipLaunchKernelGGL(pack_count_kernel, dim3(static_cast<unsigned>((groups + 3) / 4)), dim3(kT), 0, s, idx, counts, groups,
+                       s_len, dedup);
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, s, counts, group_offsets, groups, moments, zero, nzero);
+  if (groups > 0)
+    hipLaunchKernelGGL(pack_scatter_kernel, dim3(static_cast<unsigned>((groups * s_len + kT - 1) / kT)), dim3(kT), 0, s,
+                       grouped, counts, group_offsets, x, row_weight, row_group, moments, groups, s_len);
+  return launch_status();
+}
+
+CODA_API int coda_sa_l1_sums_f32(const double *moments, const float *w1, double *sums, int c, void *stream) {
+  if (c <= 0 || !moments || !w1 || !sums) return CODA_EINVAL;
+  clear_sticky_error();
+  hipLaunchKernelGGL(l1_sums_kernel, dim3((c + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), moments, w1, sums, c);
+  return launch_status();
+}
+
+CODA_API int coda_sa_mfma_fwd_f32(const float *src, const float *w1, const float *stats_in, const float *w,
+                                  const float *row_weight, const int32_t *group_offsets, const int32_t *row_group,
+                                  long long groups, int s_len, int cin, int cout, float *y_out, double *sums,
+                                  const float *gamma, float *ysel, int32_t *sel, float *part_y, int32_t *part_sel,
+                                  int32_t *part_gid, int nblocks, void *stream) {
+  if (groups < 0 || s_len <= 0 || s_len > kRows || nblocks <= 0) return CODA_EINVAL;
+  if (groups == 0) return CODA_OK;
+  if (!src || !stats_in || !w || !row_weight || !group_offsets || !row_group || !sums) return CODA_EINVAL;
+  const bool pool = ysel != nullptr;
+  if (pool && (!gamma || !sel || !part_y || !part_sel || !part_gid)) return CODA_EINVAL;
+  FwdArgs a{src, w1, stats_in, w, row_weight, group_offsets, row_group, groups, y_out, sums, gamma, ysel, sel, part_y, part_sel, part_gid};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_sticky_error();
+  if (w1 && !pool && cin == 64 && cout == 128) return launch_fwd<64, 128, true, false>(a, nblocks, s);
+  if (!w1 && pool && cin == 128 && cout == 256) return launch_fwd<128, 256, false, true>(a, nblocks, s);
+  return CODA_EINVAL;
+}
+
+CODA_API int coda_sa_pool_finish_f32(float *ysel, int32_t *sel, const float *part_y, const int32_t *part_sel,
+                                     const int32_t *part_gid, const int32_t *group_offsets, const float *gamma,
+                                     const float *stats, float *out, long long groups, int c, int nblocks, void *stream) {
+  if (groups < 0 || c <= 0 || nblocks <= 0) return CODA_EINVAL;
+  if (groups == 0) return CODA_OK;
+  if (!ysel || !sel || !part_y || !part_sel || !part_gid || !group_offsets || !gamma || !stats || !out) return CODA_EINVAL;
+  long long blocks = (groups * c + kT * 4 - 1) / (kT * 4);
+  blocks = blocks > 8192 ? 8192 : blocks;
+  clear_sticky_error();
+  hipLaunchKernelGGL(pool_finish_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kT), 0, static_cast<hipStream_t>(stream),
+                     ysel, sel, part_y, part_sel, part_gid, group_offsets, gamma, stats, out, groups, c, nblocks);
+  return launch_status();
+}
+
+namespace {
+int bwd_args(BwdArgs &a, const float *y_out, const float *dmid, const float *d, const int32_t *sel, const float *coef,
+             int layout, const float *src_in, const float *w1, const float *stats_in, const float *row_weight,
+             const int32_t *group_offsets, const int32_t *row_group, long long groups, int s_len, int cout, int nblocks) {
+  if (groups < 0 || s_len <= 0 || s_len > kRows || nblocks <= 0) return CODA_EINVAL;
+  if (!y_out || !src_in || !stats_in || !row_weight || !group_offsets || !row_group) return CODA_EINVAL;
+  const bool last = d != nullptr;
+  if (last ? (!sel || dmid || layout != 1) : (!dmid || layout != 0)) return CODA_EINVAL;
+  a = BwdArgs{};
+  a.y_out = y_out; a.dmid = dmid; a.d = d; a.sel = sel;
+  if (!fill_coef(a, coef, layout, cout)) return CODA_EINVAL;
+  a.src_in = src_in; a.w1 = w1; a.st_in = stats_in; a.roww = row_weight; a.goff = group_offsets; a.grow = row_group;
+  a.groups = groups;
+  return CODA_OK;
+}
+}  // namespace
+
+CODA_API int coda_sa_mfma_bwd_dx_f32(const float *y_out, const float *dmid, const float *d, const int32_t *sel,
+                                     const float *coef, int layout, const float *w, const float *src_in, const float *w1,
+                                     const float *stats_in, const float *row_weight, const int32_t *group_offsets,
+                                     const int32_t *row_group, long long groups, int s_len, int cin, int cout,
+                                     float *dmid_in, double *sums_in, int nblocks, void *stream) {
+  if (!sums_in || cin <= 0) return CODA_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(sums_in, 0, sizeof(double) * (w1 ? 5 : 2) * cin, s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (groups == 0) return CODA_OK;
+  BwdArgs a;
+  int st = bwd_args(a, y_out, dmid, d, sel, coef, layout, src_in, w1, stats_in, row_weight, group_offsets, row_group,
+                    groups, s_len, cout, nblocks);
+  if (st != CODA_OK) return st;
+  if (!w || (!w1 && !dmid_in)) return CODA_EINVAL;
+  a.w = w; a.dmid_in = dmid_in; a.sums_in = sums_in;
+  clear_sticky_error();
+  if (d && !w1 && cin == 128 && cout == 256) return launch_dx<128, 256, true, false>(a, nblocks, s);
+  if (!d && w1 && cin == 64 && cout == 128) return launch_dx<64, 128, false, true>(a, nblocks, s);
+  return CODA_EINVAL;
+}
+
+CODA_API int coda_sa_mfma_bwd_dw_f32(const float *y_out, const float *dmid, const float *d, const int32_t *sel,
+                                     const float *coef, int layout, const float *src_in, const float *w1,
+                                     const float *stats_in, const float *row_weight, const int32_t *group_offsets,
+                                     const int32_t *row_group, long long groups, int s_len, int cin, int cout,
+                                     float *partials, float *dw, int nblocks, void *stream) {
+  if (!dw || !partials || cin <= 0 || cout <= 0) return CODA_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (groups == 0) return static_cast<int>(hipMemsetAsync(dw, 0, sizeof(float) * cin * cout, s));
+  BwdArgs a;
+  int st = bwd_args(a, y_out, dmid, d, sel, coef, layout, src_in, w1, stats_in, row_weight, group_offsets, row_group,
+                    groups, s_len, cout, nblocks);
+  if (st != CODA_OK) return st;
+  a.partials = partials;
+  clear_sticky_error();
+  if (d && !w1 && cin == 128 && cout == 256) st = launch_dw<128, 256, true, false>(a, nblocks, s);
+  else if (!d && w1 && cin == 64 && cout == 128) st = launch_dw<64, 128, false, true>(a, nblocks, s);
+  else return CODA_EINVAL;
+  if (st != CODA_OK) return st;
+  const int n = cin * cout;
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((n + kT - 1) / kT), dim3(kT), 0, s, partials, dw, n, nblocks);
+  return launch_status();
+}
+
+CODA_API int coda_sa_l1_bwd_f32(const double *sums5, const double *sums_bn, double n, const float *gamma, const float *stats,
+                                const double *moments, const float *w1, float *dw1, float *dbeta, float *dgamma, int c,
+                                void *stream) {
+  if (c <= 0 || !sums5) return CODA_EINVAL;
+  if (dw1 && (!sums_bn || !gamma || !stats || !moments || !w1)) return CODA_EINVAL;
+  clear_sticky_error();
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3((c + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sums5, sums_bn, n,
+                     gamma, stats, moments, w1, dw1, dbeta, dgamma, c);
+  return launch_status();
+}

@@ -1,4 +1,4 @@
-"""Cross-rank gathering of the evaluation loop (utils/dist.py:164-185).
+"""Cross-rank helpers the reference's engine.py calls around the path (utils/dist.py:67-115, 164-185).
 
 ``all_gather_dict`` keeps the reference's contract -- every tensor of a dictionary concatenated over the ranks along
 dim 0, ``logit_scale`` and non-tensors dropped when distributed -- with one ``all_gather_into_tensor`` per entry
@@ -21,6 +21,32 @@ def get_world_size():
 
 def get_rank():
     return dist.get_rank() if is_distributed() else 0
+
+
+def all_reduce_average(tensor):
+    """utils/dist.py:67-87: the loss summed over the ranks / world size; the tensor itself when not distributed.
+    (engine.py:152 calls it on the loss every training step.)"""
+    if not is_distributed():
+        return tensor
+    t = tensor.detach()
+    t = t[None] if t.ndim == 0 else t.clone()
+    dist.all_reduce(t)
+    return (t.squeeze(0) if tensor.ndim == 0 else t) / get_world_size()
+
+
+def reduce_dict(input_dict, average=True):
+    """utils/dist.py:91-115 (engine.py:153): every value of the loss dictionary averaged over the ranks -- keys
+    sorted so that all ranks stack them in the same order, ONE all-reduce of the stacked scalars."""
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k].detach().reshape(()) for k in names], dim=0)
+        dist.all_reduce(values)
+        if average:
+            values /= world
+        return dict(zip(names, values))
 
 
 def all_gather_dict(data, skip=()):

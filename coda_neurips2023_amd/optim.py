@@ -267,6 +267,8 @@ class FlatGradReducer:
             for seg in self.segments:
                 for p in seg.params:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._hook_for(seg)))
+            if self.module is not None:  # re-arm at the start of every synchronised forward / backward pair
+                self._handles.append(self.module.register_forward_pre_hook(self.rearm))
         if broadcast and self.world > 1:
             self.sync_parameters(self.module)
 
@@ -293,8 +295,34 @@ class FlatGradReducer:
                 return
             seg.pending -= 1
             if seg.pending == 0:
-                self._fire(seg)
+                self._fire_ready()
         return hook
+
+    def _fire_ready(self):
+        """Fire, IN SEGMENT ORDER, every leading segment whose gradients are complete.  The collectives of all
+        ranks must be issued in the same order whatever order the gradients land in (a parameter without a
+        gradient on one rank leaves its segment to ``reduce()`` there): segment k is only ever issued after
+        segments 0..k-1, from a hook or from ``reduce()`` -- so every rank issues 0, 1, ... (round 3's advisor
+        finding: a hook-fired late segment in front of a ``reduce()``-fired early one mismatched the all-reduces)."""
+        for seg in self.segments:
+            if seg.fired:
+                continue
+            if seg.pending != 0:
+                break
+            self._fire(seg)
+
+    def rearm(self, *_):
+        """Reset the hook state (also the module's forward pre-hook): a backward that raised part-way, or a step
+        that skipped ``reduce()`` (engine.py:155-157's non-finite-loss exit, a ``continue`` in a caller's loop), must
+        not leave counters half decremented or a segment marked as fired for the next step."""
+        if not self._sync or not torch.is_grad_enabled():
+            return
+        for seg in self.segments:
+            if seg.work is not None:
+                seg.work.wait()
+                seg.work = None
+            seg.fired = False
+            seg.pending = len(seg.params)
 
     def no_sync(self):
         """Context manager: ``backward`` calls inside accumulate locally (no pack, no all-reduce), like DDP's."""

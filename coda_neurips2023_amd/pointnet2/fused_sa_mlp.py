@@ -4,10 +4,17 @@ Computes exactly what ``SharedMLP`` (1x1 Conv2d, no bias -> BatchNorm2d -> ReLU,
 layer) followed by ``F.max_pool2d`` over the nsample axis computes in the reference
 (pointnet2_modules.py:247-253, pytorch_utils.py:8-117), including train-mode batch
 statistics, running-statistics updates and SyncBatchNorm semantics, but on
-channels-last activations with the streaming kernels of ``csrc/sa_mlp.hip`` around plain
-library GEMMs (``torch.mm`` -> rocBLAS).  The parameters stay in the reference modules
-(``mlp_module.layer{i}.conv.weight``, ``...bn.bn.*``); this file only holds the autograd
-function that reads them.
+channels-last activations.  Two implementations:
+
+* ``_MfmaMlpPool`` (default for the pre-encoder's widths [3, 64, 128, 256]): the 1x1 convolutions
+  are hand-written fp32-MFMA GEMMs with BN / ReLU / statistics / pooling fused into their
+  prologues and epilogues (``csrc/sa_mfma.hip``, include/coda_sa_mlp.h "MFMA pipeline"); the
+  de-duplicated groups are packed on the device, so nothing waits for a row count on the host;
+* ``_FusedMlpPool`` (other widths; ``CODA_SA_MLP=streams`` for the A/B): the streaming kernels of
+  ``csrc/sa_mlp.hip`` around plain library GEMMs (``torch.mm`` -> rocBLAS).
+
+The parameters stay in the reference modules (``mlp_module.layer{i}.conv.weight``,
+``...bn.bn.*``); this file only holds the autograd functions that read them.
 """
 import os
 
@@ -255,6 +262,191 @@ class _FusedMlpPool(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+
+def _bn_stats(bn, s, n, gamma, beta, training, c, dev):
+    """stats = [scale, shift, mean, invstd][c] of one BatchNorm layer from sums s = [sum y, sum y^2] over n rows
+    (train mode: batch statistics + running-statistics update; SyncBatchNorm: sums all-reduced first) or from the
+    running statistics (eval mode) -- the bookkeeping of ``_FusedMlpPool.forward``, shared with the MFMA path."""
+    st = torch.empty((4, c), dtype=torch.float32, device=dev)
+    if training and (bn.momentum is not None or not bn.track_running_stats or bn.running_mean is None):
+        _all_reduce(s, bn)
+        track = bn.track_running_stats and bn.running_mean is not None
+        _call("coda_sa_bn_finalize_f32", _p(s), float(n), float(bn.eps), float(bn.momentum) if track else 0.0,
+              _p(gamma.detach()), _p(beta.detach()), _p(bn.running_mean) if track else None,
+              _p(bn.running_var) if track else None, _p(bn.num_batches_tracked) if track else None, _p(st), c)
+    elif training:  # cumulative moving average (momentum=None): the factor depends on a device counter
+        tot = _all_reduce(s.clone(), bn)
+        mean = tot[:c] / n
+        var = (tot[c:] / n - mean * mean).clamp_(min=0.0)
+        invstd = torch.rsqrt(var + bn.eps)
+        with torch.no_grad():
+            mom = 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(torch.float32), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1.0, 1.0))).to(torch.float32), alpha=mom)
+            bn.num_batches_tracked += 1
+        st[2], st[3] = mean.to(torch.float32), invstd.to(torch.float32)
+        st[0] = gamma * st[3]
+        st[1] = beta - st[2] * st[0]
+    else:
+        st[2], st[3] = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+        st[0] = gamma * st[3]
+        st[1] = beta - st[2] * st[0]
+    return st
+
+
+def pack_groups(idx, grouped_cl, widths, dedup=True):
+    """The parameter-free front of the MFMA path (``coda_sa_pack_groups_f32``; the sampling prefetcher runs it on
+    its side stream): the distinct rows of every ball-query group packed back to back, with their multiplicity,
+    group offsets, (group, row-in-group) words and the 3x3 moments of the packed xyz -- all on the device, no row
+    count travels to the host.  Also zeroes the statistics accumulators of the two MFMA layers.
+    idx (B,M,S) int32, grouped_cl (B,M,S,3) / (B*M*S,3) float32 -> tuple of tensors."""
+    b, m, s = idx.shape
+    g = b * m
+    dev = idx.device
+    cap = g * s
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    x = torch.empty((cap, 3), **f32)
+    roww = torch.empty(cap, **f32)
+    goff = torch.empty(g + 1, **i32)
+    grow = torch.empty(cap, **i32)
+    counts = torch.empty(max(g, 1), **i32)
+    mom = torch.empty(10, dtype=torch.float64, device=dev)
+    sums = torch.empty(2 * sum(widths), dtype=torch.float64, device=dev)  # [l1 | l2 | l3] x [sum, sum of squares]
+    zero = sums[2 * widths[0]:]
+    src = grouped_cl if grouped_cl.is_contiguous() else grouped_cl.contiguous()
+    _call("coda_sa_pack_groups_f32", _p(src), _p(idx.contiguous()), 1 if dedup else 0, _p(x), _p(roww), _p(goff), _p(grow),
+          _p(mom), _p(counts), _p(zero), zero.numel(), g, s)
+    return x, roww, goff, grow, mom, sums
+
+
+class _MfmaMlpPool(torch.autograd.Function):
+    """``packed`` = pack_groups(...) of the grouped xyz.  Returns (groups, C3).  Three layers [3 -> C1 -> C2 -> C3]
+    (coda_sa_mfma_supported)."""
+
+    @staticmethod
+    def forward(ctx, packed, groups, nsample, bns, training, *params):
+        lib = _lib.load()
+        x, roww, goff, grow, mom, sums = packed
+        dev = x.device
+        cap = x.shape[0]
+        ws = [params[3 * i].reshape(params[3 * i].shape[0], -1).contiguous() for i in range(3)]
+        gammas = [params[3 * i + 1] for i in range(3)]
+        betas = [params[3 * i + 2] for i in range(3)]
+        c1, c2, c3 = (w.shape[0] for w in ws)
+        world = [dist.get_world_size(bn.process_group) if _is_sync(bn) else 1 for bn in bns]
+        n_rows = groups * nsample  # rows the statistics are taken over (copies included)
+        nblk = lib.coda_sa_mfma_blocks()
+        f32 = dict(dtype=torch.float32, device=dev)
+        s1, s2, s3 = sums[:2 * c1], sums[2 * c1:2 * (c1 + c2)], sums[2 * (c1 + c2):]
+
+        # layer 1: y1 = x W1^T is linear in x -> batch statistics from the 3x3 moments; never formed in memory
+        if training:
+            _call("coda_sa_l1_sums_f32", _p(mom), _p(ws[0]), _p(s1), c1)
+        st1 = _bn_stats(bns[0], s1, float(n_rows * world[0]), gammas[0], betas[0], training, c1, dev)
+        # layer 2: prologue = layer 1 recomputed from x + BN + ReLU, epilogue = statistics
+        y2 = torch.empty((cap, c2), **f32)
+        _call("coda_sa_mfma_fwd_f32", _p(x), _p(ws[0]), _p(st1), _p(ws[1]), _p(roww), _p(goff), _p(grow), groups, nsample,
+              c1, c2, _p(y2), _p(s2), None, None, None, None, None, None, nblk)
+        st2 = _bn_stats(bns[1], s2, float(n_rows * world[1]), gammas[1], betas[1], training, c2, dev)
+        # layer 3: prologue = BN + ReLU of layer 2, epilogue = statistics + pooling (sign of gamma: max or min)
+        y3 = torch.empty((cap, c3), **f32)
+        ysel = torch.empty((groups, c3), **f32)
+        sel = torch.empty((groups, c3), dtype=torch.int32, device=dev)
+        part_y = torch.empty((nblk, c3), **f32)
+        part_sel = torch.empty((nblk, c3), dtype=torch.int32, device=dev)
+        part_gid = torch.empty(nblk, dtype=torch.int32, device=dev)
+        g3 = gammas[2].detach()
+        _call("coda_sa_mfma_fwd_f32", _p(y2), None, _p(st2), _p(ws[2]), _p(roww), _p(goff), _p(grow), groups, nsample,
+              c2, c3, _p(y3), _p(s3), _p(g3), _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), nblk)
+        st3 = _bn_stats(bns[2], s3, float(n_rows * world[2]), gammas[2], betas[2], training, c3, dev)
+        out = torch.empty((groups, c3), **f32)
+        _call("coda_sa_pool_finish_f32", _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), _p(goff), _p(g3),
+              _p(st3), _p(out), groups, c3, nblk)
+
+        ctx.meta = (groups, nsample, bns, training, world, n_rows, nblk)
+        ctx.wshape = [params[3 * i].shape for i in range(3)]
+        ctx.stats = [st1, st2, st3]
+        ctx.save_for_backward(x, roww, goff, grow, mom, y2, y3, ysel, sel, out, *ws, *gammas)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        groups, nsample, bns, training, world, n_rows, nblk = ctx.meta
+        x, roww, goff, grow, mom, y2, y3, ysel, sel, out = ctx.saved_tensors[:10]
+        ws = list(ctx.saved_tensors[10:13])
+        gammas = list(ctx.saved_tensors[13:16])
+        st1, st2, st3 = ctx.stats
+        dev = x.device
+        cap = x.shape[0]
+        c1, c2, c3 = (w.shape[0] for w in ws)
+        grads = [None] * 9
+        f32 = dict(dtype=torch.float32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+
+        # ---- layer 3: max-pool + ReLU backward on the pooled tensor, then BN backward inside the two GEMM kernels
+        d = torch.empty_like(out)
+        sums = torch.empty(2 * c3, **f64)
+        _call("coda_sa_pool_bwd_stats_f32", _p(gout.contiguous()), _p(out), _p(ysel), _p(st3), _p(d), groups, c3, _p(sums))
+        coef3 = _bwd_coef(ctx, 2, sums, st3, gammas[2], bns[2], training, n_rows * world[2], 1, grads, dev)
+        dmid2 = torch.empty((cap, c2), **f32)
+        sums2 = torch.empty(2 * c2, **f64)
+        _call("coda_sa_mfma_bwd_dx_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(ws[2]), _p(y2), None, _p(st2),
+              _p(roww), _p(goff), _p(grow), groups, nsample, c2, c3, _p(dmid2), _p(sums2), nblk)
+        partials = torch.empty((nblk, c3 * c2), **f32)
+        dw3 = torch.empty((c3, c2), **f32)
+        _call("coda_sa_mfma_bwd_dw_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(y2), None, _p(st2), _p(roww),
+              _p(goff), _p(grow), groups, nsample, c2, c3, _p(partials), _p(dw3), nblk)
+        grads[6] = dw3.reshape(ctx.wshape[2])
+
+        # ---- layer 2
+        prm2 = _bwd_coef(ctx, 1, sums2, st2, gammas[1], bns[1], training, n_rows * world[1], 0, grads, dev)
+        sums1 = torch.empty(5 * c1, **f64)
+        _call("coda_sa_mfma_bwd_dx_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(ws[1]), _p(x), _p(ws[0]), _p(st1),
+              _p(roww), _p(goff), _p(grow), groups, nsample, c1, c2, None, _p(sums1), nblk)
+        dw2 = torch.empty((c2, c1), **f32)
+        _call("coda_sa_mfma_bwd_dw_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(x), _p(ws[0]), _p(st1), _p(roww),
+              _p(goff), _p(grow), groups, nsample, c1, c2, _p(partials), _p(dw2), nblk)
+        grads[3] = dw2.reshape(ctx.wshape[1])
+
+        # ---- layer 1, closed form: dW1 / dgamma / dbeta from five sums per channel and the xyz moments
+        sums_bn = sums1
+        if training and _is_sync(bns[0]):
+            sums_bn = sums1[:2 * c1].clone()
+            _all_reduce(sums_bn, bns[0])
+        dw1 = torch.empty((c1, 3), **f32)
+        dbeta, dgamma = torch.empty(c1, **f32), torch.empty(c1, **f32)
+        _call("coda_sa_l1_bwd_f32", _p(sums1), _p(sums_bn), float(n_rows * world[0]) if training else 0.0, _p(gammas[0]),
+              _p(st1), _p(mom), _p(ws[0]), _p(dw1), _p(dbeta), _p(dgamma), c1)
+        grads[0], grads[1], grads[2] = dw1.reshape(ctx.wshape[0]), dgamma, dbeta
+        return (None, None, None, None, None, *grads)
+
+
+def mfma_eligible(mlp_module, nsample):
+    """Three layers at the widths csrc/sa_mfma.hip is instantiated for (the pre-encoder's [3, 64, 128, 256])."""
+    if os.environ.get("CODA_SA_MLP", "mfma") != "mfma":
+        return False
+    layers = list(mlp_module.children())
+    if len(layers) != 3:
+        return False
+    c = [layer.conv.out_channels for layer in layers]
+    return bool(_lib.load().coda_sa_mfma_supported(c[0], c[1], c[2], int(nsample)))
+
+
+def mfma_widths(mlp_module):
+    return [layer.conv.out_channels for layer in mlp_module.children()]
+
+
+def mfma_mlp_pool(packed, groups, nsample, mlp_module):
+    """packed = pack_groups(idx, grouped, mfma_widths(mlp_module)) -> (groups, C3)."""
+    layers = list(mlp_module.children())
+    bns = [layer.bn.bn for layer in layers]
+    params = []
+    for layer in layers:
+        params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
+    return _MfmaMlpPool.apply(packed, groups, nsample, bns, bns[0].training, *params)
+
+
 def fused_mlp_pool(x_cl, groups, nsample, mlp_module, idx=None, counts=None, total=None):
     """x_cl (P,3) float32 cuda grouped xyz (P = groups*nsample rows); mlp_module: the
     reference-shaped SharedMLP; idx: the ball-query indices (B,M,S) the rows came from.
@@ -264,6 +456,9 @@ def fused_mlp_pool(x_cl, groups, nsample, mlp_module, idx=None, counts=None, tot
     device anyway (the unchanged caller's step: 407 vs 376 scenes/s).  ``CODA_SA_DEDUP=nosync`` only
     de-duplicates with a prefetched count, ``CODA_SA_DEDUP=0`` never.
     -> (groups, C_last)."""
+    if idx is not None and mfma_eligible(mlp_module, nsample):
+        packed = pack_groups(idx, x_cl, mfma_widths(mlp_module), dedup=os.environ.get("CODA_SA_DEDUP", "auto") != "0")
+        return mfma_mlp_pool(packed, groups, nsample, mlp_module)
     layers = list(mlp_module.children())
     bns = [layer.bn.bn for layer in layers]
     params = []
@@ -272,6 +467,8 @@ def fused_mlp_pool(x_cl, groups, nsample, mlp_module, idx=None, counts=None, tot
     training = bns[0].training
     dedup = None
     mode = os.environ.get("CODA_SA_DEDUP", "auto")
+    if total is None and mode == "auto" and torch.cuda.is_current_stream_capturing():
+        mode = "nosync"  # the row count cannot be read back inside a stream capture
     if idx is not None and mode != "0" and (total is not None or mode != "nosync"):
         compact = compact_groups(idx, x_cl, counts, total)
         if compact is not None:

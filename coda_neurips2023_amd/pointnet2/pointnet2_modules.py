@@ -58,11 +58,19 @@ class PointnetSAModuleVotes(nn.Module):
         new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         idx, grouped_cl = _ext.query_and_group_xyz(new_xyz, xyz, self.radius, self.nsample,
                                                    self.normalize_xyz, channels_last=True)
+        front = {"xyz": xyz, "inds": inds, "new_xyz": new_xyz, "idx": idx, "grouped_cl": grouped_cl}
+        if fused_sa_mlp.mfma_eligible(self.mlp_module, self.nsample):
+            # MFMA path: groups packed on the device, nothing goes to the host
+            import os
+            front["packed"] = fused_sa_mlp.pack_groups(idx, grouped_cl, fused_sa_mlp.mfma_widths(self.mlp_module),
+                                                       dedup=os.environ.get("CODA_SA_DEDUP", "auto") != "0")
+            front["total_host"] = None
+            return front
         cnt, goff, tot = fused_sa_mlp.count_distinct_rows(idx)
         total_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
         total_host.copy_(tot, non_blocking=True)
-        return {"xyz": xyz, "inds": inds, "new_xyz": new_xyz, "idx": idx, "grouped_cl": grouped_cl,
-                "counts": (cnt, goff, tot), "total_host": total_host}
+        front.update(counts=(cnt, goff, tot), total_host=total_host)
+        return front
 
     @_lib.on_tensor_device()
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None,
@@ -73,6 +81,9 @@ class PointnetSAModuleVotes(nn.Module):
         row count must have arrived, i.e. the stream it ran on has been waited for)."""
         if prepared is not None and features is None and self._fused(xyz, None):
             b, npoint = prepared["new_xyz"].shape[0], prepared["new_xyz"].shape[1]
+            if "packed" in prepared:
+                pooled = fused_sa_mlp.mfma_mlp_pool(prepared["packed"], b * npoint, self.nsample, self.mlp_module)
+                return prepared["new_xyz"], pooled.view(b, npoint, -1).permute(0, 2, 1), prepared["inds"]
             pooled = fused_sa_mlp.fused_mlp_pool(prepared["grouped_cl"].view(-1, 3), b * npoint, self.nsample,
                                                  self.mlp_module, idx=prepared["idx"], counts=prepared["counts"],
                                                  total=None if prepared["total_host"] is None

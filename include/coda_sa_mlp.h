@@ -95,6 +95,90 @@ int coda_sa_compact_groups_f32(const float *grouped, const int64_t *cnt, const i
                                float *row_weight, int32_t *goff32, long long groups, int s_len, long long total,
                                long long rows_padded, void *stream);
 
+
+/* ---- MFMA pipeline (csrc/sa_mfma.hip) -------------------------------------------------------------------------
+ * The shared MLP [3 -> C1 -> C2 -> C3] + BN + ReLU + max-pool of the pre-encoder (pointnet2_modules.py:247-253,
+ * pytorch_utils.py:8-33; C1, C2, C3 = 64, 128, 256, models/model_3detr.py:3935-3944) with the 1x1 convolutions as
+ * hand-written fp32-MFMA GEMMs (v_mfma_f32_32x32x2_f32) fused with what surrounds them, instead of library GEMMs
+ * between streaming kernels:
+ *   forward   layer 1 is never formed in memory: its batch statistics follow from the 3x3 second moments of the
+ *             grouped xyz (y1 = x W1^T is linear), its activations are recomputed from x in the prologue of layer 2;
+ *             BN + ReLU of layer l is applied in the prologue of layer l + 1; per-channel sum / sum of squares of
+ *             the GEMM's output in its epilogue; the last layer pools (max or min by the sign of gamma, with the
+ *             arg) in its epilogue, so no kernel ever reads the 256-channel activation for statistics or pooling.
+ *             y2 and y3 (pre-BN) are stored once for the backward.
+ *   backward  dy of a layer is formed on the fly from (y, upstream gradient, BN coefficients) while the tile is
+ *             staged -- the pooled sparse gradient of the last layer never becomes a dense tensor -- and feeds
+ *             dA = dy W (epilogue: ReLU mask of the layer below + its BN-backward sums) and dW = dy^T A (per-workgroup
+ *             partial tiles, fixed-order reduction).  Layer 1's dW / dgamma / dbeta follow in closed form from
+ *             five sums per channel of layer 2's dA epilogue and the xyz moments.
+ * Rows: the DISTINCT rows of the ball-query groups (see "De-duplicated groups" above), packed on the device without
+ * a host read-back: every kernel takes the row count from group_offsets[groups] in device memory and splits the
+ * rows evenly over `nblocks` persistent workgroups (coda_sa_mfma_blocks(): one per CU).
+ */
+int coda_sa_mfma_blocks(void);
+/* Supported widths of coda_sa_mfma_*: (cin, cout) = (64, 128) [first: w1 != NULL] and (128, 256) [pooled]. */
+int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len);
+
+/* grouped (groups, s_len, 3) channels-last grouped xyz, idx (groups, s_len) its ball-query indices.
+ * dedup != 0: group g keeps its distinct rows (slot 0 and the slots whose index differs from slot 0's);
+ * dedup == 0: all s_len rows.  Outputs (capacity groups * s_len rows):
+ *   x (rows,3), row_weight (rows), group_offsets (groups + 1) int32, row_group (rows) int32 = (group << 6) | row
+ *   index inside the group (s_len <= 64),
+ *   moments (10 doubles): sum w, sum w x_j (3), sum w x_i x_j (xx, xy, xz, yy, yz, zz) over the packed rows.
+ * counts: scratch of `groups` int32.  `zero` / `nzero`: optional buffer of doubles zeroed by the call (the
+ * statistics accumulators of the forward kernels that follow: saves their memset launches). */
+int coda_sa_pack_groups_f32(const float *grouped, const int32_t *idx, int dedup, float *x, float *row_weight,
+                            int32_t *group_offsets, int32_t *row_group, double *moments, int32_t *counts,
+                            double *zero, int nzero, long long groups, int s_len, void *stream);
+/* sums[0:C] = sum_p w_p y1, sums[C:2C] = sum_p w_p y1^2 for y1 = x . w1[c] from the moments (w1 (C,3)). */
+int coda_sa_l1_sums_f32(const double *moments, const float *w1, double *sums, int c, void *stream);
+
+/* One layer, forward: y_out (rows, cout) = act_in W^T, W (cout, cin) row-major (the conv weight),
+ *   act_in = relu(scale_in * y_in + shift_in), y_in = src (rows, cin), or, first layer (w1 != NULL, (cin,3)):
+ *   y_in = src (rows,3) . w1^T recomputed on the fly;  stats_in = [scale, shift, ...][cin].
+ * sums (2*cout doubles, ACCUMULATED: zero them before, e.g. through coda_sa_pack_groups_f32) += [sum w y, sum w y^2].
+ * Pooled layer (ysel != NULL): per (group, channel) the pre-BN value with the largest sign(gamma[c]) * y and its row
+ * index inside the group (lowest on ties): ysel / sel (groups, cout) for the part of a group inside the workgroup
+ * that holds its first row, part_y / part_sel (nblocks, cout) + part_gid (nblocks) for the part a group has in the
+ * next workgroup; coda_sa_pool_finish_f32 merges them.  y_out may be NULL (not stored). */
+int coda_sa_mfma_fwd_f32(const float *src, const float *w1, const float *stats_in, const float *w,
+                         const float *row_weight, const int32_t *group_offsets, const int32_t *row_group,
+                         long long groups, int s_len, int cin, int cout, float *y_out, double *sums,
+                         const float *gamma, float *ysel, int32_t *sel, float *part_y, int32_t *part_sel,
+                         int32_t *part_gid, int nblocks, void *stream);
+/* merges the partial pools, then out = relu(ysel * scale + shift) (stats = [scale, shift, ..][c]) */
+int coda_sa_pool_finish_f32(float *ysel, int32_t *sel, const float *part_y, const int32_t *part_sel,
+                            const int32_t *part_gid, const int32_t *group_offsets, const float *gamma,
+                            const float *stats, float *out, long long groups, int c, int nblocks, void *stream);
+
+/* One layer, backward.  dy (rows, cout) is never stored:
+ *   dy[p][c] = a[c] * (dsel[p][c] - w_p * (m1[c] + (y_out[p][c] - mean[c]) * invstd[c] * m2[c]))
+ *   dsel = d[g][c] if row-in-group == sel[g][c] else 0   (pooled layer: d, sel (groups, cout), layout 1 coef)
+ *        = dmid[p][c]                                    (hidden layer: dmid (rows, cout), layout 0 coef)
+ *   coef as written by coda_sa_bn_bwd_coef_f32 (layout 1: [a, m1, m2, mean, invstd], layout 0: [scale, shift,
+ *   mean, invstd, a, m1, m2]).
+ * dx:  dmid_in (rows, cin) = (dy W) where relu'(act_in) else 0 (NULL for the first layer: not stored),
+ *      sums_in (zeroed by the call): [sum dmid_in, sum dmid_in * xhat_in][cin], first layer: + [sum dmid_in * x_j]
+ *      (3 more blocks of cin: 5 * cin doubles).  stats_in = [scale, shift, mean, invstd][cin].
+ * dw:  dw (cout, cin) = dy^T act_in through `partials` (nblocks, cout, cin) floats, summed in workgroup order. */
+int coda_sa_mfma_bwd_dx_f32(const float *y_out, const float *dmid, const float *d, const int32_t *sel,
+                            const float *coef, int layout, const float *w, const float *src_in, const float *w1,
+                            const float *stats_in, const float *row_weight, const int32_t *group_offsets,
+                            const int32_t *row_group, long long groups, int s_len, int cin, int cout,
+                            float *dmid_in, double *sums_in, int nblocks, void *stream);
+int coda_sa_mfma_bwd_dw_f32(const float *y_out, const float *dmid, const float *d, const int32_t *sel,
+                            const float *coef, int layout, const float *src_in, const float *w1,
+                            const float *stats_in, const float *row_weight, const int32_t *group_offsets,
+                            const int32_t *row_group, long long groups, int s_len, int cin, int cout,
+                            float *partials, float *dw, int nblocks, void *stream);
+/* First layer, closed form.  sums5 = the 5*c doubles of coda_sa_mfma_bwd_dx_f32 (local rows); sums_bn = [sum d,
+ * sum d xhat] over the whole batch (= sums5 unless SyncBatchNorm reduced a copy across ranks); n <= 0: eval mode.
+ * dw1 (c,3), dbeta / dgamma (c) (NULL: skip; from the LOCAL sums). */
+int coda_sa_l1_bwd_f32(const double *sums5, const double *sums_bn, double n, const float *gamma, const float *stats,
+                       const double *moments, const float *w1, float *dw1, float *dbeta, float *dgamma, int c,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

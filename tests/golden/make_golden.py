@@ -214,6 +214,44 @@ def _args(**over):
     return ns
 
 
+def golden_sa_module_wide():
+    """The pre-encoder's own widths: PointnetSAModuleVotes(mlp=[0, 64, 128, 256]) of the REFERENCE
+    (pointnet2_modules.py:161-268, SharedMLP pytorch_utils.py:8-33), xyz only, train-mode batch statistics, a
+    quarter of the BatchNorm gammas negative (the pooled layer then keeps a group's MINIMUM pre-BN value) --
+    the fixture of the hand-written MFMA pipeline (csrc/sa_mfma.hip), which is instantiated for these widths only."""
+    import pointnet2_modules as RM  # the REFERENCE module
+
+    torch.manual_seed(21)
+    b, n, npoint, nsample, radius = 2, 2048, 96, 64, 0.25
+    mod = RM.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=npoint, radius=radius, nsample=nsample,
+                                   normalize_xyz=True)
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            if "bn" in k and k.endswith("weight"):
+                p.copy_((torch.rand_like(p) + 0.5) * torch.where(torch.rand_like(p) < 0.25, -1.0, 1.0))
+            elif "bn" in k:
+                p.copy_(torch.randn_like(p) * 0.1)
+    pc, _, _ = make_batch(b, n, seed=556)
+    xyz = torch.from_numpy(pc)
+    out = {"xyz": _np(xyz)}
+    for k, v in mod.state_dict().items():
+        out[f"state0/{k}"] = _np(v).copy()
+    mod.train()
+    new_xyz, new_feat, inds = mod(xyz, None)
+    gw = torch.randn_like(new_feat)
+    (new_feat * gw).sum().backward()
+    out.update({"new_xyz": _np(new_xyz), "inds": _np(inds), "new_feat_train": _np(new_feat), "gw": _np(gw)})
+    for k, p in mod.named_parameters():
+        out[f"grad/{k}"] = _np(p.grad)
+    for k, v in mod.state_dict().items():
+        out[f"state1/{k}"] = _np(v).copy()
+    mod.eval()
+    with torch.no_grad():
+        _, new_feat_eval, _ = mod(xyz, None)
+    out["new_feat_eval"] = _np(new_feat_eval)
+    _save("sa_module_wide.npz", **out)
+
+
 def golden_transformer():
     """TransformerEncoder / MaskedTransformerEncoder / TransformerDecoder stacks
     (models/transformer.py) at d=64 with full gradient digests, plus single layers at
@@ -784,6 +822,6 @@ if __name__ == "__main__":
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det"]
+    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det"]
     for w in which:
         globals()["golden_" + w]()

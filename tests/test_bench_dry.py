@@ -19,7 +19,7 @@ def _run(cmd, port=None):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     env["MASTER_ADDR"] = "127.0.0.1"
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=480)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -42,6 +42,10 @@ def test_single_process_flow():
     out = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1"])
     _check(out, 1, 3, 1)
     assert "cpu_baseline" not in out  # the dry run measures nothing, least of all the oracle
+    # the unchanged caller's leg (engine.py:136-164 with its blocking finite check) is reported at top level
+    assert out["value_unchanged"] > 0 and out["ms_per_step_unchanged"] > 0
+    assert "loss.item()" in out["value_unchanged_caller"]["what"]
+    assert "comm" not in out
 
 
 @pytest.mark.timeout(300)
@@ -50,3 +54,24 @@ def test_two_ranks_run_the_same_collectives():
                 "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "3",
                 "--warmup", "1"])
     _check(out, 2, 3, 1)
+    _check_multi(out, 2)
+
+
+def _check_multi(out, world):
+    """what the first real scaling run needs to be self-diagnosing: the collectives of a step timed alone, and the
+    reference's unchanged wrap (SyncBatchNorm + DistributedDataParallel + the per-step loss all-reduce and
+    .item()) timed beside this package's gradient synchronisation"""
+    assert out["comm"]["rccl_ranks"] == world and out["comm"]["backend"] == "gloo"
+    assert all(v > 0 for v in out["comm"]["allreduce_ms"].values()) and out["comm"]["syncbn_ms"] > 0
+    assert out["value_unchanged"] > 0
+    assert "DistributedDataParallel" in out["value_unchanged_caller"]["what"]
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_like_the_scaling_run():
+    """the driver's 8-GPU command line, on 8 CPU processes"""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                "--master-addr", "127.0.0.1", "--master-port", "29547", "bench.py", "--gpus", "8", "--steps", "2",
+                "--warmup", "1"])
+    _check(out, 8, 2, 1)
+    _check_multi(out, 8)

@@ -136,3 +136,65 @@ def test_flat_grad_reducer_single_process(dev):
     n = optim.clip_grad_norm_(params, 0.1)               # the clipping sees (and scales) the flat views
     want = torch.sqrt(sum((g.double() ** 2).sum() for g in grads))
     assert abs(float(n) - float(want)) < 1e-3 * float(want)
+
+
+def _logic_only_reducer(sizes):
+    """FlatGradReducer's hook bookkeeping without a device: stub segments, ``_fire`` records the issue order."""
+    import types
+    red = optim.FlatGradReducer.__new__(optim.FlatGradReducer)
+    red._sync = True
+    red.segments = [types.SimpleNamespace(params=[object()] * n, pending=n, fired=False, work=None) for n in sizes]
+    red.issued = []
+
+    def fire(seg):
+        red.issued.append(red.segments.index(seg))
+        seg.fired = True
+
+    red._fire = fire
+    return red
+
+
+def test_segments_are_issued_in_index_order_whatever_order_the_gradients_land_in():
+    """Round 3's advisor finding: every rank must issue all_reduce(segment 0) before all_reduce(segment 1), also
+    when segment 1's gradients are complete first, or when segment 0 is left to reduce() on one rank only."""
+    # rank A: segment 0 completes first
+    a = _logic_only_reducer([2, 3])
+    hooks = [a._hook_for(s) for s in a.segments]
+    for k in (0, 0, 1, 1, 1):
+        hooks[k](None)
+    # rank B: segment 1 completes first -> deferred until segment 0 has fired
+    b = _logic_only_reducer([2, 3])
+    hooks = [b._hook_for(s) for s in b.segments]
+    for k in (1, 1, 1, 0):
+        hooks[k](None)
+    assert b.issued == []
+    hooks[0](None)
+    # rank C: one parameter of segment 0 gets no gradient -> nothing fires from the hooks, reduce() issues 0, 1
+    c = _logic_only_reducer([2, 3])
+    hooks = [c._hook_for(s) for s in c.segments]
+    for k in (1, 1, 1, 0):
+        hooks[k](None)
+    assert c.issued == []
+    optim.FlatGradReducer.reduce(c)
+    assert a.issued == b.issued == c.issued == [0, 1]
+    assert all(s.pending == len(s.params) and not s.fired for s in c.segments)  # re-armed by reduce()
+
+
+def test_rearm_resets_a_step_that_never_reached_reduce():
+    """A step abandoned after backward (engine.py:155-157's exit, a caller's ``continue``) must not leave a segment
+    marked as fired or counters half decremented: the module's forward pre-hook re-arms."""
+    r = _logic_only_reducer([2, 2])
+    hooks = [r._hook_for(s) for s in r.segments]
+    for k in (0, 0, 1):          # segment 0 fired, segment 1 half way, reduce() never called
+        hooks[k](None)
+    assert r.issued == [0] and r.segments[1].pending == 1
+    with torch.enable_grad():
+        r.rearm()
+    assert [(s.pending, s.fired) for s in r.segments] == [(2, False), (2, False)]
+    for k in (0, 0, 1, 1):
+        hooks[k](None)
+    assert r.issued == [0, 0, 1]
+    with r.no_sync():            # accumulation passes neither count nor re-arm
+        r.rearm()
+        hooks[0](None)
+    assert r.segments[0].fired and r.segments[1].fired

@@ -1,0 +1,311 @@
+"""The fp32-MFMA pipeline of the set-abstraction shared MLP (csrc/sa_mfma.hip, include/coda_sa_mlp.h "MFMA pipeline"),
+kernel by kernel against plain torch expressions of what the reference's SharedMLP + max_pool2d compute
+(third_party_pointnet2/pointnet2/pytorch_utils.py:8-33, pointnet2_modules.py:247-253): the packing of the ball-query
+groups, each forward layer (prologue BN + ReLU, GEMM, statistics, pooling with the arg), each backward kernel (dy formed
+on the fly, dA with the ReLU mask and BN sums of the layer below, dW through per-workgroup partial tiles) and layer 1's
+closed form.  Grids of 1, 3, 7 and 256 workgroups exercise groups that straddle two workgroups and workgroups
+without rows.  Tolerances: fp32 GEMM round-off (K <= 256), 2e-5 relative to the largest entry."""
+import numpy as np
+import pytest
+import torch
+
+from coda_neurips2023_amd import _lib
+from coda_neurips2023_amd.pointnet2 import fused_sa_mlp as F
+
+pytestmark = pytest.mark.gpu
+
+C1, C2, C3 = 64, 128, 256
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.load(), name)(*args, _lib.current_stream_handle()), name)
+
+
+def _close(got, ref, tol=2e-5, what=""):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    err = float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+    assert err < tol, f"{what}: max err / max|ref| = {err:.3e}"
+
+
+def _groups(dev, g, s, seed, min_rows=1):
+    """Ball-query-shaped indices: `cnt` distinct ascending hits, then copies of the first one."""
+    gen = torch.Generator().manual_seed(seed)
+    cnt = torch.randint(min_rows, s + 1, (g,), generator=gen)
+    cnt[0] = s  # a full group
+    if g > 1:
+        cnt[1] = 1  # a single hit (63 copies)
+    idx = torch.zeros(g, s, dtype=torch.int32)
+    for i in range(g):
+        hits = torch.sort(torch.randperm(5000, generator=gen)[:int(cnt[i])])[0].int()
+        idx[i, :cnt[i]] = hits
+        idx[i, cnt[i]:] = hits[0]
+    grouped = torch.randn(g, s, 3, generator=gen)
+    # padded slots hold copies of the first row (what grouping by index produces)
+    for i in range(g):
+        grouped[i, cnt[i]:] = grouped[i, 0]
+    return idx.to(dev), grouped.to(dev), cnt
+
+
+def _pack(idx, grouped, dedup=True):
+    g, s = idx.shape
+    return F.pack_groups(idx.view(1, g, s), grouped, [C1, C2, C3], dedup=dedup)
+
+
+def _row_maps(cnt, s, dedup=True):
+    """Host-side description of the packed rows: (group of row, row-in-group, weight)."""
+    g_of, rin, w = [], [], []
+    for g, c in enumerate(cnt.tolist()):
+        c = c if dedup else s
+        for j in range(c):
+            g_of.append(g)
+            rin.append(j)
+            w.append(float(s - c + 1) if j == 0 else 1.0)
+    return torch.tensor(g_of), torch.tensor(rin), torch.tensor(w)
+
+
+@pytest.mark.parametrize("dedup", [True, False])
+def test_pack_groups(dev, dedup):
+    g, s = 37, 64
+    idx, grouped, cnt = _groups(dev, g, s, seed=1)
+    x, roww, goff, grow, mom, sums = _pack(idx, grouped, dedup)
+    g_of, rin, w = _row_maps(cnt, s, dedup)
+    total = g_of.numel()
+    assert int(goff[-1]) == total
+    off = torch.zeros(g + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(cnt if dedup else torch.full((g,), s), 0)
+    assert torch.equal(goff.cpu().long(), off)
+    want_x = grouped.cpu()[g_of, rin]
+    assert torch.equal(x[:total].cpu(), want_x)
+    assert torch.equal(roww[:total].cpu(), w)
+    assert torch.equal(grow[:total].cpu().long(), g_of * 64 + rin)
+    xd, wd = want_x.double(), w.double()
+    want_m = torch.cat([wd.sum()[None], (wd[:, None] * xd).sum(0),
+                        torch.stack([(wd * xd[:, i] * xd[:, j]).sum() for i, j in
+                                     ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))])])
+    _close(mom, want_m, 1e-6, "moments")
+    assert float(mom[0]) == g * s  # every group stands for s rows
+    assert float(sums[2 * C1:].abs().max()) == 0.0  # the accumulators of layers 2 / 3 are zeroed
+
+
+def _stats(c, seed, dev):
+    gen = torch.Generator().manual_seed(seed)
+    st = torch.empty(4, c)
+    st[0] = (torch.rand(c, generator=gen) + 0.5) * torch.where(torch.rand(c, generator=gen) < 0.3, -1.0, 1.0)  # scale
+    st[1] = torch.randn(c, generator=gen) * 0.3
+    st[2] = torch.randn(c, generator=gen) * 0.2
+    st[3] = torch.rand(c, generator=gen) + 0.5
+    return st.to(dev)
+
+
+def _l1(x, w1, st1):
+    y1 = x @ w1.t()
+    return y1, torch.relu(y1 * st1[0] + st1[1])
+
+
+@pytest.mark.parametrize("nblk", [1, 3, 256])
+def test_forward_layer2_from_xyz(dev, nblk):
+    g, s = 41, 64
+    idx, grouped, cnt = _groups(dev, g, s, seed=2)
+    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    total = int(goff[-1])
+    gen = torch.Generator().manual_seed(3)
+    w1 = torch.randn(C1, 3, generator=gen).to(dev)
+    w2 = (torch.randn(C2, C1, generator=gen) / 8).to(dev)
+    st1 = _stats(C1, 4, dev)
+    y2 = torch.full((x.shape[0], C2), float("nan"), device=dev)
+    s2 = sums[2 * C1:2 * (C1 + C2)]
+    _call("coda_sa_mfma_fwd_f32", _p(x), _p(w1), _p(st1), _p(w2), _p(roww), _p(goff), _p(grow), g, s, C1, C2, _p(y2), _p(s2),
+          None, None, None, None, None, None, nblk)
+    _, a1 = _l1(x[:total].double(), w1.double(), st1.double())
+    ref = a1 @ w2.double().t()
+    _close(y2[:total], ref, what="y2")
+    assert torch.isnan(y2[total:]).all(), "rows past the packed count are not written"
+    wd = roww[:total].double()[:, None]
+    _close(s2[:C2], (wd * ref).sum(0), 1e-5, "sum y2")
+    _close(s2[C2:], (wd * ref * ref).sum(0), 1e-5, "sum y2^2")
+    # layer 1's sums from the moments
+    s1 = sums[:2 * C1]
+    _call("coda_sa_l1_sums_f32", _p(mom), _p(w1), _p(s1), C1)
+    y1 = x[:total].double() @ w1.double().t()
+    _close(s1[:C1], (wd * y1).sum(0), 1e-6, "sum y1")
+    _close(s1[C1:], (wd * y1 * y1).sum(0), 1e-6, "sum y1^2")
+
+
+def _pool_ref(y3, g_of, rin, gamma, ngroups):
+    """first arg-max of sign(gamma) * y over the rows of each group"""
+    sg = torch.where(gamma >= 0, 1.0, -1.0).double()
+    v = y3.double() * sg
+    ysel = torch.empty(ngroups, y3.shape[1], dtype=torch.float64)
+    sel = torch.empty(ngroups, y3.shape[1], dtype=torch.int64)
+    for g in range(ngroups):
+        rows = (g_of == g).nonzero()[:, 0]
+        vg = v[rows]
+        m = vg.max(0).values
+        first = (vg == m).int().argmax(0)  # argmax of a 0/1 tensor = the first maximum
+        sel[g] = rin[rows][first]
+        ysel[g] = y3.double()[rows[first], torch.arange(y3.shape[1])]
+    return ysel, sel
+
+
+@pytest.mark.parametrize("nblk", [1, 3, 7, 256])
+def test_forward_layer3_with_pooling(dev, nblk):
+    g, s = 45, 64
+    idx, grouped, cnt = _groups(dev, g, s, seed=5)
+    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    total = int(goff[-1])
+    g_of, rin, w = _row_maps(cnt, s)
+    gen = torch.Generator().manual_seed(6)
+    y2 = torch.randn(x.shape[0], C2, generator=gen).to(dev)
+    # ties inside a group: duplicate a row (distinct indices with identical coordinates)
+    y2[3] = y2[1]
+    w3 = (torch.randn(C3, C2, generator=gen) / 11).to(dev)
+    st2, st3 = _stats(C2, 7, dev), _stats(C3, 8, dev)
+    gamma = st3[0].clone()  # its sign selects max or min
+    y3 = torch.empty(x.shape[0], C3, device=dev)
+    ysel = torch.full((g, C3), float("nan"), device=dev)
+    sel = torch.full((g, C3), -7, dtype=torch.int32, device=dev)
+    part_y = torch.empty(nblk, C3, device=dev)
+    part_sel = torch.empty(nblk, C3, dtype=torch.int32, device=dev)
+    part_gid = torch.empty(nblk, dtype=torch.int32, device=dev)
+    s3 = sums[2 * (C1 + C2):]
+    _call("coda_sa_mfma_fwd_f32", _p(y2), None, _p(st2), _p(w3), _p(roww), _p(goff), _p(grow), g, s, C2, C3, _p(y3), _p(s3),
+          _p(gamma), _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), nblk)
+    out = torch.empty(g, C3, device=dev)
+    _call("coda_sa_pool_finish_f32", _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), _p(goff), _p(gamma), _p(st3),
+          _p(out), g, C3, nblk)
+    a2 = torch.relu(y2[:total].double() * st2[0].double() + st2[1].double())
+    ref = a2 @ w3.double().t()
+    _close(y3[:total], ref, what="y3")
+    wd = roww[:total].double()[:, None]
+    _close(s3[:C3], (wd * ref).sum(0), 1e-5, "sum y3")
+    _close(s3[C3:], (wd * ref * ref).sum(0), 1e-5, "sum y3^2")
+    # pooling is checked on the kernel's own y3 (exact comparisons)
+    want_y, want_sel = _pool_ref(y3[:total].cpu(), g_of, rin, gamma.cpu(), g)
+    assert torch.equal(sel.cpu().long(), want_sel)
+    assert torch.equal(ysel.cpu().double(), want_y)
+    want_out = torch.relu(want_y.float() * st3[0].cpu() + st3[1].cpu())
+    assert torch.allclose(out.cpu(), want_out, rtol=1e-6, atol=1e-7)
+
+
+def _coef(c, seed, dev, layout):
+    gen = torch.Generator().manual_seed(seed)
+    a = torch.randn(c, generator=gen)
+    m1, m2 = torch.randn(c, generator=gen) * 0.1, torch.randn(c, generator=gen) * 0.1
+    mean, invstd = torch.randn(c, generator=gen) * 0.2, torch.rand(c, generator=gen) + 0.5
+    if layout == 1:
+        t = torch.stack([a, m1, m2, mean, invstd])
+    else:
+        t = torch.stack([torch.zeros(c), torch.zeros(c), mean, invstd, a, m1, m2])
+    return t.to(dev), (a.double(), m1.double(), m2.double(), mean.double(), invstd.double())
+
+
+def _dy_ref(y, dsel, w, coef):
+    a, m1, m2, mean, invstd = coef
+    return a * (dsel - w[:, None] * (m1 + (y - mean) * invstd * m2))
+
+
+@pytest.mark.parametrize("nblk", [1, 5, 256])
+def test_backward_last_layer(dev, nblk):
+    g, s = 39, 64
+    idx, grouped, cnt = _groups(dev, g, s, seed=9)
+    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    total = int(goff[-1])
+    g_of, rin, w = _row_maps(cnt, s)
+    gen = torch.Generator().manual_seed(10)
+    y3 = torch.randn(x.shape[0], C3, generator=gen).to(dev)
+    y2 = torch.randn(x.shape[0], C2, generator=gen).to(dev)
+    w3 = (torch.randn(C3, C2, generator=gen) / 11).to(dev)
+    d = torch.randn(g, C3, generator=gen).to(dev)
+    sel = torch.stack([torch.randint(0, int(c), (C3,), generator=gen) for c in cnt]).int().to(dev)
+    coef, cf = _coef(C3, 11, dev, 1)
+    st2 = _stats(C2, 12, dev)
+    dmid2 = torch.full((x.shape[0], C2), float("nan"), device=dev)
+    sums2 = torch.empty(2 * C2, dtype=torch.float64, device=dev)
+    _call("coda_sa_mfma_bwd_dx_f32", _p(y3), None, _p(d), _p(sel), _p(coef), 1, _p(w3), _p(y2), None, _p(st2), _p(roww),
+          _p(goff), _p(grow), g, s, C2, C3, _p(dmid2), _p(sums2), nblk)
+    partials = torch.empty(nblk, C3 * C2, device=dev)
+    dw3 = torch.empty(C3, C2, device=dev)
+    _call("coda_sa_mfma_bwd_dw_f32", _p(y3), None, _p(d), _p(sel), _p(coef), 1, _p(y2), None, _p(st2), _p(roww), _p(goff),
+          _p(grow), g, s, C2, C3, _p(partials), _p(dw3), nblk)
+    yd = y3[:total].double().cpu()
+    dsel = torch.where(rin[:, None] == sel.cpu().long()[g_of], d.double().cpu()[g_of], torch.zeros(1, dtype=torch.float64))
+    dy = _dy_ref(yd, dsel, w.double(), cf)
+    pre2 = y2[:total].double().cpu() * st2[0].double().cpu() + st2[1].double().cpu()
+    a2 = torch.relu(pre2)
+    da2 = dy @ w3.double().cpu()
+    dm = torch.where(pre2 > 0, da2, torch.zeros(1, dtype=torch.float64))
+    _close(dmid2[:total], dm, what="dmid2")
+    assert torch.isnan(dmid2[total:]).all()
+    xhat = (y2[:total].double().cpu() - st2[2].double().cpu()) * st2[3].double().cpu()
+    _close(sums2[:C2], dm.sum(0), 1e-5, "sum d")
+    _close(sums2[C2:], (dm * xhat).sum(0), 1e-5, "sum d xhat")
+    _close(dw3, dy.t() @ a2, what="dW3")
+
+
+@pytest.mark.parametrize("nblk", [1, 5, 256])
+def test_backward_hidden_layer_and_layer1_closed_form(dev, nblk):
+    g, s = 39, 64
+    idx, grouped, cnt = _groups(dev, g, s, seed=13)
+    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    total = int(goff[-1])
+    g_of, rin, w = _row_maps(cnt, s)
+    gen = torch.Generator().manual_seed(14)
+    y2 = torch.randn(x.shape[0], C2, generator=gen).to(dev)
+    dmid2 = torch.randn(x.shape[0], C2, generator=gen).to(dev)
+    w1 = torch.randn(C1, 3, generator=gen).to(dev)
+    w2 = (torch.randn(C2, C1, generator=gen) / 8).to(dev)
+    prm, cf = _coef(C2, 15, dev, 0)
+    st1 = _stats(C1, 16, dev)
+    sums1 = torch.empty(5 * C1, dtype=torch.float64, device=dev)
+    _call("coda_sa_mfma_bwd_dx_f32", _p(y2), _p(dmid2), None, None, _p(prm), 0, _p(w2), _p(x), _p(w1), _p(st1), _p(roww),
+          _p(goff), _p(grow), g, s, C1, C2, None, _p(sums1), nblk)
+    partials = torch.empty(nblk, C2 * C1, device=dev)
+    dw2 = torch.empty(C2, C1, device=dev)
+    _call("coda_sa_mfma_bwd_dw_f32", _p(y2), _p(dmid2), None, None, _p(prm), 0, _p(x), _p(w1), _p(st1), _p(roww), _p(goff),
+          _p(grow), g, s, C1, C2, _p(partials), _p(dw2), nblk)
+    xd = x[:total].double().cpu()
+    dy2 = _dy_ref(y2[:total].double().cpu(), dmid2[:total].double().cpu(), w.double(), cf)
+    y1, a1 = _l1(xd, w1.double().cpu(), st1.double().cpu())
+    _close(dw2, dy2.t() @ a1, what="dW2")
+    pre1 = y1 * st1[0].double().cpu() + st1[1].double().cpu()
+    d1 = torch.where(pre1 > 0, dy2 @ w2.double().cpu(), torch.zeros(1, dtype=torch.float64))
+    xhat1 = (y1 - st1[2].double().cpu()) * st1[3].double().cpu()
+    want = torch.cat([d1.sum(0), (d1 * xhat1).sum(0)] + [(d1 * xd[:, j:j + 1]).sum(0) for j in range(3)])
+    _close(sums1, want, 1e-5, "layer-1 sums")
+    # closed form of layer 1 against the explicit BN backward + dW1 = dy1^T x
+    n = float(g * s)
+    gamma1 = (torch.rand(C1, generator=gen) + 0.5).to(dev)
+    dw1 = torch.empty(C1, 3, device=dev)
+    dbeta, dgamma = torch.empty(C1, device=dev), torch.empty(C1, device=dev)
+    _call("coda_sa_l1_bwd_f32", _p(sums1), _p(sums1), n, _p(gamma1), _p(st1), _p(mom), _p(w1), _p(dw1), _p(dbeta), _p(dgamma), C1)
+    a = (gamma1 * st1[3]).double().cpu()
+    m1, m2 = d1.sum(0) / n, (d1 * xhat1).sum(0) / n
+    dy1 = a * (d1 - w.double()[:, None] * (m1 + xhat1 * m2))
+    _close(dw1, dy1.t() @ xd, 1e-5, "dW1")
+    _close(dbeta, d1.sum(0), 1e-5, "dbeta1")
+    _close(dgamma, (d1 * xhat1).sum(0), 1e-5, "dgamma1")
+
+
+def test_empty_and_tiny_inputs(dev):
+    """one group with one row; grids larger than the number of sub-tiles"""
+    idx = torch.zeros(1, 64, dtype=torch.int32, device=dev)  # an empty ball: all zeros = one distinct row
+    grouped = torch.randn(1, 64, 3, device=dev)
+    grouped[:] = grouped[:, :1]
+    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    assert int(goff[-1]) == 1 and float(roww[0]) == 64.0
+    gen = torch.Generator().manual_seed(0)
+    w1, w2 = torch.randn(C1, 3, generator=gen).to(dev), torch.randn(C2, C1, generator=gen).to(dev)
+    st1 = _stats(C1, 1, dev)
+    y2 = torch.empty(64, C2, device=dev)
+    s2 = sums[2 * C1:2 * (C1 + C2)]
+    _call("coda_sa_mfma_fwd_f32", _p(x), _p(w1), _p(st1), _p(w2), _p(roww), _p(goff), _p(grow), 1, 64, C1, C2, _p(y2), _p(s2),
+          None, None, None, None, None, None, 256)
+    _, a1 = _l1(x[:1].double(), w1.double(), st1.double())
+    _close(y2[:1], a1 @ w2.double().t(), what="single row")
+    _close(s2[:C2], 64.0 * (a1 @ w2.double().t())[0], 1e-5, "weighted sum")
+    assert _lib.load().coda_sa_mfma_supported(64, 128, 256, 64) == 1
+    assert _lib.load().coda_sa_mfma_supported(16, 32, 64, 32) == 0 and _lib.load().coda_sa_mfma_supported(64, 128, 256, 65) == 0

@@ -53,13 +53,56 @@ def test_sa_module_matches_reference(dev, golden_sa, tag, c_in):
     _close(new_feat_eval, g[f"{tag}_new_feat_eval"], "eval-mode features")
 
 
+def test_pre_encoder_widths_match_reference_through_the_mfma_pipeline(dev, monkeypatch):
+    """PointnetSAModuleVotes(mlp=[0, 64, 128, 256]) -- the pre-encoder's own widths, where the shared MLP runs on the
+    hand-written fp32-MFMA pipeline (csrc/sa_mfma.hip) -- against the fixture the REFERENCE's module produced
+    (tests/golden/make_golden.py: golden_sa_module_wide; a quarter of the BatchNorm gammas negative): sampled
+    indices bit-exact, train- and eval-mode features, every parameter gradient and the running statistics within
+    1e-3 relative (north_star tolerance)."""
+    import os
+
+    from coda_neurips2023_amd.pointnet2 import fused_sa_mlp
+    from tests._modes import fixture_mode, set_distance_mode
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sa_module_wide.npz"))
+    set_distance_mode(fixture_mode(g))
+    monkeypatch.delenv("CODA_SA_MLP", raising=False)
+    used = []
+    real = fused_sa_mlp._MfmaMlpPool.apply
+    monkeypatch.setattr(fused_sa_mlp._MfmaMlpPool, "apply", lambda *a: (used.append(1), real(*a))[1])
+    mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=96, radius=0.25, nsample=64,
+                                                  normalize_xyz=True)
+    mod.load_state_dict({k.split("/", 1)[1]: torch.from_numpy(np.asarray(g[k])) for k in g.files
+                         if k.startswith("state0/")}, strict=True)
+    mod.to(dev).train()
+    xyz = torch.from_numpy(g["xyz"]).to(dev)
+    new_xyz, new_feat, inds = mod(xyz)
+    assert used, "the MFMA pipeline did not run"
+    assert np.array_equal(inds.cpu().numpy(), g["inds"])
+    assert np.array_equal(new_xyz.cpu().numpy(), g["new_xyz"])
+    _close(new_feat, g["new_feat_train"], "train-mode features")
+    (new_feat * torch.from_numpy(g["gw"]).to(dev)).sum().backward()
+    for k, p in mod.named_parameters():
+        _close(p.grad, g[f"grad/{k}"], f"grad {k}")
+    for k, v in mod.state_dict().items():
+        ref = g[f"state1/{k}"]
+        if ref.dtype.kind == "f":
+            _close(v, ref, f"state {k}")
+        else:
+            assert int(v) == int(ref)
+    mod.eval()
+    with torch.no_grad():
+        _, new_feat_eval, _ = mod(xyz)
+    _close(new_feat_eval, g["new_feat_eval"], "eval-mode features")
+
+
 @pytest.mark.parametrize("dedup", ["1", "0"])
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train, dedup):
-    """The fused channels-last shared MLP + BN + ReLU + max-pool (csrc/sa_mlp.hip + library GEMMs)
-    against the per-layer Conv2d/BatchNorm2d/ReLU/max_pool2d path of the same module, same weights,
-    at the pre-encoder's widths [3,64,128,256]: outputs, every parameter gradient and the
-    BatchNorm running statistics."""
+@pytest.mark.parametrize("impl", ["mfma", "fused"])
+def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train, dedup, impl):
+    """The fused channels-last shared MLP + BN + ReLU + max-pool -- "mfma": the hand-written fp32-MFMA pipeline
+    (csrc/sa_mfma.hip), "fused": the streaming kernels of csrc/sa_mlp.hip around library GEMMs -- against the
+    per-layer Conv2d/BatchNorm2d/ReLU/max_pool2d path of the same module, same weights, at the pre-encoder's
+    widths [3,64,128,256]: outputs, every parameter gradient and the BatchNorm running statistics."""
     import os
 
     from coda_neurips2023_amd.synthetic_scenes import make_batch
@@ -88,7 +131,7 @@ def test_fused_shared_mlp_matches_layer_path(dev, monkeypatch, train, dedup):
         return feat.detach(), {k: p.grad for k, p in mod.named_parameters()}, \
             {k: v.clone() for k, v in mod.state_dict().items() if "running" in k or "tracked" in k}
 
-    f1, g1, s1 = run("fused")
+    f1, g1, s1 = run(impl)
     f2, g2, s2 = run("layers")
     assert f1.shape == f2.shape == (2, 256, 512)
     assert float((f1 - f2).abs().max() / f2.abs().max()) < 1e-5
