@@ -53,7 +53,7 @@ SIGNATURES = {
     "coda_sa_compact_groups_f32": (_c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, ctypes.c_longlong,
                                              ctypes.c_longlong, _P]),
     # MFMA pipeline (csrc/sa_mfma.hip)
-    "coda_sa_mfma_blocks": (_c_int, []),
+    "coda_sa_mfma_blocks": (_c_int, [_c_int]),
     "coda_sa_mfma_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int]),
     "coda_sa_pack_groups_f32": (_c_int, [_P, _P, _c_int, _P, _P, _P, _P, _P, _P, _P, _c_int, ctypes.c_longlong, _c_int, _P]),
     "coda_sa_l1_sums_f32": (_c_int, [_P, _P, _P, _c_int, _P]),

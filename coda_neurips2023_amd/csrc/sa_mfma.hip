@@ -122,17 +122,19 @@ __global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t *__restri
   if (t == 1023) goff[groups] = s_part[1023];
 }
 
-// one thread per (group, slot): row group_offsets[g] + j <- grouped[g][j] for j < cnt[g]
+// a thread per (group, slot), grid-stride: row group_offsets[g] + j <- grouped[g][j] for j < cnt[g]; the moments are
+// reduced per workgroup first (10 double atomics per workgroup, a few thousand per call)
 __global__ __launch_bounds__(kT) void pack_scatter_kernel(const float *__restrict__ grouped, const int32_t *__restrict__ cnt,
                                                           const int32_t *__restrict__ goff, float *__restrict__ x,
                                                           float *__restrict__ roww, int32_t *__restrict__ grow,
                                                           double *__restrict__ moments, long long groups, int s_len) {
   __shared__ float s_m[10][kT / 64];
-  const long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x;
   float m[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) m[k] = 0.0f;
-  if (i < groups * s_len) {
+  const long long slots = groups * s_len;
+  for (long long i = static_cast<long long>(blockIdx.x) * kT + threadIdx.x; i < slots;
+       i += static_cast<long long>(gridDim.x) * kT) {
     const long long g = i / s_len;
     const int j = static_cast<int>(i - g * s_len);
     const int c = cnt[g];
@@ -144,9 +146,9 @@ __global__ __launch_bounds__(kT) void pack_scatter_kernel(const float *__restric
       x[r * 3] = x0; x[r * 3 + 1] = x1; x[r * 3 + 2] = x2;
       roww[r] = w;
       grow[r] = static_cast<int32_t>((g << 6) | j);  // group and row-in-group (s_len <= 64) in one word
-      m[0] = w; m[1] = w * x0; m[2] = w * x1; m[3] = w * x2;
-      m[4] = w * x0 * x0; m[5] = w * x0 * x1; m[6] = w * x0 * x2;
-      m[7] = w * x1 * x1; m[8] = w * x1 * x2; m[9] = w * x2 * x2;
+      m[0] += w; m[1] += w * x0; m[2] += w * x1; m[3] += w * x2;
+      m[4] += w * x0 * x0; m[5] += w * x0 * x1; m[6] += w * x0 * x2;
+      m[7] += w * x1 * x1; m[8] += w * x1 * x2; m[9] += w * x2 * x2;
     }
   }
 #pragma unroll
@@ -823,13 +825,28 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
       }
 }
 
-// dw[i] = sum over the workgroups' partial tiles, in workgroup order (deterministic)
+// dw[i] = sum over the workgroups' partial tiles in a fixed order (deterministic): a workgroup owns 64 outputs, its 4
+// waves take a quarter of the tiles each (8 loads in flight per lane), the quarters are added in order
 __global__ __launch_bounds__(kT) void dw_reduce_kernel(const float *__restrict__ partials, float *__restrict__ dw, int n, int nblk) {
-  const int i = blockIdx.x * kT + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float s_p[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const int per = (nblk + 3) / 4, b0 = q * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partials[static_cast<size_t>(b) * n + i];
-  dw[i] = s;
+  if (i < n) {
+    const float *p = partials + i;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[static_cast<size_t>(b + u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += p[static_cast<size_t>(b) * n];
+  }
+  s_p[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && i < n) dw[i] = ((s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + s_p[2][threadIdx.x]) + s_p[3][threadIdx.x];
 }
 
 int device_cus() {
@@ -893,7 +910,11 @@ bool fill_coef(BwdArgs &a, const float *coef, int layout, int cout) {
 
 using namespace coda;
 
-CODA_API int coda_sa_mfma_blocks(void) { return device_cus(); }
+// kind 0: forward / dx kernels -- 4 row ranges per CU, dealt to the CUs as they become free (a range costs its
+// workgroup only the weight fragments, ~2 % of its time; with exactly one workgroup per CU a concurrent kernel that
+// holds a few CUs -- the sampling of the next batch on its side stream -- doubled the kernel's duration: 8 of the 256
+// workgroups had to wait for a whole pass of the others).  kind 1: dw kernels -- one per CU (a 128 KB partial tile each).
+CODA_API int coda_sa_mfma_blocks(int kind) { return kind == 0 ? 4 * device_cus() : device_cus(); }
 
 CODA_API int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len) {
   return c1 == 64 && c2 == 128 && c3 == 256 && s_len >= 1 && s_len <= kRows ? 1 : 0;
@@ -912,8 +933,12 @@ CODA_API int coda_sa_pack_groups_f32(const float *grouped, const int32_t *idx, i
                        s_len, dedup);
   hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, s, counts, group_offsets, groups, moments, zero, nzero);
   if (groups > 0)
-    hipLaunchKernelGGL(pack_scatter_kernel, dim3(static_cast<unsigned>((groups * s_len + kT - 1) / kT)), dim3(kT), 0, s,
-                       grouped, counts, group_offsets, x, row_weight, row_group, moments, groups, s_len);
+  {
+    long long blocks = (groups * s_len + kT - 1) / kT;
+    blocks = blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(pack_scatter_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kT), 0, s, grouped, counts,
+                       group_offsets, x, row_weight, row_group, moments, groups, s_len);
+  }
   return launch_status();
 }
 
@@ -1014,7 +1039,7 @@ CODA_API int coda_sa_mfma_bwd_dw_f32(const float *y_out, const float *dmid, cons
   else return CODA_EINVAL;
   if (st != CODA_OK) return st;
   const int n = cin * cout;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((n + kT - 1) / kT), dim3(kT), 0, s, partials, dw, n, nblocks);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((n + 63) / 64), dim3(kT), 0, s, partials, dw, n, nblocks);
   return launch_status();
 }
 

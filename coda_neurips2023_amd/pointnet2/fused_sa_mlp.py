@@ -336,7 +336,7 @@ class _MfmaMlpPool(torch.autograd.Function):
         c1, c2, c3 = (w.shape[0] for w in ws)
         world = [dist.get_world_size(bn.process_group) if _is_sync(bn) else 1 for bn in bns]
         n_rows = groups * nsample  # rows the statistics are taken over (copies included)
-        nblk = lib.coda_sa_mfma_blocks()
+        nblk = lib.coda_sa_mfma_blocks(0)
         f32 = dict(dtype=torch.float32, device=dev)
         s1, s2, s3 = sums[:2 * c1], sums[2 * c1:2 * (c1 + c2)], sums[2 * (c1 + c2):]
 
@@ -364,7 +364,7 @@ class _MfmaMlpPool(torch.autograd.Function):
         _call("coda_sa_pool_finish_f32", _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), _p(goff), _p(g3),
               _p(st3), _p(out), groups, c3, nblk)
 
-        ctx.meta = (groups, nsample, bns, training, world, n_rows, nblk)
+        ctx.meta = (groups, nsample, bns, training, world, n_rows, nblk, lib.coda_sa_mfma_blocks(1))
         ctx.wshape = [params[3 * i].shape for i in range(3)]
         ctx.stats = [st1, st2, st3]
         ctx.save_for_backward(x, roww, goff, grow, mom, y2, y3, ysel, sel, out, *ws, *gammas)
@@ -372,7 +372,7 @@ class _MfmaMlpPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        groups, nsample, bns, training, world, n_rows, nblk = ctx.meta
+        groups, nsample, bns, training, world, n_rows, nblk, nblk_w = ctx.meta
         x, roww, goff, grow, mom, y2, y3, ysel, sel, out = ctx.saved_tensors[:10]
         ws = list(ctx.saved_tensors[10:13])
         gammas = list(ctx.saved_tensors[13:16])
@@ -393,10 +393,10 @@ class _MfmaMlpPool(torch.autograd.Function):
         sums2 = torch.empty(2 * c2, **f64)
         _call("coda_sa_mfma_bwd_dx_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(ws[2]), _p(y2), None, _p(st2),
               _p(roww), _p(goff), _p(grow), groups, nsample, c2, c3, _p(dmid2), _p(sums2), nblk)
-        partials = torch.empty((nblk, c3 * c2), **f32)
+        partials = torch.empty((nblk_w, c3 * c2), **f32)
         dw3 = torch.empty((c3, c2), **f32)
         _call("coda_sa_mfma_bwd_dw_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(y2), None, _p(st2), _p(roww),
-              _p(goff), _p(grow), groups, nsample, c2, c3, _p(partials), _p(dw3), nblk)
+              _p(goff), _p(grow), groups, nsample, c2, c3, _p(partials), _p(dw3), nblk_w)
         grads[6] = dw3.reshape(ctx.wshape[2])
 
         # ---- layer 2
@@ -406,7 +406,7 @@ class _MfmaMlpPool(torch.autograd.Function):
               _p(roww), _p(goff), _p(grow), groups, nsample, c1, c2, None, _p(sums1), nblk)
         dw2 = torch.empty((c2, c1), **f32)
         _call("coda_sa_mfma_bwd_dw_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(x), _p(ws[0]), _p(st1), _p(roww),
-              _p(goff), _p(grow), groups, nsample, c1, c2, _p(partials), _p(dw2), nblk)
+              _p(goff), _p(grow), groups, nsample, c1, c2, _p(partials), _p(dw2), nblk_w)
         grads[3] = dw2.reshape(ctx.wshape[1])
 
         # ---- layer 1, closed form: dW1 / dgamma / dbeta from five sums per channel and the xyz moments

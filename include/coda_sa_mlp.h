@@ -114,9 +114,10 @@ int coda_sa_compact_groups_f32(const float *grouped, const int64_t *cnt, const i
  *             five sums per channel of layer 2's dA epilogue and the xyz moments.
  * Rows: the DISTINCT rows of the ball-query groups (see "De-duplicated groups" above), packed on the device without
  * a host read-back: every kernel takes the row count from group_offsets[groups] in device memory and splits the
- * rows evenly over `nblocks` persistent workgroups (coda_sa_mfma_blocks(): one per CU).
+ * rows evenly over `nblocks` workgroups (coda_sa_mfma_blocks()).
  */
-int coda_sa_mfma_blocks(void);
+/* workgroups (= row ranges) of the forward / dx kernels (kind 0) and of the dw kernels (kind 1, = partial tiles) */
+int coda_sa_mfma_blocks(int kind);
 /* Supported widths of coda_sa_mfma_*: (cin, cout) = (64, 128) [first: w1 != NULL] and (128, 256) [pooled]. */
 int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len);
 
