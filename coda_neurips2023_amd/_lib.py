@@ -23,22 +23,25 @@ _c_size_t = ctypes.c_size_t
 _P = _c_void_p
 SIGNATURES = {
     "coda_version": (ctypes.c_char_p, []),
-    "coda_set_distance_mode": (_c_int, [_c_int]),
     "coda_get_distance_mode": (_c_int, []),
     "coda_furthest_point_sampling_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "coda_furthest_point_sampling_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _P]),
+    "coda_furthest_point_sampling_opt_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _c_int, _c_int, _P]),
     "coda_gather_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_gather_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
-    "coda_set_ball_query_route": (_c_int, [_c_int]),
-    "coda_set_fps_waves": (_c_int, [_c_int]),
     "coda_ball_query_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "coda_ball_query_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _P, _c_size_t, _P]),
+    "coda_ball_query_opt_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _P, _c_size_t, _c_int, _c_int, _P]),
     "coda_group_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_group_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_query_and_group_xyz_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _P, _c_size_t, _P]),
+    "coda_query_and_group_xyz_opt_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _P, _c_size_t,
+                                                  _c_int, _c_int, _P]),
     "coda_three_nn_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_three_interpolate_grad_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_three_nn_opt_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_three_interpolate_opt_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     # include/coda_sa_mlp.h
     "coda_sa_col_stats_f32": (_c_int, [_P, _P, ctypes.c_longlong, _c_int, _P, _P, _P]),
     "coda_sa_bn_relu_apply_f32": (_c_int, [_P, _P, _P, _P, ctypes.c_longlong, _c_int, _P, _P]),
@@ -145,6 +148,11 @@ SIGNATURES = {
     "coda_mha_bwd_parts_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
                                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                         ctypes.c_uint64, _P, _c_int, _P]),
+    "coda_mha_fwd_opt_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                      _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _c_int, _P]),
+    "coda_mha_bwd_parts_opt_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
+                                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                            ctypes.c_uint64, _P, _c_int, _c_int, _P]),
     # include/coda_gemm.h
     "coda_gemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                _P, ctypes.c_longlong, _P, _c_int, _P]),
@@ -154,13 +162,47 @@ SIGNATURES = {
                                              _P, ctypes.c_longlong, _P, _c_float, ctypes.c_uint64, _P]),
     "coda_gemm_tn_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_longlong, ctypes.c_longlong,
                                   ctypes.c_longlong, _c_int, _P]),
-    "coda_mha_set_mfma_dtype": (_c_int, [_c_int]),
     "coda_mha_get_mfma_dtype": (_c_int, []),
     "coda_mha_timing_enable": (_c_int, [_c_int]),
     "coda_mha_timing_collect": (_c_int, [_P, _P, _P, _P, _c_int]),
 }
 
 _lib = None
+
+# ---- per-call options --------------------------------------------------------------------------------------------------
+# The C library has no mutable process-wide state: the arithmetic / kernel-selection switches are ARGUMENTS of its *_opt
+# entry points (include/coda_pointnet2.h, coda_attention.h).  On the Python side the values travel in a THREAD-LOCAL
+# record that the wrappers read when they issue a call (autograd functions capture them in their forward and hand them
+# to their backward, which runs on another thread): two models -- or two threads -- with different options never
+# interact.  ``options(...)`` scopes values to a ``with`` block; ``set_option`` makes one stick for the calling thread
+# (tests, bench.py).  Every value defaults to "library default" (an environment variable read once by the library).
+import contextlib as _contextlib
+import threading as _threading
+
+OPTION_DEFAULTS = {"distance_mode": -1, "fps_waves": 0, "bq_route": 0, "mfma_dtype": -1}
+_tls = _threading.local()
+
+
+def opt(name):
+    return getattr(_tls, name, OPTION_DEFAULTS[name])
+
+
+def set_option(name, value):
+    if name not in OPTION_DEFAULTS:
+        raise KeyError(name)
+    setattr(_tls, name, int(value))
+
+
+@_contextlib.contextmanager
+def options(**values):
+    saved = {k: opt(k) for k in values}
+    try:
+        for k, v in values.items():
+            set_option(k, v)
+        yield
+    finally:
+        for k, v in saved.items():
+            set_option(k, v)
 
 
 class CodaLibraryError(RuntimeError):

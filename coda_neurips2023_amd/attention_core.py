@@ -18,16 +18,36 @@ import torch
 from . import _lib
 
 
+_DTYPE_CODES = {"default": -1, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x3": 2, "x3": 2}
+
+
+def _dtype_code(dtype):
+    if isinstance(dtype, int):
+        return dtype
+    return _DTYPE_CODES[str(dtype).replace("torch.", "")]
+
+
 def set_mfma_dtype(dtype):
-    """'fp32' (default), 'bf16' or 'bf16x3': operand type of the matrix-core products inside the fused attention
-    kernels (coda_mha_set_mfma_dtype, include/coda_attention.h).  Tensors stay float32 in every mode; 'bf16x3'
-    carries each fp32 operand as three bf16 pieces and gives fp32-level results on the bf16 matrix cores."""
-    code = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x3": 2, "x3": 2}[str(dtype).replace("torch.", "")]
-    _lib.check(_lib.load().coda_mha_set_mfma_dtype(code), "coda_mha_set_mfma_dtype")
+    """'fp32', 'bf16', 'bf16x3' or 'default': operand type of the matrix-core products inside the fused attention kernels
+    for the calls of THIS thread from now on (a per-call argument of coda_mha_*_opt_f32, include/coda_attention.h --
+    the library itself keeps no switch).  Tensors stay float32 in every mode; 'bf16x3' carries each fp32 operand as
+    three bf16 pieces and gives fp32-level results on the bf16 matrix cores.  Prefer the scoped form ``mfma_dtype``."""
+    _lib.set_option("mfma_dtype", _dtype_code(dtype))
+
+
+def mfma_dtype(dtype):
+    """``with attention_core.mfma_dtype("bf16"): loss = model(batch)...; loss.backward()`` -- the forward passes issued
+    inside the block (and their backward passes, whenever they run) use that operand type; other threads and the code
+    outside the block are unaffected."""
+    return _lib.options(mfma_dtype=_dtype_code(dtype))
 
 
 def get_mfma_dtype():
-    return ("fp32", "bf16", "bf16x3")[_lib.load().coda_mha_get_mfma_dtype()]
+    """What a call issued now would use."""
+    code = _lib.opt("mfma_dtype")
+    if code < 0:
+        code = _lib.load().coda_mha_get_mfma_dtype()
+    return ("fp32", "bf16", "bf16x3")[code]
 
 
 def merge_masks(attn_mask, key_padding_mask, bsz, h, tgt_len, src_len):
@@ -102,18 +122,19 @@ class _FusedAttention(torch.autograd.Function):
         lse = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
         seed, seed_dev = _next_seed() if dropout_p > 0.0 else (0, None)
         with torch.cuda.device(q.device):
-            st = lib.coda_mha_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
-                                      b, h, l, s, d, ldq, ldk, ldv, float(scale), float(dropout_p), seed,
-                                      _ptr(seed_dev), _lib.current_stream_handle())
+            dt = _lib.opt("mfma_dtype")  # this thread's option; the backward (another thread) gets it through ctx
+            st = lib.coda_mha_fwd_opt_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
+                                          b, h, l, s, d, ldq, ldk, ldv, float(scale), float(dropout_p), seed,
+                                          _ptr(seed_dev), dt, _lib.current_stream_handle())
         _lib.check(st, "mha_fwd")
         ctx.save_for_backward(q, k, v, mask_u8, out, lse)
-        ctx.meta = (ldq, ldk, ldv, float(scale), float(dropout_p), seed, seed_dev)
+        ctx.meta = (ldq, ldk, ldv, float(scale), float(dropout_p), seed, seed_dev, dt)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, mask_u8, out, lse = ctx.saved_tensors
-        ldq, ldk, ldv, scale, dropout_p, seed, seed_dev = ctx.meta
+        ldq, ldk, ldv, scale, dropout_p, seed, seed_dev, dt = ctx.meta
         lib = _lib.load()
         l, b, h, d = q.shape
         s = k.shape[0]
@@ -123,10 +144,10 @@ class _FusedAttention(torch.autograd.Function):
         dv = torch.empty((s, b, h, d), dtype=torch.float32, device=q.device)
         delta = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
-            st = lib.coda_mha_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
-                                      _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
-                                      ldq, ldk, ldv, 0, 0, 0, scale, dropout_p, seed, _ptr(seed_dev),
-                                      _lib.current_stream_handle())
+            st = lib.coda_mha_bwd_parts_opt_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
+                                                _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
+                                                ldq, ldk, ldv, 0, 0, 0, scale, dropout_p, seed, _ptr(seed_dev), 7, dt,
+                                                _lib.current_stream_handle())
         _lib.check(st, "mha_bwd")
         return dq, dk, dv, None, None, None
 

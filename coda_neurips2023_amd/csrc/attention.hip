@@ -1536,19 +1536,21 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   return launch_status();
 }
 
-// 0: fp32 MFMA operands (default), 1: bf16 MFMA operands (attention_bf16.hip); coda_mha_set_mfma_dtype
-std::atomic<int> g_mfma_dtype{-1};
-int mfma_dtype() {
-  int v = g_mfma_dtype.load(std::memory_order_relaxed);
-  if (v < 0) {
+// MFMA operand type of this call: 0 fp32 (default), 1 bf16 (attention_bf16.hip), 2 three bf16 pieces per fp32 operand.
+// The *_opt entry points pass it as an argument (common.hip.h: CallOptions); the library default is CODA_ATTN_DTYPE.
+int default_mfma_dtype() {
+  static const int v = [] {
     const char *e = getenv("CODA_ATTN_DTYPE");
     // "bf16" / "1": bf16 operands; "bf16x3" / "x3" / "2": three bf16 pieces per fp32 operand (fp32-level results)
-    v = 0;
-    if (e && (e[0] == '2' || e[0] == 'x' || (e[0] == 'b' && strstr(e, "x3")))) v = 2;
-    else if (e && (e[0] == 'b' || e[0] == '1')) v = 1;
-    g_mfma_dtype.store(v, std::memory_order_relaxed);
-  }
+    if (e && (e[0] == '2' || e[0] == 'x' || (e[0] == 'b' && strstr(e, "x3")))) return 2;
+    if (e && (e[0] == 'b' || e[0] == '1')) return 1;
+    return 0;
+  }();
   return v;
+}
+int mfma_dtype() {
+  const int v = call_options().mfma_dtype;
+  return v >= 0 && v <= 2 ? v : default_mfma_dtype();
 }
 
 template <int D>
@@ -1775,13 +1777,30 @@ CODA_API int coda_mha_bwd_parts_f32(const float *q, const float *k, const float 
   return d == 64 ? launch_bwd<64>(p, st) : launch_bwd<128>(p, st);
 }
 
-CODA_API int coda_mha_set_mfma_dtype(int dtype) {
-  if (dtype < 0 || dtype > 2) return CODA_EINVAL;
-  coda::g_mfma_dtype.store(dtype, std::memory_order_relaxed);
-  return CODA_OK;
+CODA_API int coda_mha_fwd_opt_f32(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,
+                                  float *lse, int b, int h, int l, int s, int d, int ldq, int ldk, int ldv, float scale,
+                                  float dropout_p, uint64_t seed, const uint64_t *seed_dev, int mfma_dtype, void *stream) {
+  if (mfma_dtype < -1 || mfma_dtype > 2) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.mfma_dtype = mfma_dtype;
+  coda::ScopedCallOptions scope(o);
+  return coda_mha_fwd_f32(q, k, v, mask, out, lse, b, h, l, s, d, ldq, ldk, ldv, scale, dropout_p, seed, seed_dev, stream);
 }
 
-CODA_API int coda_mha_get_mfma_dtype(void) { return coda::mfma_dtype(); }
+CODA_API int coda_mha_bwd_parts_opt_f32(const float *q, const float *k, const float *v, const uint8_t *mask,
+                                        const float *out, const float *lse, const float *dout, float *dq, float *dk,
+                                        float *dv, float *delta, int b, int h, int l, int s, int d, int ldq, int ldk,
+                                        int ldv, int lddq, int lddk, int lddv, float scale, float dropout_p,
+                                        uint64_t seed, const uint64_t *seed_dev, int parts, int mfma_dtype, void *stream) {
+  if (mfma_dtype < -1 || mfma_dtype > 2) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.mfma_dtype = mfma_dtype;
+  coda::ScopedCallOptions scope(o);
+  return coda_mha_bwd_parts_f32(q, k, v, mask, out, lse, dout, dq, dk, dv, delta, b, h, l, s, d, ldq, ldk, ldv, lddq, lddk,
+                                lddv, scale, dropout_p, seed, seed_dev, parts, stream);
+}
+
+CODA_API int coda_mha_get_mfma_dtype(void) { return coda::default_mfma_dtype(); }
 
 CODA_API int coda_mha_timing_enable(int min_len) {
   using namespace coda;

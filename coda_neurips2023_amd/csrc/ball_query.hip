@@ -34,15 +34,14 @@ int ball_query_tile(const float *new_xyz, const float *xyz, int32_t *idx, float 
                     int nsample, int normalize, hipStream_t s);
 
 namespace {
-std::atomic<int> g_bq_route{-1};
 int ball_query_route() {
-  int r = g_bq_route.load(std::memory_order_relaxed);
-  if (r < 0) {  // first use: CODA_BQ = auto | grid | scan | tile
+  const int r = call_options().bq_route;  // this call's option (coda_ball_query_opt_f32), else CODA_BQ = auto | grid | scan | tile
+  if (r >= 1 && r <= 3) return r;
+  static const int dflt = [] {
     const char *e = getenv("CODA_BQ");
-    r = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0)));
-    g_bq_route.store(r, std::memory_order_relaxed);
-  }
-  return r;
+    return !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0)));
+  }();
+  return dflt;
 }
 
 constexpr int kBqWaves = 4;  // waves per workgroup
@@ -189,11 +188,6 @@ int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, fl
 }  // namespace
 }  // namespace coda
 
-CODA_API int coda_set_ball_query_route(int route) {
-  if (route < 0 || route > 3) return CODA_EINVAL;
-  coda::g_bq_route.store(route, std::memory_order_relaxed);
-  return CODA_OK;
-}
 
 CODA_API size_t coda_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
   (void)m;
@@ -221,4 +215,28 @@ CODA_API int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz
   return coda::ball_query_dispatch(new_xyz, xyz, idx, grouped_xyz, b, n, m, radius, nsample,
                                    normalize, workspace, workspace_bytes,
                                    static_cast<hipStream_t>(stream));
+}
+
+CODA_API int coda_ball_query_opt_f32(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n, int m,
+                                     float radius, int nsample, void *workspace, size_t workspace_bytes,
+                                     int distance_mode, int route, void *stream) {
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes || route < 0 || route > 3) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.distance_mode = distance_mode;
+  o.bq_route = route;
+  coda::ScopedCallOptions scope(o);
+  return coda_ball_query_f32(new_xyz, xyz, idx, b, n, m, radius, nsample, workspace, workspace_bytes, stream);
+}
+
+CODA_API int coda_query_and_group_xyz_opt_f32(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped_xyz,
+                                              int b, int n, int m, float radius, int nsample, int normalize,
+                                              void *workspace, size_t workspace_bytes, int distance_mode, int route,
+                                              void *stream) {
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes || route < 0 || route > 3) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.distance_mode = distance_mode;
+  o.bq_route = route;
+  coda::ScopedCallOptions scope(o);
+  return coda_query_and_group_xyz_f32(new_xyz, xyz, idx, grouped_xyz, b, n, m, radius, nsample, normalize, workspace,
+                                      workspace_bytes, stream);
 }

@@ -29,7 +29,7 @@ inline int launch_status() {
 // (interpolate_gpu.cu:101-102) in a binary built by nvcc with the default
 // -fmad=true (setup.py:26-28), i.e. with FMA contraction.  Which contraction is
 // not recoverable without nvcc, so the kernels implement all three candidates
-// and the mode is selected at run time (coda_set_distance_mode):
+// and the mode is selected per call (the *_opt entry points; default CODA_DISTANCE_MODE):
 //   0  no contraction:            (a*a' + b*b') + c*c'      one rounding per operation
 //   1  fma(c,c', fma(a,a', b*b'))  (first product of the inner sum contracted: LLVM/NVVM order)
 //   2  fma(c,c', fma(b,b', a*a'))
@@ -37,7 +37,29 @@ inline int launch_status() {
 // __f*_rn intrinsics make every mode independent of compiler flags.
 constexpr int kDistanceModes = 3;
 constexpr int kDefaultDistanceMode = 1;
-int distance_mode();  // version.hip: process-wide, atomic
+// ---- per-call options -------------------------------------------------------------------------------------------
+// The library keeps NO mutable process-wide state (the reference's ops are stateless): every switch has a
+// library default -- an environment variable read once -- and the *_opt entry points take the value as an argument.
+// An *_opt entry point installs its arguments in this thread-local record for the duration of the call; the plain
+// entry points and the kernels' launch code read it (an unset field = the library default), so concurrent calls from
+// different threads with different options never see each other, and an entry point that issues other entry points
+// (csrc/decoder_stack.hip) passes its options on without extra parameters.
+struct CallOptions {
+  int distance_mode = -1;  // -1 default | 0 | 1 | 2
+  int fps_waves = 0;       // 0 default | 8 | 16
+  int bq_route = 0;        // 0 auto | 1 grid | 2 scan | 3 tile
+  int mfma_dtype = -1;     // -1 default | 0 fp32 | 1 bf16 | 2 bf16x3
+};
+CallOptions &call_options();  // version.hip: thread_local
+struct ScopedCallOptions {
+  CallOptions saved;
+  explicit ScopedCallOptions(const CallOptions &o) : saved(call_options()) { call_options() = o; }
+  ~ScopedCallOptions() { call_options() = saved; }
+  ScopedCallOptions(const ScopedCallOptions &) = delete;
+  ScopedCallOptions &operator=(const ScopedCallOptions &) = delete;
+};
+int distance_mode();          // this call's mode: the option if set, else the library default
+int default_distance_mode();  // CODA_DISTANCE_MODE (0|1|2) if set, else 1
 
 template <int DM>
 __device__ __forceinline__ float dot3(float a, float a2, float b, float b2, float c, float c2) {

@@ -112,6 +112,10 @@ CODA_API size_t coda_decoder_stack_ws_floats(int nl, int nq, int bsz, int e, int
 CODA_API int coda_decoder_stack_fwd_f32(const CodaDecoderStack *a, void *stream) {
   if (!a || bad_dims(a->nl, a->nq, a->bsz, a->e, a->nheads, a->ffn) || a->ns <= 0) return CODA_EINVAL;
   if (a->ld_kv != 0 && (a->ld_kv < a->nl * a->e || a->ld_kv % 4 != 0)) return CODA_EINVAL;
+  if (a->mfma_dtype < -1 || a->mfma_dtype > 2) return CODA_EINVAL;
+  coda::CallOptions opt = coda::call_options();
+  opt.mfma_dtype = a->mfma_dtype;  // the attention launches below read it (common.hip.h: per-call options)
+  coda::ScopedCallOptions scope(opt);
   if (!a->tgt || !a->query_pos || !a->k_all || !a->v_all || !a->norm_g || !a->norm_b || !a->params || !a->outs || !a->ws)
     return CODA_EINVAL;
   const Dims d = dims_of(a->nl, a->nq, a->bsz, a->e, a->ns, a->nheads, a->ffn);
@@ -205,6 +209,10 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
                                         void *stream) {
   if (!a || bad_dims(a->nl, a->nq, a->bsz, a->e, a->nheads, a->ffn) || a->ns <= 0) return CODA_EINVAL;
   if (a->ld_kv != 0 && (a->ld_kv < a->nl * a->e || a->ld_kv % 4 != 0)) return CODA_EINVAL;
+  if (a->mfma_dtype < -1 || a->mfma_dtype > 2) return CODA_EINVAL;
+  coda::CallOptions opt = coda::call_options();
+  opt.mfma_dtype = a->mfma_dtype;
+  coda::ScopedCallOptions scope(opt);
   if (!a->tgt || !a->query_pos || !a->k_all || !a->v_all || !a->norm_g || !a->params || !a->ws || !dstack || !d_tgt ||
       !d_query_pos || !dk_all || !dv_all || !grads || !sums || !bwd_ws)
     return CODA_EINVAL;

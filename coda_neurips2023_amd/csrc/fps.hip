@@ -791,15 +791,17 @@ int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, 
 // slots).  More waves spread the buckets a round touches -- a dozen, spatially clustered -- over more issue ports:
 // 2.02 vs 2.16 ms for 8 x 20 000 -> 2048 with one workgroup per scene (default 16); with two workgroups per scene the
 // round is dominated by the mailbox round trip and 8 waves are slightly ahead (3.58 vs 3.64 ms for 8 x 40 000: default
-// 8).  coda_set_fps_waves() / CODA_FPS_WAVES force one shape for both (A/B, tests).
-std::atomic<int> g_fps_waves{-1};
-int bucket_waves(int workgroups_per_scene = 1) {
-  int v = g_fps_waves.load(std::memory_order_relaxed);
-  if (v < 0) {
+// 8).  The `waves` argument of coda_furthest_point_sampling_opt_f32 / CODA_FPS_WAVES force one shape for both (A/B, tests).
+int default_fps_waves() {
+  static const int v = [] {
     const char *e = getenv("CODA_FPS_WAVES");
-    v = !e ? 0 : (atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0));
-    g_fps_waves.store(v, std::memory_order_relaxed);
-  }
+    return !e ? 0 : (atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0));
+  }();
+  return v;
+}
+int bucket_waves(int workgroups_per_scene = 1) {
+  int v = call_options().fps_waves;  // this call's option (coda_furthest_point_sampling_opt_f32), else the default
+  if (v != 8 && v != 16) v = default_fps_waves();
   return v != 0 ? v : (workgroups_per_scene == 2 ? 8 : 16);
 }
 
@@ -1019,10 +1021,15 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   return launch_status();
 }
 
-CODA_API int coda_set_fps_waves(int waves) {
+CODA_API int coda_furthest_point_sampling_opt_f32(const float *xyz, int b, int n, int m, int32_t *idx, void *workspace,
+                                                  size_t workspace_bytes, int distance_mode, int waves, void *stream) {
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes) return CODA_EINVAL;
   if (waves != 0 && waves != 8 && waves != 16) return CODA_EINVAL;
-  coda::g_fps_waves.store(waves, std::memory_order_relaxed);
-  return CODA_OK;
+  coda::CallOptions o = coda::call_options();
+  o.distance_mode = distance_mode;
+  o.fps_waves = waves;
+  coda::ScopedCallOptions scope(o);
+  return coda_furthest_point_sampling_f32(xyz, b, n, m, idx, workspace, workspace_bytes, stream);
 }
 
 #ifdef CODA_FPS_PROF

@@ -215,7 +215,8 @@ CODA_API int coda_sgemm_relu_dropout_f32(int transb, int m, int n, int k, const 
   using namespace coda;
   if (m < 0 || n < 0 || k < 0 || !(dropout_p >= 0.f) || dropout_p >= 1.f) return CODA_EINVAL;
   if (m == 0 || n == 0) return CODA_OK;
-  if (!a || !b || !c) return CODA_EINVAL;
+  if (!a || !b || !c || k == 0) return CODA_EINVAL;
+  if (lda < k || ldb < (transb ? k : n)) return CODA_EINVAL;  // same operand checks as coda_sgemm_f32
   // the launch-sized split-K kernel only (a wave-0 epilogue owns whole sums there); anything else: separate passes
   if (m % 64 || n % 64 || k % 128 || (lda | ldb) % 4 || ldc != n || (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 ||
       static_cast<long long>(m) * n > 2048ll * 1024)

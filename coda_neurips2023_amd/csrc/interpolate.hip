@@ -150,3 +150,21 @@ CODA_API int coda_three_interpolate_grad_f32(const float *grad_out, const int32_
                      weight, grad_points, c, n, m);
   return launch_status();
 }
+
+CODA_API int coda_three_nn_opt_f32(const float *unknown, const float *known, float *dist2, int32_t *idx, int b, int n,
+                                   int m, int distance_mode, void *stream) {
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.distance_mode = distance_mode;
+  coda::ScopedCallOptions scope(o);
+  return coda_three_nn_f32(unknown, known, dist2, idx, b, n, m, stream);
+}
+
+CODA_API int coda_three_interpolate_opt_f32(const float *points, const int32_t *idx, const float *weight, float *out,
+                                            int b, int c, int m, int n, int distance_mode, void *stream) {
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.distance_mode = distance_mode;
+  coda::ScopedCallOptions scope(o);
+  return coda_three_interpolate_f32(points, idx, weight, out, b, c, m, n, stream);
+}

@@ -1,4 +1,4 @@
-// version.hip -- library identification and the process-wide distance-arithmetic mode.
+// version.hip -- library identification, the per-call options record and the default distance-arithmetic mode.
 #include "common.hip.h"
 
 #include <atomic>
@@ -14,16 +14,19 @@ int initial_mode() {
   if (e && e[0] >= '0' && e[0] < '0' + kDistanceModes && e[1] == 0) return e[0] - '0';
   return kDefaultDistanceMode;
 }
-std::atomic<int> g_distance_mode{-1};
+thread_local CallOptions tls_call_options;
 }  // namespace
 
+CallOptions &call_options() { return tls_call_options; }
+
+int default_distance_mode() {
+  static const int mode = initial_mode();  // read once
+  return mode;
+}
+
 int distance_mode() {
-  int m = g_distance_mode.load(std::memory_order_relaxed);
-  if (m < 0) {
-    m = initial_mode();
-    g_distance_mode.store(m, std::memory_order_relaxed);
-  }
-  return m;
+  const int m = tls_call_options.distance_mode;
+  return m >= 0 && m < kDistanceModes ? m : default_distance_mode();
 }
 }  // namespace coda
 
@@ -57,12 +60,6 @@ int raise_dynamic_lds(const void *kernel, size_t bytes, size_t static_bytes) {
 }
 }  // namespace coda
 
-CODA_API const char *coda_version(void) { return "coda_hip gfx950 abi2"; }
+CODA_API const char *coda_version(void) { return "coda_hip gfx950 abi3"; }
 
-CODA_API int coda_set_distance_mode(int mode) {
-  if (mode < 0 || mode >= coda::kDistanceModes) return CODA_EINVAL;
-  coda::g_distance_mode.store(mode, std::memory_order_relaxed);
-  return CODA_OK;
-}
-
-CODA_API int coda_get_distance_mode(void) { return coda::distance_mode(); }
+CODA_API int coda_get_distance_mode(void) { return coda::default_distance_mode(); }

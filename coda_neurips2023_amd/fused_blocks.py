@@ -299,11 +299,11 @@ class _DecoderStack(torch.autograd.Function):
             attn = torch.empty((nq * bsz, e), dtype=torch.float32, device=dev)
             lse = torch.empty((bsz, nheads, nq), dtype=torch.float32, device=dev)
             seed, seed_dev = _core._next_seed() if p_attn > 0.0 else (0, None)
-            _lib.check(lib.coda_mha_fwd_f32(q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e,
-                                            mask_ptr, attn.data_ptr(), lse.data_ptr(), bsz, nheads, nq, ns, d, e, ld_kv,
-                                            ld_kv, scale, float(p_attn), seed,
-                                            seed_dev.data_ptr() if seed_dev is not None else None,
-                                            _lib.current_stream_handle()), "mha_fwd")
+            _lib.check(lib.coda_mha_fwd_opt_f32(q.data_ptr(), k_all.data_ptr() + 4 * l * e, v_all.data_ptr() + 4 * l * e,
+                                                mask_ptr, attn.data_ptr(), lse.data_ptr(), bsz, nheads, nq, ns, d, e, ld_kv,
+                                                ld_kv, scale, float(p_attn), seed,
+                                                seed_dev.data_ptr() if seed_dev is not None else None,
+                                                _lib.opt("mfma_dtype"), _lib.current_stream_handle()), "mha_fwd")
             a2 = gemm.linear(attn, ow2).view(nq, bsz, e)
             c5 = _Ctx()
             s3, y3, _ = _AddLN.forward(c5, a2, ob2, s2, None, g3, b3n, eps, p2)
@@ -315,6 +315,7 @@ class _DecoderStack(torch.autograd.Function):
             res = s4
         ctx.blocks = blocks
         ctx.dims = (nl, nq, bsz, e, ns, nheads, scale, float(p_attn), query_pos is not None, pos is not None)
+        ctx.mfma_dtype = _lib.opt("mfma_dtype")
         ctx.cross_mask = cross_mask
         ctx.save_for_backward(mem2, mp2, k_all, v_all, wk_all, wv_all, *params)
         return torch.stack(outs)
@@ -367,19 +368,20 @@ class _DecoderStack(torch.autograd.Function):
                         seed_dev.data_ptr() if seed_dev is not None else None)
             dkv_ptrs = (dk_all.data_ptr() + 4 * l * e, dv_all.data_ptr() + 4 * l * e)
             if side is None:
-                _lib.check(lib.coda_mha_bwd_f32(*bwd_args, dq.data_ptr(), *dkv_ptrs, delta.data_ptr(), *bwd_dims,
-                                                _lib.current_stream_handle()), "mha_bwd")
+                _lib.check(lib.coda_mha_bwd_parts_opt_f32(*bwd_args, dq.data_ptr(), *dkv_ptrs, delta.data_ptr(), *bwd_dims,
+                                                          7, ctx.mfma_dtype, _lib.current_stream_handle()), "mha_bwd")
             else:
                 # only dQ is on the dependency chain of this backward; dK / dV of every layer are consumed after
                 # the loop.  delta + dQ run here, the dK/dV kernel on the side stream behind an event, where it
                 # fills the CUs that the chain of launch-sized kernels below leaves idle.
-                _lib.check(lib.coda_mha_bwd_parts_f32(*bwd_args, dq.data_ptr(), None, None, delta.data_ptr(),
-                                                      *bwd_dims, 1 | 4, _lib.current_stream_handle()), "mha_bwd dq")
+                _lib.check(lib.coda_mha_bwd_parts_opt_f32(*bwd_args, dq.data_ptr(), None, None, delta.data_ptr(),
+                                                          *bwd_dims, 1 | 4, ctx.mfma_dtype,
+                                                          _lib.current_stream_handle()), "mha_bwd dq")
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
-                _lib.check(lib.coda_mha_bwd_parts_f32(*bwd_args, None, *dkv_ptrs, delta.data_ptr(), *bwd_dims, 2,
-                                                      side.cuda_stream), "mha_bwd dkv")
+                _lib.check(lib.coda_mha_bwd_parts_opt_f32(*bwd_args, None, *dkv_ptrs, delta.data_ptr(), *bwd_dims, 2,
+                                                          ctx.mfma_dtype, side.cuda_stream), "mha_bwd dkv")
                 held.append((dattn, delta))  # read by the side stream: freed only after the join below
             defer.add(din2_all[l, :e], dq, xq2)
             _colsum_into(dib2_all[l, :e], dq.unsqueeze(0), defer)
@@ -438,7 +440,7 @@ class _StackArgs(ctypes.Structure):
                 ("tgt", ctypes.c_void_p), ("query_pos", ctypes.c_void_p), ("k_all", ctypes.c_void_p),
                 ("v_all", ctypes.c_void_p), ("norm_g", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
                 ("params", ctypes.c_void_p), ("outs", ctypes.c_void_p), ("ws", ctypes.c_void_p),
-                ("ld_kv", ctypes.c_int)]
+                ("ld_kv", ctypes.c_int), ("mfma_dtype", ctypes.c_int)]
 
 
 def _ptr_table(tensors):
@@ -473,9 +475,10 @@ class _DecoderStackC(torch.autograd.Function):
         table = _ptr_table(params)
         args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
                           query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
-                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr(), k_all.stride(0))
+                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr(), k_all.stride(0), _lib.opt("mfma_dtype"))
         _lib.check(lib.coda_decoder_stack_fwd_f32(ctypes.byref(args), _lib.current_stream_handle()), "decoder_stack_fwd")
         ctx.args = (nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, pos is not None)
+        ctx.mfma_dtype = args.mfma_dtype
         ctx.save_for_backward(tgt, query_pos, mem2, mp2, k_all, v_all, wk_all, wv_all, ws, norm_g, norm_b, *params)
         return outs
 
@@ -516,7 +519,7 @@ class _DecoderStackC(torch.autograd.Function):
         table = _ptr_table(params)
         args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
                           query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
-                          ctypes.addressof(table), None, ws.data_ptr(), k_all.stride(0))
+                          ctypes.addressof(table), None, ws.data_ptr(), k_all.stride(0), ctx.mfma_dtype)
         _lib.check(lib.coda_decoder_stack_bwd_f32(ctypes.byref(args), dstack.data_ptr(), d_tgt.data_ptr(), d_qpos.data_ptr(),
                                                   dk_all.data_ptr(), dv_all.data_ptr(), ctypes.addressof(gtable),
                                                   sums.data_ptr(), bws.data_ptr(), _lib.current_stream_handle()),

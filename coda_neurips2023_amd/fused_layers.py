@@ -189,11 +189,13 @@ class _MHA(torch.autograd.Function):
         lse = torch.empty((bsz, nheads, tgt_len), dtype=torch.float32, device=xq.device)
         seed, seed_dev = _core._next_seed() if p > 0.0 else (0, None)
         scale = 1.0 / (d ** 0.5)
-        _lib.check(lib.coda_mha_fwd_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), bsz, nheads, tgt_len,
-                                        src_len, d, ldq, ldk, ldv, scale, float(p), seed, _p(seed_dev), _stream()),
+        dt = _lib.opt("mfma_dtype")  # per-call MFMA operand type (this thread's option), kept for the backward
+        _lib.check(lib.coda_mha_fwd_opt_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), bsz, nheads, tgt_len,
+                                            src_len, d, ldq, ldk, ldv, scale, float(p), seed, _p(seed_dev), dt, _stream()),
                    "mha_fwd")
         out = gemm.linear(attn, w_out).view(tgt_len, bsz, e)
         ctx.meta = (tgt_len, src_len, bsz, e, nheads, ldq, ldk, ldv, scale, float(p), seed, seed_dev, same_qk, same_kv)
+        ctx.mfma_dtype = dt
         ctx.save_for_backward(xq2, xk2, xv2, q, k, v, attn, lse, w_in, w_out, mask_u8)
         return out
 
@@ -222,9 +224,10 @@ class _MHA(torch.autograd.Function):
             dkv = torch.empty((2, rk, e), dtype=torch.float32, device=dev)
             dk, dv = dkv[0], dkv[1]
         delta = torch.empty((bsz, nheads, tgt_len), dtype=torch.float32, device=dev)
-        _lib.check(lib.coda_mha_bwd_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), _p(dattn), _p(dq), _p(dk),
-                                        _p(dv), _p(delta), bsz, nheads, tgt_len, src_len, d, ldq, ldk, ldv, 0, 0, 0, scale, p,
-                                        seed, _p(seed_dev), _stream()), "mha_bwd")
+        _lib.check(lib.coda_mha_bwd_parts_opt_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), _p(dattn), _p(dq),
+                                                  _p(dk), _p(dv), _p(delta), bsz, nheads, tgt_len, src_len, d, ldq, ldk, ldv,
+                                                  0, 0, 0, scale, p, seed, _p(seed_dev), 7, ctx.mfma_dtype, _stream()),
+                   "mha_bwd")
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * e, dtype=torch.float32, device=dev)
         if dqkv is not None:

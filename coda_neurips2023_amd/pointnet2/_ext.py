@@ -82,9 +82,11 @@ def _ptr(t):
 
 
 def set_fps_waves(waves=0):
-    """Waves per workgroup of the bucketed FPS kernels: 0 (default: 16, or 8 with two workgroups per scene), 8 or 16.
-    Process-wide; same indices."""
-    _lib.check(_lib.load().coda_set_fps_waves(int(waves)), "coda_set_fps_waves")
+    """Waves per workgroup of the bucketed FPS kernels for the calls of THIS thread: 0 (default: 16, or 8 with two
+    workgroups per scene), 8 or 16; same indices (a per-call argument of coda_furthest_point_sampling_opt_f32)."""
+    if waves not in (0, 8, 16):
+        raise ValueError("waves must be 0, 8 or 16")
+    _lib.set_option("fps_waves", waves)
 
 
 def furthest_point_sampling(points, nsamples):
@@ -98,8 +100,8 @@ def furthest_point_sampling(points, nsamples):
     ws_bytes = lib.coda_furthest_point_sampling_workspace_bytes(b, n, nsamples)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=points.device) if ws_bytes else None
     with torch.cuda.device(points.device), _timed("furthest_point_sampling"):
-        st = lib.coda_furthest_point_sampling_f32(_ptr(points), b, n, nsamples, _ptr(out),
-                                                  _ptr(ws), ws_bytes, _stream())
+        st = lib.coda_furthest_point_sampling_opt_f32(_ptr(points), b, n, nsamples, _ptr(out), _ptr(ws), ws_bytes,
+                                                      _lib.opt("distance_mode"), _lib.opt("fps_waves"), _stream())
     _lib.check(st, "furthest_point_sampling")
     return out
 
@@ -141,24 +143,14 @@ def gather_points_grad(grad_out, idx, n):
 _ROUTES = {"auto": 0, "grid": 1, "scan": 2, "tile": 3}
 
 
-class _ball_query_route:
+def _route(algorithm):
     """``algorithm``: "auto" (the cell table in a workspace where it applies, else the scan) | "grid" | "scan" (brute
     force) | "tile" (one launch, no workspace: include/coda_pointnet2.h).  All give identical results; the non-default
-    ones exist for the parity tests and A/B timing, and switch the library's process-wide route for the duration
-    of the call."""
-
-    def __init__(self, lib, algorithm):
-        if algorithm not in _ROUTES:
-            raise ValueError(f"unknown ball_query algorithm {algorithm!r}")
-        self.lib, self.route = lib, _ROUTES[algorithm]
-
-    def __enter__(self):
-        if self.route:
-            self.lib.coda_set_ball_query_route(self.route)
-
-    def __exit__(self, *exc):
-        if self.route:
-            self.lib.coda_set_ball_query_route(0)
+    ones exist for the parity tests and A/B timing.  The route is an argument of the call (coda_ball_query_opt_f32):
+    "auto" defers to the calling thread's option, then to the library default (CODA_BQ)."""
+    if algorithm not in _ROUTES:
+        raise ValueError(f"unknown ball_query algorithm {algorithm!r}")
+    return _ROUTES[algorithm] or _lib.opt("bq_route")
 
 
 def _ball_query_workspace(lib, b, n, m, nsample, device, algorithm):
@@ -184,9 +176,9 @@ def ball_query(new_xyz, xyz, radius, nsample, algorithm="auto"):
     m = new_xyz.size(1)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
-    with torch.cuda.device(new_xyz.device), _ball_query_route(lib, algorithm), _timed("ball_query"):
-        st = lib.coda_ball_query_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), b, n, m, float(radius),
-                                     int(nsample), _ptr(ws), ws_bytes, _stream())
+    with torch.cuda.device(new_xyz.device), _timed("ball_query"):
+        st = lib.coda_ball_query_opt_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), b, n, m, float(radius), int(nsample),
+                                         _ptr(ws), ws_bytes, _lib.opt("distance_mode"), _route(algorithm), _stream())
     _lib.check(st, "ball_query")
     return idx
 
@@ -240,8 +232,8 @@ def three_nn(unknowns, knows):
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
     dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
     with torch.cuda.device(unknowns.device), _timed("three_nn"):
-        st = lib.coda_three_nn_f32(_ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), b, n, m,
-                                   _stream())
+        st = lib.coda_three_nn_opt_f32(_ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), b, n, m,
+                                       _lib.opt("distance_mode"), _stream())
     _lib.check(st, "three_nn")
     return [dist2, idx]
 
@@ -260,8 +252,8 @@ def three_interpolate(points, idx, weight):
     n = idx.size(1)
     out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device), _timed("three_interpolate"):
-        st = lib.coda_three_interpolate_f32(_ptr(points), _ptr(idx), _ptr(weight), _ptr(out), b, c,
-                                            m, n, _stream())
+        st = lib.coda_three_interpolate_opt_f32(_ptr(points), _ptr(idx), _ptr(weight), _ptr(out), b, c, m, n,
+                                                _lib.opt("distance_mode"), _stream())
     _lib.check(st, "three_interpolate")
     return out
 
@@ -308,11 +300,11 @@ def query_and_group_xyz(new_xyz, xyz, radius, nsample, normalize_xyz, algorithm=
     shape = (b, m, nsample, 3) if channels_last else (b, 3, m, nsample)
     grouped = torch.empty(shape, dtype=torch.float32, device=new_xyz.device)
     ws, ws_bytes = _ball_query_workspace(lib, b, n, m, nsample, new_xyz.device, algorithm)
-    with torch.cuda.device(new_xyz.device), _ball_query_route(lib, algorithm), _timed("query_and_group_xyz"):
-        st = lib.coda_query_and_group_xyz_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(grouped),
-                                              b, n, m, float(radius), int(nsample),
-                                              (1 if normalize_xyz else 0) | (2 if channels_last else 0),
-                                              _ptr(ws), ws_bytes,
-                                              _stream())
+    with torch.cuda.device(new_xyz.device), _timed("query_and_group_xyz"):
+        st = lib.coda_query_and_group_xyz_opt_f32(_ptr(new_xyz), _ptr(xyz), _ptr(idx), _ptr(grouped),
+                                                  b, n, m, float(radius), int(nsample),
+                                                  (1 if normalize_xyz else 0) | (2 if channels_last else 0),
+                                                  _ptr(ws), ws_bytes, _lib.opt("distance_mode"), _route(algorithm),
+                                                  _stream())
     _lib.check(st, "query_and_group_xyz")
     return idx, grouped

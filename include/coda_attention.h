@@ -70,8 +70,9 @@ int coda_mha_bwd_parts_f32(const float *q, const float *k, const float *v,
                            int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
                            float dropout_p, uint64_t seed, const uint64_t *seed_dev, int parts, void *stream);
 
-/* MFMA operand type of the two entry points above (process-wide, like the distance mode of
- * coda_pointnet2.h): 0 = fp32 operands (v_mfma_f32_32x32x2_f32, default), 1 = bf16 operands
+/* MFMA operand type -- a per-call argument of the *_opt entry points (the plain ones use the library default;
+ * the library keeps no mutable process-wide state, see coda_pointnet2.h): 0 = fp32 operands
+ * (v_mfma_f32_32x32x2_f32), 1 = bf16 operands
  * (v_mfma_f32_32x32x16_bf16): Q, K, V, dO and the probabilities are rounded to bf16 on their way
  * into the matrix cores, accumulation / softmax / lse / every tensor in memory stay fp32.  This is
  * BASELINE.json configs[4] ("bf16 MFMA attention"); parity target there is 2e-2 relative to the
@@ -84,8 +85,20 @@ int coda_mha_bwd_parts_f32(const float *q, const float *k, const float *v,
  * off by default: the operand splitting is itself VALU work, and the measured gain is 1.2-1.3x on the
  * long-sequence forward and dQ kernels only; every other problem (dK/dV, the decoder shapes, head_dim 128) runs the
  * fp32-MFMA kernels in this mode too.
- * Initial value: environment variable CODA_ATTN_DTYPE: "bf16" / "1" -> 1, "bf16x3" / "x3" / "2" -> 2, else 0. */
-int coda_mha_set_mfma_dtype(int dtype);
+ * -1 = the library default: environment variable CODA_ATTN_DTYPE ("bf16" / "1" -> 1, "bf16x3" / "x3" / "2" -> 2,
+ * else 0), read once; coda_mha_get_mfma_dtype() returns it. */
+int coda_mha_fwd_opt_f32(const float *q, const float *k, const float *v,
+                         const uint8_t *mask, float *out, float *lse, int b, int h,
+                         int l, int s, int d, int ldq, int ldk, int ldv, float scale,
+                         float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                         int mfma_dtype, void *stream);
+int coda_mha_bwd_parts_opt_f32(const float *q, const float *k, const float *v,
+                               const uint8_t *mask, const float *out, const float *lse,
+                               const float *dout, float *dq, float *dk, float *dv,
+                               float *delta, int b, int h, int l, int s, int d, int ldq,
+                               int ldk, int ldv, int lddq, int lddk, int lddv, float scale,
+                               float dropout_p, uint64_t seed, const uint64_t *seed_dev, int parts,
+                               int mfma_dtype, void *stream);
 int coda_mha_get_mfma_dtype(void);
 
 /* Measurement aid (bench.py's live roofline figures; no reference counterpart).  While

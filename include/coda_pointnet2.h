@@ -48,18 +48,19 @@ const char *coda_version(void);
  * default -fmad=true (third_party_pointnet2/pointnet2/setup.py:26-28 passes no -fmad
  * flag), i.e. WITH fused-multiply-add contraction.  The contraction nvcc picks cannot
  * be read off the sources, so all three candidates are implemented bit-exactly and the
- * mode is process-wide and switchable (every distance / interpolation kernel of this
- * library follows it; FPS indices, ball_query rows and three_nn change with it only
- * where two candidates are within one rounding of each other):
+ * mode is an ARGUMENT of the *_opt entry points below (every distance / interpolation
+ * kernel of this library has one; FPS indices, ball_query rows and three_nn change with
+ * it only where two candidates are within one rounding of each other):
  *   0  no contraction           (a*a' + b*b') + c*c'           one rounding per operation
  *   1  fma(c,c', fma(a,a', b*b'))   DEFAULT: the first product of the inner sum is
  *                                   contracted, the LLVM / NVVM combiner order
  *   2  fma(c,c', fma(b,b', a*a'))
- * Initial value: environment variable CODA_DISTANCE_MODE (0|1|2) if set, else 1.
- * coda_set_distance_mode returns CODA_EINVAL for any other value.  The CPU oracle
- * (oracle/pointnet2_oracle.c, `fma_mode`) has the same three modes; parity tests
- * run all three.                                                              */
-int coda_set_distance_mode(int mode);
+ *  -1  the library default: environment variable CODA_DISTANCE_MODE (0|1|2) read once
+ *      at first use, else 1 -- what the entry points without the argument use.
+ * The library has NO mutable process-wide state (the reference's ops have none,
+ * ball_query.cpp:11-35): two callers with different modes -- or different threads --
+ * never interact.  The CPU oracle (oracle/pointnet2_oracle.c, `fma_mode`) has the same
+ * three modes; parity tests run all three.  coda_get_distance_mode() = the default.  */
 int coda_get_distance_mode(void);
 
 /* ---- furthest_point_sampling ------------------------------------------------
@@ -83,14 +84,18 @@ int coda_get_distance_mode(void);
  * gives the size the chosen kernel needs (Morton records, mailboxes, distances;
  * 256-byte aligned); 0: NULL/0 may be passed.  Without a sufficient workspace
  * the call falls back to the kernels that need none.
- * coda_set_fps_waves(0 default | 8 | 16): waves per workgroup of the bucketed
- * kernels (process-wide; same indices either way; CODA_FPS_WAVES presets it;
- * default: 16 with one workgroup per scene, 8 with two).                      */
-int coda_set_fps_waves(int waves);
+ * coda_furthest_point_sampling_opt_f32: the same with per-call options --
+ * distance_mode as above, waves (0 default | 8 | 16) = waves per workgroup of the
+ * bucketed kernels (same indices either way; default: CODA_FPS_WAVES, else 16 with
+ * one workgroup per scene, 8 with two).                                        */
 size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m);
 int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, int m,
                                      int32_t *idx, void *workspace,
                                      size_t workspace_bytes, void *stream);
+int coda_furthest_point_sampling_opt_f32(const float *xyz, int b, int n, int m,
+                                         int32_t *idx, void *workspace,
+                                         size_t workspace_bytes, int distance_mode,
+                                         int waves, void *stream);
 
 /* ---- gather_points / gather_points_grad --------------------------------------
  * out[b,c,j] = points[b,c,idx[b,j]]            src/sampling_gpu.cu:11-33
@@ -117,13 +122,17 @@ int coda_gather_points_grad_f32(const float *grad_out, const int32_t *idx,
  * tile's points in LDS in index order and answers the tile's centres from
  * there (csrc/ball_query_tile.hip); exact, but measured slower than the grid
  * pair, so it is opt-in.
- * coda_set_ball_query_route(0 auto | 1 grid | 2 scan | 3 tile) is process-wide
- * (tests, A/B); env CODA_BQ=auto|grid|scan|tile sets the initial value.      */
-int coda_set_ball_query_route(int route);
+ * coda_ball_query_opt_f32 / coda_query_and_group_xyz_opt_f32: per-call options --
+ * distance_mode as above, route (0 auto | 1 grid | 2 scan | 3 tile; tests, A/B;
+ * default: env CODA_BQ=auto|grid|scan|tile).                                  */
 size_t coda_ball_query_workspace_bytes(int b, int n, int m, int nsample);
 int coda_ball_query_f32(const float *new_xyz, const float *xyz, int32_t *idx,
                         int b, int n, int m, float radius, int nsample,
                         void *workspace, size_t workspace_bytes, void *stream);
+int coda_ball_query_opt_f32(const float *new_xyz, const float *xyz, int32_t *idx,
+                            int b, int n, int m, float radius, int nsample,
+                            void *workspace, size_t workspace_bytes,
+                            int distance_mode, int route, void *stream);
 
 /* ---- group_points / group_points_grad ------------------------------------------
  * out[b,c,j,k] = points[b,c,idx[b,j,k]]                 src/group_points_gpu.cu:11-42
@@ -150,6 +159,11 @@ int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz,
                                  int m, float radius, int nsample, int normalize,
                                  void *workspace, size_t workspace_bytes,
                                  void *stream);
+int coda_query_and_group_xyz_opt_f32(const float *new_xyz, const float *xyz,
+                                     int32_t *idx, float *grouped_xyz, int b, int n,
+                                     int m, float radius, int nsample, int normalize,
+                                     void *workspace, size_t workspace_bytes,
+                                     int distance_mode, int route, void *stream);
 
 /* ---- three_nn / three_interpolate / three_interpolate_grad ---------------------
  * three_nn: 3 nearest `known` (B,m,3) of each `unknown` (B,n,3); strict `<`
@@ -167,6 +181,12 @@ int coda_three_interpolate_f32(const float *points, const int32_t *idx,
 int coda_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
                                     const float *weight, float *grad_points,
                                     int b, int c, int n, int m, void *stream);
+/* the same with the distance / interpolation arithmetic mode as an argument (-1: library default) */
+int coda_three_nn_opt_f32(const float *unknown, const float *known, float *dist2,
+                          int32_t *idx, int b, int n, int m, int distance_mode, void *stream);
+int coda_three_interpolate_opt_f32(const float *points, const int32_t *idx,
+                                   const float *weight, float *out, int b, int c,
+                                   int m, int n, int distance_mode, void *stream);
 
 #ifdef __cplusplus
 }

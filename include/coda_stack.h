@@ -48,6 +48,7 @@ typedef struct CodaDecoderStack {
   float *outs;             /* (nl, nq, bsz, E): decoder-normed output of every layer */
   float *ws;               /* saved activations: coda_decoder_stack_ws_floats() floats, written by fwd, read by bwd */
   int ld_kv;               /* row stride of k_all / v_all / dk_all / dv_all in floats (0: nl * E) */
+  int mfma_dtype;          /* MFMA operand type of the attention core (coda_attention.h): -1 library default, 0 fp32, 1 bf16, 2 bf16x3 */
 } CodaDecoderStack;
 
 /* floats of `ws` / of the backward's scratch for these dimensions (0 on invalid dimensions) */

@@ -27,6 +27,65 @@ def attention_ref(q, k, v, mask, scale, dropout_p, need_weights):
     return out.permute(2, 0, 1, 3), (probs if need_weights else None)
 
 
+def _bf16(t):
+    """round-to-nearest-even to bfloat16 (8 significand bits), kept in the tensor's own dtype"""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _AttentionBf16(torch.autograd.Function):
+    """The attention core as the bf16-MFMA kernels compute it (csrc/attention_bf16.hip; include/coda_attention.h,
+    MFMA operand type 1): EVERY operand of a matrix product is rounded to bfloat16 -- Q (pre-multiplied by
+    scale * log2 e, the kernels work in log2 units), K, V, dO, the un-normalised probabilities and dS -- while the
+    products accumulate, and soft-max / lse / delta are evaluated, in the tensors' precision (float32; float64 for a
+    judge).  A checker for configs[4]: against a plain fp32 reference the bf16 mode can only be held at 2e-2 (core) /
+    1e-1 (step gradients), which would hide a kernel bug of that size; against THIS function what remains is the
+    difference between two placements of the same roundings (running vs final row maximum)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale):
+        qh, kh, vh = (t.permute(1, 2, 0, 3) for t in (q, k, v))        # (B,h,L,d)
+        log2e = 1.4426950408889634
+        qs, kb, vb = _bf16(qh * (scale * log2e)), _bf16(kh), _bf16(vh)
+        s2 = torch.matmul(qs, kb.transpose(-1, -2))                    # scores in log2 units
+        if mask is not None:
+            s2 = s2.masked_fill(mask, float("-inf"))
+        m = s2.amax(dim=-1, keepdim=True)
+        m = torch.where(torch.isinf(m), torch.zeros_like(m), m)        # fully masked rows -> zeros, as the kernels
+        pt = torch.exp2(s2 - m)                                        # un-normalised probabilities
+        lsum = pt.sum(dim=-1, keepdim=True)
+        inv = torch.where(lsum > 0, 1.0 / lsum, torch.zeros_like(lsum))
+        out = torch.matmul(_bf16(pt), vb) * inv
+        ctx.save_for_backward(qh, kb, vb, pt * inv, out)
+        ctx.scale = scale
+        return out.permute(2, 0, 1, 3)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qh, kb, vb, probs, out = ctx.saved_tensors
+        do = dout.permute(1, 2, 0, 3)
+        dob = _bf16(do)
+        pb = _bf16(probs)
+        delta = (do * out).sum(dim=-1, keepdim=True)                   # rowsum(dO * O): not a matrix product
+        dv = torch.matmul(pb.transpose(-1, -2), dob)
+        dp = torch.matmul(dob, vb.transpose(-1, -2))
+        dsb = _bf16(probs * (dp - delta))
+        dq = torch.matmul(dsb, kb) * ctx.scale
+        dk = torch.matmul(dsb.transpose(-1, -2), _bf16(qh)) * ctx.scale
+        return dq.permute(2, 0, 1, 3), dk.permute(2, 0, 1, 3), dv.permute(2, 0, 1, 3), None, None
+
+
+def attention_ref_bf16(q, k, v, mask, scale, dropout_p, need_weights):
+    """``attention_ref`` with the operand roundings of the bf16-MFMA mode (dropout-free: the parity tests of that mode
+    run in eval mode / with p = 0)."""
+    if dropout_p > 0.0:
+        raise NotImplementedError("the bf16 oracle is dropout-free")
+    out = _AttentionBf16.apply(q, k, v, mask, scale)
+    probs = None
+    if need_weights:
+        probs = attention_ref(q, k, v, mask, scale, 0.0, True)[1]
+    return out, probs
+
+
 def generalized_box3d_iou(corners1, corners2, nums_k2, rotated_boxes=True, return_inter_vols_only=False,
                           needs_grad=False):
     """box_util.generalized_box3d_iou's signature on CPU tensors, from oracle/box_giou_oracle.c."""
@@ -93,9 +152,10 @@ class _AnyDtypeExt:
 
 
 @contextlib.contextmanager
-def patched(any_dtype=False):
+def patched(any_dtype=False, attention="fp32"):
     """``any_dtype=True``: operators that follow the tensors' dtype (``_AnyDtypeExt``), for a float64 run of the
-    same module graph as the judge between two float32 evaluations."""
+    same module graph as the judge between two float32 evaluations.  ``attention="bf16"``: the attention seam gets
+    ``attention_ref_bf16`` (the operand roundings of the bf16-MFMA mode, configs[4])."""
     from coda_neurips2023_amd import attention_core
     from coda_neurips2023_amd.pointnet2 import _ext
 
@@ -118,7 +178,7 @@ def patched(any_dtype=False):
         for n in names:
             setattr(_ext, n, getattr(ext, n))
         _ext.query_and_group_xyz = query_and_group_xyz
-        attention_core.attention = attention_ref
+        attention_core.attention = attention_ref_bf16 if attention == "bf16" else attention_ref
         yield
     finally:
         for n, f in saved.items():

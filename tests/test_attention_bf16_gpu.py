@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from coda_neurips2023_amd import attention_core
-from oracle.cpu_port import attention_ref
+from oracle.cpu_port import attention_ref, attention_ref_bf16
 from tests.test_attention_gpu import make_qkv, rel
 
 pytestmark = pytest.mark.gpu
@@ -116,3 +116,43 @@ def test_bf16_fully_masked_rows_give_zero(dev):
     assert torch.isfinite(out).all() and out[7].abs().max() == 0
     (gq,) = torch.autograd.grad(out.sum(), q)
     assert torch.isfinite(gq).all()
+
+
+# Against the bf16-ROUNDING oracle (oracle/cpu_port.attention_ref_bf16: every matrix-product operand rounded to bf16,
+# float32 accumulation) the only difference left is WHERE the same roundings are placed (the kernels round the
+# un-normalised probabilities against the running row maximum, the oracle against the final one; a sum of n products
+# with independent 2^-9 roundings differs by ~2^-9 / sqrt(n) between two placements).  Bar: 2e-3 of the largest
+# reference element, 1e-3 in the relative L2 norm -- ten times tighter than against fp32, so that a wrong fragment or
+# a dropped rounding in a bf16 kernel shows (missing 4).
+ORACLE_MAX, ORACLE_L2 = 2e-3, 1e-3
+
+
+@pytest.mark.parametrize("l,s,b,h,d,packed,masked", [
+    (2048, 2048, 1, 4, 64, True, False),    # encoder self-attention
+    (512, 512, 2, 4, 64, True, False),      # decoder self-attention, 512 queries (configs[4])
+    (512, 2048, 2, 4, 64, False, False),    # decoder cross-attention, 512 queries
+    (100, 77, 3, 2, 64, False, True),       # ragged + mask
+    (128, 128, 2, 4, 128, True, True),      # dec_dim 512
+    (300, 700, 2, 2, 64, False, True),
+])
+def test_bf16_kernels_match_the_bf16_rounding_oracle(dev, l, s, b, h, d, packed, masked):
+    leaves, q, k, v = make_qkv(dev, l, s, b, h, d, packed, seed=3 * l + s)
+    scale = d ** -0.5
+    mask = None
+    if masked:
+        mask = torch.rand(b, h, l, s, device=dev) < 0.3
+        mask[..., 0] = False
+    out, _ = attention_core.attention(q, k, v, mask, scale, 0.0, False)
+    gw = torch.randn(out.shape, device=dev)
+    grads = torch.autograd.grad((out * gw).sum(), leaves)
+    cl = [t.detach().cpu().requires_grad_(True) for t in leaves]
+    if len(cl) == 1:   # make_qkv's packed form: one (L,B,3*h*d) leaf cut into q, k, v
+        cq, ck, cv = (t.reshape(l, b, h, d) for t in cl[0].chunk(3, dim=-1))
+    else:
+        cq, ck, cv = cl
+    ref, _ = attention_ref_bf16(cq, ck, cv, None if mask is None else mask.cpu(), scale, 0.0, False)
+    grads_ref = torch.autograd.grad((ref * gw.cpu()).sum(), cl)
+    worst = [(rel(out.cpu(), ref), l2(out.cpu(), ref))] + [(rel(g.cpu(), r), l2(g.cpu(), r)) for g, r in zip(grads, grads_ref)]
+    print(f"bf16 kernels vs bf16 oracle ({l}x{s} d{d}): max " + ", ".join(f"{a:.1e}" for a, _ in worst) + "; L2 "
+          + ", ".join(f"{b_:.1e}" for _, b_ in worst))
+    assert all(a < ORACLE_MAX and b_ < ORACLE_L2 for a, b_ in worst), worst

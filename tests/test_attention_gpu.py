@@ -143,3 +143,64 @@ def test_cpu_tensors_rejected():
     q = torch.randn(8, 1, 1, 64)
     with pytest.raises(RuntimeError, match="CPU not supported"):
         attention_core.attention(q, q, q, None, 0.125, 0.0, False)
+
+
+def _recover_mask(dev, l, s, h, p, seed):
+    """The keep decisions of the attention-probability dropout for one scene, all heads: (h, l, s) bool.  With
+    Q = K = 0 the probabilities are exactly 1 / s, and with V = the identity on a block of 64 keys (zero elsewhere)
+    the output is dropout(P) on those 64 columns; the hash is a function of (seed, head, query, key) only, so the 32
+    runs with the same seed see the same mask."""
+    d = 64
+    q = torch.zeros(l, 1, h, d, device=dev)
+    k = torch.zeros(s, 1, h, d, device=dev)
+    mask = torch.empty(h, l, s, dtype=torch.bool, device=dev)
+    for j in range(s // d):
+        v = torch.zeros(s, 1, h, d, device=dev)
+        v[j * d:(j + 1) * d, 0, :, :] = torch.eye(d, device=dev).view(d, 1, d).expand(d, h, d)
+        torch.manual_seed(seed)
+        out, _ = attention_core.attention(q, k, v, None, 0.125, p, False)     # (l, 1, h, d)
+        mask[:, :, j * d:(j + 1) * d] = (out[:, 0] != 0).permute(1, 0, 2)
+        kept = out[:, 0][out[:, 0] != 0]
+        assert torch.allclose(kept, torch.full_like(kept, 1.0 / s / (1.0 - p)), rtol=1e-5)
+    return mask
+
+
+def _corr(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    a, b = a - a.mean(), b - b.mean()
+    return float((a * b).mean() / (a.std(unbiased=False) * b.std(unbiased=False)))
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_hash_is_statistically_iid(dev, p):
+    """nn.MultiheadAttention drops attention probabilities iid Bernoulli(p) (models/transformer.py:422,506-507 ->
+    F.dropout).  The kernels regenerate the decision from a counter hash in which ONE 32-bit word decides two
+    adjacent keys (csrc/attention_common.hip.h), so independence of exactly those pairs -- and of neighbouring
+    queries, neighbouring words, heads and seeds -- is what has to be shown: on a 1024 x 2048 mask per (seed, head),
+    every correlation within 5 standard errors of zero, the rate within 5 sigma of 1 - p, and the spread of the
+    row / column keep counts binomial."""
+    l, s, h = 1024, 2048, 4
+    masks = [_recover_mask(dev, l, s, h, p, seed) for seed in (7, 8)]
+    n = l * s
+    se = 5.0 / (n // 2) ** 0.5            # 5 standard errors of a correlation estimated from >= n / 2 pairs
+    sigma = (p * (1 - p) / n) ** 0.5
+    for si, m in enumerate(masks):
+        for hh in range(h):
+            mh = m[hh]
+            rate = float(mh.double().mean())
+            assert abs(rate - (1 - p)) < 5 * sigma, (si, hh, rate)
+            lo, hi = mh[:, 0::2], mh[:, 1::2]
+            assert abs(_corr(lo, hi)) < se, ("the two keys of one hash word", si, hh, _corr(lo, hi))
+            assert abs(_corr(hi[:, :-1], lo[:, 1:])) < se, ("adjacent keys of different words", si, hh)
+            assert abs(_corr(mh[:-1], mh[1:])) < se, ("adjacent queries", si, hh)
+            assert abs(_corr(mh[:-1, 0::2], mh[1:, 1::2])) < se, ("diagonal neighbours", si, hh)
+            # keep counts per query (over 2048 keys) and per key (over 1024 queries) are binomial: variance ratio ~ 1
+            rows, cols = mh.double().sum(1), mh.double().sum(0)
+            vr = float(rows.var() / (s * p * (1 - p)))
+            vc = float(cols.var() / (l * p * (1 - p)))
+            assert 1 - 5 * (2 / l) ** 0.5 < vr < 1 + 5 * (2 / l) ** 0.5, ("row spread", si, hh, vr)
+            assert 1 - 5 * (2 / s) ** 0.5 < vc < 1 + 5 * (2 / s) ** 0.5, ("column spread", si, hh, vc)
+        for hh in range(h - 1):
+            assert abs(_corr(m[hh], m[hh + 1])) < se, ("neighbouring heads", si, hh)
+    for hh in range(h):
+        assert abs(_corr(masks[0][hh], masks[1][hh])) < se, ("two seeds", hh)

@@ -54,7 +54,13 @@ CASES = {
 # loss 4e-6, loss terms up to 1.2e-2, gradient tensors up to 7.6e-2 in the relative L2 norm (centre head; most
 # between 2e-2 and 6e-2).  Held at: loss / loss terms 3e-2, gradients 1e-1 -- a bound that still catches a wrong
 # sign, scale or missing term, which is what a whole-step test of a reduced-precision mode can establish.
-TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3), "bf16": dict(loss=3e-2, grad=1e-1, grad_sa=1e-1)}
+# Round 4: the bf16 case is no longer held against an fp32 port at those bounds.  Its reference is the CPU port with
+# the bf16-ROUNDING attention oracle in the attention seam (oracle/cpu_port.attention_ref_bf16: every matrix-product
+# operand of the core rounded to bfloat16 like the kernels' MFMA operands, everything else float32), so what is left
+# between the two sides is the placement of the same roundings: loss / loss terms / cost matrices 1e-2, gradient
+# tensors 1e-2 in the relative L2 norm against the float64 run of the SAME oracle (the judge carries the roundings
+# too) -- a bound ten times tighter than before, under which a bf16 kernel bug of a few per cent shows.
+TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3), "bf16": dict(loss=1e-2, grad=1e-2, grad_sa=1e-2)}
 
 
 def _build(dev, nq, dec_dim, stage, provider_tensors):
@@ -134,7 +140,7 @@ def test_whole_step_forward_criterion_backward(dev, case):
     gpu_batch = {k: v.to(dev) for k, v in cpu_batch.items()}
 
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    with cpu_port.patched():
+    with cpu_port.patched(attention=attn):
         r_loss, r_dict, r_cap, r_pred = _step(ref_model, ref_crit, cpu_batch)
     if attn == "bf16":
         attention_core.set_mfma_dtype("bf16")
@@ -222,7 +228,7 @@ def test_whole_step_forward_criterion_backward(dev, case):
     j_crit.double()
     j_batch = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in cpu_batch.items()
                if k not in ("nactual_gt", "num_boxes", "num_boxes_replica")}
-    with cpu_port.patched(any_dtype=True):
+    with cpu_port.patched(any_dtype=True, attention=attn):
         j_loss, _, j_cap, _ = _step(j_model, j_crit, j_batch)
     j_pairs = j_cap["inds"] * (j_cap["mask"] > 0) - (j_cap["mask"] == 0).long()
     print(f"{case}: float64 judge loss {float(j_loss):.6f}; its assignments equal the float32 port's in "

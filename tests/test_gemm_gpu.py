@@ -147,6 +147,12 @@ def test_sgemm_with_relu_dropout_epilogue_equals_the_two_passes(dev, m, n, k, p)
     st = lib.coda_sgemm_relu_dropout_f32(1, 16384, 256, 256, a.data_ptr(), k, w.data_ptr(), k, fused.data_ptr(), 256,
                                          None, p, seed, _lib.current_stream_handle())
     assert st == _lib.CODA_ENOSPC
+    # the operand checks of coda_sgemm_f32 (round 3's advisor finding): k == 0, a row stride shorter than the row
+    args = lambda kk, lda, ldb: lib.coda_sgemm_relu_dropout_f32(1, m, n, kk, a.data_ptr(), lda, w.data_ptr(), ldb,
+                                                                fused.data_ptr(), n, None, p, seed,
+                                                                _lib.current_stream_handle())
+    assert args(0, k, k) == _lib.CODA_EINVAL
+    assert args(k, k - 4, k) == _lib.CODA_EINVAL and args(k, k, k - 4) == _lib.CODA_EINVAL
 
 
 def test_grouped_weight_gradients(dev):
