@@ -55,22 +55,32 @@ class _AttentionBf16(torch.autograd.Function):
         lsum = pt.sum(dim=-1, keepdim=True)
         inv = torch.where(lsum > 0, 1.0 / lsum, torch.zeros_like(lsum))
         out = torch.matmul(_bf16(pt), vb) * inv
-        ctx.save_for_backward(qh, kb, vb, pt * inv, out)
+        lse2 = m + torch.log2(torch.where(lsum > 0, lsum, torch.ones_like(lsum)))  # log-sum-exp in log2 units
+        dead = (lsum <= 0) if mask is None else ((lsum <= 0) | mask)
+        ctx.save_for_backward(qh, kb, vb, pt * inv, out, lse2, dead.expand_as(pt))
         ctx.scale = scale
         return out.permute(2, 0, 1, 3)
 
     @staticmethod
     def backward(ctx, dout):
-        qh, kb, vb, probs, out = ctx.saved_tensors
+        """Two kernels, two recomputations of P (csrc/attention_bf16.hip): the dQ kernel recomputes the scores like the
+        forward (Q pre-scaled, then rounded), the dK/dV kernel from the UNSCALED rounded Q with the scale applied in
+        fp32 -- both against the forward's lse, so the dK/dV kernel's probabilities are the forward's up to the
+        difference of those two roundings of Q."""
+        qh, kb, vb, probs, out, lse2, dead = ctx.saved_tensors
+        log2e = 1.4426950408889634
         do = dout.permute(1, 2, 0, 3)
         dob = _bf16(do)
-        pb = _bf16(probs)
+        qb = _bf16(qh)
         delta = (do * out).sum(dim=-1, keepdim=True)                   # rowsum(dO * O): not a matrix product
-        dv = torch.matmul(pb.transpose(-1, -2), dob)
         dp = torch.matmul(dob, vb.transpose(-1, -2))
-        dsb = _bf16(probs * (dp - delta))
-        dq = torch.matmul(dsb, kb) * ctx.scale
-        dk = torch.matmul(dsb.transpose(-1, -2), _bf16(qh)) * ctx.scale
+        # dK / dV kernel
+        p_kv = torch.exp2(torch.matmul(qb, kb.transpose(-1, -2)) * (ctx.scale * log2e) - lse2)
+        p_kv = torch.where(dead, torch.zeros_like(p_kv), p_kv)
+        dv = torch.matmul(_bf16(p_kv).transpose(-1, -2), dob)
+        dk = torch.matmul(_bf16(p_kv * (dp - delta)).transpose(-1, -2), qb) * ctx.scale
+        # dQ kernel
+        dq = torch.matmul(_bf16(probs * (dp - delta)), kb) * ctx.scale
         return dq.permute(2, 0, 1, 3), dk.permute(2, 0, 1, 3), dv.permute(2, 0, 1, 3), None, None
 
 

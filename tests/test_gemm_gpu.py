@@ -144,8 +144,8 @@ def test_sgemm_with_relu_dropout_epilogue_equals_the_two_passes(dev, m, n, k, p)
     assert torch.equal(fused, two)
     kept = float((fused != 0).float().mean())
     assert abs(kept - 0.5 * (1 - p)) < 0.05          # relu halves, dropout keeps 1 - p
-    st = lib.coda_sgemm_relu_dropout_f32(1, 16384, 256, 256, a.data_ptr(), k, w.data_ptr(), k, fused.data_ptr(), 256,
-                                         None, p, seed, _lib.current_stream_handle())
+    st = lib.coda_sgemm_relu_dropout_f32(1, 16384, 256, 256, a.data_ptr(), 256, w.data_ptr(), 256, fused.data_ptr(), 256,
+                                         None, p, seed, _lib.current_stream_handle())   # (refused before any access)
     assert st == _lib.CODA_ENOSPC
     # the operand checks of coda_sgemm_f32 (round 3's advisor finding): k == 0, a row stride shorter than the row
     args = lambda kk, lda, ldb: lib.coda_sgemm_relu_dropout_f32(1, m, n, kk, a.data_ptr(), lda, w.data_ptr(), ldb,
