@@ -627,6 +627,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     attn_ms, attn_ms_all = {}, {}
+    sa_ms, sa_rows = {}, []
     if attn_timed and graph is None:
         attn_ms = attention_core.collect_kernel_timing()
         attention_core.disable_kernel_timing()
@@ -639,11 +640,16 @@ def main():
         # be read back from inside a graph replay (the rocprofv3 trace of the same command under profiles/
         # does see the replayed kernels and is the cross-check)
         attention_core.enable_kernel_timing(0)
+        from coda_neurips2023_amd.pointnet2 import fused_sa_mlp
+        sa_events = fused_sa_mlp.enable_kernel_timing()  # the MFMA GEMM kernels of the set-abstraction MLP
         for i in range(args.steps):
             one_step_eager(i)
         sync()
         attn_ms_all = attention_core.collect_kernel_timing()
         attention_core.disable_kernel_timing()
+        fused_sa_mlp.disable_kernel_timing()
+        sa_rows = [int(t.item()) for t in sa_events.pop("rows", [])]
+        sa_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in sa_events.items() if v}
         if graph is not None:
             attn_ms = attn_ms_all
 
@@ -854,6 +860,37 @@ def main():
                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                                "flops": fl, "sum_launch_ms": round(ms, 5), "kernels": len(dec_keys)})
+            # the set-abstraction MLP's hand-written fp32-MFMA GEMM kernels (csrc/sa_mfma.hip): 2 * rows * Cin * Cout
+            # flops per launch over the packed (de-duplicated) rows of the step's 8 scenes
+            if sa_ms and sa_rows:
+                rows = sum(sa_rows) / len(sa_rows)
+                names = {"fwd2": ("sa_fwd_kernel<64,128> (layer 2: layer 1 recomputed from xyz + BN + ReLU prologue, "
+                                  "statistics epilogue)", 64, 128),
+                         "fwd3": ("sa_fwd_kernel<128,256> (layer 3: BN + ReLU prologue, statistics + max-pool "
+                                  "epilogue)", 128, 256),
+                         "dx3": ("sa_bwd_dx_kernel<128,256> (dy3 from the pooled gradient on the fly, dA2 + ReLU mask + "
+                                 "BN sums)", 128, 256),
+                         "dw3": ("sa_bwd_dw_kernel<128,256> + partial-tile reduction (dW3 = dy3^T a2)", 128, 256),
+                         "dx2": ("sa_bwd_dx_kernel<64,128> (dA1 + layer 1's sums in the epilogue)", 64, 128),
+                         "dw2": ("sa_bwd_dw_kernel<64,128> + partial-tile reduction", 64, 128)}
+                tot_fl, tot_ms = 0.0, 0.0
+                for key, (label, cin, cout) in names.items():
+                    if key in sa_ms:
+                        fl = 2.0 * rows * cin * cout
+                        tf = fl / (sa_ms[key] * 1e-3) / 1e12
+                        tot_fl += fl
+                        tot_ms += sa_ms[key]
+                        others.append({"kernel": label, "timing": note, "bound": "mfma", "achieved": round(tf, 2),
+                                       "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                       "flops_per_launch": int(fl), "flops_formula": "2 * packed rows * Cin * Cout",
+                                       "packed_rows": int(rows), "avg_launch_ms": round(sa_ms[key], 5)})
+                if tot_ms:
+                    tf = tot_fl / (tot_ms * 1e-3) / 1e12
+                    others.append({"kernel": "sa_mlp_aggregate: the six MFMA GEMM launches of the shared MLP, forward + backward",
+                                   "timing": note, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                   "flops": int(tot_fl), "sum_launch_ms": round(tot_ms, 5)})
             others.append(bq_roofline)
             if bq64 is not None:
                 others.append(bq64)

@@ -28,6 +28,7 @@
 #include "coda_sa_mlp.h"
 #include "common.hip.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace coda {
@@ -43,6 +44,15 @@ constexpr int kRows = 64;   // rows of a sub-tile
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every barrier would wait for the global stores of the previous sub-tile and for the prefetch
+// loads of the next one, which are meant to stay in flight under the MFMAs.  Global memory is not used for
+// communication inside a workgroup here, so ordering LDS is all a barrier has to do.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ i32x4 ldg4i(const int32_t *p) { return *reinterpret_cast<const i32x4 *>(p); }
@@ -214,6 +224,10 @@ struct FwdArgs {
   int32_t *part_sel, *part_gid;
 };
 
+// One workgroup per CU (up to 512 registers per lane: the weight fragments alone take 128).  A build for two workgroups
+// per CU -- the input and output LDS tiles sharing their memory, no register prefetch -- would let one workgroup's MFMAs
+// run under the other's staging / epilogue, but needs <= 256 registers: measured with 332 B of scratch per lane, layer 3
+// took 0.46 ms instead of 0.33.  (PMC, profiles/r04_pmc_sa_mlp.md: 39 % MFMA-busy, 21 % of the wave cycles parked.)
 template <int CIN, int COUT, bool FIRST, bool POOL>
 __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   static_assert(COUT % 128 == 0 && CIN % 32 == 0, "tile shape");
@@ -221,16 +235,17 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   constexpr int CBW = COUT / 128;    // 32-column blocks per wave
   constexpr int KK = CIN / 2;        // MFMA k-steps
   constexpr int SA = CIN + 4;        // LDS row stride of the A tile (floats): b128 fragment reads conflict-free
-  constexpr int SY = kRows + 4;      // LDS stride of the [channel][row] pooling tile
+  constexpr int SO = COUT + 4;       // LDS row stride of the output tile [64][COUT]
   constexpr int QPR = CIN / 4;       // float4 per input row
   constexpr int RPP = kT / QPR;      // rows per staging pass
   constexpr int NPASS = kRows / RPP;
   extern __shared__ float lds[];
   float *s_a = lds;                                  // [64][SA], column k at (k & 1) * CIN/2 + (k >> 1)
-  float *s_w = s_a + kRows * SA;                     // [64] row multiplicity (0: row not valid)
-  int *s_grow = reinterpret_cast<int *>(s_w + kRows);  // [64] group of the row
-  float *s_y = reinterpret_cast<float *>(s_grow + kRows);  // POOL: [COUT][SY]
-  float *s_w1 = POOL ? s_y + COUT * SY : s_y;        // FIRST: [CIN][4] = w1[k][0..2], 0 ; then [CIN][2] scale, shift
+  float *s_o = lds + kRows * SA;                     // [64][SO] the sub-tile's output: pooled from here and written to
+                                                     // memory as whole rows (16-byte stores)
+  float *s_w = lds + kRows * (SA + SO);              // [64] row multiplicity (0: not valid)
+  int *s_grow = reinterpret_cast<int *>(s_w + kRows);  // [64] (group << 6) | row-in-group
+  float *s_w1 = reinterpret_cast<float *>(s_grow + kRows);  // FIRST: [CIN][4] = w1[k][0..2], 0 ; then [CIN][2] scale, shift
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const Range rg = wg_range(a.goff, a.groups);
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   prefetch(rg.sub0);
   for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
     const long long s0 = sub * kRows;
-    __syncthreads();  // the previous sub-tile's fragment reads / pooling scan are done
+    lds_barrier();  // the previous sub-tile's fragment reads / pooling scan are done
     if (FIRST) {
       const bool ok = s0 + frow < rg.total;
 #pragma unroll
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
       }
     }
     if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
-    __syncthreads();
+    lds_barrier();
     if (sub + 1 < rg.sub1) prefetch(sub + 1);
 
     f32x16 acc[2][CBW];
@@ -376,41 +391,52 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
             st_s[cb][u & 1] += wy;
             st_q[cb][u & 1] = fmaf(wy, y4[u], st_q[cb][u & 1]);
           }
-          if (a.y_out) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const long long r = s0 + rowq + u;
-              if (r < rg.total) a.y_out[r * COUT + col] = y4[u];
-            }
-          }
-          if (POOL) *reinterpret_cast<f32x4 *>(s_y + col * SY + rowq) = y4;
+          for (int u = 0; u < 4; ++u) s_o[(rowq + u) * SO + col] = y4[u];  // 32 consecutive floats per half-wave
         }
       }
     }
-    if (POOL) {
-      __syncthreads();
-      const long long left = rg.total - s0;
-      const int nvalid = left < kRows ? static_cast<int>(left) : kRows;
-      const float *col = s_y + tid * SY;
-      for (int r4 = 0; r4 < nvalid; r4 += 4) {
-        const f32x4 y4 = *reinterpret_cast<const f32x4 *>(col + r4);
+    lds_barrier();
+    const long long left = rg.total - s0;
+    const int nvalid = left < kRows ? static_cast<int>(left) : kRows;
+    if (POOL) {  // thread = channel: running max of sign(gamma) * y over the rows of a group, lowest row on ties
+      // 8 rows per step: their values and group words are fetched together (one LDS round trip per step; a row at a
+      // time the loop ran at LDS latency, two dependent round trips per row)
+      for (int r8 = 0; r8 < nvalid; r8 += 8) {
+        float v8[8];
+        int p8[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int r = r4 + u;
+        for (int u = 0; u < 8; ++u) {
+          v8[u] = s_o[(r8 + u) * SO + tid];
+          p8[u] = s_grow[r8 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r8 + u;
           if (r < nvalid) {
-            const int packed = s_grow[r];  // (group << 6) | row-in-group
+            const int packed = __builtin_amdgcn_readfirstlane(p8[u]);  // (group << 6) | row-in-group: scalar
             const int g = packed >> 6, rin = packed & 63;
-            if (g != cur_g) {  // uniform over the workgroup
+            if (g != cur_g) {  // a scalar branch
               if (cur_g >= 0) flush();
               cur_g = g;
               tail = s0 + r - rin < row_first;
               best = -INFINITY;
               arg = rin;
             }
-            const float v = y4[u] * sg;
+            const float v = v8[u] * sg;
             if (v > best) { best = v; arg = rin; }
           }
         }
+      }
+    }
+    if (a.y_out) {  // whole rows, 16 bytes per lane
+      constexpr int QO = COUT / 4, RO = kT / QO;
+      const int oq = tid % QO, or0 = tid / QO;
+#pragma unroll
+      for (int j = 0; j < kRows / RO; ++j) {
+        const int row = or0 + RO * j;
+        if (row < nvalid)
+          *reinterpret_cast<f32x4 *>(a.y_out + (s0 + row) * COUT + 4 * oq) = *reinterpret_cast<const f32x4 *>(s_o + row * SO + 4 * oq);
       }
     }
   }
@@ -478,11 +504,15 @@ struct BwdArgs {
   float *partials;
 };
 
-// dy of one float4 of a row: the op order of csrc/sa_mlp.hip's bn_bwd_sparse / relu_bn_bwd_apply kernels
-__device__ __forceinline__ f32x4 dy4(f32x4 y, f32x4 dsel, float w, f32x4 ca, f32x4 m1, f32x4 m2, f32x4 mu, f32x4 is) {
+// dy of one float4 of a row.  dy = a (dsel - w (m1 + (y - mean) invstd m2)) evaluated as  a dsel + w (A + B y)  with the
+// per-channel constants A = -a (m1 - mean invstd m2), B = -a invstd m2: two fused multiply-adds per element instead
+// of seven operations (the staging of a dy tile is VALU work that the fp32 MFMAs do not overlap).  The rearrangement
+// costs eps |mean| / std of relative accuracy (the two terms of A + B y cancel to the size of the centred value),
+// ~1e-6 here against the 1e-3 bar.
+__device__ __forceinline__ f32x4 dy4(f32x4 y, f32x4 adsel, float w, f32x4 ca, f32x4 cb) {
   f32x4 o;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) o[u] = ca[u] * (dsel[u] - w * (m1[u] + (y[u] - mu[u]) * is[u] * m2[u]));
+  for (int u = 0; u < 4; ++u) o[u] = fmaf(w, fmaf(cb[u], y[u], ca[u]), adsel[u]);
   return o;
 }
 
@@ -497,7 +527,7 @@ struct DyStage {
   static constexpr int NPASS = kRows / RPP;
   f32x4 py[NPASS];
   f32x4 pd[LAST ? 1 : NPASS];
-  f32x4 ca, m1, m2, mu, is;
+  f32x4 ca, cA, cB;  // a, A, B of this thread's channel quad (dy4)
   int cq, r0;
   // LAST: prefetched (d, sel) of two groups; nA / nB: their ids one sub-tile further ahead (so that the (d, sel)
   // loads of a prefetch never wait for an id load issued in the same prefetch), -2 = not loaded yet
@@ -509,8 +539,13 @@ struct DyStage {
   __device__ __forceinline__ void init(const BwdArgs &a) {
     cq = threadIdx.x % QPR;
     r0 = threadIdx.x / QPR;
-    ca = ldg4(a.ca + 4 * cq); m1 = ldg4(a.cm1 + 4 * cq); m2 = ldg4(a.cm2 + 4 * cq);
-    mu = ldg4(a.cmean + 4 * cq); is = ldg4(a.cinv + 4 * cq);
+    ca = ldg4(a.ca + 4 * cq);
+    const f32x4 m1 = ldg4(a.cm1 + 4 * cq), m2 = ldg4(a.cm2 + 4 * cq), mu = ldg4(a.cmean + 4 * cq), is = ldg4(a.cinv + 4 * cq);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cA[u] = -ca[u] * (m1[u] - mu[u] * is[u] * m2[u]);
+      cB[u] = -ca[u] * is[u] * m2[u];
+    }
   }
   __device__ __forceinline__ void prefetch(const BwdArgs &a, long long s0, long long total) {
 #pragma unroll
@@ -530,6 +565,7 @@ struct DyStage {
       gB = nB < 0 ? nA : nB;
       nA = ra + kRows < total ? a.grow[ra + kRows] >> 6 : -1;
       nB = rb + kRows < total ? a.grow[rb + kRows] >> 6 : -1;
+      // (d is scaled by a where it is used: the loads stay in flight under the MFMAs)
       if (gA >= 0) { dA = ldg4(a.d + static_cast<size_t>(gA) * COUT + 4 * cq); sA = ldg4i(a.sel + static_cast<size_t>(gA) * COUT + 4 * cq); }
       if (gB >= 0) { dB = ldg4(a.d + static_cast<size_t>(gB) * COUT + 4 * cq); sB = ldg4i(a.sel + static_cast<size_t>(gB) * COUT + 4 * cq); }
     }
@@ -549,11 +585,12 @@ struct DyStage {
       else if (g == gB) { dg = dB; sg = sB; }
       else { dg = ldg4(a.d + static_cast<size_t>(g) * COUT + 4 * cq); sg = ldg4i(a.sel + static_cast<size_t>(g) * COUT + 4 * cq); }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dsel[u] = rin == sg[u] ? dg[u] : 0.f;
+      for (int u = 0; u < 4; ++u) dsel[u] = rin == sg[u] ? ca[u] * dg[u] : 0.f;
     } else {
-      dsel = pd[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dsel[u] = ca[u] * pd[j][u];
     }
-    return dy4(py[j], dsel, s_w[row], ca, m1, m2, mu, is);
+    return dy4(py[j], dsel, s_w[row], cA, cB);
   }
 };
 
@@ -571,6 +608,8 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
   float *s_w = s_dy + kRows * SD;                    // [64]
   int *s_grow = reinterpret_cast<int *>(s_w + kRows);  // [64]
   float *s_x = reinterpret_cast<float *>(s_grow + kRows);  // FIRST: [64][4] grouped xyz of the rows
+  constexpr int SI = CIN + 4;
+  float *s_in = s_x;  // !FIRST: [64][SI] y_in of the sub-tile, overwritten in place by dmid_in (same LDS slot as s_x)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wn = wv / WM, wm = wv % WM;
@@ -592,9 +631,19 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
     st.init(a);
     float pw = 0.f, px[3] = {0.f, 0.f, 0.f};
     int pg = 0;
+    constexpr int QI = CIN / 4, RI = kT / QI, NI = kRows / RI;  // staging of the y_in tile (16 bytes per lane)
+    const int iq = tid % QI, ir0 = tid / QI;
+    f32x4 pin[FIRST ? 1 : NI];
     auto prefetch = [&](long long sub) {
       const long long s0 = sub * kRows;
       st.prefetch(a, s0, rg.total);
+      if (!FIRST) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const long long r = s0 + ir0 + RI * j;
+          pin[j] = r < rg.total ? ldg4(a.src_in + r * CIN + 4 * iq) : f32x4{0, 0, 0, 0};
+        }
+      }
       if (tid < kRows) {
         const long long r = s0 + tid;
         const bool ok = r < rg.total;
@@ -608,12 +657,16 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
     prefetch(rg.sub0);
     for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
       const long long s0 = sub * kRows;
-      __syncthreads();
+      lds_barrier();
       if (tid < kRows) {
         s_w[tid] = pw; s_grow[tid] = pg;
         if (FIRST) { s_x[4 * tid] = px[0]; s_x[4 * tid + 1] = px[1]; s_x[4 * tid + 2] = px[2]; s_x[4 * tid + 3] = 0.f; }
       }
-      __syncthreads();
+      if (!FIRST) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4 *>(s_in + (ir0 + RI * j) * SI + 4 * iq) = pin[j];
+      }
+      lds_barrier();
 #pragma unroll
       for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
         const f32x4 v = st.value(a, j, s0, rg.total, s_w, s_grow);
@@ -621,24 +674,8 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
         *reinterpret_cast<f32x2 *>(s_dy + row * SD + 2 * st.cq) = f32x2{v[0], v[2]};
         *reinterpret_cast<f32x2 *>(s_dy + row * SD + COUT / 2 + 2 * st.cq) = f32x2{v[1], v[3]};
       }
-      __syncthreads();
+      lds_barrier();
       if (sub + 1 < rg.sub1) prefetch(sub + 1);
-
-      // y_in of this lane's accumulator elements (epilogue), in flight under the MFMAs
-      float yin[RBW][16];
-#pragma unroll
-      for (int rb = 0; rb < RBW; ++rb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = 32 * (wm * RBW + rb) + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (FIRST) {
-            const f32x4 xr = *reinterpret_cast<const f32x4 *>(s_x + 4 * row);
-            yin[rb][e] = dot3w(xr[0], xr[1], xr[2], e_w0, e_w1, e_w2);
-          } else {
-            const long long r = s0 + row;
-            yin[rb][e] = r < rg.total ? a.src_in[r * CIN + kcol] : 0.f;
-          }
-        }
 
       f32x16 acc[RBW];
 #pragma unroll
@@ -664,7 +701,13 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
         for (int e = 0; e < 16; ++e) {
           const int row = 32 * (wm * RBW + rb) + (e & 3) + 8 * (e >> 2) + 4 * h;
           const long long r = s0 + row;
-          const float y = yin[rb][e];
+          float y;  // y_in of this accumulator element
+          if (FIRST) {
+            const f32x4 xr = *reinterpret_cast<const f32x4 *>(s_x + 4 * row);
+            y = dot3w(xr[0], xr[1], xr[2], e_w0, e_w1, e_w2);
+          } else {
+            y = s_in[row * SI + kcol];
+          }
           const bool on = __fadd_rn(__fmul_rn(y, e_sc), e_sh) > 0.0f && r < rg.total;
           const float dm = on ? acc[rb][e] : 0.f;
           acc_s += dm;
@@ -672,10 +715,19 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
           if (FIRST) {
             const f32x4 xr = *reinterpret_cast<const f32x4 *>(s_x + 4 * row);
             acc_t0 = fmaf(dm, xr[0], acc_t0); acc_t1 = fmaf(dm, xr[1], acc_t1); acc_t2 = fmaf(dm, xr[2], acc_t2);
-          } else if (r < rg.total) {
-            a.dmid_in[r * CIN + kcol] = dm;
+          } else {
+            s_in[row * SI + kcol] = dm;  // in place: this lane is the only reader / writer of the element
           }
         }
+      if (!FIRST) {  // dmid_in leaves as whole rows, 16 bytes per lane
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int row = ir0 + RI * j;
+          if (s0 + row < rg.total)
+            *reinterpret_cast<f32x4 *>(a.dmid_in + (s0 + row) * CIN + 4 * iq) = *reinterpret_cast<const f32x4 *>(s_in + row * SI + 4 * iq);
+        }
+      }
     }
   }
   // sums of this lane's input channel: the two half-waves hold different rows
@@ -759,7 +811,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
     prefetch(rg.sub0);
     for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
       const long long s0 = sub * kRows;
-      __syncthreads();
+      lds_barrier();
       if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
       // activations of the layer below
       if (FIRST) {
@@ -787,14 +839,14 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
           *reinterpret_cast<f32x4 *>(s_a + row * SA + 4 * aq) = v;
         }
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
         const f32x4 v = st.value(a, j, s0, rg.total, s_w, s_grow);
         const int row = st.r0 + DyStage<COUT, LAST>::RPP * j;
         *reinterpret_cast<f32x4 *>(s_dy + row * SD + 4 * st.cq) = v;
       }
-      __syncthreads();
+      lds_barrier();
       if (sub + 1 < rg.sub1) prefetch(sub + 1);
 
       // dW[c][k] += sum_rows dy[row][c] act[row][k]: A[i = c][k = row], B[k = row][j = k-channel]
@@ -865,8 +917,7 @@ int device_cus() {
 
 template <int CIN, int COUT, bool FIRST, bool POOL>
 int launch_fwd(const FwdArgs &a, int nblk, hipStream_t s) {
-  size_t lds = sizeof(float) * (kRows * (CIN + 4) + 2 * kRows);
-  if (POOL) lds += sizeof(float) * COUT * (kRows + 4);
+  size_t lds = sizeof(float) * (kRows * (CIN + 4) + kRows * (COUT + 4) + 2 * kRows);
   if (FIRST) lds += sizeof(float) * 6 * CIN;
   auto kern = sa_fwd_kernel<CIN, COUT, FIRST, POOL>;
   int st = raise_dynamic_lds(kern, lds);
@@ -876,7 +927,7 @@ int launch_fwd(const FwdArgs &a, int nblk, hipStream_t s) {
 }
 template <int CIN, int COUT, bool LAST, bool FIRST>
 int launch_dx(const BwdArgs &a, int nblk, hipStream_t s) {
-  size_t lds = sizeof(float) * (kRows * (COUT + 4) + 2 * kRows + (FIRST ? 4 * kRows : 0));
+  size_t lds = sizeof(float) * (kRows * (COUT + 4) + 2 * kRows + (FIRST ? 4 * kRows : kRows * (CIN + 4)));
   auto kern = sa_bwd_dx_kernel<CIN, COUT, LAST, FIRST>;
   int st = raise_dynamic_lds(kern, lds);
   if (st != CODA_OK) return st;
@@ -910,11 +961,11 @@ bool fill_coef(BwdArgs &a, const float *coef, int layout, int cout) {
 
 using namespace coda;
 
-// kind 0: forward / dx kernels -- 4 row ranges per CU, dealt to the CUs as they become free (a range costs its
+// kind 0: forward / dx kernels -- 2 row ranges per CU, dealt to the CUs as they become free (a range costs its
 // workgroup only the weight fragments, ~2 % of its time; with exactly one workgroup per CU a concurrent kernel that
 // holds a few CUs -- the sampling of the next batch on its side stream -- doubled the kernel's duration: 8 of the 256
 // workgroups had to wait for a whole pass of the others).  kind 1: dw kernels -- one per CU (a 128 KB partial tile each).
-CODA_API int coda_sa_mfma_blocks(int kind) { return kind == 0 ? 4 * device_cus() : device_cus(); }
+CODA_API int coda_sa_mfma_blocks(int kind) { return kind == 0 ? 2 * device_cus() : device_cus(); }
 
 CODA_API int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len) {
   return c1 == 64 && c2 == 128 && c3 == 256 && s_len >= 1 && s_len <= kRows ? 1 : 0;

@@ -28,6 +28,8 @@ __device__ __forceinline__ float4 affine(float4 y, float4 a, float4 b) {
   return make_float4(y.x * a.x + b.x, y.y * a.y + b.y, y.z * a.z + b.z, y.w * a.w + b.w);
 }
 
+constexpr int kUnroll = 8;  // row loads a thread keeps in flight in the streaming loops
+
 template <int NACC>
 __device__ __forceinline__ void block_reduce_to_global(const float4 (&acc)[NACC], const RowMap &m, int c,
                                                        double *sums) {
@@ -71,11 +73,21 @@ __global__ __launch_bounds__(kT) void bn_stats_kernel(const float *__restrict__ 
   float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
   const long long r0 = static_cast<long long>(blockIdx.x) * rows_per_block;
   const long long r1 = min(r0 + rows_per_block, rows);
-  for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
-    const float4 y = ld4(zg + r * c + 4 * m.cq);
+  auto add = [&](float4 y) {
     acc[0].x += y.x; acc[0].y += y.y; acc[0].z += y.z; acc[0].w += y.w;
     acc[1].x += y.x * y.x; acc[1].y += y.y * y.y; acc[1].z += y.z * y.z; acc[1].w += y.w * y.w;
+  };
+  // kUnroll row loads in flight per thread (one load per iteration left the kernel latency-bound at 2 TB/s);
+  // the accumulation order is unchanged
+  long long r = r0 + m.rsub;
+  for (; r + (kUnroll - 1) * m.rpb < r1; r += kUnroll * m.rpb) {
+    float4 y[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) y[u] = ld4(zg + (r + u * m.rpb) * c + 4 * m.cq);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) add(y[u]);
   }
+  for (; r < r1; r += m.rpb) add(ld4(zg + r * c + 4 * m.cq));
   block_reduce_to_global<2>(acc, m, c, sums + static_cast<size_t>(g) * 2 * c);
 }
 
@@ -115,12 +127,23 @@ __global__ __launch_bounds__(kT) void bn_act_kernel(const float *__restrict__ z,
   const uint32_t seed = dr.thresh24 ? fold_seed(dr.seed, dr.seed_dev) : 0u;
   const long long r0 = static_cast<long long>(blockIdx.x) * rows_per_block;
   const long long r1 = min(r0 + rows_per_block, rows);
-  for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
-    const size_t off = goff + r * c + 4 * m.cq;
-    float4 v = affine(ld4(z + off), a, b);
+  auto one = [&](size_t off, float4 zin) {
+    float4 v = affine(zin, a, b);
     if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     const float4 k = keep4(seed, static_cast<uint32_t>(off), dr.thresh24, dr.inv_keep);
     st4(out + off, make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w));
+  };
+  long long r = r0 + m.rsub;
+  for (; r + (kUnroll - 1) * m.rpb < r1; r += kUnroll * m.rpb) {
+    float4 y[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) y[u] = ld4(z + goff + (r + u * m.rpb) * c + 4 * m.cq);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) one(goff + (r + u * m.rpb) * c + 4 * m.cq, y[u]);
+  }
+  for (; r < r1; r += m.rpb) {
+    const size_t off = goff + r * c + 4 * m.cq;
+    one(off, ld4(z + off));
   }
 }
 
@@ -151,14 +174,29 @@ __global__ __launch_bounds__(kT) void bn_act_bwd_stats_kernel(const float *__res
   float4 acc[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
   const long long r0 = static_cast<long long>(blockIdx.x) * rows_per_block;
   const long long r1 = min(r0 + rows_per_block, rows);
-  for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
-    const size_t off = goff + r * c + 4 * m.cq;
-    const float4 y = ld4(z + off);
+  auto one = [&](size_t off, float4 y, float4 g_in) {
     const float4 k = keep4(seed, static_cast<uint32_t>(off), dr.thresh24, dr.inv_keep);
-    const float4 d = masked_grad<RELU>(ld4(da + off), y, a, b, k);
+    const float4 d = masked_grad<RELU>(g_in, y, a, b, k);
     acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
     acc[1].x += d.x * (y.x - mu.x) * is.x; acc[1].y += d.y * (y.y - mu.y) * is.y;
     acc[1].z += d.z * (y.z - mu.z) * is.z; acc[1].w += d.w * (y.w - mu.w) * is.w;
+  };
+  constexpr int U2 = kUnroll / 2;  // two input streams
+  long long r = r0 + m.rsub;
+  for (; r + (U2 - 1) * m.rpb < r1; r += U2 * m.rpb) {
+    float4 y[U2], gi[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const size_t off = goff + (r + u * m.rpb) * c + 4 * m.cq;
+      y[u] = ld4(z + off);
+      gi[u] = ld4(da + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U2; ++u) one(goff + (r + u * m.rpb) * c + 4 * m.cq, y[u], gi[u]);
+  }
+  for (; r < r1; r += m.rpb) {
+    const size_t off = goff + r * c + 4 * m.cq;
+    one(off, ld4(z + off), ld4(da + off));
   }
   block_reduce_to_global<2>(acc, m, c, sums + static_cast<size_t>(g) * 2 * c);
 }
@@ -197,17 +235,32 @@ __global__ __launch_bounds__(kT) void bn_act_bwd_apply_kernel(const float *__res
   const uint32_t seed = dr.thresh24 ? fold_seed(dr.seed, dr.seed_dev) : 0u;
   const long long r0 = static_cast<long long>(blockIdx.x) * rows_per_block;
   const long long r1 = min(r0 + rows_per_block, rows);
-  for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
-    const size_t off = goff + r * c + 4 * m.cq;
-    const float4 y = ld4(z + off);
+  auto one = [&](size_t off, float4 y, float4 g_in) {
     const float4 k = keep4(seed, static_cast<uint32_t>(off), dr.thresh24, dr.inv_keep);
-    const float4 d = masked_grad<RELU>(ld4(da + off), y, a, b, k);
+    const float4 d = masked_grad<RELU>(g_in, y, a, b, k);
     float4 o;
     o.x = ca.x * (d.x - m1.x - (y.x - mu.x) * is.x * m2.x);
     o.y = ca.y * (d.y - m1.y - (y.y - mu.y) * is.y * m2.y);
     o.z = ca.z * (d.z - m1.z - (y.z - mu.z) * is.z * m2.z);
     o.w = ca.w * (d.w - m1.w - (y.w - mu.w) * is.w * m2.w);
     st4(dz + off, o);
+  };
+  constexpr int U2 = kUnroll / 2;
+  long long r = r0 + m.rsub;
+  for (; r + (U2 - 1) * m.rpb < r1; r += U2 * m.rpb) {
+    float4 y[U2], gi[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const size_t off = goff + (r + u * m.rpb) * c + 4 * m.cq;
+      y[u] = ld4(z + off);
+      gi[u] = ld4(da + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U2; ++u) one(goff + (r + u * m.rpb) * c + 4 * m.cq, y[u], gi[u]);
+  }
+  for (; r < r1; r += m.rpb) {
+    const size_t off = goff + r * c + 4 * m.cq;
+    one(off, ld4(z + off), ld4(da + off));
   }
 }
 

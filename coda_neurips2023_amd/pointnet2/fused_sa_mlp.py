@@ -38,6 +38,32 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args, _stream()), name)
 
 
+# measurement aid (bench.py's roofline figures of the MFMA kernels): HIP events on the launch stream around each call
+_TIMING = None
+
+
+def enable_kernel_timing():
+    """{label: [(start event, end event), ...]} filled by the MFMA pipeline's GEMM launches until disable_kernel_timing()."""
+    global _TIMING
+    _TIMING = {}
+    return _TIMING
+
+
+def disable_kernel_timing():
+    global _TIMING
+    _TIMING = None
+
+
+def _call_timed(label, name, *args):
+    if _TIMING is None:
+        return _call(name, *args)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    _call(name, *args)
+    end.record()
+    _TIMING.setdefault(label, []).append((start, end))
+
+
 def _is_sync(bn):
     return isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
         and dist.get_world_size(bn.process_group) > 1
@@ -346,7 +372,7 @@ class _MfmaMlpPool(torch.autograd.Function):
         st1 = _bn_stats(bns[0], s1, float(n_rows * world[0]), gammas[0], betas[0], training, c1, dev)
         # layer 2: prologue = layer 1 recomputed from x + BN + ReLU, epilogue = statistics
         y2 = torch.empty((cap, c2), **f32)
-        _call("coda_sa_mfma_fwd_f32", _p(x), _p(ws[0]), _p(st1), _p(ws[1]), _p(roww), _p(goff), _p(grow), groups, nsample,
+        _call_timed("fwd2", "coda_sa_mfma_fwd_f32", _p(x), _p(ws[0]), _p(st1), _p(ws[1]), _p(roww), _p(goff), _p(grow), groups, nsample,
               c1, c2, _p(y2), _p(s2), None, None, None, None, None, None, nblk)
         st2 = _bn_stats(bns[1], s2, float(n_rows * world[1]), gammas[1], betas[1], training, c2, dev)
         # layer 3: prologue = BN + ReLU of layer 2, epilogue = statistics + pooling (sign of gamma: max or min)
@@ -357,7 +383,7 @@ class _MfmaMlpPool(torch.autograd.Function):
         part_sel = torch.empty((nblk, c3), dtype=torch.int32, device=dev)
         part_gid = torch.empty(nblk, dtype=torch.int32, device=dev)
         g3 = gammas[2].detach()
-        _call("coda_sa_mfma_fwd_f32", _p(y2), None, _p(st2), _p(ws[2]), _p(roww), _p(goff), _p(grow), groups, nsample,
+        _call_timed("fwd3", "coda_sa_mfma_fwd_f32", _p(y2), None, _p(st2), _p(ws[2]), _p(roww), _p(goff), _p(grow), groups, nsample,
               c2, c3, _p(y3), _p(s3), _p(g3), _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), nblk)
         st3 = _bn_stats(bns[2], s3, float(n_rows * world[2]), gammas[2], betas[2], training, c3, dev)
         out = torch.empty((groups, c3), **f32)
@@ -365,6 +391,8 @@ class _MfmaMlpPool(torch.autograd.Function):
               _p(st3), _p(out), groups, c3, nblk)
 
         ctx.meta = (groups, nsample, bns, training, world, n_rows, nblk, lib.coda_sa_mfma_blocks(1))
+        if _TIMING is not None:
+            _TIMING.setdefault("rows", []).append(goff[-1:])  # packed row count of this call (read back after the run)
         ctx.wshape = [params[3 * i].shape for i in range(3)]
         ctx.stats = [st1, st2, st3]
         ctx.save_for_backward(x, roww, goff, grow, mom, y2, y3, ysel, sel, out, *ws, *gammas)
@@ -391,21 +419,21 @@ class _MfmaMlpPool(torch.autograd.Function):
         coef3 = _bwd_coef(ctx, 2, sums, st3, gammas[2], bns[2], training, n_rows * world[2], 1, grads, dev)
         dmid2 = torch.empty((cap, c2), **f32)
         sums2 = torch.empty(2 * c2, **f64)
-        _call("coda_sa_mfma_bwd_dx_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(ws[2]), _p(y2), None, _p(st2),
+        _call_timed("dx3", "coda_sa_mfma_bwd_dx_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(ws[2]), _p(y2), None, _p(st2),
               _p(roww), _p(goff), _p(grow), groups, nsample, c2, c3, _p(dmid2), _p(sums2), nblk)
         partials = torch.empty((nblk_w, c3 * c2), **f32)
         dw3 = torch.empty((c3, c2), **f32)
-        _call("coda_sa_mfma_bwd_dw_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(y2), None, _p(st2), _p(roww),
+        _call_timed("dw3", "coda_sa_mfma_bwd_dw_f32", _p(y3), None, _p(d), _p(sel), _p(coef3), 1, _p(y2), None, _p(st2), _p(roww),
               _p(goff), _p(grow), groups, nsample, c2, c3, _p(partials), _p(dw3), nblk_w)
         grads[6] = dw3.reshape(ctx.wshape[2])
 
         # ---- layer 2
         prm2 = _bwd_coef(ctx, 1, sums2, st2, gammas[1], bns[1], training, n_rows * world[1], 0, grads, dev)
         sums1 = torch.empty(5 * c1, **f64)
-        _call("coda_sa_mfma_bwd_dx_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(ws[1]), _p(x), _p(ws[0]), _p(st1),
+        _call_timed("dx2", "coda_sa_mfma_bwd_dx_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(ws[1]), _p(x), _p(ws[0]), _p(st1),
               _p(roww), _p(goff), _p(grow), groups, nsample, c1, c2, None, _p(sums1), nblk)
         dw2 = torch.empty((c2, c1), **f32)
-        _call("coda_sa_mfma_bwd_dw_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(x), _p(ws[0]), _p(st1), _p(roww),
+        _call_timed("dw2", "coda_sa_mfma_bwd_dw_f32", _p(y2), _p(dmid2), None, None, _p(prm2), 0, _p(x), _p(ws[0]), _p(st1), _p(roww),
               _p(goff), _p(grow), groups, nsample, c1, c2, _p(partials), _p(dw2), nblk_w)
         grads[3] = dw2.reshape(ctx.wshape[1])
 
