@@ -106,9 +106,6 @@ SIGNATURES = {
     "coda_matcher_cost_f32": (_c_int, [_P] * 8 + [_c_float] * 4 + [_P] * 3 + [_c_int] * 5 + [_P, _c_int, _P]),
     "coda_hungarian_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P]),
     "coda_grouped_gemm_tn_f32": (_c_int, [_P, _c_int, _P]),
-    "coda_gemm_x3_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
-    "coda_gemm_x3_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
-                                  ctypes.c_longlong, _P, _c_int, _P, ctypes.c_size_t, _P]),
     "coda_tok_colsum_finalize_grouped_f32": (_c_int, [_P, _c_int, _P]),
     # include/coda_stack.h
     "coda_decoder_stack_ws_floats": (ctypes.c_size_t, [_c_int] * 6),
@@ -160,8 +157,6 @@ SIGNATURES = {
                                 ctypes.c_longlong, _P, _c_int, _P]),
     "coda_sgemm_relu_dropout_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                              _P, ctypes.c_longlong, _P, _c_float, ctypes.c_uint64, _P]),
-    "coda_gemm_tn_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, ctypes.c_longlong, ctypes.c_longlong,
-                                  ctypes.c_longlong, _c_int, _P]),
     "coda_mha_get_mfma_dtype": (_c_int, []),
     "coda_mha_timing_enable": (_c_int, [_c_int]),
     "coda_mha_timing_collect": (_c_int, [_P, _P, _P, _P, _c_int]),

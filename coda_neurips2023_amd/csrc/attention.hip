@@ -513,188 +513,6 @@ __global__ __launch_bounds__(QW * kWave, (QW >= 8 && D == 64) ? 2 : 1) void mha_
   }
 }
 
-// Long-sequence forward with the S tile of the NEXT key block already in flight: a wave issues the 32 MFMAs of
-// S_{t+1} = K_{t+1} Q^T before it starts the soft-max arithmetic of S_t, so its own VALU work (exp2, dropout hash,
-// rescale) runs under MFMAs of its own instead of leaving the matrix pipe to the other wave of the SIMD only.
-// Same staging as mha_fwd_kernel<D,4,false,false,true> (two 32-key tiles per stage, double buffered), but the
-// next stage is written to LDS in the MIDDLE of a stage -- between two barriers after its first tile -- so that
-// the prefetched S of a stage's second tile can read the next stage's first K tile.  No mask, L % 32 == 0,
-// S % 64 == 0 (host-checked).
-template <int D>
-__global__ __launch_bounds__(256) void mha_fwd_pipe_kernel(MhaParams p) {
-  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = 256, TILES = 2;
-  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const int half = lane >> 5, l31 = lane & 31;
-  const TileHead th = tile_head(p.xcd_map);
-  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = (th.tile * 4 + w) * kTile;
-  const int myq = q0 + l31;
-  const bool wave_active = q0 < p.l;  // wave-uniform
-  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
-  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
-  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
-               vstride = static_cast<size_t>(p.b) * p.ldv;
-  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
-  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
-  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
-
-  float qf[HD];
-  const float qscale = p.scale * kLog2e;
-#pragma unroll
-  for (int c = 0; c < HD; c += 4) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (myq < p.l)
-      t = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(myq) * qstride + half * HD + c);
-    // scale * log2(e) folded into Q: S, the running maximum and lse are kept in log2 units (exp2 without a multiply)
-    qf[c] = t.x * qscale; qf[c + 1] = t.y * qscale; qf[c + 2] = t.z * qscale; qf[c + 3] = t.w * qscale;
-  }
-  f32x16 o[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m = -INFINITY, lsum = 0.f;
-  const bool use_drop = p.thresh16 != 0u;
-  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
-
-  constexpr int kStageFloats = 2 * TILES * kTile * LS;  // one K + V stage
-  constexpr int NLD = TILES * kTile * D / 4 / THREADS;
-  constexpr int FROWS = TILES * kTile;
-  float4 rk[NLD], rv[NLD];
-
-  auto qk = [&](const float *tk) {  // S^T tile: sacc[r] = scale * <q[myq], k[crow(r, half)]>
-    f32x16 sacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      const float4 kf = *reinterpret_cast<const float4 *>(tk + l31 * LS + half * HD + c);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[c], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[c + 1], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[c + 2], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[c + 3], sacc, 0, 0, 0);
-    }
-    return sacc;
-  };
-  // soft-max + P V of the tile whose S is `sacc`; `next_k` (may be null): K tile whose S is computed meanwhile.
-  // The MFMAs of the next S are issued in the SAME basic block as the exp2 / dropout arithmetic and interleaved
-  // with it (one MFMA, then a few VALU instructions: a wave issues in order, so a block of 32 chained MFMAs in
-  // front of the VALU code would simply be waited out).
-  auto softmax_pv = [&](const f32x16 &sacc, int s0, const float *tv, const float *next_k) {
-    float pr[16];
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pr[r] = sacc[r];
-      tmax = fmaxf(tmax, pr[r]);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m, tmax);
-    if (__ballot(m_new > m + kMaxSlack) != 0ull) {  // lazy rescale with slack (see mha_fwd_kernel)
-      const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = fast_exp2(m - m_to);
-      lsum *= alpha;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-      m = m_new;
-    }
-    const float m_safe = (m == -INFINITY) ? 0.f : m;
-    f32x16 s_next = sacc;
-    if (next_k) s_next = qk(next_k);  // wave-uniform
-    f32x2 rs2 = {0.f, 0.f};  // pairs: the subtraction and the row sum as packed fp32 operations
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const f32x2 arg = f32x2{pr[r], pr[r + 1]} - f32x2{m_safe, m_safe};
-      pr[r] = fast_exp2(arg[0]);
-      pr[r + 1] = fast_exp2(arg[1]);
-      rs2 += f32x2{pr[r], pr[r + 1]};
-    }
-    lsum += rs2[0] + rs2[1];
-    if (use_drop) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const uint32_t hsh = drop_hash(dconst, myq, p.s, s0 + crow(r, half));
-        pr[r] = drop_keep_lo(hsh, p.thresh16) ? pr[r] : 0.f;  // 1 / (1 - p) is applied once, to the output row
-        pr[r + 1] = drop_keep_hi(hsh, p.thresh16) ? pr[r + 1] : 0.f;
-      }
-    }
-    if (next_k) {
-#pragma unroll
-      for (int i = 0; i < D / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of the next S
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // six VALU instructions of this tile's soft-max
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float *vrow = tv + crow(r, half) * LS + NT * l31;
-      if (NT == 2) {
-        const float2 vv = *reinterpret_cast<const float2 *>(vrow);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, pr[r], o[1], 0, 0, 0);
-      } else {
-        const float4 vv = *reinterpret_cast<const float4 *>(vrow);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, pr[r], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, pr[r], o[1], 0, 0, 0);
-        o[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, pr[r], o[2 % NT], 0, 0, 0);
-        o[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, pr[r], o[3 % NT], 0, 0, 0);
-      }
-    }
-    return s_next;
-  };
-
-  // prologue: stage 0 straight into buffer 0, S of its first tile
-  fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, 0, p.s, tid);
-  fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, 0, p.s, tid);
-  store_tile<D, THREADS, FROWS>(s_dyn, rk, tid);
-  store_tile<D, THREADS, FROWS>(s_dyn + TILES * kTile * LS, rv, tid);
-  __syncthreads();
-  f32x16 s_cur;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s_cur[r] = 0.f;
-  if (wave_active) s_cur = qk(s_dyn);
-  int stage = 0;
-  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES, ++stage) {
-    const bool more = sbase + kTile * TILES < p.s;
-    float *bk = s_dyn + (stage & 1) * kStageFloats, *bv = bk + TILES * kTile * LS;
-    float *nk = s_dyn + ((stage + 1) & 1) * kStageFloats;
-    if (more) {  // next stage: in flight during this stage's first tile
-      fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, sbase + kTile * TILES, p.s, tid);
-      fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, sbase + kTile * TILES, p.s, tid);
-    }
-    if (wave_active) s_cur = softmax_pv(s_cur, sbase, bv, bk + kTile * LS);  // first tile; S of the second ahead
-    __syncthreads();  // every wave is past the previous stage: the other buffer is free
-    if (more) {
-      store_tile<D, THREADS, FROWS>(nk, rk, tid);
-      store_tile<D, THREADS, FROWS>(nk + TILES * kTile * LS, rv, tid);
-    }
-    __syncthreads();  // the next stage is visible
-    // second tile; S of the next stage's first tile ahead of it
-    if (wave_active) s_cur = softmax_pv(s_cur, sbase + kTile, bv + kTile * LS, more ? nk : nullptr);
-  }
-
-  lsum += __shfl_xor(lsum, 32);
-  if (myq < p.l) {
-    const float inv = lsum > 0.f ? p.inv_keep / lsum : 0.f;
-    float *orow = p.out + static_cast<size_t>(myq) * rstride + head_off;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dv = NT * crow(r, half);
-      if (NT == 2) {
-        *reinterpret_cast<float2 *>(orow + dv) = make_float2(o[0][r] * inv, o[1][r] * inv);
-      } else {
-        *reinterpret_cast<float4 *>(orow + dv) =
-            make_float4(o[0][r] * inv, o[1][r] * inv, o[2 % NT][r] * inv, o[3 % NT][r] * inv);
-      }
-    }
-    if (half == 0)
-      p.lse[static_cast<size_t>(bh) * p.l + myq] = lsum > 0.f ? m * kLn2 + __logf(lsum) : -INFINITY;
-  }
-}
-
 template <int D>
 __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
   // one thread per (q, b, h) row
@@ -725,13 +543,11 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 //                 attending to themselves) would otherwise leave one wave per CU.
 // DB (non-QSPLIT): two single-tile stages of Q / dO in the same LDS, double buffered like the
 //                 forward kernel's K / V staging.
-// VLDS (with DB): the V fragments of a lane live in LDS instead of 32 registers (each lane re-reads what it wrote:
-//                 a register spill to LDS instead of to scratch memory -- the kernel was 36 VGPRs over its 256 at
-//                 two waves per SIMD, and the scratch traffic showed up as 1.6x the algorithmic HBM bytes).
-template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false, bool VLDS = false>
+// (A variant with the V fragments of a lane in LDS instead of 32 registers removed the kernel's 72 B / lane of scratch
+// and was not faster -- 648 vs 626 us -- so the spill is not what holds this kernel; removed in round 4.)
+template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false>
 __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
-  static_assert(!VLDS || (DB && !QSPLIT), "VLDS is implemented for the double-buffered long-key-sequence kernel");
   constexpr int QT = QSPLIT ? KW : (DB ? 1 : 2);  // query tiles staged per step
   static_assert(!(DB && QSPLIT), "double buffering is implemented for the long-key-sequence kernel");
   constexpr int kStageFloats = 2 * QT * kTile * LS + 2 * QT * kTile;  // Q, dO tiles + lse, delta rows
@@ -759,9 +575,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
   const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
 
-  float kf[HD], vf[VLDS ? 4 : HD];  // B operands: K[mykey][half*HD + c], V[mykey][half*HD + c]
-  // VLDS: this lane's V fragment, behind the two Q / dO stages (row stride LS: conflict-free ds_read_b128)
-  float *v_lane = VLDS ? s_dyn + 2 * kStageFloats + (w * kTile + l31) * LS + half * HD : nullptr;
+  float kf[HD], vf[HD];  // B operands: K[mykey][half*HD + c], V[mykey][half*HD + c]
 #pragma unroll
   for (int c = 0; c < HD; c += 4) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a;
@@ -770,11 +584,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
       b4 = *reinterpret_cast<const float4 *>(vbase + static_cast<size_t>(mykey) * vstride + half * HD + c);
     }
     kf[c] = a.x; kf[c + 1] = a.y; kf[c + 2] = a.z; kf[c + 3] = a.w;
-    if (VLDS) {
-      *reinterpret_cast<float4 *>(v_lane + c) = b4;
-    } else {
-      vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
-    }
+    vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
   }
   f32x16 dk[NT], dv[NT];
 #pragma unroll
@@ -841,10 +651,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     for (int c = 0; c < HD; c += 4) {
       const float4 qa = *reinterpret_cast<const float4 *>(tq + l31 * LS + half * HD + c);
       const float4 ga = *reinterpret_cast<const float4 *>(tdo + l31 * LS + half * HD + c);
-      float4 vv;
-      if (VLDS) vv = *reinterpret_cast<const float4 *>(v_lane + c);
-      else vv = make_float4(vf[c % (VLDS ? 4 : HD)], vf[(c + 1) % (VLDS ? 4 : HD)], vf[(c + 2) % (VLDS ? 4 : HD)],
-                            vf[(c + 3) % (VLDS ? 4 : HD)]);
+      const float4 vv = make_float4(vf[c], vf[c + 1], vf[c + 2], vf[c + 3]);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kf[c], sacc, 0, 0, 0);
       pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vv.x, pacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kf[c + 1], sacc, 0, 0, 0);
@@ -1472,15 +1279,6 @@ bool double_buffered() {
   return on;
 }
 
-// CODA_ATTN_PIPE=1: long-sequence forward with the S tile of the next key block issued ahead of the soft-max
-// (mha_fwd_pipe_kernel).  Measured equal (351 vs 349 us on 2048 x 2048): fp32 MFMAs and VALU instructions do
-// not execute concurrently on a SIMD of this part (tools/mfma_valu_probe.hip), so interleaving them inside a
-// wave buys nothing over the two-waves-per-SIMD overlap the plain kernel already has.  Off by default.
-bool fwd_pipelined() {
-  static const bool on = [] { const char *e = getenv("CODA_ATTN_PIPE"); return e && atoi(e) != 0; }();
-  return on;
-}
-
 template <int D, bool GEN>
 int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one K + one V tile
@@ -1489,12 +1287,7 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   KernelTimer timer(0, p.l, p.s, s);
   if (p.l >= 1024) {
     dim3 grid(ceil_div(p.l, kTile * 4), p.b * p.h);
-    if (!GEN && p.s % (2 * kTile) == 0 && double_buffered() && fwd_pipelined()) {
-      auto kern = mha_fwd_pipe_kernel<D>;
-      int st = set_lds(kern, 4 * kTileBytes);
-      if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
-    } else if (double_buffered()) {
+    if (double_buffered()) {
       auto kern = mha_fwd_kernel<D, 4, false, GEN, true>;
       int st = set_lds(kern, 4 * kTileBytes);
       if (st != CODA_OK) return st;
@@ -1581,23 +1374,11 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   if (!(p.parts & 2)) return CODA_OK;
   KernelTimer timer(2, p.l, p.s, s);
   if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
-    // CODA_ATTN_VLDS=1 (D = 64): V fragments in LDS instead of registers -- no scratch spill (251 VGPRs, 0 bytes of
-    // scratch against 256 + 72 B/lane), but not faster: 648 vs 626 us standalone, 0.69 vs 0.685 ms in the step.
-    // The spill was not what holds this kernel; off by default.
-    static const bool vlds = [] { const char *e = getenv("CODA_ATTN_VLDS"); return e && atoi(e) != 0; }();
-    if (D == 64 && vlds) {
-      auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true, (D == 64)>;
-      const size_t lds = 2 * (kTileBytes + kRowBytes) + sizeof(float) * 4 * kTile * (D + 4);
-      int st = set_lds(kern, lds);
-      if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
-    } else {
-      auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
-      const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
-      int st = set_lds(kern, lds);
-      if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
-    }
+    auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
+    const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
+    int st = set_lds(kern, lds);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
   } else if (p.s >= 1024) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);

@@ -28,18 +28,13 @@ namespace coda {
 int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b, int n,
                     int m, float radius, int nsample, int normalize, void *workspace, hipStream_t s);
 size_t ball_query_grid_workspace(int b, int n, int nsample);
-// ball_query_tile.hip
-bool ball_query_tile_applies(int n, int m, int nsample);
-int ball_query_tile(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b, int n, int m, float radius,
-                    int nsample, int normalize, hipStream_t s);
-
 namespace {
 int ball_query_route() {
-  const int r = call_options().bq_route;  // this call's option (coda_ball_query_opt_f32), else CODA_BQ = auto | grid | scan | tile
-  if (r >= 1 && r <= 3) return r;
+  const int r = call_options().bq_route;  // this call's option (coda_ball_query_opt_f32), else CODA_BQ = auto | grid | scan
+  if (r >= 1 && r <= 2) return r;
   static const int dflt = [] {
     const char *e = getenv("CODA_BQ");
-    return !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0)));
+    return !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 's' ? 2 : 0));
   }();
   return dflt;
 }
@@ -163,13 +158,8 @@ int launch_scan(const float *new_xyz, const float *xyz, int32_t *idx, float *gro
 int ball_query_dispatch(const float *new_xyz, const float *xyz, int32_t *idx, float *grouped, int b,
                         int n, int m, float radius, int nsample, int normalize, void *workspace,
                         size_t workspace_bytes, hipStream_t s) {
-  // 0 auto (grid when the caller provided its workspace, else scan) | 1 grid | 2 scan | 3 tile (one launch,
-  // LDS-resident tiles: exact and workspace-free, but measured 2.4x slower than the grid pair -- DESIGN.md section 7)
+  // 0 auto (grid when the caller provided its workspace, else scan) | 1 grid | 2 scan
   const int route = ball_query_route();
-  if (route == 3 && radius > 0.0f && ball_query_tile_applies(n, m, nsample)) {
-    const int st = ball_query_tile(new_xyz, xyz, idx, grouped, b, n, m, radius, nsample, normalize, s);
-    if (st != CODA_ENOSPC) return st;
-  }
   // cell-binned search when the caller provided the workspace it was told to provide
   const size_t need = ball_query_grid_workspace(b, n, nsample);
   if (route != 2 && workspace && need > 0 && workspace_bytes >= need && radius > 0.0f)
@@ -220,7 +210,7 @@ CODA_API int coda_query_and_group_xyz_f32(const float *new_xyz, const float *xyz
 CODA_API int coda_ball_query_opt_f32(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n, int m,
                                      float radius, int nsample, void *workspace, size_t workspace_bytes,
                                      int distance_mode, int route, void *stream) {
-  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes || route < 0 || route > 3) return CODA_EINVAL;
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes || route < 0 || route > 2) return CODA_EINVAL;
   coda::CallOptions o = coda::call_options();
   o.distance_mode = distance_mode;
   o.bq_route = route;
@@ -232,7 +222,7 @@ CODA_API int coda_query_and_group_xyz_opt_f32(const float *new_xyz, const float 
                                               int b, int n, int m, float radius, int nsample, int normalize,
                                               void *workspace, size_t workspace_bytes, int distance_mode, int route,
                                               void *stream) {
-  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes || route < 0 || route > 3) return CODA_EINVAL;
+  if (distance_mode < -1 || distance_mode >= coda::kDistanceModes || route < 0 || route > 2) return CODA_EINVAL;
   coda::CallOptions o = coda::call_options();
   o.distance_mode = distance_mode;
   o.bq_route = route;

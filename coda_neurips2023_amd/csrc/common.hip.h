@@ -47,7 +47,7 @@ constexpr int kDefaultDistanceMode = 1;
 struct CallOptions {
   int distance_mode = -1;  // -1 default | 0 | 1 | 2
   int fps_waves = 0;       // 0 default | 8 | 16
-  int bq_route = 0;        // 0 auto | 1 grid | 2 scan | 3 tile
+  int bq_route = 0;        // 0 auto | 1 grid | 2 scan
   int mfma_dtype = -1;     // -1 default | 0 fp32 | 1 bf16 | 2 bf16x3
 };
 CallOptions &call_options();  // version.hip: thread_local

@@ -15,11 +15,6 @@ import torch
 from . import _lib
 
 _USE_TORCH = os.environ.get("CODA_GEMM", "") == "torch"  # dev A/B switch
-# Off by default: weight gradients through the hand-written split-rows MFMA kernel (coda_gemm_tn_f32,
-# csrc/gemm_tn.hip; parity-tested on hardware in tests/test_gemm_gpu.py) instead of the library GEMM /
-# the split-K bmm + sum.  CODA_TN_KERNEL=1 routes every mm_tn through it; `kernel=True` one call.
-TN_KERNEL = os.environ.get("CODA_TN_KERNEL", "0") == "1"
-
 
 def _plain(*ts):
     """True when every operand is a 2-D fp32 CUDA tensor (what coda_gemm_f32 takes); anything else
@@ -42,49 +37,9 @@ _OWN_SMALL = os.environ.get("CODA_SGEMM", "1") != "0"
 _OWN_MAX_MN = 2048 * 256
 
 
-# CODA_GEMM_X3=1 / set_x3(True): products on the bf16 matrix cores with every fp32 operand split into three
-# exact bf16 pieces and all nine piece products accumulated in fp32 (csrc/gemm_x3.hip, include/coda_gemm.h).
-X3 = os.environ.get("CODA_GEMM_X3", "0") == "1"
-_X3_MIN_FLOPS = 2 * 2048 * 256 * 256 * 2  # below this the launch-sized kernels above are the better tool
-_X3_WS = {}
-
-
-def set_x3(on):
-    global X3
-    X3 = bool(on)
-
-
-def _x3_workspace(dev):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    if key not in _X3_WS:
-        _X3_WS[key] = torch.empty(64 * 512 * 512, dtype=torch.float32, device=dev)  # 64 slices of up to 512 x 512
-    return _X3_WS[key]
-
-
-def gemm_x3(transa, transb, m, n, k, a, b, out=None, bias=None, accumulate=False):
-    """The nine-product bf16 evaluation of C = op(A) op(B) (+ bias); returns None when the kernel does not take
-    the shape (caller falls through to the other routes)."""
-    if m % 64 or n % 64 or k % 32:
-        return None
-    if out is None:
-        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    ws = _x3_workspace(a.device)
-    st = _lib.load().coda_gemm_x3_f32(transa, transb, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
-                                      out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
-                                      1 if accumulate else 0, ws.data_ptr(), ws.numel() * 4, _lib.current_stream_handle())
-    if st == _lib.CODA_ENOSPC:
-        return None
-    _lib.check(st, "coda_gemm_x3_f32")
-    return out
-
-
 def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    if X3 and 2 * m * n * k >= _X3_MIN_FLOPS:
-        r = gemm_x3(transa, transb, m, n, k, a, b, out, bias, accumulate)
-        if r is not None:
-            return r
     if _OWN_SMALL and not transa and m * n <= _OWN_MAX_MN and m % 64 == 0 and n % 64 == 0 and k % 128 == 0:
         st = _lib.load().coda_sgemm_f32(transb, m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                                         out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
@@ -131,7 +86,7 @@ def mm(a, b, out=None, accumulate=False):
     return _run(0, 0, a.shape[0], b.shape[1], a.shape[1], a, b, out, None, accumulate)
 
 
-def mm_tn(a, b, out=None, accumulate=False, kernel=None):
+def mm_tn(a, b, out=None, accumulate=False):
     """a (K,M), b (K,N) -> a.T @ b, (M,N); ``accumulate`` adds to ``out`` instead of overwriting it."""
     assert out is not None or not accumulate
     if not _plain(a, b) or a.shape[0] == 0:
@@ -140,18 +95,6 @@ def mm_tn(a, b, out=None, accumulate=False, kernel=None):
             return r
         return out.add_(r) if accumulate else out.copy_(r)
     a, b = _rows(a), _rows(b)
-    if kernel is None:
-        # own split-rows kernel: 12 vs 15 us at 2048 rows, but its output has to be zeroed first (one more
-        # 4.5 us launch per call, rocprof r02): a wash in the step, so the library stays the default
-        kernel = TN_KERNEL
-    if kernel and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
-        if out is None:
-            out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
-        st = _lib.load().coda_gemm_tn_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], b.shape[1],
-                                          a.stride(0), b.stride(0), out.stride(0), 1 if accumulate else 0,
-                                          _lib.current_stream_handle())
-        _lib.check(st, "coda_gemm_tn_f32")
-        return out
     return _run(1, 0, a.shape[1], b.shape[1], a.shape[0], a, b, out, None, accumulate)
 
 

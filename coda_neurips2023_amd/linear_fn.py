@@ -23,7 +23,7 @@ def tn_gemm(dy, x):
     # (row chunks of the ~10^6-row SA products as one grouped launch of the own kernel + a sum measure 505 vs 630 us
     # stand-alone, tools/bench_long_tn.py, but 958 vs 979 scenes/s in the SA-only step -- 32 descriptor rows and
     # slices on the host per call -- so the batched library GEMM stays)
-    if p >= _MIN_ROWS and not gemm.TN_KERNEL:
+    if p >= _MIN_ROWS:
         rows = _CHUNK if p % _CHUNK == 0 else 0
         if p >= (1 << 18) and p % 16384 == 0:
             rows = 16384

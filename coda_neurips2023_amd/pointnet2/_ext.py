@@ -140,12 +140,12 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
-_ROUTES = {"auto": 0, "grid": 1, "scan": 2, "tile": 3}
+_ROUTES = {"auto": 0, "grid": 1, "scan": 2}
 
 
 def _route(algorithm):
     """``algorithm``: "auto" (the cell table in a workspace where it applies, else the scan) | "grid" | "scan" (brute
-    force) | "tile" (one launch, no workspace: include/coda_pointnet2.h).  All give identical results; the non-default
+    force; include/coda_pointnet2.h).  All give identical results; the non-default
     ones exist for the parity tests and A/B timing.  The route is an argument of the call (coda_ball_query_opt_f32):
     "auto" defers to the calling thread's option, then to the library default (CODA_BQ)."""
     if algorithm not in _ROUTES:
@@ -154,10 +154,10 @@ def _route(algorithm):
 
 
 def _ball_query_workspace(lib, b, n, m, nsample, device, algorithm):
-    """Workspace of the cell-binned search ("auto" / "grid"); "scan" and "tile" need none."""
+    """Workspace of the cell-binned search ("auto" / "grid"); "scan" needs none."""
     if algorithm not in _ROUTES:
         raise ValueError(f"unknown ball_query algorithm {algorithm!r}")
-    ws_bytes = 0 if algorithm in ("scan", "tile") else lib.coda_ball_query_workspace_bytes(b, n, m, nsample)
+    ws_bytes = 0 if algorithm == "scan" else lib.coda_ball_query_workspace_bytes(b, n, m, nsample)
     if algorithm == "grid" and ws_bytes == 0:
         raise RuntimeError("grid ball_query not applicable to this shape (n < 1024 or nsample > 128)")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device) if ws_bytes else None

@@ -66,27 +66,6 @@ int coda_sgemm_relu_dropout_f32(int transb, int m, int n, int k, const float *a,
                                 long long ldb, float *c, long long ldc, const float *bias, float dropout_p,
                                 uint64_t seed, void *stream);
 
-/* Opt-in (CODA_TN_KERNEL=1 or gemm.mm_tn(..., kernel=True); parity-tested on MI355X, tests/test_gemm_gpu.py):
- * out (co x ci, row stride ldout) [+]= dy^T x with dy (rows x co, row stride lddy), x (rows x ci, row stride
- * ldx) -- the weight gradient of a token-wise linear layer (replaces `torch.mm(dy.t(), x)` / the split-K
- * `bmm + sum` of linear_fn.tn_gemm).  Hand-written fp32 MFMA kernel, reduction over the rows split across
- * workgroups and combined with fp32 atomics (summation order not fixed).  co and ci must be multiples of 32
- * (CODA_EINVAL otherwise).  accumulate == 0: out is zeroed first. */
-int coda_gemm_tn_f32(const float *dy, const float *x, float *out, int rows, int co, int ci,
-                     long long lddy, long long ldx, long long ldout, int accumulate, void *stream);
-
-/* The same product as coda_gemm_f32, evaluated on the bf16 matrix cores WITHOUT loss of operand precision: every
- * fp32 operand is split into three bf16 pieces (hi + mid + lo = the fp32 value exactly) and all nine piece products
- * -- each exact in fp32 -- are accumulated in fp32 (csrc/gemm_x3.hip).  Same argument meaning as coda_gemm_f32.
- * Constraints: m, n multiples of 64, k a multiple of 32, leading dimensions multiples of 4 floats, 16-byte aligned
- * pointers; anything else returns CODA_ENOSPC (use coda_gemm_f32).  Problems with few output tiles and a long k
- * (weight gradients) are split over k; the partial tiles go to `workspace` (coda_gemm_x3_workspace_bytes gives a
- * sufficient size; CODA_ENOSPC if it is too small) and are summed in a fixed order: deterministic. */
-size_t coda_gemm_x3_workspace_bytes(int m, int n, int k);
-int coda_gemm_x3_f32(int transa, int transb, int m, int n, int k, const float *a, long long lda, const float *b,
-                     long long ldb, float *c, long long ldc, const float *bias, int accumulate, void *workspace,
-                     size_t workspace_bytes, void *stream);
-
 /* Many weight gradients in one launch: out_p (m x n, row stride ldout) = dy_p^T x_p for every problem of the
  * array (dy_p rows x m, x_p rows x n; replaces one `torch.mm(dy.t(), x)` per linear layer, models/transformer.py's
  * decoder layers as autograd differentiates them).  `problems` is HOST memory, read during the call (the

@@ -114,17 +114,14 @@ int coda_gather_points_grad_f32(const float *grad_out, const int32_t *idx,
  * Row j = the nsample smallest point indices k (ascending) with
  * d2(new_xyz[j], xyz[k]) < radius*radius (strict, fp32), padded with the first
  * hit; all zeros when the ball is empty.
- * Three routes, identical results.  "grid" (default when `workspace` is given;
+ * Two routes, identical results.  "grid" (default when `workspace` is given;
  * device, >= coda_ball_query_workspace_bytes): a per-scene cell table built by
  * one launch and queried by a second (csrc/ball_query_grid.hip).  "scan": brute
- * force over the cloud (small clouds; what NULL/0 selects).  "tile": ONE launch
- * without a workspace -- a workgroup per 4 x 4-cell tile of the plane keeps the
- * tile's points in LDS in index order and answers the tile's centres from
- * there (csrc/ball_query_tile.hip); exact, but measured slower than the grid
- * pair, so it is opt-in.
+ * force over the cloud (small clouds; what NULL/0 selects).  (A third, one-launch
+ * LDS-tile route was built and measured 2.4x slower in round 3; removed.)
  * coda_ball_query_opt_f32 / coda_query_and_group_xyz_opt_f32: per-call options --
- * distance_mode as above, route (0 auto | 1 grid | 2 scan | 3 tile; tests, A/B;
- * default: env CODA_BQ=auto|grid|scan|tile).                                  */
+ * distance_mode as above, route (0 auto | 1 grid | 2 scan; tests, A/B;
+ * default: env CODA_BQ=auto|grid|scan).                                  */
 size_t coda_ball_query_workspace_bytes(int b, int n, int m, int nsample);
 int coda_ball_query_f32(const float *new_xyz, const float *xyz, int32_t *idx,
                         int b, int n, int m, float radius, int nsample,

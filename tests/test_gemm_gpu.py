@@ -72,24 +72,6 @@ def test_invalid_arguments_are_reported(dev):
     assert st == _lib.CODA_EINVAL  # lda < k
 
 
-@pytest.mark.parametrize("rows,co,ci", [(2048, 256, 256), (16384, 768, 256), (2048, 128, 256), (2048, 256, 128),
-                                        (100, 32, 32), (7, 64, 96), (131072, 64, 64)])
-def test_tn_kernel(dev, rows, co, ci):
-    """coda_gemm_tn_f32 (csrc/gemm_tn.hip): dy^T x, plain / into a row block of a packed buffer / accumulating."""
-    g = torch.Generator().manual_seed(rows + co)
-    dy = torch.randn(rows, co, generator=g).to(dev)
-    x = torch.randn(rows, ci, generator=g).to(dev)
-    ref = (dy.double().t() @ x.double()).float()
-    assert rel(gemm.mm_tn(dy, x, kernel=True), ref) < 1e-5
-    packed = torch.full((3 * co, ci), 7.0, device=dev)
-    gemm.mm_tn(dy, x, out=packed[co:2 * co], kernel=True)
-    assert rel(packed[co:2 * co], ref) < 1e-5 and bool((packed[:co] == 7).all()) and bool((packed[2 * co:] == 7).all())
-    gemm.mm_tn(dy, x, out=packed[co:2 * co], accumulate=True, kernel=True)
-    assert rel(packed[co:2 * co], 2 * ref) < 1e-5
-    wide = torch.randn(rows, 3 * co, generator=g).to(dev)          # column slice as dY (row stride 3*co)
-    assert rel(gemm.mm_tn(wide[:, co:2 * co], x, kernel=True), (wide[:, co:2 * co].double().t() @ x.double()).float()) < 1e-5
-
-
 @pytest.mark.parametrize("m,n,k,transb", [(2048, 256, 256, True), (2048, 256, 256, False), (64, 64, 128, True),
                                           (256, 128, 384, False), (16384, 256, 256, True), (16384, 128, 256, False),
                                           (4096, 192, 96, True), (128, 64, 32, False)])

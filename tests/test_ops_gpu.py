@@ -166,7 +166,7 @@ def test_ball_query_matches_oracle(dev, oracle, b, n, m, r, s):
     assert not got[:, 0].any()
 
 
-@pytest.mark.parametrize("algorithm", ["scan", "grid", "tile"])
+@pytest.mark.parametrize("algorithm", ["scan", "grid"])
 @pytest.mark.parametrize("n,m,r,s", [(1024, 100, 0.3, 16), (3000, 130, 0.25, 64), (20000, 500, 0.2, 64),
                                      (20000, 300, 0.4, 32), (5000, 64, 1.5, 128), (40000, 256, 0.2, 64),
                                      (20001, 2048, 0.2, 64), (12345, 1000, 0.05, 8)])
@@ -201,32 +201,9 @@ def test_ball_query_grid_stress(dev, oracle):
     new = np.concatenate([np.zeros((2, 1, 3), np.float32), pc[:, 1000:1063]], 1)
     for r, s in [(0.5, 64), (0.2, 16), (2.0, 128)]:
         ref = oracle.ball_query(new, pc, r, s)
-        for algorithm in ("grid", "scan", "tile"):   # tile: the whole cloud in one tile -> its global-scan fallback
+        for algorithm in ("grid", "scan"):
             got = _ext.ball_query(cu(new, dev), cu(pc, dev), r, s, algorithm=algorithm)
             assert np.array_equal(got.cpu().numpy(), ref), (r, s, algorithm)
-
-
-def test_ball_query_tile_list_overflows(dev, oracle):
-    """The one-launch route's LDS budgets: a cluster that fits the tile's list but not a sub-tile's (its centres then
-    walk the whole tile list), a tile that does not fit at all (global scan for that tile only), next to ordinary
-    tiles -- with far more than nsample hits per ball, duplicates and a centre on a tile corner."""
-    rng = np.random.default_rng(5)
-    n = 6000                                                    # -> 16 LDS blocks = 1024 points per tile, 512 per sub-tile
-    pc = (rng.random((3, n, 3)) * np.array([6.0, 6.0, 2.5])).astype(np.float32)
-    pc[0, 1000:1700] = (np.array([2.31, 2.27, 1.0]) + rng.standard_normal((700, 3)) * 0.03).astype(np.float32)
-    pc[1, 500:3500] = (np.array([4.1, 1.3, 0.7]) + rng.standard_normal((3000, 3)) * 0.05).astype(np.float32)
-    pc[2, 10:20] = pc[2, 0:10]
-    new = np.stack([pc[i, rng.integers(0, n, 300)] for i in range(3)])
-    new[0, :40] = pc[0, 1000:1040]
-    new[1, :40] = pc[1, 500:540]
-    new[:, 299] = np.float32(0.2002) * np.array([8, 12, 3], np.float32)   # a lattice corner
-    for r, s in [(0.2, 64), (0.2, 16), (0.1, 32)]:
-        ref = oracle.ball_query(new, pc, r, s)
-        idx, grouped = _ext.query_and_group_xyz(cu(new, dev), cu(pc, dev), r, s, True, algorithm="tile", channels_last=True)
-        assert np.array_equal(idx.cpu().numpy(), ref), (r, s)
-        exp = np.take_along_axis(pc, ref.reshape(3, -1, 1).astype(np.int64).repeat(3, -1), 1).reshape(3, 300, s, 3)
-        exp = (exp - new[:, :, None, :]) * (np.float32(1.0) / np.float32(r))
-        np.testing.assert_array_equal(grouped.cpu().numpy(), exp)
 
 
 def test_ball_query_golden(dev, golden_ops):
