@@ -253,12 +253,16 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int P, int DM>  // points per thread (even); 512 threads, n in [512, 512*P]
+// LX: the cloud is also kept in LDS (n * 12 bytes, dynamic) so that the winner's coordinates -- the only thing a round
+// reads back -- come from there: three dependent L2 round trips (~650 clocks of a ~2400-clock round, tools/fps_prof.py)
+// become one LDS read.  Used for small clouds (the object queries' sampling 2048 -> 256).
+template <int P, int DM, bool LX = false>  // points per thread (even); 512 threads, n in [512, 512*P]
 __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__ xyz, int n, int m,
                                                        int32_t *__restrict__ idx) {
   constexpr int THREADS = 512, H = P / 2;
   __shared__ unsigned long long s_slot[3];
   __shared__ int32_t s_out[kOutRing];
+  extern __shared__ float s_xyz[];  // LX: [n][3]
 
   const int tid = threadIdx.x;
   const int lane = lane_id();
@@ -286,6 +290,9 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
   if (tid < 3) s_slot[tid] = 0ull;
   out_put(s_out, 0, 0);
   float cx = pts[0], cy = pts[1], cz = pts[2];
+  if (LX) {
+    for (int i = tid; i < n * 3; i += THREADS) s_xyz[i] = pts[i];
+  }
   __syncthreads();
   out_flush(s_out, 0, m, out);
 
@@ -328,14 +335,21 @@ __global__ __launch_bounds__(512) void fps_t512_kernel(const float *__restrict__
     old = __builtin_amdgcn_readfirstlane(old);
     out_put(s_out, j, static_cast<int32_t>(old));
     out_flush(s_out, j, m, out);
-    cx = pts[old * 3 + 0];
-    cy = pts[old * 3 + 1];
-    cz = pts[old * 3 + 2];
+    const float *src = LX ? s_xyz : pts;
+    cx = src[old * 3 + 0];
+    cy = src[old * 3 + 1];
+    cz = src[old * 3 + 2];
   }
 }
 
 template <int P>
 void launch_t512(const float *xyz, int b, int n, int m, int32_t *idx, hipStream_t s) {
+  const size_t lx_bytes = sizeof(float) * 3 * static_cast<size_t>(n);
+  if (lx_bytes <= 48 * 1024) {  // (with the static LDS well inside the 64 KB a launch gets without opting in)
+    CODA_DISPATCH_DM(distance_mode(), hipLaunchKernelGGL((fps_t512_kernel<P, DM, true>), dim3(b), dim3(512), lx_bytes, s,
+                                                         xyz, n, m, idx));
+    return;
+  }
   CODA_DISPATCH_DM(distance_mode(),
                    hipLaunchKernelGGL((fps_t512_kernel<P, DM>), dim3(b), dim3(512), 0, s, xyz, n, m, idx));
 }

@@ -457,14 +457,28 @@ __global__ __launch_bounds__(kT) void pool_bwd_stats_kernel(const float *__restr
   const long long rows_pb = block_rows(groups, m.rpb);
   const long long r0 = static_cast<long long>(blockIdx.x) * rows_pb;
   const long long r1 = min(r0 + rows_pb, groups);
-  for (long long r = r0 + m.rsub; r < r1; r += m.rpb) {
-    const long long at = r * c + 4 * m.cq;
-    const float4 g = ld4(gout + at), o = ld4(out + at), y = ld4(ysel + at);
+  auto one = [&](long long at, float4 g, float4 o, float4 y) {
     const float4 dv = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
     st4(d + at, dv);
     acc[0].x += dv.x; acc[0].y += dv.y; acc[0].z += dv.z; acc[0].w += dv.w;
     acc[1].x += dv.x * ((y.x - mu.x) * is.x); acc[1].y += dv.y * ((y.y - mu.y) * is.y);
     acc[1].z += dv.z * ((y.z - mu.z) * is.z); acc[1].w += dv.w * ((y.w - mu.w) * is.w);
+  };
+  constexpr int U = 4;  // rows in flight per thread (three input streams each); same accumulation order
+  long long r = r0 + m.rsub;
+  for (; r + (U - 1) * m.rpb < r1; r += U * m.rpb) {
+    float4 g[U], o[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long at = (r + u * m.rpb) * c + 4 * m.cq;
+      g[u] = ld4(gout + at); o[u] = ld4(out + at); y[u] = ld4(ysel + at);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one((r + u * m.rpb) * c + 4 * m.cq, g[u], o[u], y[u]);
+  }
+  for (; r < r1; r += m.rpb) {
+    const long long at = r * c + 4 * m.cq;
+    one(at, ld4(gout + at), ld4(out + at), ld4(ysel + at));
   }
   block_reduce_to_global<2>(acc, m, c, sums);
 }
