@@ -61,7 +61,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_m
 # dK/dV kernel S = QK^T (recomputed), dP = dO V^T, dV = P^T dO, dK = dS^T Q; dQ kernel S, dP, dQ = dS K.
 # SURVEY.md 8d counts the whole backward as 8 (+4 "if recomputed") = the dV, dK, dP, dQ products plus
 # one recomputation; the two-kernel split executes 14.
-ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6}
+ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2}  # dqg: dQ = dS K alone (dS from the dK/dV kernel's workspace)
 # HBM bytes per launch of the 2048x2048 dK/dV kernel from PMC: FETCH_SIZE 55 374 KB x 2 (gfx950 correction) +
 # WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
 ATTN_DKV_TRAFFIC = 94_247_117 + 45_362_074  # FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r03_pmc_attention_hbm.md
@@ -818,7 +818,8 @@ def main():
             ms = sum(samples) / len(samples)
             flops = ATTN_FLOPS[k] * l * s_len * 256 * B_PER_GPU  # 4 heads x 64 = 256 model channels
             tf = flops / (ms * 1e-3) / 1e12
-            names = {"fwd": "mha_fwd_kernel", "dkv": "mha_bwd_dkv_kernel", "dq": "mha_bwd_dq_kernel"}
+            names = {"fwd": "mha_fwd_kernel", "dkv": "mha_bwd_dkv_kernel", "dq": "mha_bwd_dq_kernel",
+                     "dqg": "mha_bwd_dq_gemm_kernel"}
             return {"kernel": f"{names[k]} (queries {l} x keys {s_len}, {B_PER_GPU} scenes x 4 heads x 64, "
                               f"dropout 0.1)",
                     "timing": timing_note, "bound": "mfma", "achieved": round(tf, 2),
@@ -840,7 +841,7 @@ def main():
             roofline["traffic"] = ATTN_DKV_TRAFFIC
             roofline["traffic_source"] = "profiles/r03_pmc_attention_hbm.md (PMC, separate FETCH_SIZE / WRITE_SIZE passes)"
             t_bwd = sum(sum(attn_ms[(k, 2048, 2048)]) / len(attn_ms[(k, 2048, 2048)])
-                        for k in ("delta", "dkv", "dq") if (k, 2048, 2048) in attn_ms)
+                        for k in ("delta", "dkv", "dq", "dqg") if (k, 2048, 2048) in attn_ms)
             # SURVEY 8d's count for the whole backward with recomputation: 12 * Lq * Lk * d over delta + dK/dV + dQ
             roofline["frac_whole_backward_8d"] = round(
                 12 * 2048 * 2048 * 256 * B_PER_GPU / (t_bwd * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)

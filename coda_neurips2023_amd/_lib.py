@@ -147,6 +147,10 @@ SIGNATURES = {
                                         ctypes.c_uint64, _P, _c_int, _P]),
     "coda_mha_fwd_opt_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                       _c_int, _c_int, _c_float, _c_float, ctypes.c_uint64, _P, _c_int, _P]),
+    "coda_mha_bwd_ws_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "coda_mha_bwd_ws_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
+                                     _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
+                                     ctypes.c_uint64, _P, _P, _c_size_t, _c_int, _P]),
     "coda_mha_bwd_parts_opt_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int,
                                             _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float,
                                             ctypes.c_uint64, _P, _c_int, _c_int, _P]),

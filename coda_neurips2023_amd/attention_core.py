@@ -13,6 +13,8 @@ optional, off-hot-path ``need_weights=True`` output (head-averaged attention
 maps for visualisation, transformer.py:126-137) is produced by a plain torch
 softmax next to the fused output.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -144,10 +146,11 @@ class _FusedAttention(torch.autograd.Function):
         dv = torch.empty((s, b, h, d), dtype=torch.float32, device=q.device)
         delta = torch.empty((b, h, l), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
-            st = lib.coda_mha_bwd_parts_opt_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
-                                                _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
-                                                ldq, ldk, ldv, 0, 0, 0, scale, dropout_p, seed, _ptr(seed_dev), 7, dt,
-                                                _lib.current_stream_handle())
+            ws, ws_bytes = backward_workspace(b, h, l, s, d, q.device, dt) if mask_u8 is None else (None, 0)
+            st = lib.coda_mha_bwd_ws_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(mask_u8), _ptr(out), _ptr(lse),
+                                         _ptr(dout), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), b, h, l, s, d,
+                                         ldq, ldk, ldv, 0, 0, 0, scale, dropout_p, seed, _ptr(seed_dev), _ptr(ws),
+                                         ws_bytes, dt, _lib.current_stream_handle())
         _lib.check(st, "mha_bwd")
         return dq, dk, dv, None, None, None
 
@@ -178,7 +181,19 @@ def attention(q, k, v, mask, scale, dropout_p, need_weights):
 
 
 # ---- measurement aid (bench.py): per-kernel HIP-event timing inside the C library ----------------
-TIMING_KINDS = ("fwd", "delta", "dkv", "dq")
+TIMING_KINDS = ("fwd", "delta", "dkv", "dq", "dqg")  # dqg: dQ as the dS K GEMM (coda_mha_bwd_ws_f32)
+
+
+def backward_workspace(b, h, l, s, d, dev, dt):
+    """(tensor or None, bytes): the dS workspace of coda_mha_bwd_ws_f32 for this problem -- long unmasked sequences at
+    head width 64 under fp32 MFMA operands (the encoder's self-attention); scratch from torch's caching allocator."""
+    lib = _lib.load()
+    if dt > 0 or (dt < 0 and lib.coda_mha_get_mfma_dtype() != 0) or os.environ.get("CODA_ATTN_DS", "1") == "0":
+        return None, 0
+    nbytes = lib.coda_mha_bwd_ws_bytes(b, h, l, s, d)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=dev), nbytes
 
 
 def enable_kernel_timing(min_len=0):

@@ -545,7 +545,10 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(MhaBwdParams p) {
 //                 forward kernel's K / V staging.
 // (A variant with the V fragments of a lane in LDS instead of 32 registers removed the kernel's 72 B / lane of scratch
 // and was not faster -- 648 vs 626 us -- so the spill is not what holds this kernel; removed in round 4.)
-template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false>
+// WDS: dS (before the soft-max scale, exactly what this kernel feeds into dK) is also written to p.ds (B*H, L, S), so
+//      that dQ = scale * dS K is one plain GEMM (mha_bwd_dq_gemm_kernel) instead of a second kernel that recomputes S
+//      and dP: the backward executes 10 instead of 14 units of L * S * d flops per head.
+template <int D, int KW, bool QSPLIT, bool GEN, bool DB = false, bool WDS = false>
 __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mha_bwd_dkv_kernel(MhaBwdParams p) {
   constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = KW * kWave;
   constexpr int QT = QSPLIT ? KW : (DB ? 1 : 2);  // query tiles staged per step
@@ -610,13 +613,13 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
     store_tile<D, THREADS, FROWS>(s_q, rq, tid);
     store_tile<D, THREADS, FROWS>(s_do, rg, tid);
     if (tid < kTile * QT) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
-    __syncthreads();
+    if constexpr (WDS) lds_only_barrier(); else __syncthreads();
   }
   int stage = 0;
   for (int qbase0 = 0; qbase0 < p.l; qbase0 += kTile * QT, ++stage) {
     const bool more = DB && qbase0 + kTile * QT < p.l;
     if (!DB) {
-      __syncthreads();
+      if constexpr (WDS) lds_only_barrier(); else __syncthreads();
       load_tile<D, THREADS, kTile * QT>(s_q, qbase, qstride, qbase0, p.l, tid);
       load_tile<D, THREADS, kTile * QT>(s_do, p.dout + head_off, rstride, qbase0, p.l, tid);
       if (tid < kTile * QT) {
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
         s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] * kLog2e : 0.f;
         s_delta[tid] = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
       }
-      __syncthreads();
+      if constexpr (WDS) lds_only_barrier(); else __syncthreads();
     } else {
       s_q = s_dyn + (stage & 1) * kStageFloats;
       s_do = s_q + QT * kTile * LS;
@@ -705,6 +708,13 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
         ds[r] = prob * __fmaf_rn(pacc[r], keep, -t_delta[qi]);  // * scale: once, on the dK rows
       }
     }
+    if (WDS) {  // lane = key: the 32 lanes of a half-wave write 128 contiguous bytes of one query's row
+      float *dsb = p.ds + (static_cast<size_t>(bh) * p.l + q0) * p.s + k0;  // wave-uniform base, 32-bit lane offsets
+      const uint32_t off0 = static_cast<uint32_t>(4 * half) * static_cast<uint32_t>(p.s) + static_cast<uint32_t>(l31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)  // streaming stores: 16.8 MB per head must not push Q / dO out of the XCD's L2
+        __builtin_nontemporal_store(ds[r], dsb + off0 + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) * static_cast<uint32_t>(p.s));
+    }
     // dV^T? no: dV[key][dv] += sum_q Pd[q][key] dO[q][dv]  (A = Pd^T: lane = key, k = query)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -743,12 +753,12 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
           nq[2 * QT * kTile * LS + QT * kTile + tid] = r_delta;
         }
       }
-      __syncthreads();
+      if constexpr (WDS) lds_only_barrier(); else __syncthreads();
     }
   }
 
   if (QSPLIT && KW > 1) {  // sum the per-wave partial dK / dV: [wave-1][2*NT*16][64 lanes]
-    __syncthreads();
+    if constexpr (WDS) lds_only_barrier(); else __syncthreads();
     if (w > 0) {
       float *slot = s_dyn + static_cast<size_t>(w - 1) * (2 * NT * 16) * kWave;
 #pragma unroll
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
           slot[((NT + t) * 16 + r) * kWave + lane] = dv[t][r];
         }
     }
-    __syncthreads();
+    if constexpr (WDS) lds_only_barrier(); else __syncthreads();
     if (w > 0) return;
     for (int ww = 1; ww < KW; ++ww) {
       const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (2 * NT * 16) * kWave;
@@ -1252,6 +1262,90 @@ void timing_clear() {
 }
 
 // brackets the launches issued during its lifetime
+// dQ = scale * dS K as a plain GEMM per (scene, head): (L x S) . (S x D), dS from the workspace the dK/dV kernel filled.
+// A workgroup = 4 waves x 32 queries; the contraction runs over 64-key chunks.  A fragments come straight from memory:
+// the MFMA's k-slot (kk, half) is mapped to key 8 (kk / 4) + 4 half + kk % 4, so a lane's four consecutive k-steps are
+// one 16-byte load of its own query row and nothing is fetched twice; the K chunk (64 keys x D) goes through LDS,
+// double buffered, and is read as B[k-slot][column] = K[key][32 cb + lane & 31] (32 consecutive floats per half-wave).
+__device__ __forceinline__ float4 nt_load4(const float *p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p));
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+template <int D, int KC>
+__global__ __launch_bounds__(256) void mha_bwd_dq_gemm_kernel(MhaBwdParams p) {
+  constexpr int NT = D / 32, NLD = KC * D / 4 / 256;  // float4 per thread and K chunk
+  extern __shared__ __attribute__((aligned(16))) float s_kdyn[];
+  float (*s_k)[KC * D] = reinterpret_cast<float (*)[KC * D]>(s_kdyn);
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = (th.tile * 4 + w) * kTile;
+  const bool wave_active = q0 < p.l;
+  const size_t kstride = static_cast<size_t>(p.b) * p.ldk;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *arow = p.ds + (static_cast<size_t>(bh) * p.l + (wave_active ? q0 + l31 : 0)) * p.s + 4 * half;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 rk[NLD], ra[KC / 8];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i, key = e / (D / 4), c4 = e % (D / 4);
+      rk[i] = c0 + key < p.s ? *reinterpret_cast<const float4 *>(kbase + static_cast<size_t>(c0 + key) * kstride + 4 * c4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < KC / 8; ++j)
+      ra[j] = (wave_active && c0 + 8 * j + 4 * half < p.s)
+                  ? nt_load4(arow + c0 + 8 * j)  // read exactly once
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  fetch(0);
+  int stage = 0;
+  for (int c0 = 0; c0 < p.s; c0 += KC, stage ^= 1) {
+    float *sk = s_k[stage];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4 *>(sk + 4 * (tid + 256 * i)) = rk[i];
+    float4 a[KC / 8];
+#pragma unroll
+    for (int j = 0; j < KC / 8; ++j) a[j] = ra[j];
+    __syncthreads();  // (two stages: the next chunk is written while the slower waves still read this one's predecessor)
+    if (c0 + KC < p.s) fetch(c0 + KC);
+    if (wave_active) {
+#pragma unroll
+      for (int j = 0; j < KC / 8; ++j) {
+        const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float *brow = sk + (8 * j + 4 * half + i) * D + l31;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], brow[32 * t], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (wave_active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + crow(r, half);
+      if (qq < p.l) {
+        float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + l31;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) row[32 * t] = acc[t][r] * p.scale;
+      }
+    }
+  }
+}
+
+
 struct KernelTimer {
   hipStream_t stream;
   hipEvent_t e1 = nullptr;
@@ -1370,10 +1464,19 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr int SW = (8 * kTileBytes <= 160 * 1024) ? 8 : 4;
   // double-buffered Q / dO staging pays on long query sequences (encoder: -5 %); with 256 queries
   // (decoder memory) there are only 8 stages and the prologue eats the gain
+  // dS workspace route (long sequences, no mask, ragged tails excluded): dK/dV kernel writes dS, dQ is one GEMM
+  const bool via_ds = D == 64 && !GEN && p.ds != nullptr && p.s >= 1024 && p.l >= 1024 && (p.parts & 6) == 6 &&
+                      !p.fuse_delta && double_buffered();
   auto run_dkv = [&]() -> int {
   if (!(p.parts & 2)) return CODA_OK;
   KernelTimer timer(2, p.l, p.s, s);
-  if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
+  if (via_ds) {
+    auto kern = mha_bwd_dkv_kernel<D, 4, false, false, true, D == 64>;
+    const size_t lds = 2 * (kTileBytes + kRowBytes);
+    int st = set_lds(kern, lds);
+    if (st != CODA_OK) return st;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+  } else if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
     int st = set_lds(kern, lds);
@@ -1396,6 +1499,18 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   };
   auto run_dq = [&]() -> int {
   if (!(p.parts & 4)) return CODA_OK;
+  if constexpr (D == 64) {
+    if (via_ds) {
+      KernelTimer timer(4, p.l, p.s, s);  // kind 4: the dS K GEMM (2 L S d flops per head)
+      // 64-key chunks: two workgroups per CU (181 registers); 128-key chunks with one measured slower (0.31 vs 0.25 ms)
+      auto kern = mha_bwd_dq_gemm_kernel<D, 64>;
+      constexpr size_t glds = sizeof(float) * 2 * 64 * D;  // two K chunks
+      int st = set_lds(kern, glds);
+      if (st != CODA_OK) return st;
+      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), glds, s, p);
+      return CODA_OK;
+    }
+  }
   KernelTimer timer(3, p.l, p.s, s);
   if (p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN, true>;
@@ -1445,7 +1560,9 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   const size_t nrows = static_cast<size_t>(p.l) * p.b * p.h;
   // The whole backward with the fp32-MFMA kernels: delta is formed inside the dQ kernel (CODA_ATTN_FUSE_DELTA=0: A/B)
   static const bool fuse_ok = [] { const char *e = getenv("CODA_ATTN_FUSE_DELTA"); return !e || atoi(e) != 0; }();
-  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7;
+  const bool ds_route = D == 64 && p.ds != nullptr && mfma_dtype() == 0 && p.mask == nullptr && p.l >= 1024 && p.s >= 1024 &&
+                        p.l % kTile == 0 && p.s % kTile == 0 && (p.parts & 6) == 6;
+  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7 && !ds_route;
   if ((p.parts & 1) && !fuse) {
     KernelTimer timer(1, p.l, p.s, s);
     hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
@@ -1466,6 +1583,7 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   MhaBwdParams rest = p;  // what the fp32-MFMA kernels still have to do
   rest.parts = p.parts & ~1;
   rest.fuse_delta = fuse ? 1 : 0;
+  if (!ds_route) rest.ds = nullptr;
   if (mfma_dtype() == 2) {
     int st = CODA_OK;
     if ((p.parts & 2) && mha_x3_takes_dkv(p, D)) {
@@ -1554,8 +1672,35 @@ CODA_API int coda_mha_bwd_parts_f32(const float *q, const float *k, const float 
   p.seed = static_cast<uint32_t>(seed ^ (seed >> 32));
   p.seed_dev = seed_dev;
   p.xcd_map = xcd_mapped();
+  {  // optional dS workspace of coda_mha_bwd_ws_f32 (per-call options, common.hip.h)
+    const CallOptions &o = call_options();
+    const size_t need = sizeof(float) * static_cast<size_t>(b) * h * l * s;
+    if (o.attn_ds_ws && o.attn_ds_bytes >= need && (reinterpret_cast<uintptr_t>(o.attn_ds_ws) & 15) == 0)
+      p.ds = static_cast<float *>(o.attn_ds_ws);
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   return d == 64 ? launch_bwd<64>(p, st) : launch_bwd<128>(p, st);
+}
+
+CODA_API size_t coda_mha_bwd_ws_bytes(int b, int h, int l, int s, int d) {
+  // the dS route applies to long unmasked sequences at head width 64 (the encoder's self-attention); 0 = not used
+  if (b <= 0 || h <= 0 || d != 64 || l < 1024 || s < 1024 || l % 32 != 0 || s % 32 != 0) return 0;
+  return sizeof(float) * static_cast<size_t>(b) * h * l * s;
+}
+
+CODA_API int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const uint8_t *mask, const float *out,
+                                 const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta, int b,
+                                 int h, int l, int s, int d, int ldq, int ldk, int ldv, int lddq, int lddk, int lddv,
+                                 float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *workspace,
+                                 size_t workspace_bytes, int mfma_dtype, void *stream) {
+  if (mfma_dtype < -1 || mfma_dtype > 2) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.mfma_dtype = mfma_dtype;
+  o.attn_ds_ws = workspace;
+  o.attn_ds_bytes = workspace ? workspace_bytes : 0;
+  coda::ScopedCallOptions scope(o);
+  return coda_mha_bwd_parts_f32(q, k, v, mask, out, lse, dout, dq, dk, dv, delta, b, h, l, s, d, ldq, ldk, ldv, lddq, lddk,
+                                lddv, scale, dropout_p, seed, seed_dev, 7, stream);
 }
 
 CODA_API int coda_mha_fwd_opt_f32(const float *q, const float *k, const float *v, const uint8_t *mask, float *out,

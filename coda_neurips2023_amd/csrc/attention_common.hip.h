@@ -59,6 +59,14 @@ struct MhaParams {
 // XCDs in linear-id order (x fastest), so with the plain grid (x = tile, y = head) the tiles of one head
 // are spread over all 8 XCDs and every private L2 pulls every head's K/V (or Q/dO) from the fabric:
 // FETCH_SIZE showed 2.8-5x the algorithmic bytes.  Here the workgroups that share a head share an XCD.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global stores
+// (s_waitcnt vmcnt(0)), which a kernel that streams results out between barriers must not do.
+__device__ __forceinline__ void lds_only_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct TileHead {
   int tile, bh;
 };
@@ -94,6 +102,7 @@ struct MhaBwdParams {
   const uint64_t *seed_dev;
   int parts = 7;  // which launches a backward call issues: 1 = delta, 2 = dK/dV, 4 = dQ (host-side only)
   int fuse_delta = 0;  // 1: the dQ kernel forms delta = rowsum(dO * O) itself and writes it for the dK/dV kernel behind it
+  float *ds = nullptr;  // optional (B*H, L, S) workspace: the dK/dV kernel leaves dS there and dQ = dS K becomes one GEMM
 };
 
 

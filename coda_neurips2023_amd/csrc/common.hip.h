@@ -49,6 +49,8 @@ struct CallOptions {
   int fps_waves = 0;       // 0 default | 8 | 16
   int bq_route = 0;        // 0 auto | 1 grid | 2 scan
   int mfma_dtype = -1;     // -1 default | 0 fp32 | 1 bf16 | 2 bf16x3
+  void *attn_ds_ws = nullptr;  // coda_mha_bwd_ws_f32: the caller's dS workspace (coda_attention.h)
+  size_t attn_ds_bytes = 0;
 };
 CallOptions &call_options();  // version.hip: thread_local
 struct ScopedCallOptions {

@@ -224,10 +224,13 @@ class _MHA(torch.autograd.Function):
             dkv = torch.empty((2, rk, e), dtype=torch.float32, device=dev)
             dk, dv = dkv[0], dkv[1]
         delta = torch.empty((bsz, nheads, tgt_len), dtype=torch.float32, device=dev)
-        _lib.check(lib.coda_mha_bwd_parts_opt_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), _p(dattn), _p(dq),
-                                                  _p(dk), _p(dv), _p(delta), bsz, nheads, tgt_len, src_len, d, ldq, ldk, ldv,
-                                                  0, 0, 0, scale, p, seed, _p(seed_dev), 7, ctx.mfma_dtype, _stream()),
-                   "mha_bwd")
+        # long unmasked sequences (the encoder): dS through a workspace, dQ as one GEMM (include/coda_attention.h)
+        ws, ws_bytes = (_core.backward_workspace(bsz, nheads, tgt_len, src_len, d, dev, ctx.mfma_dtype)
+                        if mask_u8 is None else (None, 0))
+        _lib.check(lib.coda_mha_bwd_ws_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), _p(dattn), _p(dq),
+                                           _p(dk), _p(dv), _p(delta), bsz, nheads, tgt_len, src_len, d, ldq, ldk, ldv,
+                                           0, 0, 0, scale, p, seed, _p(seed_dev), _p(ws), ws_bytes, ctx.mfma_dtype,
+                                           _stream()), "mha_bwd")
         dw_in = torch.empty_like(w_in)
         db_in = torch.empty(3 * e, dtype=torch.float32, device=dev)
         if dqkv is not None:

@@ -101,12 +101,25 @@ int coda_mha_bwd_parts_opt_f32(const float *q, const float *k, const float *v,
                                int mfma_dtype, void *stream);
 int coda_mha_get_mfma_dtype(void);
 
+/* The whole backward with a caller-provided workspace of coda_mha_bwd_ws_bytes() bytes (0: this problem does not use
+ * one -- NULL / 0 may be passed and the call equals coda_mha_bwd_parts_opt_f32 with parts = 7).  Long unmasked
+ * sequences at head width 64 (the encoder's 2048 x 2048 self-attention): the dK/dV kernel leaves dS = P (dP - delta)
+ * in the workspace, (B, H, L, S) floats, and dQ = scale dS K is a plain GEMM -- the backward then executes S, dP, dV,
+ * dK, dQ once each (10 L S d flops per head) instead of recomputing S and dP in a second kernel (14).  Same results
+ * as the two-kernel form up to the summation order of dQ.  The workspace is scratch: nothing is kept in it. */
+size_t coda_mha_bwd_ws_bytes(int b, int h, int l, int s, int d);
+int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const uint8_t *mask, const float *out,
+                        const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta, int b,
+                        int h, int l, int s, int d, int ldq, int ldk, int ldv, int lddq, int lddk, int lddv,
+                        float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, void *workspace,
+                        size_t workspace_bytes, int mfma_dtype, void *stream);
+
 /* Measurement aid (bench.py's live roofline figures; no reference counterpart).  While
  * enabled, each kernel launched by coda_mha_fwd_f32 / coda_mha_bwd_f32 for a problem with
  * l >= min_len and s >= min_len is bracketed by two HIP events on the launch stream.
  * coda_mha_timing_enable(min_len < 0) disables; every call drops the records taken so far.
  * coda_mha_timing_collect synchronises the recorded events and writes up to `cap` records
- * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ; the call's l and s; milliseconds); returns the
+ * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ, 4 dQ as the dS K GEMM; the call's l and s; milliseconds); returns the
  * number written, CODA_EINVAL, or -(1000 + hipError_t) if an event query failed. */
 int coda_mha_timing_enable(int min_len);
 int coda_mha_timing_collect(int *kind, int *l, int *s, float *ms, int cap);

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from coda_neurips2023_amd import attention_core
+from coda_neurips2023_amd import _lib, attention_core
 from oracle.cpu_port import attention_ref
 
 pytestmark = pytest.mark.gpu
@@ -133,7 +133,7 @@ def test_kernel_timing_records_every_launch(dev):
     finally:
         attention_core.disable_kernel_timing()
     # (no "delta" record on the fp32 path: the dQ kernel forms rowsum(dO * O) itself)
-    assert sorted(rec) == [(kind, 256, 256) for kind in sorted(attention_core.TIMING_KINDS) if kind != "delta"]
+    assert sorted(rec) == [(kind, 256, 256) for kind in sorted(attention_core.TIMING_KINDS) if kind not in ("delta", "dqg")]
     for samples in rec.values():
         assert len(samples) == 3 and all(0.0 < ms < 50.0 for ms in samples)
     assert attention_core.collect_kernel_timing() == {}  # disabling dropped the records
@@ -204,3 +204,33 @@ def test_dropout_hash_is_statistically_iid(dev, p):
             assert abs(_corr(m[hh], m[hh + 1])) < se, ("neighbouring heads", si, hh)
     for hh in range(h):
         assert abs(_corr(masks[0][hh], masks[1][hh])) < se, ("two seeds", hh)
+
+
+@pytest.mark.parametrize("l,s,b,p", [(2048, 2048, 2, 0.1), (1024, 2048, 1, 0.0), (2048, 1024, 1, 0.3)])
+def test_backward_through_the_ds_workspace_equals_the_two_kernel_form(dev, monkeypatch, l, s, b, p):
+    """coda_mha_bwd_ws_f32: on long unmasked sequences the dK/dV kernel leaves dS in a workspace and dQ = scale dS K is
+    one GEMM (10 instead of 14 units of L S d flops).  Same dropout mask; dK / dV / dQ equal the two-kernel form's
+    (CODA_ATTN_DS=0) up to fp32 summation order (delta = rowsum(dO * O) comes from the stand-alone kernel instead of
+    the dQ kernel's own sum, dQ is accumulated in 64-key chunks) -- and the torch reference within 1e-3."""
+    h, d = 4, 64
+    leaves, q, k, v = make_qkv(dev, l, s, b, h, d, False, seed=l + s + b)
+    scale = d ** -0.5
+    gw = torch.randn(l, b, h, d, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def grads(flag):
+        monkeypatch.setenv("CODA_ATTN_DS", flag)
+        torch.manual_seed(77)
+        out, _ = attention_core.attention(q, k, v, None, scale, p, False)
+        return out.detach(), torch.autograd.grad((out * gw).sum(), leaves)
+
+    assert _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, d) == 4 * b * h * l * s
+    assert _lib.load().coda_mha_bwd_ws_bytes(b, h, 256, s, d) == 0 and _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, 128) == 0
+    o1, g1 = grads("1")
+    o0, g0 = grads("0")
+    assert torch.equal(o1, o0)
+    for a, r in zip(g1, g0):
+        assert rel(a, r) < 5e-6, rel(a, r)
+    if p == 0.0:
+        ref, _ = attention_ref(q, k, v, None, scale, 0.0, False)
+        for a, r in zip(g1, torch.autograd.grad((ref * gw).sum(), leaves)):
+            assert rel(a, r) < 1e-3
