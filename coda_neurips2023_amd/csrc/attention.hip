@@ -1465,6 +1465,8 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   // double-buffered Q / dO staging pays on long query sequences (encoder: -5 %); with 256 queries
   // (decoder memory) there are only 8 stages and the prologue eats the gain
   // dS workspace route (long sequences, no mask, ragged tails excluded): dK/dV kernel writes dS, dQ is one GEMM
+  // (The decoder's shapes -- 256 queries -- were tried too, with the keys split over the waves of a 32-query workgroup:
+  // 0.092 ms against the two-kernel form's 0.091 for 256 x 2048, the dK/dV kernel 8 % slower: long sequences only.)
   const bool via_ds = D == 64 && !GEN && p.ds != nullptr && p.s >= 1024 && p.l >= 1024 && (p.parts & 6) == 6 &&
                       !p.fuse_delta && double_buffered();
   auto run_dkv = [&]() -> int {

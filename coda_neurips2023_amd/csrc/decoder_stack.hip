@@ -212,6 +212,8 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
   if (a->mfma_dtype < -1 || a->mfma_dtype > 2) return CODA_EINVAL;
   coda::CallOptions opt = coda::call_options();
   opt.mfma_dtype = a->mfma_dtype;
+  opt.attn_ds_ws = a->attn_ws;  // the attention backward calls below pick the dS workspace up (coda_mha_bwd_ws_f32's route)
+  opt.attn_ds_bytes = a->attn_ws ? a->attn_ws_bytes : 0;
   coda::ScopedCallOptions scope(opt);
   if (!a->tgt || !a->query_pos || !a->k_all || !a->v_all || !a->norm_g || !a->params || !a->ws || !dstack || !d_tgt ||
       !d_query_pos || !dk_all || !dv_all || !grads || !sums || !bwd_ws)

@@ -440,7 +440,8 @@ class _StackArgs(ctypes.Structure):
                 ("tgt", ctypes.c_void_p), ("query_pos", ctypes.c_void_p), ("k_all", ctypes.c_void_p),
                 ("v_all", ctypes.c_void_p), ("norm_g", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
                 ("params", ctypes.c_void_p), ("outs", ctypes.c_void_p), ("ws", ctypes.c_void_p),
-                ("ld_kv", ctypes.c_int), ("mfma_dtype", ctypes.c_int)]
+                ("ld_kv", ctypes.c_int), ("mfma_dtype", ctypes.c_int), ("attn_ws", ctypes.c_void_p),
+                ("attn_ws_bytes", ctypes.c_size_t)]
 
 
 def _ptr_table(tensors):
@@ -475,7 +476,8 @@ class _DecoderStackC(torch.autograd.Function):
         table = _ptr_table(params)
         args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
                           query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
-                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr(), k_all.stride(0), _lib.opt("mfma_dtype"))
+                          ctypes.addressof(table), outs.data_ptr(), ws.data_ptr(), k_all.stride(0), _lib.opt("mfma_dtype"),
+                          None, 0)
         _lib.check(lib.coda_decoder_stack_fwd_f32(ctypes.byref(args), _lib.current_stream_handle()), "decoder_stack_fwd")
         ctx.args = (nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, pos is not None)
         ctx.mfma_dtype = args.mfma_dtype
@@ -485,6 +487,7 @@ class _DecoderStackC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dstack):
         from . import _lib
+        from . import attention_core as _core
         nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, has_pos = ctx.args
         saved = ctx.saved_tensors
         tgt, query_pos, mem2, mp2, k_all, v_all, wk_all, wv_all, ws, norm_g, norm_b = saved[:11]
@@ -517,9 +520,12 @@ class _DecoderStackC(torch.autograd.Function):
             gptr += row
         gtable = _ptr_table(gptr)
         table = _ptr_table(params)
+        # dS workspace of the attention backward (the cross-attention problem is the larger one; the layers share it)
+        attn_ws, attn_ws_bytes = _core.backward_workspace(bsz, nheads, nq, max(ns, nq), e // nheads, dev, ctx.mfma_dtype)
         args = _StackArgs(nl, nq, bsz, e, ns, nheads, ffn, eps, p_attn, p1, p2, p_ffn, p3, seed, tgt.data_ptr(),
                           query_pos.data_ptr(), k_all.data_ptr(), v_all.data_ptr(), norm_g.data_ptr(), norm_b.data_ptr(),
-                          ctypes.addressof(table), None, ws.data_ptr(), k_all.stride(0), ctx.mfma_dtype)
+                          ctypes.addressof(table), None, ws.data_ptr(), k_all.stride(0), ctx.mfma_dtype,
+                          attn_ws.data_ptr() if attn_ws is not None else None, attn_ws_bytes)
         _lib.check(lib.coda_decoder_stack_bwd_f32(ctypes.byref(args), dstack.data_ptr(), d_tgt.data_ptr(), d_qpos.data_ptr(),
                                                   dk_all.data_ptr(), dv_all.data_ptr(), ctypes.addressof(gtable),
                                                   sums.data_ptr(), bws.data_ptr(), _lib.current_stream_handle()),

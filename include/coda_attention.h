@@ -103,7 +103,8 @@ int coda_mha_get_mfma_dtype(void);
 
 /* The whole backward with a caller-provided workspace of coda_mha_bwd_ws_bytes() bytes (0: this problem does not use
  * one -- NULL / 0 may be passed and the call equals coda_mha_bwd_parts_opt_f32 with parts = 7).  Long unmasked
- * sequences at head width 64 (the encoder's 2048 x 2048 self-attention): the dK/dV kernel leaves dS = P (dP - delta)
+ * sequences at head width 64 (the encoder's 2048 x 2048 self-attention), fp32 MFMA operands: the dK/dV kernel
+ * leaves dS = P (dP - delta)
  * in the workspace, (B, H, L, S) floats, and dQ = scale dS K is a plain GEMM -- the backward then executes S, dP, dV,
  * dK, dQ once each (10 L S d flops per head) instead of recomputing S and dP in a second kernel (14).  Same results
  * as the two-kernel form up to the summation order of dQ.  The workspace is scratch: nothing is kept in it. */
