@@ -1274,7 +1274,7 @@ __device__ __forceinline__ float4 nt_load4(const float *p) {
 }
 
 template <int D, int KC>
-__global__ __launch_bounds__(256) void mha_bwd_dq_gemm_kernel(MhaBwdParams p) {
+__global__ __launch_bounds__(256, 2) void mha_bwd_dq_gemm_kernel(MhaBwdParams p) {
   constexpr int NT = D / 32, NLD = KC * D / 4 / 256;  // float4 per thread and K chunk
   extern __shared__ __attribute__((aligned(16))) float s_kdyn[];
   float (*s_k)[KC * D] = reinterpret_cast<float (*)[KC * D]>(s_kdyn);
@@ -1294,21 +1294,25 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_gemm_kernel(MhaBwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  float4 rk[NLD], ra[KC / 8];
-  auto fetch = [&](int c0) {
+  // K (512 KB per head, shared by the head's 16 workgroups: L2 hits) is fetched one chunk ahead; dS -- the 537 MB stream
+  // from HBM, every byte used once -- TWO chunks ahead (one chunk of MFMAs, 1.7 us, does not cover an HBM round trip).
+  float4 rk[NLD], ra0[KC / 8], ra1[KC / 8];
+  auto fetch_k = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int e = tid + 256 * i, key = e / (D / 4), c4 = e % (D / 4);
       rk[i] = c0 + key < p.s ? *reinterpret_cast<const float4 *>(kbase + static_cast<size_t>(c0 + key) * kstride + 4 * c4)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto fetch_a = [&](float4 (&ra)[KC / 8], int c0) {
 #pragma unroll
     for (int j = 0; j < KC / 8; ++j)
-      ra[j] = (wave_active && c0 + 8 * j + 4 * half < p.s)
-                  ? nt_load4(arow + c0 + 8 * j)  // read exactly once
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[j] = (wave_active && c0 + 8 * j + 4 * half < p.s) ? nt_load4(arow + c0 + 8 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  fetch(0);
+  fetch_k(0);
+  fetch_a(ra0, 0);
+  fetch_a(ra1, KC);
   int stage = 0;
   for (int c0 = 0; c0 < p.s; c0 += KC, stage ^= 1) {
     float *sk = s_k[stage];
@@ -1316,9 +1320,11 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_gemm_kernel(MhaBwdParams p) {
     for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4 *>(sk + 4 * (tid + 256 * i)) = rk[i];
     float4 a[KC / 8];
 #pragma unroll
-    for (int j = 0; j < KC / 8; ++j) a[j] = ra[j];
-    __syncthreads();  // (two stages: the next chunk is written while the slower waves still read this one's predecessor)
-    if (c0 + KC < p.s) fetch(c0 + KC);
+    for (int j = 0; j < KC / 8; ++j) { a[j] = ra0[j]; ra0[j] = ra1[j]; }
+    lds_only_barrier();  // LDS only: the loads in flight stay in flight (two K stages: the slower waves may still read
+                         // this stage's predecessor)
+    if (c0 + KC < p.s) fetch_k(c0 + KC);
+    fetch_a(ra1, c0 + 2 * KC);  // (past the end: predicated off)
     if (wave_active) {
 #pragma unroll
       for (int j = 0; j < KC / 8; ++j) {
