@@ -664,7 +664,8 @@ def main():
     # DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False).  Every rank runs it in
     # lockstep, `steps` steps right after the headline's, same barrier + synchronize bracket, max over ranks.
     unchanged = None
-    if kind in ("model", "dry"):
+    # CODA_BENCH_LEGS=headline: dev switch for kernel traces of the headline leg alone (tools/trace_gaps.py)
+    if kind in ("model", "dry") and os.environ.get("CODA_BENCH_LEGS", "both") != "headline":
         model_u = model
         if reducer is not None:
             reducer.remove_hooks()

@@ -816,12 +816,104 @@ def golden_eval_det():
     _save("eval_det.npz", **out)
 
 
+def golden_step_full():
+    """ONE WHOLE TRAINING STEP AT BASELINE.json configs[2]'s SIZE THROUGH THE REFERENCE'S OWN MODULES (8 scenes x
+    20 000 points, 2048 encoder tokens, 256 queries, 3 + 8 layers, the stage-2 loss set): models/model_3detr.py's
+    pre-encoder / encoder / decoder / heads (:1767-1794, the oracle's C ops behind pointnet2._ext), criterion.py's
+    SetCriterion.forward (:1162-1216: gIoU, Hungarian matching of all 8 layers, matched box terms, both CLIP-space
+    alignment terms) and backward, float32 on the CPU.  The CLIP image branch (checkpoint absent) is replaced by the
+    same seeded tensors tests/test_full_step_gpu.py hands to the product's region-embedding seam.  Inputs are NOT
+    stored: tests/golden/step_inputs.py rebuilds them from seeds.  Stored: loss, every loss term, the 64 assignments,
+    the pre-encoder's FPS indices, output digests and per-parameter gradient digests (sum, norm, 1024 samples)."""
+    import bench
+    import criterion as RC  # the REFERENCE module
+    import models.model_3detr as M  # the REFERENCE module
+    from datasets.sunrgbd_anonymous_aligned_image import SunrgbdAnonymousAlignedImageDatasetConfig
+    from golden import step_inputs as SI
+    from golden.weights import fill_deterministic
+
+    args = bench.recipe_args(SI.NQ, enc_dropout=0.0, dec_dropout=0.0, mlp_dropout=0.0)
+    for k, v in vars(_args()).items():  # flags the reference reads beyond the hot path's
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    for k, v in dict(only_image_class=False, only_prompt_loss=False, if_skip_no_seen_scene_objectness=False,
+                     if_only_seen_in_loss=False).items():
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    cfg = SunrgbdAnonymousAlignedImageDatasetConfig(if_print=False, args=args)
+    pre, enc, dec = M.build_preencoder(args), M.build_encoder(args), M.build_decoder(args)
+    model = M.Model3DETRPredictedBoxDistillationHead(pre, enc, dec, cfg, encoder_dim=args.enc_dim,
+                                                     decoder_dim=args.dec_dim, mlp_dropout=0.0,
+                                                     num_queries=args.nqueries, if_with_clip_train=False, args=args)
+    fill_deterministic(model, seed=SI.WEIGHT_SEED)
+    model.train()
+    # SetCriterion.__init__ parks a scratch tensor on 'cuda' (criterion.py:97): keep it on the host while constructing
+    real_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else real_to(self, *a, **k)
+    try:
+        crit = RC.build_criterion(args, cfg)
+    finally:
+        torch.Tensor.to = real_to
+    batch, seam = SI.build()
+    captured = {}
+    real_match = crit.matcher.forward
+
+    def spy(outputs, targets):
+        res = real_match(outputs, targets)
+        captured.setdefault("inds", []).append(res["per_prop_gt_inds"].clone())
+        captured.setdefault("mask", []).append(res["proposal_matched_mask"].clone())
+        return res
+
+    crit.matcher.forward = spy
+    import time
+    t0 = time.time()
+    point_clouds = batch["point_clouds"]
+    enc_xyz, enc_features, enc_inds = model.run_encoder(point_clouds)
+    enc_features = model.encoder_to_decoder_projection(enc_features.permute(1, 2, 0)).permute(2, 0, 1)
+    dims = [batch["point_cloud_dims_min"], batch["point_cloud_dims_max"]]
+    query_xyz, query_embed = model.get_query_embeddings(enc_xyz, dims)
+    enc_pos = model.pos_embedding(enc_xyz, input_range=dims).permute(2, 0, 1)
+    query_embed = query_embed.permute(2, 0, 1)
+    box_features = model.decoder(torch.zeros_like(query_embed), enc_features, query_pos=query_embed, pos=enc_pos)[0]
+    pred = model.get_box_predictions(query_xyz, dims, box_features, point_clouds, batch)
+    o = pred["outputs"]
+    o["logit_scale"] = torch.tensor(SI.LOGIT_SCALE)  # models/model_3detr.py:1796 with a released checkpoint's ln(100)
+    o["text_features_clip"] = seam["text"][:args.train_range_max].unsqueeze(0).repeat(SI.B, 1, 1)  # :1803
+    o["gt_text_correlation_embedding"] = seam["img_emb"]          # what get_predicted_box_clip_embedding adds (:1816)
+    o["gt_text_correlation_embedding_mask"] = seam["mask"]
+    o["weak_box_cate_label"] = seam["weak_label"]
+    o["weak_confidence_weight"] = seam["weak_conf"]
+    print(f"step_full: forward {time.time() - t0:.1f} s")
+    loss, loss_dict = crit(pred, batch)
+    print(f"step_full: criterion {time.time() - t0:.1f} s, loss {float(loss):.6f}")
+    loss.backward()
+    print(f"step_full: backward {time.time() - t0:.1f} s")
+    out = {"loss": np.float64(float(loss)), "sa_inds": _np(enc_inds).astype(np.int32),
+           # SetCriterion.forward matches the last layer first, then aux 0..6 (:1200-1210): stored in LAYER order
+           "assign_inds": _np(torch.cat(captured["inds"][1:] + captured["inds"][:1])).astype(np.int16),
+           "assign_mask": _np(torch.cat(captured["mask"][1:] + captured["mask"][:1])).astype(np.uint8),
+           "loss_keys": np.array(sorted(loss_dict)),
+           "loss_vals": np.array([float(loss_dict[k]) for k in sorted(loss_dict)], dtype=np.float64)}
+    for k in ["sem_cls_logits", "text_correlation_embedding", "center_normalized", "size_normalized", "angle_logits",
+              "angle_residual", "box_corners"]:
+        t = o[k].detach().double()
+        idx = np.linspace(0, t.numel() - 1, SI.SAMPLES).astype(np.int64)
+        out[f"out/{k}"] = np.concatenate([[float(t.sum()), float(t.norm())], t.reshape(-1)[idx].numpy()])
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().double().reshape(-1)
+        idx = np.linspace(0, g.numel() - 1, min(SI.SAMPLES, g.numel())).astype(np.int64)
+        out[f"grad/{name}"] = np.concatenate([[float(g.sum()), float(g.norm())], g[idx].numpy()]).astype(np.float32 if g.numel() > 64 else np.float64)
+    _save("step_full.npz", **out)
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det"]
+    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det", "step_full"]
     for w in which:
         globals()["golden_" + w]()

@@ -1,0 +1,30 @@
+"""Seeded inputs of the full-size whole-step fixture (tests/golden/step_full.npz): the SAME scenes, targets and
+region-embedding seam tensors tests/test_full_step_gpu.py uses for configs[2].  Shared by the generator (which feeds
+them to the REFERENCE's modules) and the test (which feeds them to this package): the fixture carries outputs only."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+B, NPOINTS, NQ, NCLS = 8, 20000, 256, 10
+WEIGHT_SEED = 23
+SAMPLES = 1024            # strided entries kept per tensor
+LOGIT_SCALE = 100.0       # clip(exp(ln 100), max=100): models/model_3detr.py:1796 with a released CLIP checkpoint
+LOGIT_SCALE_PARAM = math.log(100.0)
+
+
+def build():
+    """-> (batch dict of CPU tensors incl. the ground-truth entries, seam dict)."""
+    import bench
+    from coda_neurips2023_amd.synthetic_scenes import make_batch
+    gen = torch.Generator().manual_seed(11)
+    seam = {"text": F.normalize(torch.randn(NCLS, 512, generator=gen), dim=-1),
+            "img_emb": F.normalize(torch.randn(B, NQ, 512, generator=gen), dim=-1),
+            "mask": (torch.rand(B, NQ, 1, generator=gen) < 0.25).float(),
+            "weak_label": torch.randint(0, NCLS, (B, NQ), generator=gen),
+            "weak_conf": torch.rand(B, NQ, generator=gen) * (torch.rand(B, NQ, generator=gen) < 0.5)}
+    pc, mn, mx = make_batch(B, NPOINTS, seed=555)
+    batch = {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
+             "point_cloud_dims_max": torch.from_numpy(mx)}
+    batch.update(bench.synthetic_targets(batch, torch.Generator().manual_seed(2)))
+    return batch, seam

@@ -1,33 +1,36 @@
 #!/bin/bash
-# dev: one GPU-box call that refreshes the round's measured artifacts under gpurun_out/
-#   (copied by hand into profiles/ afterwards).  Usage: gpurun -- 'bash tools/run_round_end.sh [tests]'
+# dev: one GPU-box call that refreshes the round's measured artifacts under gpurun_out/final_* (copied by hand into
+# profiles/ afterwards).  Usage: gpurun -- 'bash tools/run_round_end.sh [tests]'
 cd "$GRAFT_REPO_ROOT" || exit 1
+R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$1" = "tests" ]; then
-  python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+  timeout 1500 python -m pytest tests -q -m gpu --timeout 900 > gpurun_out/final_tests.log 2>&1
+  tail -3 gpurun_out/final_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1; tail -2 gpurun_out/final_smoke.log
 fi
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
-python bench.py --prefetch off --no-cpu-baseline > gpurun_out/final_bench_noprefetch.json 2>> gpurun_out/final_bench.err
+python bench.py --prefetch off --no-cpu-baseline --no-extras > gpurun_out/final_bench_noprefetch.json 2>> gpurun_out/final_bench.err
 python bench.py --workload sa --no-cpu-baseline > gpurun_out/final_bench_sa.json 2>> gpurun_out/final_bench.err
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 cd /tmp
 rm -rf $R/gpurun_out/final_prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
   python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/final_prof_bench.json 2>/dev/null
-python $R/tools/trace_by_grid.py $R/gpurun_out/final_prof/run_kernel_trace.csv > $R/gpurun_out/final_prof/attention_by_grid.csv
-rm -f $R/gpurun_out/final_prof/run_kernel_trace.csv   # tens of MB; the stats file is what gets committed
-rm -rf $R/gpurun_out/final_tower_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_tower_prof -o tower -- \
-  python $R/tools/bench_clip_tower.py --iters 30 > $R/gpurun_out/final_tower.json 2>/dev/null
-rm -f $R/gpurun_out/final_tower_prof/tower_kernel_trace.csv
+python $R/tools/trace_by_grid.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) > $R/gpurun_out/final_prof/attention_by_grid.csv
+find $R/gpurun_out/final_prof -name run_kernel_trace.csv -delete   # tens of MB; the stats file is what gets committed
 cd $R
-cat gpurun_out/final_tower.json
+bash tools/pmc_sa.sh > /dev/null 2>&1
+bash tools/pmc_attn.sh > gpurun_out/final_pmc_attn_hbm.txt 2>&1
+bash tools/pmc_attn_mfma.sh > gpurun_out/final_pmc_attn_mfma.txt 2>&1
 python - <<'PY'
 import json
 for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_prof_bench"):
-    d = json.load(open(f"gpurun_out/{f}.json"))
-    r = d["roofline"]
-    print(f, d["value"], d["ms_per_step"], r["kernel"][:40], r["achieved"], r["frac"], r.get("avg_launch_ms"),
-          d.get("cpu_baseline", {}).get("value"))
+    for l in open(f"gpurun_out/{f}.json"):
+        if not l.startswith("{"):
+            continue
+        d = json.loads(l)
+        r = d["roofline"]
+        print(f, d["value"], d["ms_per_step"], d.get("value_unchanged"), r["kernel"][:40], r["achieved"], r["frac"], r.get("avg_launch_ms"),
+              d.get("cpu_baseline", {}).get("value"))
 PY
