@@ -816,8 +816,8 @@ def golden_eval_det():
     _save("eval_det.npz", **out)
 
 
-def golden_step_full():
-    """ONE WHOLE TRAINING STEP AT BASELINE.json configs[2]'s SIZE THROUGH THE REFERENCE'S OWN MODULES (8 scenes x
+def golden_step_full(case="configs2"):
+    """ONE WHOLE TRAINING STEP AT BASELINE.json configs[2]'s / configs[3]'s PER-GPU SIZE THROUGH THE REFERENCE'S OWN MODULES (8 scenes x
     20 000 points, 2048 encoder tokens, 256 queries, 3 + 8 layers, the stage-2 loss set): models/model_3detr.py's
     pre-encoder / encoder / decoder / heads (:1767-1794, the oracle's C ops behind pointnet2._ext), criterion.py's
     SetCriterion.forward (:1162-1216: gIoU, Hungarian matching of all 8 layers, matched box terms, both CLIP-space
@@ -832,7 +832,7 @@ def golden_step_full():
     from golden import step_inputs as SI
     from golden.weights import fill_deterministic
 
-    args = bench.recipe_args(SI.NQ, enc_dropout=0.0, dec_dropout=0.0, mlp_dropout=0.0)
+    args = SI.recipe(case)
     for k, v in vars(_args()).items():  # flags the reference reads beyond the hot path's
         if not hasattr(args, k):
             setattr(args, k, v)
@@ -854,7 +854,7 @@ def golden_step_full():
         crit = RC.build_criterion(args, cfg)
     finally:
         torch.Tensor.to = real_to
-    batch, seam = SI.build()
+    batch, seam = SI.build(case)
     captured = {}
     real_match = crit.matcher.forward
 
@@ -905,7 +905,11 @@ def golden_step_full():
         g = p.grad.detach().double().reshape(-1)
         idx = np.linspace(0, g.numel() - 1, min(SI.SAMPLES, g.numel())).astype(np.int64)
         out[f"grad/{name}"] = np.concatenate([[float(g.sum()), float(g.norm())], g[idx].numpy()]).astype(np.float32 if g.numel() > 64 else np.float64)
-    _save("step_full.npz", **out)
+    _save(f"step_full_{case}.npz", **out)
+
+
+def golden_step_full_configs3():
+    golden_step_full("configs3")
 
 
 if __name__ == "__main__":
@@ -914,6 +918,6 @@ if __name__ == "__main__":
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det", "step_full"]
+    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det", "step_full", "step_full_configs3"]
     for w in which:
         globals()["golden_" + w]()

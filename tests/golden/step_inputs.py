@@ -6,15 +6,30 @@ import math
 import torch
 import torch.nn.functional as F
 
-B, NPOINTS, NQ, NCLS = 8, 20000, 256, 10
+B, NCLS = 8, 10
+# the per-GPU shares of BASELINE.json's configs: points per scene, queries, decoder width, loss recipe
+# (stage 1 = scripts/coda_sunrgbd_stage1.sh:7-27 at its own shape: d_dec 512, 128 queries, L1 alignment term only)
+CASES = {"configs2": dict(npoints=20000, nq=256, dec_dim=256, stage=2),
+         "configs3": dict(npoints=20000, nq=128, dec_dim=512, stage=1)}
 WEIGHT_SEED = 23
 SAMPLES = 1024            # strided entries kept per tensor
 LOGIT_SCALE = 100.0       # clip(exp(ln 100), max=100): models/model_3detr.py:1796 with a released CLIP checkpoint
 LOGIT_SCALE_PARAM = math.log(100.0)
 
 
-def build():
+def recipe(case):
+    """The argparse namespace of the case (bench.recipe_args: main.py's defaults + the stage's script), dropout 0."""
+    import bench
+    c = CASES[case]
+    args = bench.recipe_args(c["nq"], dec_dim=c["dec_dim"], enc_dropout=0.0, dec_dropout=0.0, mlp_dropout=0.0)
+    if c["stage"] == 1:
+        args.loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi_weight = 0
+    return args
+
+
+def build(case):
     """-> (batch dict of CPU tensors incl. the ground-truth entries, seam dict)."""
+    NQ, NPOINTS = CASES[case]["nq"], CASES[case]["npoints"]
     import bench
     from coda_neurips2023_amd.synthetic_scenes import make_batch
     gen = torch.Generator().manual_seed(11)
