@@ -208,6 +208,30 @@ __global__ void l1_bwd_kernel(const double *__restrict__ s5, const double *__res
   }
 }
 
+// -DCODA_SA_PROF (tools/sa_prof.py builds a private copy of the library with it): shader-clock sums of the phases of a
+// sub-tile per (kernel, workgroup < 64, wave), read back with coda_sa_prof_read.  Compiles to nothing in the library.
+#ifdef CODA_SA_PROF
+__device__ unsigned long long g_sa_prof[6][64][4][10];
+#define SA_PROF_DECL unsigned long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter()
+#define SA_PROF_MARK(i)                                               \
+  do {                                                                \
+    const unsigned long long now_ = __builtin_readcyclecounter();     \
+    prof_[i] += now_ - prof_t_;                                       \
+    prof_t_ = now_;                                                   \
+  } while (0)
+#define SA_PROF_COUNT(i, v) prof_[i] += (v)
+#define SA_PROF_STORE(kind)                                                                              \
+  do {                                                                                                   \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64)                                                      \
+      for (int q_ = 0; q_ < 10; ++q_) g_sa_prof[kind][blockIdx.x][threadIdx.x >> 6][q_] = prof_[q_];     \
+  } while (0)
+#else
+#define SA_PROF_DECL
+#define SA_PROF_MARK(i)
+#define SA_PROF_COUNT(i, v)
+#define SA_PROF_STORE(kind)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
@@ -228,6 +252,8 @@ struct FwdArgs {
 // per CU -- the input and output LDS tiles sharing their memory, no register prefetch -- would let one workgroup's MFMAs
 // run under the other's staging / epilogue, but needs <= 256 registers: measured with 332 B of scratch per lane, layer 3
 // took 0.46 ms instead of 0.33.  (PMC, profiles/r04_pmc_sa_mlp.md: 39 % MFMA-busy, 21 % of the wave cycles parked.)
+constexpr bool fwd_alias(int cin, int cout) { return sizeof(float) * kRows * (cin + cout + 8) > 80 * 1024; }
+
 template <int CIN, int COUT, bool FIRST, bool POOL>
 __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   static_assert(COUT % 128 == 0 && CIN % 32 == 0, "tile shape");
@@ -239,11 +265,14 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   constexpr int QPR = CIN / 4;       // float4 per input row
   constexpr int RPP = kT / QPR;      // rows per staging pass
   constexpr int NPASS = kRows / RPP;
+  // Wide layers: the input and the output tile SHARE their memory (one more barrier per sub-tile), so that two
+  // workgroups fit a CU's 160 KB and one's MFMAs run under the other's staging / epilogue / pooling scan.
+  constexpr bool ALIAS = fwd_alias(CIN, COUT);
   extern __shared__ float lds[];
   float *s_a = lds;                                  // [64][SA], column k at (k & 1) * CIN/2 + (k >> 1)
-  float *s_o = lds + kRows * SA;                     // [64][SO] the sub-tile's output: pooled from here and written to
+  float *s_o = ALIAS ? lds : lds + kRows * SA;       // [64][SO] the sub-tile's output: pooled from here and written to
                                                      // memory as whole rows (16-byte stores)
-  float *s_w = lds + kRows * (SA + SO);              // [64] row multiplicity (0: not valid)
+  float *s_w = lds + (ALIAS ? kRows * SO : kRows * (SA + SO));  // [64] row multiplicity (0: not valid)
   int *s_grow = reinterpret_cast<int *>(s_w + kRows);  // [64] (group << 6) | row-in-group
   float *s_w1 = reinterpret_cast<float *>(s_grow + kRows);  // FIRST: [CIN][4] = w1[k][0..2], 0 ; then [CIN][2] scale, shift
 
@@ -317,9 +346,12 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   };
 
   prefetch(rg.sub0);
+  SA_PROF_DECL;
   for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
     const long long s0 = sub * kRows;
     lds_barrier();  // the previous sub-tile's fragment reads / pooling scan are done
+    SA_PROF_MARK(0);
+    SA_PROF_COUNT(9, 1);
     if (FIRST) {
       const bool ok = s0 + frow < rg.total;
 #pragma unroll
@@ -349,7 +381,9 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
       }
     }
     if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
+    SA_PROF_MARK(1);
     lds_barrier();
+    SA_PROF_MARK(2);
     if (sub + 1 < rg.sub1) prefetch(sub + 1);
 
     f32x16 acc[2][CBW];
@@ -373,6 +407,9 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     }
 
     // ---- epilogue: statistics, store, pooling tile
+    SA_PROF_MARK(3);
+    if (ALIAS) lds_barrier();  // every wave's fragment reads of s_a are done
+    SA_PROF_MARK(4);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
@@ -396,36 +433,41 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
         }
       }
     }
+    SA_PROF_MARK(5);
     lds_barrier();
+    SA_PROF_MARK(6);
     const long long left = rg.total - s0;
     const int nvalid = left < kRows ? static_cast<int>(left) : kRows;
     if (POOL) {  // thread = channel: running max of sign(gamma) * y over the rows of a group, lowest row on ties
-      // 8 rows per step: their values and group words are fetched together (one LDS round trip per step; a row at a
-      // time the loop ran at LDS latency, two dependent round trips per row)
-      for (int r8 = 0; r8 < nvalid; r8 += 8) {
-        float v8[8];
-        int p8[8];
+      // The group structure of the sub-tile is the same for every channel: lane r of each wave looks at row r once
+      // (does it start a group?), the ballot is a scalar bit mask, and the scan itself is three vector instructions
+      // per row behind a scalar bit test -- no per-row LDS round trip for the group word, no per-row validity test
+      // (rows past the end carry group -1, which is never flushed).  The values come 16 rows at a time.
+      const int mygrow = s_grow[lane];
+      const int prevg = lane ? (s_grow[lane - 1] >> 6) : cur_g;
+      const unsigned long long chg = __ballot((mygrow >> 6) != prevg);
+      int base = 0;  // row-in-group of row r = base + r while the group lasts
+      if (cur_g >= 0 && (chg & 1ull) == 0ull) base = (__builtin_amdgcn_readlane(mygrow, 0) & 63);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          v8[u] = s_o[(r8 + u) * SO + tid];
-          p8[u] = s_grow[r8 + u];
-        }
+      for (int rb = 0; rb < kRows; rb += 16) {
+        float v16[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int r = r8 + u;
-          if (r < nvalid) {
-            const int packed = __builtin_amdgcn_readfirstlane(p8[u]);  // (group << 6) | row-in-group: scalar
-            const int g = packed >> 6, rin = packed & 63;
-            if (g != cur_g) {  // a scalar branch
-              if (cur_g >= 0) flush();
-              cur_g = g;
-              tail = s0 + r - rin < row_first;
-              best = -INFINITY;
-              arg = rin;
-            }
-            const float v = v8[u] * sg;
-            if (v > best) { best = v; arg = rin; }
+        for (int u = 0; u < 16; ++u) v16[u] = s_o[(rb + u) * SO + tid];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int r = rb + u;
+          if ((chg >> r) & 1ull) {  // a scalar branch
+            if (cur_g >= 0) flush();
+            const int packed = __builtin_amdgcn_readlane(mygrow, r);
+            const int rin = packed & 63;
+            cur_g = packed >> 6;
+            tail = s0 + r - rin < row_first;
+            best = -INFINITY;
+            arg = rin;
+            base = rin - r;
           }
+          const float v = v16[u] * sg;
+          if (v > best) { best = v; arg = base + r; }
         }
       }
     }
@@ -439,8 +481,10 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
           *reinterpret_cast<f32x4 *>(a.y_out + (s0 + row) * COUT + 4 * oq) = *reinterpret_cast<const f32x4 *>(s_o + row * SO + 4 * oq);
       }
     }
+    SA_PROF_MARK(7);
   }
   if (POOL && cur_g >= 0) flush();
+  SA_PROF_STORE(POOL ? 0 : 1);
 
   // statistics: the two half-waves hold the two row halves of a column
 #pragma unroll
@@ -516,10 +560,12 @@ __device__ __forceinline__ f32x4 dy4(f32x4 y, f32x4 adsel, float w, f32x4 ca, f3
   return o;
 }
 
-// Staging of the dy tile, shared by the dx and the dw kernel.  Thread = (channel quad cq, rows r0 + RPP j).
+// Staging of the dy tile, shared by the dx and the dw kernel.  Thread = (channel quad cq, rows r0 NPASS + j): a
+// thread's NPASS rows are CONSECUTIVE, so that they belong to one or two groups almost always (a sub-tile of 64 rows
+// holds 3-4 groups on average: with rows dealt round-robin a third of the rows met a "third" group).
 // LAST: the upstream gradient is the pooled one; a wave owns whole rows (COUT == 256), so the group of a row is
-// wave-uniform.  The (d, sel) quads of the groups of the wave's first and last row of the NEXT sub-tile are
-// prefetched with the tile; a row of a third group in between reads them directly.
+// wave-uniform and every test on it is a scalar branch.  The (d, sel) quads of the groups of the wave's first and last
+// row of the NEXT sub-tile are prefetched with the tile; a row of a third group in between reads them directly.
 template <int COUT, bool LAST>
 struct DyStage {
   static constexpr int QPR = COUT / 4;
@@ -536,6 +582,7 @@ struct DyStage {
   f32x4 dA = {0, 0, 0, 0}, dB = {0, 0, 0, 0};
   i32x4 sA = {0, 0, 0, 0}, sB = {0, 0, 0, 0};
 
+  __device__ __forceinline__ int row_of(int j) const { return r0 * NPASS + j; }
   __device__ __forceinline__ void init(const BwdArgs &a) {
     cq = threadIdx.x % QPR;
     r0 = threadIdx.x / QPR;
@@ -550,19 +597,19 @@ struct DyStage {
   __device__ __forceinline__ void prefetch(const BwdArgs &a, long long s0, long long total) {
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
-      const long long r = s0 + r0 + RPP * j;
+      const long long r = s0 + row_of(j);
       const bool ok = r < total;
       py[j] = ok ? ldg4(a.y_out + r * COUT + 4 * cq) : f32x4{0, 0, 0, 0};
       if (!LAST) pd[j] = ok ? ldg4(a.dmid + r * COUT + 4 * cq) : f32x4{0, 0, 0, 0};
     }
     if (LAST) {
-      const long long ra = s0 + r0, rb = s0 + r0 + RPP * (NPASS - 1);
+      const long long ra = s0 + row_of(0), rb = s0 + row_of(NPASS - 1);
       if (nA == -2) {  // first sub-tile of the workgroup
         nA = ra < total ? a.grow[ra] >> 6 : -1;
         nB = rb < total ? a.grow[rb] >> 6 : -1;
       }
-      gA = nA;
-      gB = nB < 0 ? nA : nB;
+      gA = __builtin_amdgcn_readfirstlane(nA);
+      gB = __builtin_amdgcn_readfirstlane(nB < 0 ? nA : nB);
       nA = ra + kRows < total ? a.grow[ra + kRows] >> 6 : -1;
       nB = rb + kRows < total ? a.grow[rb + kRows] >> 6 : -1;
       // (d is scaled by a where it is used: the loads stay in flight under the MFMAs)
@@ -570,14 +617,26 @@ struct DyStage {
       if (gB >= 0) { dB = ldg4(a.d + static_cast<size_t>(gB) * COUT + 4 * cq); sB = ldg4i(a.sel + static_cast<size_t>(gB) * COUT + 4 * cq); }
     }
   }
-  // dy of pass j (row r0 + RPP j of the sub-tile at s0); zero for rows past the end
-  __device__ __forceinline__ f32x4 value(const BwdArgs &a, int j, long long s0, long long total, const float *s_w,
-                                         const int *s_grow) {
-    const int row = r0 + RPP * j;
-    if (s0 + row >= total) return f32x4{0, 0, 0, 0};
+  // the row words of this thread's rows, fetched together (one LDS round trip for the whole staging)
+  struct RowWords {
+    int packed[NPASS];
+    float w[NPASS];
+  };
+  __device__ __forceinline__ RowWords row_words(const float *s_w, const int *s_grow) const {
+    RowWords rw;
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+      rw.packed[j] = s_grow[row_of(j)];
+      rw.w[j] = s_w[row_of(j)];
+    }
+    return rw;
+  }
+  // dy of pass j (row row_of(j) of the sub-tile); zero for rows past the end (their group word is -1)
+  __device__ __forceinline__ f32x4 value(const BwdArgs &a, int j, const RowWords &rw) {
     f32x4 dsel;
     if (LAST) {
-      const int packed = s_grow[row];
+      const int packed = __builtin_amdgcn_readfirstlane(rw.packed[j]);  // wave-uniform: the wave owns the row
+      if (packed < 0) return f32x4{0, 0, 0, 0};
       const int g = packed >> 6, rin = packed & 63;
       f32x4 dg;
       i32x4 sg;
@@ -587,10 +646,11 @@ struct DyStage {
 #pragma unroll
       for (int u = 0; u < 4; ++u) dsel[u] = rin == sg[u] ? ca[u] * dg[u] : 0.f;
     } else {
+      if (rw.packed[j] < 0) return f32x4{0, 0, 0, 0};
 #pragma unroll
       for (int u = 0; u < 4; ++u) dsel[u] = ca[u] * pd[j][u];
     }
-    return dy4(py[j], dsel, s_w[row], cA, cB);
+    return dy4(py[j], dsel, rw.w[j], cA, cB);
   }
 };
 
@@ -655,9 +715,12 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
       }
     };
     prefetch(rg.sub0);
+    SA_PROF_DECL;
     for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
       const long long s0 = sub * kRows;
       lds_barrier();
+      SA_PROF_MARK(0);
+      SA_PROF_COUNT(9, 1);
       if (tid < kRows) {
         s_w[tid] = pw; s_grow[tid] = pg;
         if (FIRST) { s_x[4 * tid] = px[0]; s_x[4 * tid + 1] = px[1]; s_x[4 * tid + 2] = px[2]; s_x[4 * tid + 3] = 0.f; }
@@ -667,14 +730,20 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
         for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4 *>(s_in + (ir0 + RI * j) * SI + 4 * iq) = pin[j];
       }
       lds_barrier();
+      SA_PROF_MARK(1);
+      {
+        const auto rw = st.row_words(s_w, s_grow);
 #pragma unroll
-      for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
-        const f32x4 v = st.value(a, j, s0, rg.total, s_w, s_grow);
-        const int row = st.r0 + DyStage<COUT, LAST>::RPP * j;
-        *reinterpret_cast<f32x2 *>(s_dy + row * SD + 2 * st.cq) = f32x2{v[0], v[2]};
-        *reinterpret_cast<f32x2 *>(s_dy + row * SD + COUT / 2 + 2 * st.cq) = f32x2{v[1], v[3]};
+        for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
+          const f32x4 v = st.value(a, j, rw);
+          const int row = st.row_of(j);
+          *reinterpret_cast<f32x2 *>(s_dy + row * SD + 2 * st.cq) = f32x2{v[0], v[2]};
+          *reinterpret_cast<f32x2 *>(s_dy + row * SD + COUT / 2 + 2 * st.cq) = f32x2{v[1], v[3]};
+        }
       }
+      SA_PROF_MARK(2);
       lds_barrier();
+      SA_PROF_MARK(3);
       if (sub + 1 < rg.sub1) prefetch(sub + 1);
 
       f32x16 acc[RBW];
@@ -682,19 +751,29 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
       for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
-#pragma unroll
-      for (int kq = 0; kq < KK / 4; ++kq) {
-        f32x4 av[RBW];
+      // fragments of step kq + 1 are fetched before the MFMAs of step kq are issued (two register sets): left to itself
+      // the compiler reuses one set and every 8 RBW MFMAs wait a full LDS round trip (measured: 88 instead of 64 clocks
+      // per MFMA, tools/sa_prof.py)
+      f32x4 av[2][RBW];
+      auto frag = [&](int kq, int set) {
 #pragma unroll
         for (int rb = 0; rb < RBW; ++rb)
-          av[rb] = *reinterpret_cast<const f32x4 *>(s_dy + (32 * (wm * RBW + rb) + l31) * SD + h * (COUT / 2) + 4 * kq);
+          av[set][rb] = *reinterpret_cast<const f32x4 *>(s_dy + (32 * (wm * RBW + rb) + l31) * SD + h * (COUT / 2) + 4 * kq);
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int kq = 0; kq < KK / 4; ++kq) {
+        if (kq + 1 < KK / 4) frag(kq + 1, (kq + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int rb = 0; rb < RBW; ++rb) acc[rb] = mfma(av[rb][i], wreg[4 * kq + i], acc[rb]);
+          for (int rb = 0; rb < RBW; ++rb) acc[rb] = mfma(av[kq & 1][rb][i], wreg[4 * kq + i], acc[rb]);
+        __builtin_amdgcn_sched_barrier(0);
       }
 
       // ---- epilogue: ReLU mask of the layer below, its BN-backward sums, store
+      SA_PROF_MARK(4);
 #pragma unroll
       for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
@@ -719,8 +798,10 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
             s_in[row * SI + kcol] = dm;  // in place: this lane is the only reader / writer of the element
           }
         }
+      SA_PROF_MARK(5);
       if (!FIRST) {  // dmid_in leaves as whole rows, 16 bytes per lane
         lds_barrier();
+        SA_PROF_MARK(6);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int row = ir0 + RI * j;
@@ -728,7 +809,9 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
             *reinterpret_cast<f32x4 *>(a.dmid_in + (s0 + row) * CIN + 4 * iq) = *reinterpret_cast<const f32x4 *>(s_in + row * SI + 4 * iq);
         }
       }
+      SA_PROF_MARK(7);
     }
+    SA_PROF_STORE(LAST ? 2 : 3);
   }
   // sums of this lane's input channel: the two half-waves hold different rows
   acc_s += __shfl_xor(acc_s, 32);
@@ -809,9 +892,12 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
       }
     };
     prefetch(rg.sub0);
+    SA_PROF_DECL;
     for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
       const long long s0 = sub * kRows;
       lds_barrier();
+      SA_PROF_MARK(0);
+      SA_PROF_COUNT(9, 1);
       if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
       // activations of the layer below
       if (FIRST) {
@@ -839,30 +925,45 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
           *reinterpret_cast<f32x4 *>(s_a + row * SA + 4 * aq) = v;
         }
       }
+      SA_PROF_MARK(1);
       lds_barrier();
+      SA_PROF_MARK(2);
+      {
+        const auto rw = st.row_words(s_w, s_grow);
 #pragma unroll
-      for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
-        const f32x4 v = st.value(a, j, s0, rg.total, s_w, s_grow);
-        const int row = st.r0 + DyStage<COUT, LAST>::RPP * j;
-        *reinterpret_cast<f32x4 *>(s_dy + row * SD + 4 * st.cq) = v;
+        for (int j = 0; j < DyStage<COUT, LAST>::NPASS; ++j) {
+          const f32x4 v = st.value(a, j, rw);
+          *reinterpret_cast<f32x4 *>(s_dy + st.row_of(j) * SD + 4 * st.cq) = v;
+        }
       }
+      SA_PROF_MARK(3);
       lds_barrier();
+      SA_PROF_MARK(4);
       if (sub + 1 < rg.sub1) prefetch(sub + 1);
 
       // dW[c][k] += sum_rows dy[row][c] act[row][k]: A[i = c][k = row], B[k = row][j = k-channel]
-#pragma unroll 4
+      // two fragment register sets, as in the dx kernel: step kk + 1 is fetched before step kk's MFMAs are issued
+      float af[2][IBW], bf[2][JB];
+      auto frag = [&](int kk, int set) {
+#pragma unroll
+        for (int ib = 0; ib < IBW; ++ib) af[set][ib] = s_dy[(2 * kk + h) * SD + 32 * (IBW * wv + ib) + l31];
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) bf[set][jb] = s_a[(2 * kk + h) * SA + 32 * jb + l31];
+      };
+      frag(0, 0);
+#pragma unroll
       for (int kk = 0; kk < kRows / 2; ++kk) {
-        float af[IBW], bf[JB];
-#pragma unroll
-        for (int ib = 0; ib < IBW; ++ib) af[ib] = s_dy[(2 * kk + h) * SD + 32 * (IBW * wv + ib) + l31];
-#pragma unroll
-        for (int jb = 0; jb < JB; ++jb) bf[jb] = s_a[(2 * kk + h) * SA + 32 * jb + l31];
+        if (kk + 1 < kRows / 2) frag(kk + 1, (kk + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ib = 0; ib < IBW; ++ib)
 #pragma unroll
-          for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = mfma(af[ib], bf[jb], acc[ib][jb]);
+          for (int jb = 0; jb < JB; ++jb) acc[ib][jb] = mfma(af[kk & 1][ib], bf[kk & 1][jb], acc[ib][jb]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      SA_PROF_MARK(5);
     }
+    SA_PROF_STORE(LAST ? 4 : 5);
   }
   // this workgroup's partial tile (zeros when it had no rows)
   float *out = a.partials + static_cast<size_t>(blockIdx.x) * COUT * CIN;
@@ -917,7 +1018,7 @@ int device_cus() {
 
 template <int CIN, int COUT, bool FIRST, bool POOL>
 int launch_fwd(const FwdArgs &a, int nblk, hipStream_t s) {
-  size_t lds = sizeof(float) * (kRows * (CIN + 4) + kRows * (COUT + 4) + 2 * kRows);
+  size_t lds = sizeof(float) * ((fwd_alias(CIN, COUT) ? 0 : kRows * (CIN + 4)) + kRows * (COUT + 4) + 2 * kRows);
   if (FIRST) lds += sizeof(float) * 6 * CIN;
   auto kern = sa_fwd_kernel<CIN, COUT, FIRST, POOL>;
   int st = raise_dynamic_lds(kern, lds);
@@ -965,6 +1066,12 @@ using namespace coda;
 // workgroup only the weight fragments, ~2 % of its time; with exactly one workgroup per CU a concurrent kernel that
 // holds a few CUs -- the sampling of the next batch on its side stream -- doubled the kernel's duration: 8 of the 256
 // workgroups had to wait for a whole pass of the others).  kind 1: dw kernels -- one per CU (a 128 KB partial tile each).
+#ifdef CODA_SA_PROF
+CODA_API int coda_sa_prof_read(unsigned long long *host) {
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(coda::g_sa_prof), sizeof(coda::g_sa_prof)));
+}
+#endif
+
 CODA_API int coda_sa_mfma_blocks(int kind) { return kind == 0 ? 2 * device_cus() : device_cus(); }
 
 CODA_API int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len) {

@@ -1,6 +1,6 @@
 """The product against THE REFERENCE'S OWN MODULES on one whole training step at BASELINE.json configs[2]'s size.
 
-tests/golden/step_full.npz was written by tests/golden/make_golden.py::golden_step_full: 8 scenes x 20 000 points
+tests/golden/step_full_<case>.npz were written by tests/golden/make_golden.py::golden_step_full: 8 scenes x 20 000 points
 through /root/reference's models/model_3detr.py (pre-encoder, 3 encoder + 8 decoder layers, heads; :1767-1794),
 criterion.py's SetCriterion.forward (:1162-1216) and backward, float32 on the host with the C oracle behind
 pointnet2._ext.  This test rebuilds the same seeded inputs and weights (tests/golden/step_inputs.py,
@@ -9,13 +9,14 @@ golden/weights.py), runs the step on the GPU through this package, and compares
 * the pre-encoder's furthest-point-sampling indices: bit-exact;
 * the total loss and each of its terms: 1e-3 relative (the north-star tolerance);
 * the 64 (decoder layer, scene) Hungarian assignments: identical;
-* strided samples of every head output: 1e-3 of the tensor's RMS;
-* every parameter gradient, through the fixture's 1024 strided samples and its norm.  Two float32 evaluations of this
-  step in different summation orders differ by more than 1e-3 in some tensors (tests/test_full_step_gpu.py judges
-  that with a float64 run of the port; the reference itself cannot be run in float64 here in reasonable time), so the
-  bound here is 1e-2 on the sampled relative L2 error and on the norm -- a pin of the WHOLE step to the reference's
-  code at full size (a wrong term, scale, sign, layer order or reduction shows up at 1e-1 .. 1), with the 1e-3
-  arithmetic bound carried by tests/test_full_step_gpu.py."""
+* strided samples of every head output: 1e-3 in the relative L2 norm (and the tensor's norm);
+* every parameter gradient, through the fixture's 1024 strided samples and its norm: 2e-3 on the sampled relative L2
+  error and on the norm.  Measured on MI355X: loss 7e-8, loss terms <= 9e-7, 64 of 64 assignments, gradients <= 3.9e-4
+  (configs[2]) / <= 4.8e-4 (configs[3]), the largest in the set-abstraction MLP (1e6-row sums in another order).  The
+  float64-judged 1e-3 bound on complete tensors is tests/test_full_step_gpu.py's; the reference itself cannot be run
+  in float64 here in reasonable time, so this test holds twice the north-star figure on samples instead -- a pin of
+  the WHOLE step to the reference's own code at full size (a wrong term, scale, sign, layer order or reduction shows
+  up at 1e-1 .. 1)."""
 import os
 import sys
 
@@ -34,7 +35,7 @@ from coda_neurips2023_amd.dataset_config import HotPathDatasetConfig  # noqa: E4
 from coda_neurips2023_amd.model_3detr import build_model  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "step_full_%s.npz")
-LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-3, 1e-3, 1e-2
+LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-3, 1e-3, 2e-3
 
 
 def run_product(dev, case):
@@ -109,9 +110,9 @@ def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL):
         t = outputs[k].detach().double().cpu().reshape(-1)
         d = z[f"out/{k}"]
         idx = np.linspace(0, t.numel() - 1, SI.SAMPLES).astype(np.int64)
-        rms = d[1] / np.sqrt(t.numel())
-        err = float(np.abs(t[idx].numpy() - d[2:]).max() / rms)
-        assert err < OUT_TOL * 10 and abs(float(t.norm()) - d[1]) / d[1] < OUT_TOL, f"output {k}: {err:.2e} of rms"
+        err = float(np.linalg.norm(t[idx].numpy() - d[2:]) / np.linalg.norm(d[2:]))
+        print(f"  output {k:28s} sampled L2 {err:.2e}  norm {abs(float(t.norm()) - d[1]) / d[1]:.2e}")
+        assert err < OUT_TOL and abs(float(t.norm()) - d[1]) / d[1] < OUT_TOL, f"output {k}: {err:.2e}"
     params = dict(model.named_parameters())
     gkeys = [k[5:] for k in z.files if k.startswith("grad/")]
     assert set(gkeys) == {n for n, p in params.items() if p.grad is not None}
