@@ -211,11 +211,13 @@ __global__ void l1_bwd_kernel(const double *__restrict__ s5, const double *__res
 // -DCODA_SA_PROF (tools/sa_prof.py builds a private copy of the library with it): shader-clock sums of the phases of a
 // sub-tile per (kernel, workgroup < 64, wave), read back with coda_sa_prof_read.  Compiles to nothing in the library.
 #ifdef CODA_SA_PROF
-__device__ unsigned long long g_sa_prof[6][64][4][10];
-#define SA_PROF_DECL unsigned long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter()
+__device__ unsigned long long g_sa_prof[6][64][4][16];
+#define SA_PROF_DECL unsigned long long prof_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter()
 #define SA_PROF_MARK(i)                                               \
   do {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                \
     const unsigned long long now_ = __builtin_readcyclecounter();     \
+    __builtin_amdgcn_sched_barrier(0);                                \
     prof_[i] += now_ - prof_t_;                                       \
     prof_t_ = now_;                                                   \
   } while (0)
@@ -223,7 +225,7 @@ __device__ unsigned long long g_sa_prof[6][64][4][10];
 #define SA_PROF_STORE(kind)                                                                              \
   do {                                                                                                   \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 64)                                                      \
-      for (int q_ = 0; q_ < 10; ++q_) g_sa_prof[kind][blockIdx.x][threadIdx.x >> 6][q_] = prof_[q_];     \
+      for (int q_ = 0; q_ < 16; ++q_) g_sa_prof[kind][blockIdx.x][threadIdx.x >> 6][q_] = prof_[q_];     \
   } while (0)
 #else
 #define SA_PROF_DECL
@@ -308,6 +310,22 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   int pg = 0;
   auto prefetch = [&](long long sub) {
     const long long s0 = sub * kRows;
+    if (s0 + kRows <= rg.total) {  // a whole sub-tile (all but the last one): uniform base + constant per-thread offsets,
+                                   // no bounds test per load (see DyStage::load_row)
+      if (FIRST) {
+        const float *xb = a.src + s0 * 3;
+        px0 = xb[frow * 3]; px1 = xb[frow * 3 + 1]; px2 = xb[frow * 3 + 2];
+      } else {
+        const float *sb = a.src + s0 * CIN;
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) pre[j] = ldg4(sb + (r0 + RPP * j) * CIN + 4 * cq);
+      }
+      if (tid < kRows) {
+        pw = (a.roww + s0)[tid];
+        pg = (a.grow + s0)[tid];
+      }
+      return;
+    }
     if (FIRST) {
       const long long r = s0 + frow;
       const bool ok = r < rg.total;
@@ -333,18 +351,37 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
   bool tail = false;  // the current group began in the previous workgroup
   float best = -INFINITY;
   const long long row_first = rg.sub0 * kRows;
+  // (scalar group id -> the row base is a scalar address; the thread adds its channel)
   auto flush = [&]() {
     const float yv = best * sg;
     if (tail) {  // this workgroup holds the group's tail only
-      a.part_y[static_cast<size_t>(b) * COUT + tid] = yv;
-      a.part_sel[static_cast<size_t>(b) * COUT + tid] = arg;
+      (a.part_y + static_cast<size_t>(b) * COUT)[tid] = yv;
+      (a.part_sel + static_cast<size_t>(b) * COUT)[tid] = arg;
       if (tid == 0) a.part_gid[b] = cur_g;
     } else {
-      a.ysel[static_cast<size_t>(cur_g) * COUT + tid] = yv;
-      a.sel[static_cast<size_t>(cur_g) * COUT + tid] = arg;
+      (a.ysel + static_cast<size_t>(cur_g) * COUT)[tid] = yv;
+      (a.sel + static_cast<size_t>(cur_g) * COUT)[tid] = arg;
     }
   };
 
+  // the same loads for a WHOLE sub-tile, in pieces: piece i is issued from step i of the matrix loop (constant i)
+  constexpr int kParts = (FIRST ? 1 : NPASS) + 1;
+  static_assert(kParts <= KK / 4, "one piece per MFMA step");
+  auto prefetch_part = [&](long long sub, int i) {
+    const long long s0 = sub * kRows;
+    if (i < kParts - 1) {
+      if (FIRST) {
+        const float *xb = a.src + s0 * 3;
+        px0 = xb[frow * 3]; px1 = xb[frow * 3 + 1]; px2 = xb[frow * 3 + 2];
+      } else {
+        const float *sb = a.src + s0 * CIN;
+        pre[i] = ldg4(sb + (r0 + RPP * i) * CIN + 4 * cq);
+      }
+    } else if (tid < kRows) {
+      pw = (a.roww + s0)[tid];
+      pg = (a.grow + s0)[tid];
+    }
+  };
   prefetch(rg.sub0);
   SA_PROF_DECL;
   for (long long sub = rg.sub0; sub < rg.sub1; ++sub) {
@@ -384,7 +421,9 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     SA_PROF_MARK(1);
     lds_barrier();
     SA_PROF_MARK(2);
-    if (sub + 1 < rg.sub1) prefetch(sub + 1);
+    const bool more = sub + 1 < rg.sub1;
+    const bool whole = more && (sub + 2) * kRows <= rg.total;  // the next sub-tile is a whole one: loads ride the loop
+    if (more && !whole) prefetch(sub + 1);
 
     f32x16 acc[2][CBW];
 #pragma unroll
@@ -397,6 +436,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     for (int kq = 0; kq < KK / 4; ++kq) {
       const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_a + l31 * SA + h * (CIN / 2) + 4 * kq);
       const f32x4 a1 = *reinterpret_cast<const f32x4 *>(s_a + (32 + l31) * SA + h * (CIN / 2) + 4 * kq);
+      if (kq < kParts && whole) prefetch_part(sub + 1, kq);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -448,37 +488,60 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
       const unsigned long long chg = __ballot((mygrow >> 6) != prevg);
       int base = 0;  // row-in-group of row r = base + r while the group lasts
       if (cur_g >= 0 && (chg & 1ull) == 0ull) base = (__builtin_amdgcn_readlane(mygrow, 0) & 63);
+      // The channel's 64 values in one LDS round trip (the accumulators are dead here: registers are free), then four
+      // rows per scalar test: three of four quads hold no group start (3-4 groups per sub-tile).  Measured
+      // (tools/sa_prof.py, clocks per sub-tile): row at a time with its own LDS reads 13.6 k, this form 7.1 k, the same as
+      // a rolled loop over quads 8.9 k; the pooling as a separate pass over the stored rows (328 MB re-read) was
+      // 33 us slower than this scan in the step.
+      float vall[kRows];
 #pragma unroll
-      for (int rb = 0; rb < kRows; rb += 16) {
-        float v16[16];
+      for (int r = 0; r < kRows; ++r) vall[r] = s_o[r * SO + tid];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v16[u] = s_o[(rb + u) * SO + tid];
+      for (int rq = 0; rq < kRows; rq += 4) {
+        if (((chg >> rq) & 0xfull) == 0ull) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int r = rb + u;
-          if ((chg >> r) & 1ull) {  // a scalar branch
-            if (cur_g >= 0) flush();
-            const int packed = __builtin_amdgcn_readlane(mygrow, r);
-            const int rin = packed & 63;
-            cur_g = packed >> 6;
-            tail = s0 + r - rin < row_first;
-            best = -INFINITY;
-            arg = rin;
-            base = rin - r;
+          for (int u = 0; u < 4; ++u) {
+            const float v = vall[rq + u] * sg;
+            if (v > best) { best = v; arg = base + rq + u; }
           }
-          const float v = v16[u] * sg;
-          if (v > best) { best = v; arg = base + r; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int r = rq + u;
+            if ((chg >> r) & 1ull) {  // a scalar branch
+              if (cur_g >= 0) flush();
+              const int packed = __builtin_amdgcn_readlane(mygrow, r);
+              const int rin = packed & 63;
+              cur_g = packed >> 6;
+              tail = s0 + r - rin < row_first;
+              best = -INFINITY;
+              arg = rin;
+              base = rin - r;
+            }
+            const float v = vall[r] * sg;
+            if (v > best) { best = v; arg = base + r; }
+          }
         }
       }
     }
+    SA_PROF_MARK(8);
     if (a.y_out) {  // whole rows, 16 bytes per lane
       constexpr int QO = COUT / 4, RO = kT / QO;
       const int oq = tid % QO, or0 = tid / QO;
+      if (nvalid == kRows) {  // (uniform) no per-row test: the tile is read from LDS in one go, then stored
+        float *ob = a.y_out + s0 * COUT;
+        f32x4 t[kRows / RO];
 #pragma unroll
-      for (int j = 0; j < kRows / RO; ++j) {
-        const int row = or0 + RO * j;
-        if (row < nvalid)
-          *reinterpret_cast<f32x4 *>(a.y_out + (s0 + row) * COUT + 4 * oq) = *reinterpret_cast<const f32x4 *>(s_o + row * SO + 4 * oq);
+        for (int j = 0; j < kRows / RO; ++j) t[j] = *reinterpret_cast<const f32x4 *>(s_o + (or0 + RO * j) * SO + 4 * oq);
+#pragma unroll
+        for (int j = 0; j < kRows / RO; ++j) *reinterpret_cast<f32x4 *>(ob + (or0 + RO * j) * COUT + 4 * oq) = t[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < kRows / RO; ++j) {
+          const int row = or0 + RO * j;
+          if (row < nvalid)
+            *reinterpret_cast<f32x4 *>(a.y_out + (s0 + row) * COUT + 4 * oq) = *reinterpret_cast<const f32x4 *>(s_o + row * SO + 4 * oq);
+        }
       }
     }
     SA_PROF_MARK(7);
@@ -594,14 +657,26 @@ struct DyStage {
       cB[u] = -ca[u] * is[u] * m2[u];
     }
   }
-  __device__ __forceinline__ void prefetch(const BwdArgs &a, long long s0, long long total) {
-#pragma unroll
-    for (int j = 0; j < NPASS; ++j) {
-      const long long r = s0 + row_of(j);
-      const bool ok = r < total;
-      py[j] = ok ? ldg4(a.y_out + r * COUT + 4 * cq) : f32x4{0, 0, 0, 0};
-      if (!LAST) pd[j] = ok ? ldg4(a.dmid + r * COUT + 4 * cq) : f32x4{0, 0, 0, 0};
+  // FULL: every row of the sub-tile exists -- no per-load bounds test, and the addresses are a wave-uniform base (the
+  // sub-tile's first row: scalar registers) plus an offset that never changes for this thread.  The loads of a whole
+  // sub-tile are issued ONE PER MFMA STEP from inside the matrix loop of the sub-tile before (load_row / load_groups
+  // called with constant j): in front of the loop, the ~30 loads of a wave -- each an exec-mask branch in the general
+  // form -- were issued with the matrix pipe idle (tools/sa_prof.py: 4-6 thousand clocks per sub-tile).
+  template <bool FULL>
+  __device__ __forceinline__ void load_row(const BwdArgs &a, long long s0, long long total, int j) {
+    const float *yb = a.y_out + s0 * COUT;
+    const float *db = LAST ? nullptr : a.dmid + s0 * COUT;
+    const int off = row_of(j) * COUT + 4 * cq;
+    if (FULL) {
+      py[j] = ldg4(yb + off);
+      if (!LAST) pd[j] = ldg4(db + off);
+    } else {
+      const bool ok = s0 + row_of(j) < total;
+      py[j] = ok ? ldg4(yb + off) : f32x4{0, 0, 0, 0};
+      if (!LAST) pd[j] = ok ? ldg4(db + off) : f32x4{0, 0, 0, 0};
     }
+  }
+  __device__ __forceinline__ void load_groups(const BwdArgs &a, long long s0, long long total) {
     if (LAST) {
       const long long ra = s0 + row_of(0), rb = s0 + row_of(NPASS - 1);
       if (nA == -2) {  // first sub-tile of the workgroup
@@ -616,6 +691,12 @@ struct DyStage {
       if (gA >= 0) { dA = ldg4(a.d + static_cast<size_t>(gA) * COUT + 4 * cq); sA = ldg4i(a.sel + static_cast<size_t>(gA) * COUT + 4 * cq); }
       if (gB >= 0) { dB = ldg4(a.d + static_cast<size_t>(gB) * COUT + 4 * cq); sB = ldg4i(a.sel + static_cast<size_t>(gB) * COUT + 4 * cq); }
     }
+  }
+  template <bool FULL>
+  __device__ __forceinline__ void prefetch(const BwdArgs &a, long long s0, long long total) {
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) load_row<FULL>(a, s0, total, j);
+    load_groups(a, s0, total);
   }
   // the row words of this thread's rows, fetched together (one LDS round trip for the whole staging)
   struct RowWords {
@@ -663,6 +744,10 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
   constexpr int RBW = 2 / WM;        // 32-row blocks per wave
   constexpr int KK = COUT / 2;       // MFMA k-steps (contraction over the output channels of the layer)
   constexpr int SD = COUT + 4;
+  // Wide layer (8 MFMAs per step): the next sub-tile's loads ride the matrix loop, one per step.  Narrow layer (4 per
+  // step do not cover a load's issue): everything in front of the loop in the bounds-tested form -- whose exec-mask
+  // branches happen to space the loads; the same loads back to back were slower (tools/sa_prof.py: 10.1 -> 12.8 k clocks).
+  constexpr bool RIDE = RBW * 4 >= 8;
   extern __shared__ float lds[];
   float *s_dy = lds;                                 // [64][SD], channel c at (c & 1) * COUT/2 + (c >> 1)
   float *s_w = s_dy + kRows * SD;                    // [64]
@@ -696,7 +781,24 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
     f32x4 pin[FIRST ? 1 : NI];
     auto prefetch = [&](long long sub) {
       const long long s0 = sub * kRows;
-      st.prefetch(a, s0, rg.total);
+      if (RIDE && s0 + kRows <= rg.total) {  // a whole sub-tile (all but the last one): see DyStage::load_row
+        st.template prefetch<true>(a, s0, rg.total);
+        if (!FIRST) {
+          const float *ib = a.src_in + s0 * CIN;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) pin[j] = ldg4(ib + (ir0 + RI * j) * CIN + 4 * iq);
+        }
+        if (tid < kRows) {
+          pw = (a.roww + s0)[tid];
+          pg = (a.grow + s0)[tid];
+          if (FIRST) {
+            const float *xb = a.src_in + s0 * 3;
+            px[0] = xb[tid * 3]; px[1] = xb[tid * 3 + 1]; px[2] = xb[tid * 3 + 2];
+          }
+        }
+        return;
+      }
+      st.template prefetch<false>(a, s0, rg.total);
       if (!FIRST) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -712,6 +814,31 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
         if (FIRST) {
           px[0] = ok ? a.src_in[r * 3] : 0.f; px[1] = ok ? a.src_in[r * 3 + 1] : 0.f; px[2] = ok ? a.src_in[r * 3 + 2] : 0.f;
         }
+      }
+    };
+    // the same loads for a WHOLE sub-tile, in pieces: piece i is issued from step i of the matrix loop (constant i)
+    constexpr int NP = DyStage<COUT, LAST>::NPASS;
+    constexpr int kParts = NP + (FIRST ? 0 : NI) + 2;
+    static_assert(kParts <= KK / 4, "one piece per MFMA step");
+    auto prefetch_part = [&](long long sub, int i) {
+      const long long s0 = sub * kRows;
+      if (i < NP) {
+        st.template load_row<true>(a, s0, rg.total, i);
+      } else if (!FIRST && i < NP + NI) {
+        const float *ib = a.src_in + s0 * CIN;
+        const int j = i - NP;
+        pin[j] = ldg4(ib + (ir0 + RI * j) * CIN + 4 * iq);
+      } else if (i == kParts - 2) {
+        if (tid < kRows) {
+          pw = (a.roww + s0)[tid];
+          pg = (a.grow + s0)[tid];
+          if (FIRST) {
+            const float *xb = a.src_in + s0 * 3;
+            px[0] = xb[tid * 3]; px[1] = xb[tid * 3 + 1]; px[2] = xb[tid * 3 + 2];
+          }
+        }
+      } else if (i == kParts - 1) {
+        st.load_groups(a, s0, rg.total);
       }
     };
     prefetch(rg.sub0);
@@ -744,7 +871,9 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
       SA_PROF_MARK(2);
       lds_barrier();
       SA_PROF_MARK(3);
-      if (sub + 1 < rg.sub1) prefetch(sub + 1);
+      const bool more = sub + 1 < rg.sub1;
+      const bool whole = RIDE && more && (sub + 2) * kRows <= rg.total;  // the next sub-tile is a whole one: loads ride the loop
+      if (more && !whole) prefetch(sub + 1);
 
       f32x16 acc[RBW];
 #pragma unroll
@@ -764,6 +893,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
 #pragma unroll
       for (int kq = 0; kq < KK / 4; ++kq) {
         if (kq + 1 < KK / 4) frag(kq + 1, (kq + 1) & 1);
+        if (kq < kParts && whole) prefetch_part(sub + 1, kq);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -802,11 +932,20 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
       if (!FIRST) {  // dmid_in leaves as whole rows, 16 bytes per lane
         lds_barrier();
         SA_PROF_MARK(6);
+        if (s0 + kRows <= rg.total) {  // (uniform) a whole sub-tile: read from LDS in one go, then stored
+          float *ob = a.dmid_in + s0 * CIN;
+          f32x4 t[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int row = ir0 + RI * j;
-          if (s0 + row < rg.total)
-            *reinterpret_cast<f32x4 *>(a.dmid_in + (s0 + row) * CIN + 4 * iq) = *reinterpret_cast<const f32x4 *>(s_in + row * SI + 4 * iq);
+          for (int j = 0; j < NI; ++j) t[j] = *reinterpret_cast<const f32x4 *>(s_in + (ir0 + RI * j) * SI + 4 * iq);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) *reinterpret_cast<f32x4 *>(ob + (ir0 + RI * j) * CIN + 4 * iq) = t[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int row = ir0 + RI * j;
+            if (s0 + row < rg.total)
+              *reinterpret_cast<f32x4 *>(a.dmid_in + (s0 + row) * CIN + 4 * iq) = *reinterpret_cast<const f32x4 *>(s_in + row * SI + 4 * iq);
+          }
         }
       }
       SA_PROF_MARK(7);
@@ -837,6 +976,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
   constexpr int SD = COUT;           // dy tile [64][COUT], natural layout
   constexpr int SA = CIN;            // act tile [64][CIN]
   constexpr int QPA = CIN / 4, RPA = kT / QPA, NPA = kRows / RPA;
+  constexpr bool RIDE = IBW * JB >= 8;  // as in the dx kernel (narrow layer: 2 MFMAs per step)
   extern __shared__ float lds[];
   float *s_dy = lds;
   float *s_a = s_dy + kRows * SD;
@@ -873,7 +1013,23 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
     int pg = 0;
     auto prefetch = [&](long long sub) {
       const long long s0 = sub * kRows;
-      st.prefetch(a, s0, rg.total);
+      if (RIDE && s0 + kRows <= rg.total) {  // a whole sub-tile (all but the last one): see DyStage::load_row
+        st.template prefetch<true>(a, s0, rg.total);
+        if (FIRST) {
+          const float *xb = a.src_in + s0 * 3;
+          px0 = xb[frow * 3]; px1 = xb[frow * 3 + 1]; px2 = xb[frow * 3 + 2];
+        } else {
+          const float *ab = a.src_in + s0 * CIN;
+#pragma unroll
+          for (int j = 0; j < NPA; ++j) pa[j] = ldg4(ab + (ar0 + RPA * j) * CIN + 4 * aq);
+        }
+        if (tid < kRows) {
+          pw = (a.roww + s0)[tid];
+          pg = (a.grow + s0)[tid];
+        }
+        return;
+      }
+      st.template prefetch<false>(a, s0, rg.total);
       if (FIRST) {
         const long long r = s0 + frow;
         const bool ok = r < rg.total;
@@ -889,6 +1045,32 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
         const long long r = s0 + tid;
         pw = r < rg.total ? a.roww[r] : 0.f;
         pg = r < rg.total ? a.grow[r] : -1;
+      }
+    };
+    // the same loads for a WHOLE sub-tile, in pieces: piece i is issued from step i of the matrix loop (constant i)
+    constexpr int NP = DyStage<COUT, LAST>::NPASS;
+    constexpr int kParts = NP + (FIRST ? 1 : NPA) + 2;
+    static_assert(kParts <= kRows / 2, "one piece per MFMA step");
+    auto prefetch_part = [&](long long sub, int i) {
+      const long long s0 = sub * kRows;
+      if (i < NP) {
+        st.template load_row<true>(a, s0, rg.total, i);
+      } else if (i < kParts - 2) {
+        if (FIRST) {
+          const float *xb = a.src_in + s0 * 3;
+          px0 = xb[frow * 3]; px1 = xb[frow * 3 + 1]; px2 = xb[frow * 3 + 2];
+        } else {
+          const float *ab = a.src_in + s0 * CIN;
+          const int j = i - NP;
+          pa[j] = ldg4(ab + (ar0 + RPA * j) * CIN + 4 * aq);
+        }
+      } else if (i == kParts - 2) {
+        if (tid < kRows) {
+          pw = (a.roww + s0)[tid];
+          pg = (a.grow + s0)[tid];
+        }
+      } else if (i == kParts - 1) {
+        st.load_groups(a, s0, rg.total);
       }
     };
     prefetch(rg.sub0);
@@ -939,7 +1121,9 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
       SA_PROF_MARK(3);
       lds_barrier();
       SA_PROF_MARK(4);
-      if (sub + 1 < rg.sub1) prefetch(sub + 1);
+      const bool more = sub + 1 < rg.sub1;
+      const bool whole = RIDE && more && (sub + 2) * kRows <= rg.total;  // the next sub-tile is a whole one: loads ride the loop
+      if (more && !whole) prefetch(sub + 1);
 
       // dW[c][k] += sum_rows dy[row][c] act[row][k]: A[i = c][k = row], B[k = row][j = k-channel]
       // two fragment register sets, as in the dx kernel: step kk + 1 is fetched before step kk's MFMAs are issued
@@ -954,6 +1138,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
 #pragma unroll
       for (int kk = 0; kk < kRows / 2; ++kk) {
         if (kk + 1 < kRows / 2) frag(kk + 1, (kk + 1) & 1);
+        if (kk < kParts && whole) prefetch_part(sub + 1, kk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ib = 0; ib < IBW; ++ib)

@@ -379,14 +379,14 @@ class _MfmaMlpPool(torch.autograd.Function):
         y3 = torch.empty((cap, c3), **f32)
         ysel = torch.empty((groups, c3), **f32)
         sel = torch.empty((groups, c3), dtype=torch.int32, device=dev)
+        g3 = gammas[2].detach()
+        out = torch.empty((groups, c3), **f32)
         part_y = torch.empty((nblk, c3), **f32)
         part_sel = torch.empty((nblk, c3), dtype=torch.int32, device=dev)
         part_gid = torch.empty(nblk, dtype=torch.int32, device=dev)
-        g3 = gammas[2].detach()
         _call_timed("fwd3", "coda_sa_mfma_fwd_f32", _p(y2), None, _p(st2), _p(ws[2]), _p(roww), _p(goff), _p(grow), groups, nsample,
               c2, c3, _p(y3), _p(s3), _p(g3), _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), nblk)
         st3 = _bn_stats(bns[2], s3, float(n_rows * world[2]), gammas[2], betas[2], training, c3, dev)
-        out = torch.empty((groups, c3), **f32)
         _call("coda_sa_pool_finish_f32", _p(ysel), _p(sel), _p(part_y), _p(part_sel), _p(part_gid), _p(goff), _p(g3),
               _p(st3), _p(out), groups, c3, nblk)
 

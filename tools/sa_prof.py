@@ -9,7 +9,7 @@ through it:
 
 Phases (clocks per 64-row sub-tile, mean over waves and the first 64 workgroups):
   fwd: 0 top barrier, 1 staging (BN+ReLU -> LDS), 2 barrier, 3 prefetch issue + MFMA loop, 4 alias barrier,
-       5 epilogue (statistics, tile -> LDS), 6 barrier, 7 pooling scan / row store
+       5 epilogue (statistics, tile -> LDS), 6 barrier, 8 pooling scan (CODA_SA_POOL=fused only), 7 row store
   dx:  0 top barrier, 1 y_in tile -> LDS + barrier, 2 dy staging, 3 barrier, 4 prefetch issue + MFMA loop,
        5 epilogue (ReLU mask, sums, tile -> LDS), 6 barrier, 7 row store
   dw:  0 top barrier, 1 activation staging, 2 barrier, 3 dy staging, 4 barrier, 5 prefetch issue + MFMA loop
@@ -59,18 +59,22 @@ def main():
         feats.square().sum().backward()
     torch.cuda.synchronize()
     lib = _lib.load()
-    host = (ctypes.c_ulonglong * (6 * 64 * 4 * 10))()
+    host = (ctypes.c_ulonglong * (6 * 64 * 4 * 16))()
     lib.coda_sa_prof_read.restype = ctypes.c_int
     assert lib.coda_sa_prof_read(host) == 0
-    p = np.frombuffer(host, dtype=np.uint64).reshape(6, 64, 4, 10).astype(np.float64)
+    p = np.frombuffer(host, dtype=np.uint64).reshape(6, 64, 4, 16).astype(np.float64)
     for k, name in enumerate(KINDS):
         tiles = p[k, :, :, 9]
         if tiles.sum() == 0:
             continue
-        per = p[k, :, :, :8].sum((0, 1)) / tiles.sum()
+        per = p[k, :, :, :9].sum((0, 1)) / tiles.sum()
         print(f"{name}: {tiles.mean():.1f} sub-tiles per workgroup, {per.sum():.0f} clocks per sub-tile")
         print("   phases: " + "  ".join(f"{i}:{v:.0f}" for i, v in enumerate(per)))
-        spread = p[k, :, :, :8].sum(-1) / np.maximum(tiles, 1)
+        if p[k, :, :, 10:14].sum() > 0:
+            extra = p[k, :, :, 10:14].sum((0, 1)) / tiles.sum()
+            print(f"   scan detail per sub-tile: fetch + test {extra[0]:.0f}, quads without a group start {extra[1]:.0f}, "
+                  f"quads with one {extra[2]:.0f} ({extra[3]:.2f} of them)")
+        spread = p[k, :, :, :9].sum(-1) / np.maximum(tiles, 1)
         print(f"   per wave-workgroup clocks/sub-tile: min {spread.min():.0f} max {spread.max():.0f}")
 
 
