@@ -473,11 +473,6 @@ def make_batch_t(bsz, n, seed, dev):
     return torch.from_numpy(pc).to(dev)[..., :3].contiguous()
 
 
-def _tuned_gemms():
-    from coda_neurips2023_amd import tuning
-    return tuning.is_on()
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -494,8 +489,6 @@ def main():
         dev = torch.device("cpu")
     else:
         torch.cuda.set_device(local_rank)
-        from coda_neurips2023_amd import tuning
-        tuning.enable_tuned_gemms()  # also for the workloads that never call build_model (configs[1])
         dev = torch.device("cuda", local_rank)
 
     def sync():
@@ -919,8 +912,7 @@ def main():
                        "sampling": ("FPS + ball query of batch i+1 run on a side stream during step i (once per "
                                     "step, inside the timed region); padded group copies are computed once"
                                     if prefetch else "in line"),
-                       "library_gemms": ("kernel per shape from the shipped look-up table (tuning.py, TunableOp without "
-                                         "run-time tuning)" if _tuned_gemms() else "library heuristics")},
+                       "library_gemms": "the libraries' own heuristics (no tuning table)"},
             "roofline": roofline,
             # host side of the timed region on rank 0: time until the last step was enqueued (close to the wall
             # time when the host is the bottleneck -- or when the GPU is and the launch queue fills up) and what

@@ -466,11 +466,7 @@ MODEL_FUNCS = {
 
 
 def build_model(args, dataset_config, **extra):
-    """models/__init__.py:8-10.  Also points the library GEMMs of the model's shapes at their measured winners on
-    gfx950 (tuning.enable_tuned_gemms: a look-up table, no tuning at run time; CODA_TUNED_GEMMS=0 to leave the
-    libraries' own choice)."""
-    from . import tuning
-    tuning.enable_tuned_gemms()
+    """models/__init__.py:8-10."""
     return MODEL_FUNCS[args.model_name](args, dataset_config, **extra)
 
 

@@ -12,6 +12,9 @@ fi
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 python bench.py --prefetch off --no-cpu-baseline --no-extras > gpurun_out/final_bench_noprefetch.json 2>> gpurun_out/final_bench.err
 python bench.py --workload sa --no-cpu-baseline > gpurun_out/final_bench_sa.json 2>> gpurun_out/final_bench.err
+# the multi-GPU wrapping forced onto the one rank (SyncBatchNorm conversion, RCCL group of 1, gradient all-reduce executed,
+# comm diagnostics, the unchanged leg under DistributedDataParallel)
+CODA_BENCH_FORCE_DDP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 python bench.py --no-cpu-baseline --no-extras > gpurun_out/final_bench_force_ddp.json 2>> gpurun_out/final_bench.err
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $R/gpurun_out/final_prof
@@ -25,7 +28,7 @@ bash tools/pmc_attn.sh > gpurun_out/final_pmc_attn_hbm.txt 2>&1
 bash tools/pmc_attn_mfma.sh > gpurun_out/final_pmc_attn_mfma.txt 2>&1
 python - <<'PY'
 import json
-for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_prof_bench"):
+for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_bench_force_ddp", "final_prof_bench"):
     for l in open(f"gpurun_out/{f}.json"):
         if not l.startswith("{"):
             continue
