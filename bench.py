@@ -64,7 +64,10 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_m
 ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2}  # dqg: dQ = dS K alone (dS from the dK/dV kernel's workspace)
 # HBM bytes per launch of the 2048x2048 dK/dV kernel from PMC: FETCH_SIZE 55 374 KB x 2 (gfx950 correction) +
 # WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
-ATTN_DKV_TRAFFIC = 94_247_117 + 45_362_074  # FETCH_SIZE x2 + WRITE_SIZE per launch, profiles/r03_pmc_attention_hbm.md
+# HBM bytes per launch of the encoder's dK/dV kernel from PMC passes (FETCH_SIZE x2 + WRITE_SIZE): with the dS workspace
+# route of round 4 (the kernel also streams dS = 8 x 4 x 2048 x 2048 floats = 537 MB out) / the two-kernel form of round 3
+ATTN_DKV_TRAFFIC_DS = 93_994_598 + 578_992_026  # profiles/r04_pmc_attention_hbm.md; algorithmic: 84 MB in + 570 MB out
+ATTN_DKV_TRAFFIC = 94_247_117 + 45_362_074      # profiles/r03_pmc_attention_hbm.md
 
 
 def parse():
@@ -832,8 +835,14 @@ def main():
                                   "be read back): HIP events around each launch (coda_mha_timing_*, launch stream) in "
                                   "`steps` eagerly enqueued steps of the same workload right after it")
             # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes), not collected in this run
-            roofline["traffic"] = ATTN_DKV_TRAFFIC
-            roofline["traffic_source"] = "profiles/r03_pmc_attention_hbm.md (PMC, separate FETCH_SIZE / WRITE_SIZE passes)"
+            via_ds = ("dqg", 2048, 2048) in attn_ms_all
+            roofline["traffic"] = ATTN_DKV_TRAFFIC_DS if via_ds else ATTN_DKV_TRAFFIC
+            roofline["traffic_source"] = ("profiles/r04_pmc_attention_hbm.md" if via_ds else "profiles/r03_pmc_attention_hbm.md") + \
+                " (PMC, separate FETCH_SIZE / WRITE_SIZE passes)"
+            if via_ds:
+                roofline["traffic_algorithmic"] = 5 * 16_777_216 + 536_870_912 + 2 * 16_777_216  # Q K V dO O in; dS dK dV out
+            # the part sustains 2.16 GHz under matrix load (tools/mfma_lds_probe.hip): what the nominal-clock peak becomes
+            roofline["frac_of_sustained_clock_peak"] = round(roofline["achieved"] / (MFMA_F32_PEAK_TFLOPS * 2.16 / 2.4), 4)
             t_bwd = sum(sum(attn_ms[(k, 2048, 2048)]) / len(attn_ms[(k, 2048, 2048)])
                         for k in ("delta", "dkv", "dq", "dqg") if (k, 2048, 2048) in attn_ms)
             # SURVEY 8d's count for the whole backward with recomputation: 12 * Lq * Lk * d over delta + dK/dV + dQ

@@ -124,7 +124,6 @@ SIGNATURES = {
     "coda_vit_fwd": (_c_int, [_P, _P, _c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "coda_vit_attention_f16": (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
     "coda_vit_quickgelu_fused": (_c_int, [_c_int]),
-    "coda_gemm_set_tuning": (_c_int, [_c_int]),
     "coda_gemm_ex": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P,
                               ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_float, _c_float, _P]),
     # include/coda_optim.h

@@ -133,13 +133,12 @@ int ensure_workspace(State &s, hipStream_t hs, size_t bytes, void **out) {
   return CODA_OK;
 }
 
-// -1 = per-dtype default (fp16: on, fp32: off -- the fp32 path keeps the heuristic's first answer so that a
-// process always runs the same kernels); CODA_GEMM_TUNE=0/1 or coda_gemm_set_tuning() force it for both.
-int g_tuning = -1;
+// per-dtype default (fp16: on, fp32: off -- the fp32 path keeps the heuristic's first answer so that a process always
+// runs the same kernels); CODA_GEMM_TUNE=0/1, read once, forces it for both (no setter: the library keeps no mutable
+// process-wide state)
 bool tuning_enabled(int dtype) {
   static const int env = [] { const char *e = getenv("CODA_GEMM_TUNE"); return e ? atoi(e) != 0 : -1; }();
-  const int v = g_tuning >= 0 ? g_tuning : env;
-  return v >= 0 ? v != 0 : dtype == CODA_DTYPE_F16;
+  return env >= 0 ? env != 0 : dtype == CODA_DTYPE_F16;
 }
 
 // First use of a shape: time the heuristic's candidates on the caller's operands (output to a scratch matrix)
@@ -186,12 +185,6 @@ void tune(State &s, Plan &p, const void *a, const void *b, size_t c_bytes, const
 
 }  // namespace
 }  // namespace coda
-
-CODA_API int coda_gemm_set_tuning(int mode) {
-  if (mode < -1 || mode > 1) return CODA_EINVAL;
-  coda::g_tuning = mode;
-  return CODA_OK;
-}
 
 CODA_API int coda_gemm_ex(int dtype, int epilogue, int transa, int transb, int m, int n, int k, const void *a,
                           long long lda, const void *b, long long ldb, void *c, long long ldc, const float *bias,

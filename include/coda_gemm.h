@@ -45,9 +45,9 @@ int coda_gemm_ex(int dtype, int epilogue, int transa, int transb, int m, int n, 
 
 /* First-use timing of the library's candidate algorithms for a shape (the heuristic's first answer is not always
  * the fastest): the candidates run on the caller's operands into a scratch output and the fastest is kept for the
- * process.  mode 1 / 0: on / off for every dtype; -1 (default): on for CODA_DTYPE_F16, off for CODA_DTYPE_F32 (a
- * process then always runs the same fp32 kernels).  Env CODA_GEMM_TUNE=0|1 sets the start-up value. */
-int coda_gemm_set_tuning(int mode);
+ * process.  On for CODA_DTYPE_F16, off for CODA_DTYPE_F32 (a process then always runs the same fp32 kernels); the
+ * environment variable CODA_GEMM_TUNE=0|1, read once, forces it for both.  (No setter: the library keeps no mutable
+ * process-wide state.) */
 
 /* Own fp32-MFMA kernel for the same product (csrc/gemm_nn.hip), used for the launch-sized problems of the
  * transformer stacks where the library costs ~14 us of host time per call:

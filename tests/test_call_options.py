@@ -16,8 +16,15 @@ def test_the_library_exports_no_process_wide_setter():
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    for name in ("coda_set_distance_mode", "coda_set_fps_waves", "coda_set_ball_query_route", "coda_mha_set_mfma_dtype"):
+    for name in ("coda_set_distance_mode", "coda_set_fps_waves", "coda_set_ball_query_route", "coda_mha_set_mfma_dtype",
+                 "coda_gemm_set_tuning"):
         assert not hasattr(lib, name), name
+    # ... and nothing else that looks like one: the only mutable library state left is the measurement aid
+    # coda_mha_timing_enable / coda_pointnet2 timing (bench.py's live roofline figures, off by default)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout.split()
+    setters = [x for x in syms if x.startswith("coda_") and "_set_" in x]
+    assert not setters, setters
     for name in ("coda_furthest_point_sampling_opt_f32", "coda_ball_query_opt_f32", "coda_query_and_group_xyz_opt_f32",
                  "coda_three_nn_opt_f32", "coda_three_interpolate_opt_f32", "coda_mha_fwd_opt_f32",
                  "coda_mha_bwd_parts_opt_f32"):

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace --stats CSV: per-step time by category + own kernels.
 
-    python tools/prof_summary.py <kernel_stats.csv> <steps incl. warmup> [--md]
+    python tools/prof_summary.py <kernel_stats.csv> <steps incl. warmup | auto> [--md]
+
+`auto`: the number of optimizer steps in the trace (launches of this package's adamw_kernel, one per step).
 """
 import csv
 import sys
@@ -11,6 +13,9 @@ def cat(nm):
     if "fps_" in nm: return "FPS (hip)"
     if "ball_query" in nm or "grid_" in nm: return "ball_query+group (hip)"
     if "mha_" in nm: return "attention (hip)"
+    if "coda" in nm and any(k in nm for k in ("sa_fwd_kernel", "sa_bwd_d", "dw_reduce", "pack_", "pool_finish", "pool_bwd_stats",
+                                              "l1_sums", "l1_bwd")):
+        return "SA shared-MLP MFMA pipeline (hip)"
     if "coda" in nm and any(k in nm for k in ("col_stats", "bn_relu_apply", "bn_bwd_sparse", "relu_bn")):
         return "SA shared-MLP streaming (hip)"
     if "coda" in nm and any(k in nm for k in ("bn_stats", "bn_finalize", "bn_act", "bn_bwd_finalize")):
@@ -39,7 +44,10 @@ def cat(nm):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    n = int(sys.argv[2])
+    if sys.argv[2] == "auto":
+        n = sum(int(r["Calls"]) for r in rows if "adamw_kernel" in r["Name"])
+    else:
+        n = int(sys.argv[2])
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"GPU-busy per step: {tot / n / 1e6:.2f} ms; kernel launches per step: "
           f"{sum(int(r['Calls']) for r in rows) / n:.0f}\n")

@@ -18,11 +18,15 @@ CODA_BENCH_FORCE_DDP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 python bench.py -
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $R/gpurun_out/final_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
+# the headline leg alone (CODA_BENCH_LEGS=headline: no unchanged-caller leg), so that per-step figures are the headline's
+CODA_BENCH_LEGS=headline rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_prof -o run -- \
   python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/final_prof_bench.json 2>/dev/null
 python $R/tools/trace_by_grid.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) > $R/gpurun_out/final_prof/attention_by_grid.csv
+python $R/tools/trace_gaps.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) 0.3 > $R/gpurun_out/final_prof/gaps.txt
+python $R/tools/prof_summary.py $(find $R/gpurun_out/final_prof -name run_kernel_stats.csv) auto > $R/gpurun_out/final_prof/summary.md
 find $R/gpurun_out/final_prof -name run_kernel_trace.csv -delete   # tens of MB; the stats file is what gets committed
 cd $R
+timeout 300 python tools/sa_prof.py > gpurun_out/final_sa_prof.txt 2>&1
 bash tools/pmc_sa.sh > /dev/null 2>&1
 bash tools/pmc_attn.sh > gpurun_out/final_pmc_attn_hbm.txt 2>&1
 bash tools/pmc_attn_mfma.sh > gpurun_out/final_pmc_attn_mfma.txt 2>&1
