@@ -490,15 +490,17 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
       if (cur_g >= 0 && (chg & 1ull) == 0ull) base = (__builtin_amdgcn_readlane(mygrow, 0) & 63);
       // The channel's 64 values in one LDS round trip (the accumulators are dead here: registers are free), then four
       // rows per scalar test: three of four quads hold no group start (3-4 groups per sub-tile).  Measured
-      // (tools/sa_prof.py, clocks per sub-tile): row at a time with its own LDS reads 13.6 k, this form 7.1 k, the same as
-      // a rolled loop over quads 8.9 k; the pooling as a separate pass over the stored rows (328 MB re-read) was
-      // 33 us slower than this scan in the step.
+      // (tools/sa_prof.py, clocks per sub-tile): row at a time with its own LDS reads 13.6 k, this form 7.1 k -- 6.3 k
+      // with the no-start quads marked likely (the compiler had put THEM out of line) --, the same as a rolled loop over
+      // quads 8.9 k; the pooling as a separate pass over the stored rows (328 MB re-read) was 33 us slower than this
+      // scan in the step.  Of the 6.3 k: the compare chain 2.4 k (tools/scan_probe.hip), the 3-4 group ends 1.5 k (cold
+      // code: each quad has its own copy), the 64 LDS reads 0.5 k.
       float vall[kRows];
 #pragma unroll
       for (int r = 0; r < kRows; ++r) vall[r] = s_o[r * SO + tid];
 #pragma unroll
       for (int rq = 0; rq < kRows; rq += 4) {
-        if (((chg >> rq) & 0xfull) == 0ull) {
+        if (__builtin_expect(((chg >> rq) & 0xfull) == 0ull, 1)) {  // (likely: the quads WITH a start go out of line)
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float v = vall[rq + u] * sg;
