@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     SA_PROF_MARK(2);
     const bool more = sub + 1 < rg.sub1;
     const bool whole = more && (sub + 2) * kRows <= rg.total;  // the next sub-tile is a whole one: loads ride the loop
-    if (more && !whole) prefetch(sub + 1);
+    if (__builtin_expect(more && !whole, 0)) prefetch(sub + 1);
 
     f32x16 acc[2][CBW];
 #pragma unroll
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     for (int kq = 0; kq < KK / 4; ++kq) {
       const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_a + l31 * SA + h * (CIN / 2) + 4 * kq);
       const f32x4 a1 = *reinterpret_cast<const f32x4 *>(s_a + (32 + l31) * SA + h * (CIN / 2) + 4 * kq);
-      if (kq < kParts && whole) prefetch_part(sub + 1, kq);
+      if (kq < kParts && __builtin_expect(whole, 1)) prefetch_part(sub + 1, kq);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     if (a.y_out) {  // whole rows, 16 bytes per lane
       constexpr int QO = COUT / 4, RO = kT / QO;
       const int oq = tid % QO, or0 = tid / QO;
-      if (nvalid == kRows) {  // (uniform) no per-row test: the tile is read from LDS in one go, then stored
+      if (__builtin_expect(nvalid == kRows, 1)) {  // (uniform) no per-row test: the tile is read from LDS in one go, then stored
         float *ob = a.y_out + s0 * COUT;
         f32x4 t[kRows / RO];
 #pragma unroll
@@ -719,12 +719,12 @@ struct DyStage {
     f32x4 dsel;
     if (LAST) {
       const int packed = __builtin_amdgcn_readfirstlane(rw.packed[j]);  // wave-uniform: the wave owns the row
-      if (packed < 0) return f32x4{0, 0, 0, 0};
+      if (__builtin_expect(packed < 0, 0)) return f32x4{0, 0, 0, 0};
       const int g = packed >> 6, rin = packed & 63;
       f32x4 dg;
       i32x4 sg;
-      if (g == gA) { dg = dA; sg = sA; }
-      else if (g == gB) { dg = dB; sg = sB; }
+      if (__builtin_expect(g == gA, 1)) { dg = dA; sg = sA; }
+      else if (__builtin_expect(g == gB, 1)) { dg = dB; sg = sB; }
       else { dg = ldg4(a.d + static_cast<size_t>(g) * COUT + 4 * cq); sg = ldg4i(a.sel + static_cast<size_t>(g) * COUT + 4 * cq); }
 #pragma unroll
       for (int u = 0; u < 4; ++u) dsel[u] = rin == sg[u] ? ca[u] * dg[u] : 0.f;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
       SA_PROF_MARK(3);
       const bool more = sub + 1 < rg.sub1;
       const bool whole = RIDE && more && (sub + 2) * kRows <= rg.total;  // the next sub-tile is a whole one: loads ride the loop
-      if (more && !whole) prefetch(sub + 1);
+      if (__builtin_expect(more && !whole, 0)) prefetch(sub + 1);
 
       f32x16 acc[RBW];
 #pragma unroll
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
 #pragma unroll
       for (int kq = 0; kq < KK / 4; ++kq) {
         if (kq + 1 < KK / 4) frag(kq + 1, (kq + 1) & 1);
-        if (kq < kParts && whole) prefetch_part(sub + 1, kq);
+        if (kq < kParts && __builtin_expect(whole, 1)) prefetch_part(sub + 1, kq);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dx_kernel(const BwdArgs a) {
       if (!FIRST) {  // dmid_in leaves as whole rows, 16 bytes per lane
         lds_barrier();
         SA_PROF_MARK(6);
-        if (s0 + kRows <= rg.total) {  // (uniform) a whole sub-tile: read from LDS in one go, then stored
+        if (__builtin_expect(s0 + kRows <= rg.total, 1)) {  // (uniform) a whole sub-tile: read from LDS in one go, then stored
           float *ob = a.dmid_in + s0 * CIN;
           f32x4 t[NI];
 #pragma unroll
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
       SA_PROF_MARK(4);
       const bool more = sub + 1 < rg.sub1;
       const bool whole = RIDE && more && (sub + 2) * kRows <= rg.total;  // the next sub-tile is a whole one: loads ride the loop
-      if (more && !whole) prefetch(sub + 1);
+      if (__builtin_expect(more && !whole, 0)) prefetch(sub + 1);
 
       // dW[c][k] += sum_rows dy[row][c] act[row][k]: A[i = c][k = row], B[k = row][j = k-channel]
       // two fragment register sets, as in the dx kernel: step kk + 1 is fetched before step kk's MFMAs are issued
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
 #pragma unroll
       for (int kk = 0; kk < kRows / 2; ++kk) {
         if (kk + 1 < kRows / 2) frag(kk + 1, (kk + 1) & 1);
-        if (kk < kParts && whole) prefetch_part(sub + 1, kk);
+        if (kk < kParts && __builtin_expect(whole, 1)) prefetch_part(sub + 1, kk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ib = 0; ib < IBW; ++ib)
