@@ -156,10 +156,16 @@ class _EncoderLayer(torch.autograd.Function):
     def backward(ctx, ds_out, do):
         first, has_pos, use_ffn = ctx.flags
         dg2 = db2n = dw1 = dfb1 = dw2 = dob1 = None
+        # nothing inside this backward reads a weight / bias / LayerNorm gradient: the sums over the row chunks of
+        # the six weight-gradient products and the ~5 column-sum reductions of the layer close in two grouped launches
+        # at its end (11 launches before)
+        defer = gemm.DeferredWeightGrads(sums_only=True) if gemm.DEFER_SUMS else None
+        for c in ctx.blocks[:3]:
+            c.defer = defer
         if use_ffn:
             c1, c2, c3, ffn_saved = ctx.blocks
             w1, w2 = ctx.saved_tensors
-            dy2, dw1, dfb1, dw2 = _ffn_backward(ffn_saved, do, w1, w2)
+            dy2, dw1, dfb1, dw2 = _ffn_backward(ffn_saved, do, w1, w2, defer)
             da1, dob1, ds1, _, dg2, db2n, _, _ = _AddLN.backward(c3, ds_out, dy2, None)
         else:
             c1, c2 = ctx.blocks
@@ -172,6 +178,8 @@ class _EncoderLayer(torch.autograd.Function):
         dx, dbias_prev, dres, dpos, dg1, db1n = g[0], g[1], g[2], g[3], g[4], g[5]
         if first:
             dres, dx, dbias_prev = dx, None, None
+        if defer is not None:
+            defer.flush()
         return (dres, dx, dbias_prev, dpos if has_pos else None, None, None,
                 dg1, db1n, din1, dib1, dow1, dob1, dg2, db2n, dw1, dfb1, dw2)
 

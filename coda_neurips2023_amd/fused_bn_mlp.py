@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, gemm
 from . import attention_core as _core
 
 _SPLIT_ROWS = 2048
@@ -109,15 +109,27 @@ def eligible(mlps, x):
     return parsed
 
 
-def _split_k_tn(dz, a):
-    """dz (G,T,Co), a (G,T,Ci) contiguous -> dz^T a (G,Co,Ci) with the T reduction split."""
+def _split_k_tn(dz, a, defer=None, out=None):
+    """dz (G,T,Co), a (G,T,Ci) contiguous -> dz^T a (G,Co,Ci) with the T reduction split.  With a collector
+    (gemm.DeferredWeightGrads) the sum over the row chunks is closed by the collector's grouped launch: the returned
+    tensor (``out`` if given: (G,Co,Ci), contiguous) holds its values only after ``defer.flush()``."""
     g, t, co = dz.shape
     ci = a.shape[-1]
     if t >= 2 * _SPLIT_ROWS and t % _SPLIT_ROWS == 0:
         nc = t // _SPLIT_ROWS
         part = torch.bmm(dz.view(g * nc, _SPLIT_ROWS, co).transpose(1, 2), a.view(g * nc, _SPLIT_ROWS, ci))
-        return part.view(g, nc, co, ci).sum(1)
-    return torch.bmm(dz.transpose(1, 2), a)
+        if defer is not None:
+            if out is None:
+                out = torch.empty((g, co, ci), dtype=torch.float32, device=dz.device)
+            defer.add_colsum(part, out, nc, co * ci, g)   # partials (G, nc, Co*Ci) -> out (G, Co*Ci)
+            return out
+        res = part.view(g, nc, co, ci).sum(1)
+    else:
+        res = torch.bmm(dz.transpose(1, 2), a)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 class _HiddenStack(torch.autograd.Function):
@@ -238,6 +250,8 @@ class _HiddenStack(torch.autograd.Function):
         t = x.shape[0]
         grads = [None] * (3 * groups * nb)
         tail_grads = []
+        # the sums over the row chunks of the ~12 weight-gradient products close in one grouped launch at the end
+        defer = gemm.DeferredWeightGrads(sums_only=True) if (gemm.DEFER_SUMS and x.is_cuda) else None
         if has_tail:
             # gradients of the G tail layers; dA is assembled in place, group by group
             dout = None
@@ -249,7 +263,7 @@ class _HiddenStack(torch.autograd.Function):
                 for g in range(ns):
                     dpad[g, :, :tail_ws[g].shape[0]].copy_(douts[g])
                 torch.bmm(dpad, wpad, out=da[:ns])
-                dwp = _split_k_tn(dpad, acts[-1][:ns])                                     # (ns, width, C)
+                dwp = _split_k_tn(dpad, acts[-1][:ns], defer)                              # (ns, width, C)
                 dbp = dpad.sum(1)
                 for g in range(ns):
                     og = tail_ws[g].shape[0]
@@ -257,7 +271,7 @@ class _HiddenStack(torch.autograd.Function):
             for g in range(ns, groups):
                 dg = douts[g].contiguous()
                 torch.mm(dg, tail_ws[g], out=da[g])
-                dw = _split_k_tn(dg.unsqueeze(0), acts[-1][g].unsqueeze(0))[0]
+                dw = _split_k_tn(dg.unsqueeze(0), acts[-1][g].unsqueeze(0), defer)[0]
                 tail_grads += [dw.view(ctx.tail_shapes[g]), _colsum(dg) if ctx.tail_bias[g] else None]
         else:
             dout = douts[0]
@@ -284,15 +298,17 @@ class _HiddenStack(torch.autograd.Function):
                   p, seed, _p(seed_dev), _p(dz))
             # weight gradients (split-K) and the gradient of the block input
             if i > 0:
-                dw = _split_k_tn(dz, acts[i - 1])
+                dw = _split_k_tn(dz, acts[i - 1], defer)
                 da = torch.bmm(dz, ws[i])
             else:
                 xs = x.unsqueeze(0)
                 if groups == 1:
-                    dw = _split_k_tn(dz, xs)
+                    dw = _split_k_tn(dz, xs, defer)
                     dx = torch.mm(dz[0], ws[0][0]) if ctx.needs_input_grad[0] else None
                 else:
-                    dw = torch.stack([_split_k_tn(dz[g:g + 1], xs)[0] for g in range(groups)])
+                    dw = torch.empty((groups, dz.shape[2], xs.shape[2]), dtype=torch.float32, device=dev)
+                    for g in range(groups):  # (x is shared by the groups: one product per group, written in place)
+                        _split_k_tn(dz[g:g + 1], xs, defer, out=dw[g:g + 1])
                     if ctx.needs_input_grad[0]:
                         dx = torch.mm(dz[0], ws[0][0])
                         for g in range(1, groups):
@@ -302,6 +318,8 @@ class _HiddenStack(torch.autograd.Function):
                 grads[base] = dw[g].view(ctx.wshapes[i])
                 grads[base + 1] = dgamma[g]
                 grads[base + 2] = dbeta[g]
+        if defer is not None:
+            defer.flush()
         return (dx, None, *grads, *tail_grads)
 
 

@@ -105,7 +105,11 @@ class DeferredWeightGrads:
     grouped kernel does not take (columns not multiples of 64, rows not a multiple of 8, non-unit inner strides)
     are computed on the spot with ``mm_tn``."""
 
-    def __init__(self):
+    def __init__(self, sums_only=False):
+        # sums_only: long reductions (the encoder's 16 384 tokens, the heads' 2048 x 6) -- the products are issued on
+        # the spot as ONE batched library GEMM over row chunks (the grouped kernel is built for launch-sized
+        # problems), and only the sum over the chunks joins the grouped reduction at flush()
+        self.sums_only = sums_only
         self._rows = []   # 8 int64 per problem: the CodaTnProblem layout (include/coda_gemm.h)
         self._sums = []   # 3 int64 per open column-sum reduction: the CodaColsumItem layout (coda_token_ops.h)
         self._keep = []   # operands stay referenced until the launch has been enqueued
@@ -116,7 +120,21 @@ class DeferredWeightGrads:
         self._sums.append((partials.data_ptr(), out.data_ptr(), blocks | (n << 32), groups))
         self._keep.append((partials, out))
 
+    def add_split(self, out, dy, x, chunk=2048, min_rows=4096):
+        """out (Co, Ci) <- dy^T x with the row reduction split into `chunk`-row pieces: the batched product now, the
+        sum over the pieces at flush() (one grouped launch for all sums of a node instead of one torch.sum each)."""
+        p = dy.shape[0]
+        if (p >= min_rows and p % chunk == 0 and out.is_contiguous() and dy.is_contiguous() and x.is_contiguous()
+                and dy.dtype == torch.float32 and dy.is_cuda):
+            nc = p // chunk
+            part = torch.bmm(dy.view(nc, chunk, -1).transpose(1, 2), x.view(nc, chunk, -1))
+            self.add_colsum(part, out, nc, out.numel())
+        else:
+            mm_tn(dy, x, out=out)
+
     def add(self, out, dy, x):
+        if self.sums_only:
+            return self.add_split(out, dy, x)
         rows, m = dy.shape
         n = x.shape[1]
         if (GROUPED_TN and rows % 8 == 0 and m % 64 == 0 and n % 64 == 0 and dy.stride(1) == 1 and x.stride(1) == 1
@@ -131,11 +149,13 @@ class DeferredWeightGrads:
 
     def flush(self):
         import numpy as np
-        if self._sums:
-            table = np.array(self._sums, dtype=np.int64)
-            st = _lib.load().coda_tok_colsum_finalize_grouped_f32(table.ctypes.data, len(self._sums),
-                                                                 _lib.current_stream_handle())
-            _lib.check(st, "coda_tok_colsum_finalize_grouped_f32")
+        # (the launch's grid is sized by its widest item: bias-sized and weight-sized reductions go separately)
+        for sums in ([t for t in self._sums if (t[2] >> 32) <= 4096], [t for t in self._sums if (t[2] >> 32) > 4096]):
+            if sums:
+                table = np.array(sums, dtype=np.int64)
+                st = _lib.load().coda_tok_colsum_finalize_grouped_f32(table.ctypes.data, len(sums),
+                                                                     _lib.current_stream_handle())
+                _lib.check(st, "coda_tok_colsum_finalize_grouped_f32")
         if self._rows:
             table = np.array(self._rows, dtype=np.int64)
             st = _lib.load().coda_grouped_gemm_tn_f32(table.ctypes.data, len(self._rows), _lib.current_stream_handle())
@@ -144,3 +164,5 @@ class DeferredWeightGrads:
 
 
 GROUPED_TN = os.environ.get("CODA_GROUPED_TN", "1") != "0"
+# the encoder layers' and the heads' split-K sums and column sums closed by one grouped launch per node (A/B switch)
+DEFER_SUMS = GROUPED_TN and os.environ.get("CODA_DEFER_SUMS", "1") != "0"

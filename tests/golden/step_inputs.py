@@ -45,7 +45,7 @@ def build(case):
     return batch, seam
 
 
-def condition_query_projection(model, batch, nq, margin=2e-5, rounds=8):
+def condition_query_projection(model, batch, nq, margin=2e-5, rounds=16):
     """Moves the two biases of ``model.query_projection`` (Linear + ReLU + Linear + ReLU on the 8 x nq query tokens) by
     a few 1e-5 so that NO pre-activation of the step's inputs lies within ``margin`` x rms of zero.
 
@@ -80,11 +80,15 @@ def condition_query_projection(model, batch, nq, margin=2e-5, rounds=8):
                 lim = margin * float(z.pow(2).mean().sqrt())
                 near = z.abs() < lim
                 if near.any():
-                    # per channel: push the closest entry away from zero, in the direction it already points
+                    # per channel: the smallest shift (in steps of the margin) that leaves none of its entries close
                     for c in torch.nonzero(near.any(0).any(0)).flatten().tolist():
                         col = z[..., c].reshape(-1)
-                        v = col[col.abs().argmin()]
-                        bias[c] += (1.0 if v >= 0 else -1.0) * 3.0 * lim
+                        for k in (3, -3, 5, -5, 7, -7, 9, -9, 13, -13, 21, -21):
+                            if bool(((col + k * lim).abs() >= lim).all()):
+                                bias[c] += k * lim
+                                break
+                        else:
+                            raise RuntimeError("query projection: no small shift clears channel %d" % c)
                     moved = True
                     break  # layer 1 moved: layer 2's inputs changed, evaluate again
             if not moved:
