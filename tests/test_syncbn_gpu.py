@@ -30,15 +30,22 @@ def _free_port():
     return p
 
 
-def _modules(dev):
+WIDTHS = {"streaming": [0, 16, 32, 64],      # pointnet2/fused_sa_mlp.py's streaming kernels around library GEMMs
+          "mfma": [0, 64, 128, 256]}          # the pre-encoder's own widths: the hand-written pipeline of csrc/sa_mfma.hip
+
+
+def _modules(dev, path="streaming"):
     from functools import partial
 
     from coda_neurips2023_amd.helpers import GenericMLP
     from coda_neurips2023_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
     torch.manual_seed(11)
-    sa = PointnetSAModuleVotes(radius=0.4, nsample=16, npoint=64, mlp=[0, 16, 32, 64], normalize_xyz=True)
+    sa = PointnetSAModuleVotes(radius=0.4, nsample=16, npoint=64, mlp=list(WIDTHS[path]), normalize_xyz=True)
+    if path == "mfma":
+        from coda_neurips2023_amd.pointnet2 import fused_sa_mlp
+        assert fused_sa_mlp.mfma_eligible(sa.mlp_module, 16), "this case is meant to run the MFMA pipeline"
     mk = partial(GenericMLP, norm_fn_name="bn1d", activation="relu", use_conv=True, hidden_dims=[64, 64], dropout=0.0,
-                 input_dim=64)
+                 input_dim=WIDTHS[path][-1])
     heads = torch.nn.ModuleList([mk(output_dim=5), mk(output_dim=32)])
     for m in list(sa.modules()) + list(heads.modules()):
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
@@ -47,10 +54,10 @@ def _modules(dev):
     return sa.to(dev).train(), heads.to(dev).train()
 
 
-def _data(dev):
+def _data(dev, path="streaming"):
     g = torch.Generator().manual_seed(5)
     xyz = torch.rand(4, 700, 3, generator=g) * 2
-    w_feat = torch.randn(4, 64, 64, generator=g)
+    w_feat = torch.randn(4, WIDTHS[path][-1], 64, generator=g)
     w_head = [torch.randn(4 * 64, 5, generator=g), torch.randn(4 * 64, 32, generator=g)]
     return xyz.to(dev), w_feat.to(dev), [w.to(dev) for w in w_head]
 
@@ -59,7 +66,7 @@ def _run(sa, heads, xyz, w_feat, w_head):
     """SA module -> features (B,64,npoint) -> tokens (B*npoint,64) -> the two heads; loss = weighted sums."""
     from coda_neurips2023_amd import fused_bn_mlp
     _, feat, _ = sa(xyz)
-    tokens = feat.permute(0, 2, 1).reshape(-1, 64)
+    tokens = feat.permute(0, 2, 1).reshape(-1, feat.shape[1])
     parsed = fused_bn_mlp.eligible(list(heads), tokens)
     assert parsed is not None
     outs = fused_bn_mlp.run_stacks(tokens, parsed)
@@ -78,16 +85,16 @@ def _state(sa, heads):
     return grads, bufs
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    sa, heads = _modules(dev)
+    sa, heads = _modules(dev, path)
     sa = torch.nn.SyncBatchNorm.convert_sync_batchnorm(sa)
     heads = torch.nn.SyncBatchNorm.convert_sync_batchnorm(heads)
-    xyz, w_feat, w_head = _data(dev)
+    xyz, w_feat, w_head = _data(dev, path)
     sl = slice(2 * rank, 2 * rank + 2)
     feat, outs = _run(sa, heads, xyz[sl].contiguous(), w_feat[sl], [w.view(4, 64, -1)[sl].reshape(128, -1) for w in w_head])
     grads, bufs = _state(sa, heads)
@@ -97,14 +104,15 @@ def _worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_whole_batch(dev, tmp_path):
+@pytest.mark.parametrize("path", list(WIDTHS))
+def test_two_ranks_equal_one_process_on_the_whole_batch(dev, tmp_path, path):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), path), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
 
-    sa, heads = _modules(dev)
-    xyz, w_feat, w_head = _data(dev)
+    sa, heads = _modules(dev, path)
+    xyz, w_feat, w_head = _data(dev, path)
     feat, outs = _run(sa, heads, xyz, w_feat, w_head)
     grads, bufs = _state(sa, heads)
 
