@@ -916,12 +916,16 @@ def golden_step_full_configs3():
     golden_step_full("configs3")
 
 
+def golden_step_full_configs4():
+    golden_step_full("configs4_fp32")
+
+
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
     install_reference()
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det", "step_full", "step_full_configs3"]
+    which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det", "step_full", "step_full_configs3", "step_full_configs4"]
     for w in which:
         globals()["golden_" + w]()

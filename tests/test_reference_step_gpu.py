@@ -1,4 +1,5 @@
-"""The product against THE REFERENCE'S OWN MODULES on one whole training step at BASELINE.json configs[2]'s size.
+"""The product against THE REFERENCE'S OWN MODULES on one whole training step at the sizes of BASELINE.json's configs
+(configs[2], configs[3]'s recipe, and configs[4]'s shape in float32).
 
 tests/golden/step_full_<case>.npz were written by tests/golden/make_golden.py::golden_step_full: 8 scenes x 20 000 points
 through /root/reference's models/model_3detr.py (pre-encoder, 3 encoder + 8 decoder layers, heads; :1767-1794),
