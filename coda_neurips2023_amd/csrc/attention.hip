@@ -29,6 +29,10 @@
 #include <vector>
 
 namespace coda {
+PendingTiming &pending_timing() {
+  thread_local PendingTiming t;
+  return t;
+}
 namespace {
 
 // Cooperative copy of `rows` x D floats (row stride `gstride` floats) into a padded LDS tile.
@@ -1351,19 +1355,29 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_gemm_kernel(MhaBwdParams p)
 
 
 struct KernelTimer {
-  hipStream_t stream;
-  hipEvent_t e1 = nullptr;
-  KernelTimer(int kind, int l, int s, hipStream_t st) : stream(st) {
+  bool armed = false;
+  KernelTimer(int kind, int l, int s, hipStream_t) {
     if (g_timing_min_len < 0 || l < g_timing_min_len || s < g_timing_min_len || g_timing.size() >= kTimingCap)
       return;
     TimingRecord r{kind, l, s, nullptr, nullptr};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-    (void)hipEventRecord(r.e0, stream);
-    e1 = r.e1;
+    PendingTiming &t = pending_timing();  // the scope's kernel launch (mha_launch) takes the pair as its own events
+    t.e0 = r.e0;
+    t.e1 = r.e1;
+    armed = true;
     g_timing.push_back(r);
   }
   ~KernelTimer() {
-    if (e1) (void)hipEventRecord(e1, stream);
+    if (!armed) return;
+    PendingTiming &t = pending_timing();
+    if (t.e0) {  // nothing was launched in the scope (an error return): drop the record
+      t.e0 = t.e1 = nullptr;
+      if (!g_timing.empty()) {
+        (void)hipEventDestroy(g_timing.back().e0);
+        (void)hipEventDestroy(g_timing.back().e1);
+        g_timing.pop_back();
+      }
+    }
   }
 };
 
@@ -1389,12 +1403,12 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
       auto kern = mha_fwd_kernel<D, 4, false, GEN, true>;
       int st = set_lds(kern, 4 * kTileBytes);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+      mha_launch(kern, grid, dim3(256), 4 * kTileBytes, s, p);
     } else {
       auto kern = mha_fwd_kernel<D, 4, false, GEN>;
       int st = set_lds(kern, 4 * kTileBytes);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, grid, dim3(256), 4 * kTileBytes, s, p);
+      mha_launch(kern, grid, dim3(256), 4 * kTileBytes, s, p);
     }
   } else {
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
@@ -1405,23 +1419,23 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
         auto kern = mha_fwd_direct_kernel<D, 8, GEN>;
         int st = set_lds(kern, mlds8);
         if (st != CODA_OK) return st;
-        hipLaunchKernelGGL(kern, grid, dim3(8 * kWave), mlds8, s, p);
+        mha_launch(kern, grid, dim3(8 * kWave), mlds8, s, p);
       } else {
         auto kern = mha_fwd_direct_kernel<D, 4, GEN>;
         int st = set_lds(kern, mlds4);
         if (st != CODA_OK) return st;
-        hipLaunchKernelGGL(kern, grid, dim3(4 * kWave), mlds4, s, p);
+        mha_launch(kern, grid, dim3(4 * kWave), mlds4, s, p);
       }
     } else if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
       auto kern = mha_fwd_kernel<D, 4, true, GEN, true>;  // 4 waves, 2 x 4 tile pairs
       int st = set_lds(kern, 8 * kTileBytes);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, grid, dim3(4 * kWave), 8 * kTileBytes, s, p);
+      mha_launch(kern, grid, dim3(4 * kWave), 8 * kTileBytes, s, p);
     } else {
       auto kern = mha_fwd_kernel<D, SW, true, GEN>;
       int st = set_lds(kern, SW * kTileBytes);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, grid, dim3(SW * kWave), SW * kTileBytes, s, p);
+      mha_launch(kern, grid, dim3(SW * kWave), SW * kTileBytes, s, p);
     }
   }
   return launch_status();
@@ -1481,25 +1495,25 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     const size_t lds = 2 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
   } else if (p.s >= 1024 && p.l >= 1024 && double_buffered()) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN, true>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);  // two single-tile stages
     int st = set_lds(kern, lds);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
   } else if (p.s >= 1024) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, GEN>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), lds, s, p);
   } else {
     auto kern = mha_bwd_dkv_kernel<D, 4, true, GEN>;
     const size_t lds = 4 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(256), lds, s, p);
   }
   return CODA_OK;
   };
@@ -1513,7 +1527,7 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
       auto kern = mha_bwd_dq_gemm_kernel<D, 64>;
       int st = set_lds(kern, glds);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), glds, s, p);
+      mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), glds, s, p);
       return CODA_OK;
     }
   }
@@ -1522,12 +1536,12 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN, true>;
     int st = set_lds(kern, 4 * kTileBytes);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else if (p.l >= 1024) {
     auto kern = mha_bwd_dq_kernel<D, 4, false, GEN>;
     int st = set_lds(kern, 4 * kTileBytes);
     if (st != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 4 * kTileBytes, s, p);
   } else {
     // K / V fragments straight from L2 into registers (mha_bwd_dq_direct_kernel): head width 128 only -- 250 -> 133 us
     // on 256 x 2048; at width 64 the LDS-staged kernel below is the faster one (83 vs 93 us: 32 narrow VMEM
@@ -1538,17 +1552,17 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
       auto kern = mha_bwd_dq_direct_kernel<D, 4, GEN>;
       int st = set_lds(kern, mlds);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(4 * kWave), mlds, s, p);
+      mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(4 * kWave), mlds, s, p);
     } else if (split_double_buffered() && 8 * kTileBytes <= 160 * 1024) {
       auto kern = mha_bwd_dq_kernel<D, 4, true, GEN, true>;
       int st = set_lds(kern, 8 * kTileBytes);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(4 * kWave), 8 * kTileBytes, s, p);
+      mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(4 * kWave), 8 * kTileBytes, s, p);
     } else {
       auto kern = mha_bwd_dq_kernel<D, SW, true, GEN>;
       int st = set_lds(kern, SW * kTileBytes);
       if (st != CODA_OK) return st;
-      hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
+      mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(SW * kWave), SW * kTileBytes, s, p);
     }
   }
   return CODA_OK;
@@ -1571,7 +1585,7 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7 && !ds_route;
   if ((p.parts & 1) && !fuse) {
     KernelTimer timer(1, p.l, p.s, s);
-    hipLaunchKernelGGL((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
+    mha_launch((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
   }
   if (mfma_dtype() == 1) {
     int st = CODA_OK;

@@ -715,19 +715,19 @@ int fwd_launch(const MhaParams &p, hipStream_t s) {
     const size_t lds = static_cast<size_t>(NS == 3 ? 2 : 4) * NS * (L::ROWB + L::TRB);
     auto kern = mha_fwd_bf16_kernel<D, false, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
   } else if (NS == 1 && D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
     // at most one workgroup per CU: 8 waves / 8 key tiles per stage put twice the bytes in flight per CU
     // (measured 64 -> 53 us at 256 x 2048, but 87 -> 101 us at 512 x 2048 where two 4-wave workgroups share a CU)
     const size_t lds = 8 * (L::ROWB + L::TRB);
     auto kern = mha_fwd_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4), 1>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
   } else {
     const size_t lds = static_cast<size_t>(4) * NS * (L::ROWB + L::TRB);
     auto kern = mha_fwd_bf16_kernel<D, true, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
   }
   return CODA_OK;
 }
@@ -742,13 +742,13 @@ int dkv_launch(const MhaBwdParams &p, hipStream_t s) {
     const size_t lds = static_cast<size_t>(QT) * NS * (2 * L::ROWB + 2 * L::TRB) + sizeof(float) * 2 * kTile * QT;
     auto kern = mha_bwd_dkv_bf16_kernel<D, false, GEN, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
   } else {
     if (NS != 1) return CODA_EINVAL;  // x3_takes_dkv() keeps these shapes away
     const size_t lds = 4 * (2 * L::ROWB + 2 * L::TRB) + sizeof(float) * 2 * kTile * 4;
     auto kern = mha_bwd_dkv_bf16_kernel<D, true, GEN, 1>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.s, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
   }
   return CODA_OK;
 }
@@ -761,19 +761,19 @@ int dq_launch(const MhaBwdParams &p, hipStream_t s) {
     const size_t lds = static_cast<size_t>(NS == 3 ? 1 : 4) * NS * (2 * L::ROWB + L::TRB);
     auto kern = mha_bwd_dq_bf16_kernel<D, false, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
   } else if (NS != 1) {
     return CODA_EINVAL;  // x3_takes_dq() keeps these shapes away
   } else if (D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
     const size_t lds = 8 * (2 * L::ROWB + L::TRB);
     auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4), 1>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
   } else {
     const size_t lds = 4 * (2 * L::ROWB + L::TRB);
     auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, 4, 1>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
+    mha_launch(kern, dim3(ceil_div(p.l, kTile), p.b * p.h), dim3(kThreads), lds, s, p);
   }
   return CODA_OK;
 }

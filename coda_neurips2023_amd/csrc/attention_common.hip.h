@@ -1,9 +1,31 @@
 // attention_common.hip.h -- parameter blocks and small device helpers shared by the fp32-MFMA
 // (attention.hip) and bf16-MFMA (attention_bf16.hip) attention kernels.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "common.hip.h"
 
 namespace coda {
+
+// Measurement aid (coda_mha_timing_*): while a KernelTimer is alive on this thread, the NEXT kernel launched through
+// mha_launch() carries the timer's event pair as its own start / stop events (hipExtLaunchKernelGGL: the timestamps of
+// the dispatch itself, what rocprofv3's kernel trace reports).  Events recorded around the launch instead measured the
+// launch gap and two marker packets too: +3 us on a 10-20 us decoder kernel (round 3's "event-timed vs traced").
+struct PendingTiming {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+PendingTiming &pending_timing();  // thread-local, defined in attention.hip
+
+template <class K, class... Args>
+inline void mha_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+  PendingTiming &t = pending_timing();
+  if (t.e0) {
+    hipExtLaunchKernelGGL(kern, grid, block, static_cast<uint32_t>(lds), stream, t.e0, t.e1, 0, args...);
+    t.e0 = t.e1 = nullptr;
+  } else {
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, args...);
+  }
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

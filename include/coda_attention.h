@@ -117,7 +117,9 @@ int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const ui
 
 /* Measurement aid (bench.py's live roofline figures; no reference counterpart).  While
  * enabled, each kernel launched by coda_mha_fwd_f32 / coda_mha_bwd_f32 for a problem with
- * l >= min_len and s >= min_len is bracketed by two HIP events on the launch stream.
+ * l >= min_len and s >= min_len carries a HIP event pair as the start / stop events OF ITS DISPATCH (hipExtLaunchKernelGGL:
+ * the kernel's own begin / end timestamps, what a rocprofv3 kernel trace reports; events recorded around the launch also
+ * measured the launch gap and two marker packets, +3 us on a 10-20 us kernel).
  * coda_mha_timing_enable(min_len < 0) disables; every call drops the records taken so far.
  * coda_mha_timing_collect synchronises the recorded events and writes up to `cap` records
  * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ, 4 dQ as the dS K GEMM; the call's l and s; milliseconds); returns the
