@@ -393,7 +393,10 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
       const bool ok = s0 + frow < rg.total;
 #pragma unroll
       for (int i = 0; i < CIN / 4; i += 4) {
-        const int k0 = fpart * (CIN / 4) + i;
+        // channels 16 j + 4 fpart + u: the four lanes of a row write ADJACENT 8-byte pieces, so a wave's 64 b64 writes
+        // touch every bank exactly twice (with a contiguous quarter of the channels per lane -- 8 floats apart -- the
+        // lanes of neighbouring rows collided: 44 % of the kernel's LDS cycles were bank conflicts)
+        const int k0 = 4 * i + 4 * fpart;
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -976,7 +979,8 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
   static_assert(IB % 4 == 0, "wave tiling");
   constexpr int IBW = IB / 4;        // 32-row blocks of dW per wave (all JB column blocks)
   constexpr int SD = COUT;           // dy tile [64][COUT], natural layout
-  constexpr int SA = CIN;            // act tile [64][CIN]
+  constexpr int SA = FIRST ? CIN + 16 : CIN;  // act tile [64][SA]: FIRST's writers hold a quarter row each (4 rows per
+                                              // 16-lane group): 16 floats of padding spread the rows over the banks
   constexpr int QPA = CIN / 4, RPA = kT / QPA, NPA = kRows / RPA;
   constexpr bool RIDE = IBW * JB >= 8;  // as in the dx kernel (narrow layer: 2 MFMAs per step)
   extern __shared__ float lds[];
@@ -1088,7 +1092,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
         const bool ok = s0 + frow < rg.total;
 #pragma unroll
         for (int i = 0; i < CIN / 4; i += 4) {
-          const int k0 = fpart * (CIN / 4) + i;
+          const int k0 = 4 * i + 4 * fpart;  // (see the forward kernel; with SA = CIN + 16 the b128 writes are conflict-free)
           f32x4 v;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -1224,7 +1228,7 @@ int launch_dx(const BwdArgs &a, int nblk, hipStream_t s) {
 }
 template <int CIN, int COUT, bool LAST, bool FIRST>
 int launch_dw(const BwdArgs &a, int nblk, hipStream_t s) {
-  size_t lds = sizeof(float) * (kRows * COUT + kRows * CIN + 2 * kRows + (FIRST ? 6 * CIN : 0));
+  size_t lds = sizeof(float) * (kRows * COUT + kRows * (FIRST ? CIN + 16 : CIN) + 2 * kRows + (FIRST ? 6 * CIN : 0));
   auto kern = sa_bwd_dw_kernel<CIN, COUT, LAST, FIRST>;
   int st = raise_dynamic_lds(kern, lds);
   if (st != CODA_OK) return st;
