@@ -390,7 +390,10 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
     SA_PROF_MARK(0);
     SA_PROF_COUNT(9, 1);
     if (FIRST) {
-      const bool ok = s0 + frow < rg.total;
+      // rows past the end: their outputs are zeroed by a MULTIPLICATION with 0 / 1.  Written as `ok ? f(x) : 0` the
+      // compiler put every channel's constant reads and arithmetic under an exec-mask branch of its own: 16 serialised
+      // LDS round trips per thread and sub-tile (tools/sa_prof.py: 5.2 k of the narrow forward's 13.5 k clocks)
+      const float okf = s0 + frow < rg.total ? 1.0f : 0.0f;
 #pragma unroll
       for (int i = 0; i < CIN / 4; i += 4) {
         // channels 16 j + 4 fpart + u: the four lanes of a row write ADJACENT 8-byte pieces, so a wave's 64 b64 writes
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kT) void sa_fwd_kernel(const FwdArgs a) {
         for (int u = 0; u < 4; ++u) {
           const f32x4 wk = *reinterpret_cast<const f32x4 *>(s_w1 + 4 * (k0 + u));
           const f32x2 ss = *reinterpret_cast<const f32x2 *>(s_w1 + 4 * CIN + 2 * (k0 + u));
-          v[u] = ok ? bn_act(dot3w(px0, px1, px2, wk[0], wk[1], wk[2]), ss[0], ss[1]) : 0.f;
+          v[u] = okf * bn_act(dot3w(px0, px1, px2, wk[0], wk[1], wk[2]), ss[0], ss[1]);
         }
         *reinterpret_cast<f32x2 *>(s_a + frow * SA + (k0 >> 1)) = f32x2{v[0], v[2]};
         *reinterpret_cast<f32x2 *>(s_a + frow * SA + CIN / 2 + (k0 >> 1)) = f32x2{v[1], v[3]};
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
       if (tid < kRows) { s_w[tid] = pw; s_grow[tid] = pg; }
       // activations of the layer below
       if (FIRST) {
-        const bool ok = s0 + frow < rg.total;
+        const float okf = s0 + frow < rg.total ? 1.0f : 0.0f;  // (a multiplication, not a branch: see the forward kernel)
 #pragma unroll
         for (int i = 0; i < CIN / 4; i += 4) {
           const int k0 = 4 * i + 4 * fpart;  // (see the forward kernel; with SA = CIN + 16 the b128 writes are conflict-free)
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(kT) void sa_bwd_dw_kernel(const BwdArgs a) {
           for (int u = 0; u < 4; ++u) {
             const f32x4 wk = *reinterpret_cast<const f32x4 *>(s_w1 + 4 * (k0 + u));
             const f32x2 ss = *reinterpret_cast<const f32x2 *>(s_w1 + 4 * CIN + 2 * (k0 + u));
-            v[u] = ok ? bn_act(dot3w(px0, px1, px2, wk[0], wk[1], wk[2]), ss[0], ss[1]) : 0.f;
+            v[u] = okf * bn_act(dot3w(px0, px1, px2, wk[0], wk[1], wk[2]), ss[0], ss[1]);
           }
           *reinterpret_cast<f32x4 *>(s_a + frow * SA + k0) = v;
         }
