@@ -46,6 +46,26 @@ def test_fps_matches_oracle(dev, oracle, b, n, m):
     assert np.array_equal(got, oracle.furthest_point_sampling(x, m))
 
 
+@pytest.mark.parametrize("n,m,kind", [(512, 512, "normal"), (513, 40, "dup"), (1024, 300, "grid"), (1025, 64, "normal"),
+                                      (1500, 1500, "dup"), (2047, 256, "grid"), (2048, 128, "skip"), (2048, 2100, "dup")])
+def test_fps_small_clouds(dev, oracle, n, m, kind):
+    """512 .. 2048 points (the object queries' sampling, fps_t512_kernel with the cloud in LDS): the reference's tie
+    rule (duplicates, lattice points with many equal distances), the skip rule and m > n."""
+    rng = np.random.default_rng(n * 7 + m)
+    if kind == "dup":
+        base = (rng.random((37, 3), dtype=np.float32) * 3 + 1).astype(np.float32)
+        x = base[rng.integers(0, 37, (3, n))]
+    elif kind == "grid":
+        x = rng.integers(1, 9, (3, n, 3)).astype(np.float32) * 0.25
+    else:
+        x = (rng.standard_normal((3, n, 3)) * 1.5).astype(np.float32)
+        if kind == "skip":
+            x[:, rng.integers(1, n, 200)] *= 1e-3   # inside the skip radius: never sampled
+            x[1, 5:900] = 0.0
+    got = _ext.furthest_point_sampling(cu(x, dev), m).cpu().numpy()
+    assert np.array_equal(got, oracle.furthest_point_sampling(x, m))
+
+
 @pytest.mark.parametrize("n", [700, 1200, 4000, 20000])
 def test_fps_tie_rule_with_duplicates(dev, oracle, n):
     rng = np.random.default_rng(n)
