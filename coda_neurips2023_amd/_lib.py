@@ -70,12 +70,13 @@ SIGNATURES = {
     "coda_sa_l1_bwd_f32": (_c_int, [_P, _P, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _c_int, _P]),
     # include/coda_token_ops.h
     "coda_tok_bn_stats_f32": (_c_int, [_P, _c_int, ctypes.c_longlong, _c_int, _P, _P]),
-    "coda_tok_bn_finalize_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, ctypes.c_double, _c_float, _P, _P, _P]),
+    "coda_tok_bn_parts": (_c_int, [_c_int, ctypes.c_longlong, _c_int]),
+    "coda_tok_bn_finalize_f32": (_c_int, [_P, _c_int, _P, _P, _c_int, _c_int, ctypes.c_double, _c_float, _P, _P, _P]),
     "coda_tok_bn_act_f32": (_c_int, [_P, _P, _c_int, ctypes.c_longlong, _c_int, _c_int, _c_float, ctypes.c_uint64,
                                      _P, _P, _P]),
     "coda_tok_bn_act_bwd_stats_f32": (_c_int, [_P, _P, _P, _c_int, ctypes.c_longlong, _c_int, _c_int, _c_float,
                                                ctypes.c_uint64, _P, _P, _P]),
-    "coda_tok_bn_bwd_finalize_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, ctypes.c_double, _P, _P, _P, _P]),
+    "coda_tok_bn_bwd_finalize_f32": (_c_int, [_P, _c_int, _P, _P, _P, _c_int, _c_int, ctypes.c_double, _P, _P, _P, _P]),
     "coda_tok_bn_act_bwd_apply_f32": (_c_int, [_P, _P, _P, _P, _c_int, ctypes.c_longlong, _c_int, _c_int, _c_float,
                                                ctypes.c_uint64, _P, _P, _P]),
     "coda_tok_add_ln_fwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_float, _c_float,

@@ -30,9 +30,12 @@ __device__ __forceinline__ float4 affine(float4 y, float4 a, float4 b) {
 
 constexpr int kUnroll = 8;  // row loads a thread keeps in flight in the streaming loops
 
+// The block's sums of NACC quantities -> its own slot of the partial-sum array (P, G, NACC, C): plain stores.  (fp64
+// atomics on the G*NACC*C result addresses serialise: 512 blocks of the 16 384-token projection spent 50 of their 59 us
+// queueing on 512 addresses; the finalize kernels add the P slots in index order instead -- deterministic as well.)
 template <int NACC>
-__device__ __forceinline__ void block_reduce_to_global(const float4 (&acc)[NACC], const RowMap &m, int c,
-                                                       double *sums) {
+__device__ __forceinline__ void block_reduce_to_part(const float4 (&acc)[NACC], const RowMap &m, int c,
+                                                     double *part) {
   __shared__ float4 s_part[NACC][kT];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) s_part[k][threadIdx.x] = acc[k];
@@ -45,8 +48,50 @@ __device__ __forceinline__ void block_reduce_to_global(const float4 (&acc)[NACC]
         const float4 v = s_part[k][r * m.tpr + m.cq];
         t0 += v.x; t1 += v.y; t2 += v.z; t3 += v.w;
       }
-      double *dst = sums + static_cast<size_t>(k) * c + 4 * m.cq;
-      atomicAdd(dst + 0, t0); atomicAdd(dst + 1, t1); atomicAdd(dst + 2, t2); atomicAdd(dst + 3, t3);
+      double *dst = part + static_cast<size_t>(k) * c + 4 * m.cq;
+      *reinterpret_cast<double2 *>(dst) = make_double2(t0, t1);
+      *reinterpret_cast<double2 *>(dst + 2) = make_double2(t2, t3);
+    }
+  }
+}
+
+// sum over the P slots of (P, G, 2, C) for 16 channels of group g: 16 x 16 threads, thread (pl, cl) adds the slots
+// pl, pl + 16, ... of channel c0 + cl in index order, lane pl == 0 then adds the 16 sub-sums in order.  Returns the two
+// totals to the threads with pl == 0 (others: unspecified).
+constexpr int kFinCh = 16, kFinT = 256;
+__device__ __forceinline__ void sum_parts(const double *__restrict__ parts, int nparts, int groups, int g, int c, int ch,
+                                          bool live, double &t0, double &t1) {
+  __shared__ double s_sub[2][kFinT];
+  const int pl = threadIdx.x / kFinCh;
+  double a0 = 0.0, a1 = 0.0;
+  if (live) {
+    const size_t stride = static_cast<size_t>(groups) * 2 * c;
+    const double *src = parts + (static_cast<size_t>(g) * 2) * c + ch;
+    int p = pl;
+    for (; p + 3 * (kFinT / kFinCh) < nparts; p += 4 * (kFinT / kFinCh)) {  // 8 loads in flight
+      double v0[4], v1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double *q = src + (p + u * (kFinT / kFinCh)) * stride;
+        v0[u] = q[0];
+        v1[u] = q[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0 += v0[u]; a1 += v1[u]; }
+    }
+    for (; p < nparts; p += kFinT / kFinCh) {
+      a0 += src[p * stride];
+      a1 += src[p * stride + c];
+    }
+  }
+  s_sub[0][threadIdx.x] = a0;
+  s_sub[1][threadIdx.x] = a1;
+  __syncthreads();
+  t0 = t1 = 0.0;
+  if (pl == 0) {
+    for (int q = 0; q < kFinT / kFinCh; ++q) {
+      t0 += s_sub[0][q * kFinCh + threadIdx.x];
+      t1 += s_sub[1][q * kFinCh + threadIdx.x];
     }
   }
 }
@@ -66,7 +111,7 @@ struct Drop {
 };
 
 __global__ __launch_bounds__(kT) void bn_stats_kernel(const float *__restrict__ z, long long rows, int c,
-                                                      int rows_per_block, double *__restrict__ sums) {
+                                                      int rows_per_block, double *__restrict__ parts) {
   const RowMap m = row_map(c);
   const int g = blockIdx.y;
   const float *zg = z + static_cast<size_t>(g) * rows * c;
@@ -88,17 +133,21 @@ __global__ __launch_bounds__(kT) void bn_stats_kernel(const float *__restrict__ 
     for (int u = 0; u < kUnroll; ++u) add(y[u]);
   }
   for (; r < r1; r += m.rpb) add(ld4(zg + r * c + 4 * m.cq));
-  block_reduce_to_global<2>(acc, m, c, sums + static_cast<size_t>(g) * 2 * c);
+  block_reduce_to_part<2>(acc, m, c, parts + (static_cast<size_t>(blockIdx.x) * gridDim.y + g) * 2 * c);
 }
 
-__global__ void bn_finalize_kernel(const double *__restrict__ sums, const float *__restrict__ gamma,
-                                   const float *__restrict__ beta, int c, double count, float eps,
-                                   float *__restrict__ prm, float *__restrict__ stat) {
+__global__ __launch_bounds__(kFinT) void bn_finalize_kernel(const double *__restrict__ sums, int nparts, int groups,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int c, double count,
+                                                            float eps, float *__restrict__ prm,
+                                                            float *__restrict__ stat) {
   const int g = blockIdx.y;
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  const double mean = sums[(static_cast<size_t>(g) * 2) * c + ch] / count;
-  double var = sums[(static_cast<size_t>(g) * 2 + 1) * c + ch] / count - mean * mean;
+  const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
+  double t0, t1;
+  sum_parts(sums, nparts, groups, g, c, ch, ch < c, t0, t1);
+  if (threadIdx.x >= kFinCh || ch >= c) return;
+  const double mean = t0 / count;
+  double var = t1 / count - mean * mean;
   var = var > 0.0 ? var : 0.0;
   const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
   const float meanf = static_cast<float>(mean);
@@ -164,7 +213,7 @@ __global__ __launch_bounds__(kT) void bn_act_bwd_stats_kernel(const float *__res
                                                               const float *__restrict__ z,
                                                               const float *__restrict__ prm, long long rows,
                                                               int c, int rows_per_block, Drop dr,
-                                                              double *__restrict__ sums) {
+                                                              double *__restrict__ parts) {
   const RowMap m = row_map(c);
   const int g = blockIdx.y;
   const size_t goff = static_cast<size_t>(g) * rows * c;
@@ -198,24 +247,29 @@ __global__ __launch_bounds__(kT) void bn_act_bwd_stats_kernel(const float *__res
     const size_t off = goff + r * c + 4 * m.cq;
     one(off, ld4(z + off), ld4(da + off));
   }
-  block_reduce_to_global<2>(acc, m, c, sums + static_cast<size_t>(g) * 2 * c);
+  block_reduce_to_part<2>(acc, m, c, parts + (static_cast<size_t>(blockIdx.x) * gridDim.y + g) * 2 * c);
 }
 
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ sums_local, const double *__restrict__ sums_total,
-                                       const float *__restrict__ gamma, const float *__restrict__ prm, int c,
-                                       double count, float *__restrict__ prmb, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta) {
+__global__ __launch_bounds__(kFinT) void bn_bwd_finalize_kernel(const double *__restrict__ sums_local, int nparts,
+                                                                const double *__restrict__ sums_total, int groups,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ prm, int c, double count,
+                                                                float *__restrict__ prmb, float *__restrict__ dgamma,
+                                                                float *__restrict__ dbeta) {
   const int g = blockIdx.y;
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  const int ch = blockIdx.x * kFinCh + threadIdx.x % kFinCh;
+  double l0, l1;
+  sum_parts(sums_local, nparts, groups, g, c, ch, ch < c, l0, l1);
+  if (threadIdx.x >= kFinCh || ch >= c) return;
   const size_t s0 = (static_cast<size_t>(g) * 2) * c + ch, s1 = s0 + c;
+  const double tot0 = sums_total ? sums_total[s0] : l0, tot1 = sums_total ? sums_total[s1] : l1;
   const float invstd = prm[static_cast<size_t>(g) * 4 * c + 3 * c + ch];
   float *p = prmb + static_cast<size_t>(g) * 3 * c + ch;
   p[0] = gamma[static_cast<size_t>(g) * c + ch] * invstd;
-  p[c] = static_cast<float>(sums_total[s0] / count);
-  p[2 * c] = static_cast<float>(sums_total[s1] / count);
-  dbeta[static_cast<size_t>(g) * c + ch] = static_cast<float>(sums_local[s0]);
-  dgamma[static_cast<size_t>(g) * c + ch] = static_cast<float>(sums_local[s1]);
+  p[c] = static_cast<float>(tot0 / count);
+  p[2 * c] = static_cast<float>(tot1 / count);
+  dbeta[static_cast<size_t>(g) * c + ch] = static_cast<float>(l0);
+  dgamma[static_cast<size_t>(g) * c + ch] = static_cast<float>(l1);
 }
 
 template <bool RELU>
@@ -297,26 +351,31 @@ Drop make_drop(float p, uint64_t seed, const uint64_t *seed_dev) {
 
 using namespace coda;
 
-CODA_API int coda_tok_bn_stats_f32(const float *z, int groups, long long rows, int c, double *sums,
+CODA_API int coda_tok_bn_parts(int groups, long long rows, int c) {
+  if (groups <= 0 || rows < 0 || bad_c(c)) return CODA_EINVAL;
+  if (rows == 0) return 1;
+  return static_cast<int>(row_grid(groups, rows, rows_per_block(groups, rows, c)).x);
+}
+
+CODA_API int coda_tok_bn_stats_f32(const float *z, int groups, long long rows, int c, double *parts,
                                    void *stream) {
-  if (groups <= 0 || rows < 0 || bad_c(c) || !sums) return CODA_EINVAL;
+  if (groups <= 0 || rows < 0 || bad_c(c) || !parts) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * groups, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  if (rows == 0) return CODA_OK;
+  if (rows == 0) return static_cast<int>(hipMemsetAsync(parts, 0, sizeof(double) * 2 * c * groups, s));
   if (!z) return CODA_EINVAL;
   const int rb = rows_per_block(groups, rows, c);
   clear_sticky_error();
-  hipLaunchKernelGGL(bn_stats_kernel, row_grid(groups, rows, rb), dim3(kT), 0, s, z, rows, c, rb, sums);
+  hipLaunchKernelGGL(bn_stats_kernel, row_grid(groups, rows, rb), dim3(kT), 0, s, z, rows, c, rb, parts);
   return launch_status();
 }
 
-CODA_API int coda_tok_bn_finalize_f32(const double *sums, const float *gamma, const float *beta, int groups,
-                                      int c, double count, float eps, float *prm, float *stat, void *stream) {
-  if (groups <= 0 || c <= 0 || !(count > 0.0) || !sums || !gamma || !beta || !prm) return CODA_EINVAL;
+CODA_API int coda_tok_bn_finalize_f32(const double *sums, int nparts, const float *gamma, const float *beta,
+                                      int groups, int c, double count, float eps, float *prm, float *stat,
+                                      void *stream) {
+  if (groups <= 0 || c <= 0 || nparts <= 0 || !(count > 0.0) || !sums || !gamma || !beta || !prm) return CODA_EINVAL;
   clear_sticky_error();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256, groups), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), sums, gamma, beta, c, count, eps, prm, stat);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh, groups), dim3(kFinT), 0,
+                     static_cast<hipStream_t>(stream), sums, nparts, groups, gamma, beta, c, count, eps, prm, stat);
   return launch_status();
 }
 
@@ -337,31 +396,29 @@ CODA_API int coda_tok_bn_act_f32(const float *z, const float *prm, int groups, l
 
 CODA_API int coda_tok_bn_act_bwd_stats_f32(const float *da, const float *z, const float *prm, int groups,
                                            long long rows, int c, int relu, float dropout_p, uint64_t seed,
-                                           const uint64_t *seed_dev, double *sums, void *stream) {
-  if (groups <= 0 || rows < 0 || bad_c(c) || bad_p(dropout_p) || !sums) return CODA_EINVAL;
+                                           const uint64_t *seed_dev, double *parts, void *stream) {
+  if (groups <= 0 || rows < 0 || bad_c(c) || bad_p(dropout_p) || !parts) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * c * groups, s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  if (rows == 0) return CODA_OK;
+  if (rows == 0) return static_cast<int>(hipMemsetAsync(parts, 0, sizeof(double) * 2 * c * groups, s));
   if (!da || !z || !prm) return CODA_EINVAL;
   const int rb = rows_per_block(groups, rows, c);
   const Drop dr = make_drop(dropout_p, seed, seed_dev);
   clear_sticky_error();
-  if (relu) hipLaunchKernelGGL(bn_act_bwd_stats_kernel<true>, row_grid(groups, rows, rb), dim3(kT), 0, s, da, z, prm, rows, c, rb, dr, sums);
-  else hipLaunchKernelGGL(bn_act_bwd_stats_kernel<false>, row_grid(groups, rows, rb), dim3(kT), 0, s, da, z, prm, rows, c, rb, dr, sums);
+  if (relu) hipLaunchKernelGGL(bn_act_bwd_stats_kernel<true>, row_grid(groups, rows, rb), dim3(kT), 0, s, da, z, prm, rows, c, rb, dr, parts);
+  else hipLaunchKernelGGL(bn_act_bwd_stats_kernel<false>, row_grid(groups, rows, rb), dim3(kT), 0, s, da, z, prm, rows, c, rb, dr, parts);
   return launch_status();
 }
 
-CODA_API int coda_tok_bn_bwd_finalize_f32(const double *sums_local, const double *sums_total, const float *gamma,
-                                          const float *prm, int groups, int c, double count, float *prmb,
-                                          float *dgamma, float *dbeta, void *stream) {
-  if (groups <= 0 || c <= 0 || !(count > 0.0) || !sums_local || !sums_total || !gamma || !prm || !prmb ||
-      !dgamma || !dbeta)
+CODA_API int coda_tok_bn_bwd_finalize_f32(const double *sums_local, int nparts, const double *sums_total,
+                                          const float *gamma, const float *prm, int groups, int c, double count,
+                                          float *prmb, float *dgamma, float *dbeta, void *stream) {
+  if (groups <= 0 || c <= 0 || nparts <= 0 || !(count > 0.0) || !sums_local || !gamma || !prm || !prmb || !dgamma ||
+      !dbeta)
     return CODA_EINVAL;
   clear_sticky_error();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256, groups), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), sums_local, sums_total, gamma, prm, c, count, prmb, dgamma,
-                     dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + kFinCh - 1) / kFinCh, groups), dim3(kFinT), 0,
+                     static_cast<hipStream_t>(stream), sums_local, nparts, sums_total, groups, gamma, prm, c, count,
+                     prmb, dgamma, dbeta);
   return launch_status();
 }
 

@@ -4,9 +4,11 @@
 //
 // LayerNorm kernels: one wave per token row, a lane owns float4 chunks at channels
 // 256*k + 4*lane (k < NV), so each wave instruction reads/writes 1 KiB contiguous.  Row
-// statistics are wave reductions (two-pass: mean, then centred variance).  A block is 4
-// waves; the backward keeps per-lane column accumulators over the rows its wave visits and
-// writes one (3,C) partial per block.
+// statistics are wave reductions (two-pass: mean, then centred variance).  A forward block
+// is 4 waves; the backward keeps per-lane column accumulators over the rows its wave visits
+// and writes one (3,C) partial per block, so its blocks are 16 / NV waves (48 KB of LDS for
+// the cross-wave sum): the same number of partials with 4 x the waves in flight -- the
+// decoder's 2048 rows are one row per wave, the encoder's 16 384 four.
 #include "coda_token_ops.h"
 #include "common.hip.h"
 #include "dropout.hip.h"
@@ -112,8 +114,11 @@ struct LnBwd {
   Drop dr;
 };
 
+constexpr int bwd_waves(int nv) { return 16 / nv; }
+
 template <int NV>
-__global__ __launch_bounds__(kThreads) void add_ln_bwd_kernel(LnBwd p) {
+__global__ __launch_bounds__(bwd_waves(NV) * kWave) void add_ln_bwd_kernel(LnBwd p) {
+  constexpr int kWavesPerBlock = bwd_waves(NV);  // (shadows the forward's 4)
   __shared__ float4 s_acc[kWavesPerBlock][3][NV][kWave];
   const int lane = lane_id(), w = wave_id();
   const uint32_t seed = p.dr.thresh24 ? fold_seed(p.dr.seed, p.dr.seed_dev) : 0u;
@@ -337,8 +342,10 @@ int ln_blocks(long long rows) {  // forward: a wave per row, 4 rows per block an
   const long long want = (rows + kWavesPerBlock - 1) / kWavesPerBlock;
   return static_cast<int>(want < 1 ? 1 : (want > 4096 ? 4096 : want));
 }
-int ln_bwd_blocks(long long rows) {  // backward: >= 4 passes per block, one (3,C) partial per block
-  const long long want = (rows + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+int ln_bwd_nv(int c) { return c <= 256 ? 1 : (c <= 512 ? 2 : 4); }
+int ln_bwd_blocks(long long rows, int c) {  // backward: one (3,C) partial per block, at most 256 of them
+  const int waves = bwd_waves(ln_bwd_nv(c));
+  const long long want = (rows + waves - 1) / waves;
   return static_cast<int>(want < 1 ? 1 : (want > 256 ? 256 : want));
 }
 bool bad_row_c(int c) { return c < 4 || c > 1024 || (c % 4) != 0 || (kT % (c / 4)) != 0; }
@@ -379,7 +386,7 @@ CODA_API int coda_tok_add_ln_fwd_f32(const float *x, const float *bias, const fl
 
 CODA_API int coda_tok_add_ln_bwd_blocks(long long rows, int c) {
   if (rows < 0 || bad_ln_c(c)) return CODA_EINVAL;
-  return ln_bwd_blocks(rows);
+  return ln_bwd_blocks(rows, c);
 }
 
 CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, const float *s_in,
@@ -392,7 +399,7 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
   if (!gamma && !ds) return CODA_EINVAL;
   if (!dres_out && !dx_out) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int blocks = ln_bwd_blocks(rows);
+  const int blocks = ln_bwd_blocks(rows, c);
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(partials, 0, sizeof(float) * 3 * c * blocks, s);
     if (e == hipSuccess && sums_out) e = hipMemsetAsync(sums_out, 0, sizeof(float) * 3 * c, s);
@@ -402,9 +409,9 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
           make_drop(dropout_p, seed, seed_dev)};
   const dim3 grid(blocks);
   clear_sticky_error();
-  if (c <= 256) hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, dim3(kThreads), 0, s, p);
-  else if (c <= 512) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, dim3(kThreads), 0, s, p);
-  else hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, dim3(kThreads), 0, s, p);
+  if (c <= 256) hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, dim3(bwd_waves(1) * kWave), 0, s, p);
+  else if (c <= 512) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, dim3(bwd_waves(2) * kWave), 0, s, p);
+  else hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, dim3(bwd_waves(4) * kWave), 0, s, p);
   if (sums_out)  // second launch of the same call: fixed-order reduction of the per-block partials
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((3 * c + 63) / 64, 1), dim3(1024), 0, s, partials, blocks, 3 * c,
                        sums_out);

@@ -32,6 +32,14 @@ def _call(name, *args):
     _lib.check(getattr(lib, name)(*args, _lib.current_stream_handle()), name)
 
 
+def _parts(groups, rows, c):
+    """Partial sums per group and channel the statistics kernels leave for this shape (include/coda_token_ops.h)."""
+    n = _lib.load().coda_tok_bn_parts(groups, rows, c)
+    if n <= 0:
+        raise RuntimeError("coda_tok_bn_parts(%d, %d, %d) failed: %d" % (groups, rows, c, n))
+    return n
+
+
 def _is_sync(bn):
     return isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() \
         and dist.get_world_size(bn.process_group) > 1
@@ -168,16 +176,19 @@ class _HiddenStack(torch.autograd.Function):
                     z = torch.bmm(x.unsqueeze(0).expand(groups, -1, -1), ws[i].transpose(1, 2))
             else:
                 z = torch.bmm(cur, ws[i].transpose(1, 2))
-            sums = torch.empty((groups, 2, c), dtype=torch.float64, device=dev)
+            # one partial sum per row block; the finalize kernel adds them (no atomics, no memset)
+            nparts = _parts(groups, t, c)
+            sums = torch.empty((nparts, groups, 2, c), dtype=torch.float64, device=dev)
             _call("coda_tok_bn_stats_f32", _p(z), groups, t, c, _p(sums))
             world = 1
             if _is_sync(bns[0]):
                 world = dist.get_world_size(bns[0].process_group)
+                sums, nparts = sums.sum(0), 1
                 dist.all_reduce(sums, group=bns[0].process_group)
             n = float(t * world)
             prm = torch.empty((groups, 4, c), dtype=torch.float32, device=dev)
             stat = torch.empty((groups, 2, c), dtype=torch.float32, device=dev)
-            _call("coda_tok_bn_finalize_f32", _p(sums), _p(gammas[i]), _p(betas[i]), groups, c, n,
+            _call("coda_tok_bn_finalize_f32", _p(sums), nparts, _p(gammas[i]), _p(betas[i]), groups, c, n,
                   float(bns[0].eps), _p(prm), _p(stat))
             for g, bn in enumerate(bns):
                 run_stats += [bn.running_mean, bn.running_var]
@@ -281,17 +292,19 @@ class _HiddenStack(torch.autograd.Function):
             bns, relu, p = blocks[i]
             seed, seed_dev, n = ctx.seeds[i]
             c = ws[i].shape[1]
-            sums = torch.empty((groups, 2, c), dtype=torch.float64, device=dev)
+            nparts = _parts(groups, t, c)
+            sums = torch.empty((nparts, groups, 2, c), dtype=torch.float64, device=dev)
             _call("coda_tok_bn_act_bwd_stats_f32", _p(da), _p(zs[i]), _p(prms[i]), groups, t, c, int(relu), p, seed,
                   _p(seed_dev), _p(sums))
-            total = sums
+            total = None  # single process: the local sums
             if _is_sync(bns[0]):
+                sums, nparts = sums.sum(0), 1
                 total = sums.clone()
                 dist.all_reduce(total, group=bns[0].process_group)
             prmb = torch.empty((groups, 3, c), dtype=torch.float32, device=dev)
             dgamma = torch.empty((groups, c), dtype=torch.float32, device=dev)
             dbeta = torch.empty((groups, c), dtype=torch.float32, device=dev)
-            _call("coda_tok_bn_bwd_finalize_f32", _p(sums), _p(total), _p(gammas[i]), _p(prms[i]), groups, c, n,
+            _call("coda_tok_bn_bwd_finalize_f32", _p(sums), nparts, _p(total), _p(gammas[i]), _p(prms[i]), groups, c, n,
                   _p(prmb), _p(dgamma), _p(dbeta))
             dz = da if (dout is None or da.data_ptr() != dout.data_ptr()) else torch.empty_like(da)
             _call("coda_tok_bn_act_bwd_apply_f32", _p(da), _p(zs[i]), _p(prms[i]), _p(prmb), groups, t, c, int(relu),

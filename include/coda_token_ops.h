@@ -14,8 +14,10 @@
  *   forward    stats -> finalize -> act        a = dropout(relu(z * scale + shift))
  *   backward   act_bwd_stats -> bwd_finalize -> act_bwd_apply
  *
- * Batch statistics are summed in fp64.  With SyncBatchNorm the caller all-reduces the
- * `sums` buffers between the stats and the finalize call.  Dropout masks come from a
+ * Batch statistics are summed in fp64: the two statistics kernels leave one partial sum per row block
+ * ("parts", coda_tok_bn_parts() of them), the finalize kernels add them in index order (no atomics: 512 blocks
+ * queueing on 2*C result addresses took 6 x the streaming time, and the result is deterministic).  With
+ * SyncBatchNorm the caller sums the parts itself, all-reduces the (G,2,C) result and passes it with nparts = 1.  Dropout masks come from a
  * counter hash of (seed, element index) and are regenerated, not stored, in the backward.
  *
  * C must be a multiple of 4 with C/4 dividing 256 (4 ... 1024).  Conventions as in
@@ -32,15 +34,21 @@
 extern "C" {
 #endif
 
-/* sums (G,2,C) doubles, zeroed by the call: [g][0][c] = sum_r z, [g][1][c] = sum_r z^2 */
-int coda_tok_bn_stats_f32(const float *z, int groups, long long rows, int c, double *sums,
+/* number of row blocks (= partial sums per group and channel) of the two statistics kernels for this shape (>= 1),
+ * or CODA_EINVAL */
+int coda_tok_bn_parts(int groups, long long rows, int c);
+
+/* parts (P,G,2,C) doubles, P = coda_tok_bn_parts(), every entry written by the call:
+ * sum_p parts[p][g][0][c] = sum_r z, sum_p parts[p][g][1][c] = sum_r z^2 */
+int coda_tok_bn_stats_f32(const float *z, int groups, long long rows, int c, double *parts,
                           void *stream);
 
-/* Batch-norm parameters of this step from the (all-reduced) sums over `count` tokens:
+/* Batch-norm parameters of this step from the sums over `count` tokens -- sums (nparts,G,2,C), added over the
+ * leading index in order (nparts = 1: sums that are complete already, e.g. all-reduced):
  * prm (G,4,C) = scale (gamma*invstd), shift (beta - mean*scale), mean, invstd;
  * stat (G,2,C) = mean, unbiased variance (what the running statistics take; may be NULL).
  * gamma / beta (G,C). */
-int coda_tok_bn_finalize_f32(const double *sums, const float *gamma, const float *beta,
+int coda_tok_bn_finalize_f32(const double *sums, int nparts, const float *gamma, const float *beta,
                              int groups, int c, double count, float eps, float *prm,
                              float *stat, void *stream);
 
@@ -51,16 +59,16 @@ int coda_tok_bn_act_f32(const float *z, const float *prm, int groups, long long 
                         float *a, void *stream);
 
 /* d = da * keep/(1-p) where the activation is positive (relu) else da * keep/(1-p);
- * sums (G,2,C) doubles, zeroed by the call: sum_r d, sum_r d * xhat */
+ * parts (P,G,2,C) doubles as above: sum_r d, sum_r d * xhat */
 int coda_tok_bn_act_bwd_stats_f32(const float *da, const float *z, const float *prm,
                                   int groups, long long rows, int c, int relu,
                                   float dropout_p, uint64_t seed, const uint64_t *seed_dev,
-                                  double *sums, void *stream);
+                                  double *parts, void *stream);
 
-/* From the local sums (-> dgamma = sum d*xhat, dbeta = sum d, both (G,C) fp32) and the
- * all-reduced sums over `count` tokens (== local sums single-process):
+/* From the local sums (nparts_local,G,2,C) (-> dgamma = sum d*xhat, dbeta = sum d, both (G,C) fp32) and the
+ * all-reduced sums (G,2,C) over `count` tokens (NULL: the local sums, single process):
  * prmb (G,3,C) = gamma*invstd, sum d / count, sum d*xhat / count. */
-int coda_tok_bn_bwd_finalize_f32(const double *sums_local, const double *sums_total,
+int coda_tok_bn_bwd_finalize_f32(const double *sums_local, int nparts_local, const double *sums_total,
                                  const float *gamma, const float *prm, int groups, int c,
                                  double count, float *prmb, float *dgamma, float *dbeta,
                                  void *stream);

@@ -139,6 +139,70 @@ def test_dropout_statistics_and_backward_mask(dev):
     assert torch.allclose(dz[kept], torch.full_like(dz[kept], 1 / (1 - p)), rtol=1e-6)
 
 
+@pytest.mark.parametrize("g,r,c", [(1, 16384, 256), (6, 12288, 256), (1, 2048, 512), (2, 1001, 4), (3, 77, 1024),
+                                   (1, 5, 64)])
+def test_statistics_as_partial_sums(dev, g, r, c):
+    """The statistics kernels leave one partial sum per row block (no atomics); the finalize kernels add them in order:
+    the summed parts are the fp64 column sums, the finalized parameters those of BatchNorm1d, bit-identical run to run."""
+    lib = _lib.load()
+    gen = torch.Generator(device="cpu").manual_seed(g * 1000 + c)
+    z = (torch.randn(g, r, c, generator=gen) * 2 + 0.5).to(dev)
+    nparts = lib.coda_tok_bn_parts(g, r, c)
+    assert nparts >= 1
+    parts = torch.full((nparts, g, 2, c), float("nan"), dtype=torch.float64, device=dev)   # every entry must be written
+    _lib.check(lib.coda_tok_bn_stats_f32(z.data_ptr(), g, r, c, parts.data_ptr(), None), "stats")
+    sums = parts.sum(0)
+    zd = z.double()
+    assert torch.allclose(sums[:, 0], zd.sum(1), rtol=1e-6, atol=1e-6 * r)
+    assert torch.allclose(sums[:, 1], (zd * zd).sum(1), rtol=1e-6)
+    gamma = torch.rand(g, c, device=dev) + 0.5
+    beta = torch.randn(g, c, device=dev)
+    outs = []
+    for src, n in ((parts, nparts), (sums.contiguous(), 1), (parts, nparts)):
+        prm = torch.empty(g, 4, c, device=dev)
+        stat = torch.empty(g, 2, c, device=dev)
+        _lib.check(lib.coda_tok_bn_finalize_f32(src.data_ptr(), n, gamma.data_ptr(), beta.data_ptr(), g, c, float(r),
+                                                1e-5, prm.data_ptr(), stat.data_ptr(), None), "finalize")
+        outs.append((prm, stat))
+    mean = zd.mean(1)
+    var = zd.var(1, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    prm, stat = outs[0]
+    assert torch.allclose(prm[:, 2].double(), mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(prm[:, 3].double(), invstd, rtol=1e-5)
+    assert torch.allclose(prm[:, 0].double(), gamma.double() * invstd, rtol=1e-5)
+    assert torch.allclose(prm[:, 1].double(), beta.double() - mean * gamma.double() * invstd, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(stat[:, 1].double(), var * (r / max(r - 1, 1)), rtol=1e-5)
+    assert torch.allclose(outs[1][0], prm, rtol=1e-6, atol=1e-7)          # already reduced sums, nparts = 1
+    assert torch.equal(outs[2][0], prm) and torch.equal(outs[2][1], stat)  # deterministic
+    # backward statistics: sum d, sum d * xhat (no ReLU, no dropout: d = da), local parts vs an explicit total
+    da = torch.randn(g, r, c, generator=gen).to(dev)
+    bparts = torch.full((nparts, g, 2, c), float("nan"), dtype=torch.float64, device=dev)
+    _lib.check(lib.coda_tok_bn_act_bwd_stats_f32(da.data_ptr(), z.data_ptr(), prm.data_ptr(), g, r, c, 0, 0.0, 0, None,
+                                                 bparts.data_ptr(), None), "bwd_stats")
+    bs = bparts.sum(0)
+    xhat = (zd - prm[:, 2].double().unsqueeze(1)) * prm[:, 3].double().unsqueeze(1)
+    assert torch.allclose(bs[:, 0], da.double().sum(1), rtol=1e-5, atol=1e-5 * r ** 0.5)
+    assert torch.allclose(bs[:, 1], (da.double() * xhat).sum(1), rtol=1e-5, atol=1e-5 * r ** 0.5)
+    res = []
+    for total in (None, (2 * bs).contiguous()):
+        prmb = torch.empty(g, 3, c, device=dev)
+        dgamma = torch.empty(g, c, device=dev)
+        dbeta = torch.empty(g, c, device=dev)
+        _lib.check(lib.coda_tok_bn_bwd_finalize_f32(bparts.data_ptr(), nparts, total.data_ptr() if total is not None
+                                                    else None, gamma.data_ptr(), prm.data_ptr(), g, c, float(r),
+                                                    prmb.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), None), "bwd_fin")
+        res.append((prmb, dgamma, dbeta))
+    prmb, dgamma, dbeta = res[0]
+    assert torch.allclose(dbeta.double(), bs[:, 0], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(dgamma.double(), bs[:, 1], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(prmb[:, 1].double(), bs[:, 0] / r, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(prmb[:, 2].double(), bs[:, 1] / r, rtol=1e-6, atol=1e-7)
+    assert torch.equal(prmb[:, 0], gamma * prm[:, 3])
+    assert torch.allclose(res[1][0][:, 1:], 2 * prmb[:, 1:], rtol=1e-6, atol=1e-7)   # the all-reduced totals are used
+    assert torch.equal(res[1][1], dgamma) and torch.equal(res[1][2], dbeta)          # ... but not for dgamma / dbeta
+
+
 def test_bad_arguments_are_rejected(dev):
     lib = _lib.load()
     z = torch.zeros(1, 8, 16, device=dev)
@@ -149,3 +213,4 @@ def test_bad_arguments_are_rejected(dev):
     assert lib.coda_tok_bn_act_f32(z.data_ptr(), z.data_ptr(), 1, 8, 16, 1, 1.0, 0, None, z.data_ptr(),
                                    None) == _lib.CODA_EINVAL  # p == 1
     assert lib.coda_tok_bn_stats_f32(None, 1, 0, 16, sums.data_ptr(), None) == _lib.CODA_OK  # empty input
+    assert lib.coda_tok_bn_parts(1, 0, 16) == 1 and lib.coda_tok_bn_parts(1, 8, 10) == _lib.CODA_EINVAL
