@@ -135,25 +135,44 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
   const float *arow = a + static_cast<size_t>(m0 + l31) * lda + kw + 16 * half;
   const float *brow = BT ? b + static_cast<size_t>(n0 + l31) * ldb + kw + 16 * half
                          : b + static_cast<size_t>(kw + 16 * half) * ldb + n0 + l31;
-  for (int k0 = 0; k0 < kc; k0 += kStep) {
-    float av[16], bv[16];
+  // Two register sets, two steps per pass: the loads of both steps are issued together and the 16 MFMAs of the first
+  // run under the second's (a wave has only K / 128 steps -- two at K = 256 -- and every step used to pay a full
+  // memory round trip before its MFMAs).
+  float av[2][16], bv[2][16];
+  auto load = [&](int set, int k0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 t = *reinterpret_cast<const float4 *>(arow + k0 + 4 * q);
-      av[4 * q] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+      av[set][4 * q] = t.x; av[set][4 * q + 1] = t.y; av[set][4 * q + 2] = t.z; av[set][4 * q + 3] = t.w;
     }
     if (BT) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 t = *reinterpret_cast<const float4 *>(brow + k0 + 4 * q);
-        bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+        bv[set][4 * q] = t.x; bv[set][4 * q + 1] = t.y; bv[set][4 * q + 2] = t.z; bv[set][4 * q + 3] = t.w;
       }
     } else {
 #pragma unroll
-      for (int sidx = 0; sidx < 16; ++sidx) bv[sidx] = brow[static_cast<size_t>(k0 + sidx) * ldb];
+      for (int sidx = 0; sidx < 16; ++sidx) bv[set][sidx] = brow[static_cast<size_t>(k0 + sidx) * ldb];
     }
+  };
+  auto mfma = [&](int set) {
 #pragma unroll
-    for (int sidx = 0; sidx < 16; ++sidx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], bv[sidx], acc, 0, 0, 0);
+    for (int sidx = 0; sidx < 16; ++sidx)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][sidx], bv[set][sidx], acc, 0, 0, 0);
+  };
+  int k0 = 0;
+  for (; k0 + 2 * kStep <= kc; k0 += 2 * kStep) {  // (no branch between the loads and the MFMAs: partial vmcnt waits)
+    load(0, k0);
+    load(1, k0 + kStep);
+    __builtin_amdgcn_sched_barrier(0);  // (else the scheduler sinks every load next to its MFMA: one round trip each)
+    mfma(0);
+    mfma(1);
+  }
+  if (k0 < kc) {
+    load(0, k0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(0);
   }
   if (w > 0) {
 #pragma unroll

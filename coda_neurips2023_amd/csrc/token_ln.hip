@@ -232,12 +232,40 @@ struct ColsumBatch {
   CodaColsumItem item[kMaxColsumItems];
 };
 
+// Items of at most 16 partial rows (the split-K chunk sums of the weight gradients: 8 rows x up to 196 608 columns) take
+// four columns per thread: a quarter of the workgroups, 16-byte accesses, the same order of additions.
+__host__ __device__ __forceinline__ bool colsum_item_wide(const CodaColsumItem &it) {
+  return it.blocks <= 16 && (it.n & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(it.partials) | reinterpret_cast<uintptr_t>(it.out)) & 15) == 0;
+}
+__host__ __device__ __forceinline__ int colsum_item_tiles(const CodaColsumItem &it) {
+  return colsum_item_wide(it) ? (it.n + 255) / 256 : (it.n + 63) / 64;
+}
+
 // the same reduction for many (partials, out) pairs: blockIdx.y = item, blockIdx.z = group, blockIdx.x = 64 columns
+// (256 for the wide items)
 __global__ __launch_bounds__(1024) void colsum_finalize_grouped_kernel(const ColsumBatch batch) {
   __shared__ float s_part[16][64];
+  __shared__ float4 s_part4[16][64];
   const CodaColsumItem &it = batch.item[blockIdx.y];
-  if (static_cast<int>(blockIdx.x) * 64 >= it.n || static_cast<int>(blockIdx.z) >= it.groups) return;  // block-uniform
+  if (static_cast<int>(blockIdx.x) >= colsum_item_tiles(it) || static_cast<int>(blockIdx.z) >= it.groups)
+    return;  // block-uniform
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  if (colsum_item_wide(it)) {
+    const int col = blockIdx.x * 256 + 4 * lane, n = it.n;
+    const float *pg = it.partials + static_cast<size_t>(blockIdx.z) * it.blocks * n;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n && slice < it.blocks) t = ld4(pg + static_cast<size_t>(slice) * n + col);
+    s_part4[slice][lane] = t;
+    __syncthreads();
+    if (slice == 0 && col < n) {
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r = add4(r, s_part4[q][lane]);
+      st4(it.out + static_cast<size_t>(blockIdx.z) * n + col, r);
+    }
+    return;
+  }
   const int col = blockIdx.x * 64 + lane, n = it.n, blocks = it.blocks;
   const float *pg = it.partials + static_cast<size_t>(blockIdx.z) * blocks * n;
   float t = 0.f;
@@ -437,13 +465,13 @@ CODA_API int coda_tok_colsum_finalize_grouped_f32(const CodaColsumItem *items, i
   for (int first = 0; first < count; first += kMaxColsumItems) {
     ColsumBatch b;
     const int m = min(kMaxColsumItems, count - first);
-    int max_n = 0, max_g = 0;
+    int max_tiles = 0, max_g = 0;
     for (int i = 0; i < m; ++i) {
       b.item[i] = items[first + i];
-      max_n = max(max_n, b.item[i].n);
+      max_tiles = max(max_tiles, colsum_item_tiles(b.item[i]));
       max_g = max(max_g, b.item[i].groups);
     }
-    hipLaunchKernelGGL(colsum_finalize_grouped_kernel, dim3((max_n + 63) / 64, m, max_g), dim3(1024), 0,
+    hipLaunchKernelGGL(colsum_finalize_grouped_kernel, dim3(max_tiles, m, max_g), dim3(1024), 0,
                        static_cast<hipStream_t>(stream), b);
     const int st = launch_status();
     if (st != CODA_OK) return st;

@@ -172,6 +172,44 @@ def test_grouped_weight_gradients(dev):
         assert torch.equal(a, b)
 
 
+def test_grouped_column_sums(dev):
+    """coda_tok_colsum_finalize_grouped_f32 through DeferredWeightGrads.add_colsum / add_split: out = sum over the partial
+    rows, for the few-rows / many-columns items of the split weight gradients (four columns per thread), the many-rows
+    items of the bias and LayerNorm gradients (one), outputs that are not 16-byte aligned, column counts that are not
+    multiples of 4 or 256, several groups -- all in one flush, in a fixed order of additions."""
+    g = torch.Generator().manual_seed(9)
+    cases = [(8, 65536, 1, 0), (8, 196608, 1, 0), (16, 1000, 1, 0), (3, 260, 2, 0), (8, 1024, 1, 1), (17, 768, 1, 0),
+             (256, 768, 1, 0), (40, 100, 3, 0), (1, 4, 1, 0), (12, 6, 1, 0), (8, 4096, 1, 0), (8, 4100, 1, 0)]
+    outs = []
+    for rep in range(2):
+        d = gemm.DeferredWeightGrads(sums_only=True)
+        res = []
+        gen = torch.Generator().manual_seed(10)
+        for blocks, n, groups, shift in cases:
+            part = torch.randn(groups, blocks, n, generator=gen).to(dev)
+            buf = torch.full((groups * n + 4,), float("nan"), device=dev)
+            out = buf[shift:shift + groups * n].view(groups, n)     # shift 1: a 4-byte-aligned output
+            d.add_colsum(part, out, blocks, n, groups)
+            res.append((part, out))
+        dy = torch.randn(8192, 128, generator=gen).to(dev)           # add_split: 4 chunks of 2048 rows
+        x = torch.randn(8192, 256, generator=gen).to(dev)
+        w = torch.full((128, 256), float("nan"), device=dev)
+        d.add(w, dy, x)
+        d.flush()
+        for (blocks, n, groups, shift), (part, out) in zip(cases, res):
+            seq = torch.zeros(groups, n, device=dev)
+            for b in range(blocks):
+                seq += part[:, b]
+            if blocks <= 16:      # one partial row per slice: the additions are sequential in both kernels
+                assert torch.equal(out, seq), (blocks, n, groups, shift)
+            else:
+                assert rel(out, part.double().sum(1)) < 1e-6, (blocks, n, groups)
+        assert rel(w, dy.double().t() @ x.double()) < 1e-5
+        outs.append([o.clone() for _, o in res] + [w.clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32"])
 @pytest.mark.parametrize("epilogue,beta,alpha", [(0, 0.0, 1.0), (1, 0.0, 1.0), (1, 1.0, 0.5), (2, 0.0, 1.702)])
 def test_gemm_ex_epilogues(dev, dtype, epilogue, beta, alpha):
