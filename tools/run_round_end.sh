@@ -24,12 +24,15 @@ CODA_BENCH_LEGS=headline rocprofv3 --kernel-trace --stats --output-format csv -d
 python $R/tools/trace_by_grid.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) > $R/gpurun_out/final_prof/attention_by_grid.csv
 python $R/tools/trace_gaps.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) 0.3 > $R/gpurun_out/final_prof/gaps.txt
 python $R/tools/prof_summary.py $(find $R/gpurun_out/final_prof -name run_kernel_stats.csv) auto > $R/gpurun_out/final_prof/summary.md
+python $R/tools/trace_by_grid.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) _kernel > $R/gpurun_out/final_prof/all_by_grid.csv
 find $R/gpurun_out/final_prof -name run_kernel_trace.csv -delete   # tens of MB; the stats file is what gets committed
 cd $R
+if [ -z "$SKIP_PMC" ]; then   # (SKIP_PMC=1: the counter passes, when the kernels they look at have not changed)
 timeout 300 python tools/sa_prof.py > gpurun_out/final_sa_prof.txt 2>&1
 bash tools/pmc_sa.sh > /dev/null 2>&1
 bash tools/pmc_attn.sh > gpurun_out/final_pmc_attn_hbm.txt 2>&1
 bash tools/pmc_attn_mfma.sh > gpurun_out/final_pmc_attn_mfma.txt 2>&1
+fi
 python - <<'PY'
 import json
 for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_bench_force_ddp", "final_prof_bench"):
