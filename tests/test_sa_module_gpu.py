@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-3
 
 
-def _close(got, ref, what):
+def _close(got, ref, what, tol=None):
     got = got.detach().cpu().numpy()
     scale = np.abs(ref).max() + 1e-12
     err = np.abs(got - ref).max() / scale
-    assert err < RTOL, f"{what}: max err / max|ref| = {err:.3e}"
+    assert err < (RTOL if tol is None else tol), f"{what}: max err / max|ref| = {err:.3e}"
 
 
 @pytest.mark.parametrize("tag,c_in", [("xyz", 0), ("feat", 5)])
@@ -93,6 +93,37 @@ def test_pre_encoder_widths_match_reference_through_the_mfma_pipeline(dev, monke
     with torch.no_grad():
         _, new_feat_eval, _ = mod(xyz)
     _close(new_feat_eval, g["new_feat_eval"], "eval-mode features")
+
+
+def test_prepared_front_equals_the_inline_forward(dev):
+    """forward(xyz, prepared=prepare(xyz)) -- the sampling prefetcher's route through the MFMA pipeline -- equals
+    forward(xyz): same indices, features, parameter gradients and running statistics (a quarter of the BatchNorm
+    gammas negative: min-pooling channels)."""
+    from coda_neurips2023_amd.synthetic_scenes import make_batch
+    pc, _, _ = make_batch(3, 6000, seed=21)
+    xyz = torch.from_numpy(pc).to(dev)
+    torch.manual_seed(4)
+    mods = [pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=256, radius=0.2, nsample=64,
+                                                    normalize_xyz=True).to(dev).train() for _ in range(2)]
+    mods[1].load_state_dict(mods[0].state_dict())
+    with torch.no_grad():
+        for m in mods:
+            for bn in (layer.bn.bn for layer in m.mlp_module.children()):
+                bn.weight.mul_(torch.where(torch.arange(bn.weight.numel(), device=dev) % 4 == 0, -1.0, 1.0))
+    gw = torch.randn(3, 256, 256, device=dev)
+    ref_xyz, ref_feat, ref_inds = mods[0](xyz)
+    (ref_feat * gw).sum().backward()
+    prepared = mods[1].prepare(xyz)
+    assert prepared is not None and "packed" in prepared
+    new_xyz, feat, inds = mods[1](xyz, prepared=prepared)
+    assert torch.equal(inds, ref_inds) and torch.equal(new_xyz, ref_xyz)
+    _close(feat, ref_feat.detach().cpu().numpy(), "features", tol=1e-5)
+    (feat * gw).sum().backward()
+    for (k, p), (_, q) in zip(mods[1].named_parameters(), mods[0].named_parameters()):
+        _close(p.grad, q.grad.cpu().numpy(), f"grad {k}", tol=1e-4)
+    for (k, v), (_, w) in zip(mods[1].state_dict().items(), mods[0].state_dict().items()):
+        if v.dtype.is_floating_point:
+            _close(v, w.cpu().numpy(), f"state {k}", tol=1e-5)
 
 
 @pytest.mark.parametrize("dedup", ["1", "0"])
