@@ -453,17 +453,26 @@ __global__ __launch_bounds__(QW * kWave, (QW >= 8 && D == 64) ? 2 : 1) void mha_
 
   const int ntile = (p.s + kTile - 1) / kTile;
   if (q0 < p.l) {  // wave-uniform (all waves of a workgroup share the query tile)
+    // The prefetch of the wave's next tile is UNCONDITIONAL (the last one re-reads the final tile): behind an `if` the
+    // compiler has to assume at the join that the loads were NOT issued, and the waits it then places in front of the
+    // current tile's MFMAs (vmcnt(15) .. vmcnt(0), counted for 24 outstanding loads) drain the prefetch as well whenever
+    // it was -- every tile waited for the next tile's K / V before its second GEMM.  (Worth 1-2 % here, 6 % in the
+    // head-width-128 dQ kernel: with one wave per SIMD the exposed soft-max arithmetic is the larger share.)
     Frag fa, fb;
     int t = w;
-    if (t < ntile) load(fa, t * kTile);
-    while (t < ntile) {
-      if (t + QW < ntile) load(fb, (t + QW) * kTile);
-      compute(fa, t * kTile);
-      t += QW;
-      if (t >= ntile) break;
-      if (t + QW < ntile) load(fa, (t + QW) * kTile);
-      compute(fb, t * kTile);
-      t += QW;
+    const int last = ntile - 1;
+    if (t < ntile) {
+      load(fa, t * kTile);
+      while (true) {
+        load(fb, min(t + QW, last) * kTile);
+        compute(fa, t * kTile);
+        t += QW;
+        if (t >= ntile) break;
+        load(fa, min(t + QW, last) * kTile);
+        compute(fb, t * kTile);
+        t += QW;
+        if (t >= ntile) break;
+      }
     }
   }
 
@@ -1158,30 +1167,39 @@ __global__ __launch_bounds__(QW * kWave) void mha_bwd_dq_direct_kernel(MhaBwdPar
   const int ntile = (p.s + kTile - 1) / kTile;
   const bool wave_active = q0 < p.l;
   if (wave_active && D <= 64) {  // two register sets: the whole next tile in flight during this tile's MFMAs
+    // (unconditional prefetch, the last one re-reads the final tile: see mha_fwd_direct_kernel)
     Frag fa, fb;
     int t = w;
-    if (t < ntile) { load_kv(fa, t * kTile); load_kc(fa, t * kTile); }
-    while (t < ntile) {
-      if (t + QW < ntile) { load_kv(fb, (t + QW) * kTile); load_kc(fb, (t + QW) * kTile); }
-      scores(fa, t * kTile);
-      accumulate(fa);
-      t += QW;
-      if (t >= ntile) break;
-      if (t + QW < ntile) { load_kv(fa, (t + QW) * kTile); load_kc(fa, (t + QW) * kTile); }
-      scores(fb, t * kTile);
-      accumulate(fb);
-      t += QW;
+    const int last = ntile - 1;
+    if (t < ntile) {
+      load_kv(fa, t * kTile);
+      load_kc(fa, t * kTile);
+      while (true) {
+        load_kv(fb, min(t + QW, last) * kTile);
+        load_kc(fb, min(t + QW, last) * kTile);
+        scores(fa, t * kTile);
+        accumulate(fa);
+        t += QW;
+        if (t >= ntile) break;
+        load_kv(fa, min(t + QW, last) * kTile);
+        load_kc(fa, min(t + QW, last) * kTile);
+        scores(fb, t * kTile);
+        accumulate(fb);
+        t += QW;
+        if (t >= ntile) break;
+      }
     }
   } else if (wave_active) {
     // head width 128: 192 registers per fragment set -- one set, phased: the K columns of the CURRENT tile load
     // under its S / dP MFMAs (128 of them), the K / V rows of the NEXT tile under its dQ MFMAs (64) + soft-max
     Frag f;
     int t = w;
+    const int last = ntile - 1;
     if (t < ntile) load_kv(f, t * kTile);
     while (t < ntile) {
       load_kc(f, t * kTile);
       scores(f, t * kTile);
-      if (t + QW < ntile) load_kv(f, (t + QW) * kTile);
+      load_kv(f, min(t + QW, last) * kTile);  // (unconditional: exact waits in front of the dQ MFMAs)
       accumulate(f);
       t += QW;
     }
