@@ -84,9 +84,14 @@ __device__ __forceinline__ void store_tile(float *lds, const float4 (&regs)[ROWS
 // DB (non-SPLIT only): the same LDS holds two half-size stages; the global loads of stage i+1 are
 //                 in flight while stage i is computed and land in the other buffer afterwards --
 //                 one barrier per stage and no wave parked on an HBM round trip.
-template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
-__global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
-  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
+// QT (SPLIT only): query tiles per workgroup.  The split-key launches of the decoder are bound by the delivery of K / V
+//                 from L2 (8 workgroups per head each read the head's whole K and V: 256 MB per launch at 4.7 TB/s), not
+//                 by the MFMAs; with QT = 2 a workgroup is 2 x QW waves, wave (qt, ks) takes key tile ks of the stage for
+//                 query tile qt, and every staged tile serves two query tiles -- half the traffic.
+template <int D, int QW, bool SPLIT, bool GEN, bool DB = false, int QT = 1>
+__global__ __launch_bounds__(QW * QT * kWave) void mha_fwd_kernel(MhaParams p) {
+  static_assert(QT == 1 || SPLIT, "several query tiles per workgroup: split-key form only");
+  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * QT * kWave;
   // K/V tiles staged per step (SPLIT: one per wave; else all waves walk all of them)
   // (DB: two stages in LDS -- half-size ones in the same footprint for the long-sequence kernel,
   //  full-size ones, i.e. twice the LDS, for the split-key kernel where every wave needs its tile)
@@ -96,11 +101,12 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   float *s_v = s_dyn + TILES * kTile * LS;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int qt = SPLIT ? w / QW : 0, ks = SPLIT ? w % QW : w;  // SPLIT: query tile of the workgroup, key split
   const int half = lane >> 5, l31 = lane & 31;
   const TileHead th = tile_head(p.xcd_map);
   const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = SPLIT ? th.tile * kTile : (th.tile * QW + w) * kTile;
-  const int my_tile = SPLIT ? w : 0;
+  const int q0 = SPLIT ? (th.tile * QT + qt) * kTile : (th.tile * QW + w) * kTile;
+  const int my_tile = SPLIT ? ks : 0;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;  // wave-uniform
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;  // dense outputs
@@ -262,8 +268,9 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
   if (SPLIT && QW > 1) {
     // merge the per-wave partial softmax states: slot layout [wave-1][NT*16 + 2][64 lanes]
     __syncthreads();  // everyone is done with the K/V tiles
-    float *slot = s_dyn + static_cast<size_t>(w > 0 ? w - 1 : 0) * (NT * 16 + 2) * kWave;
-    if (w > 0) {
+    float *sq = s_dyn + static_cast<size_t>(qt) * (QW - 1) * (NT * 16 + 2) * kWave;  // this query tile's slots
+    float *slot = sq + static_cast<size_t>(ks > 0 ? ks - 1 : 0) * (NT * 16 + 2) * kWave;
+    if (ks > 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -272,9 +279,9 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
       slot[(NT * 16 + 1) * kWave + lane] = lsum;
     }
     __syncthreads();
-    if (w > 0) return;
+    if (ks > 0) return;
     float m_all = m;
-    for (int ww = 1; ww < QW; ++ww) m_all = fmaxf(m_all, s_dyn[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
+    for (int ww = 1; ww < QW; ++ww) m_all = fmaxf(m_all, sq[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
     const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
     const float f0 = fast_exp2(m - m_ref);
     lsum *= f0;
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(QW * kWave) void mha_fwd_kernel(MhaParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] *= f0;
     for (int ww = 1; ww < QW; ++ww) {
-      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
+      const float *sl = sq + static_cast<size_t>(ww - 1) * (NT * 16 + 2) * kWave;
       const float fw = fast_exp2(sl[(NT * 16) * kWave + lane] - m_ref);
       lsum += sl[(NT * 16 + 1) * kWave + lane] * fw;
 #pragma unroll
@@ -838,20 +845,29 @@ __device__ __forceinline__ float row_delta(const MhaBwdParams &p, const float (&
 
 // dQ: a wave owns 32 queries, loops over key tiles.  S^T / dP^T are evaluated transposed as in
 // the forward (lane = query, registers = keys), which is the A-operand layout of dQ = dS K.
-template <int D, int QW, bool SPLIT, bool GEN, bool DB = false>
-__global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) void mha_bwd_dq_kernel(MhaBwdParams p) {
-  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * kWave;
+// QT: see mha_fwd_kernel.  KH (SPLIT only): workgroups per query-tile group, each over 1 / KH of the keys -- 256 queries
+// give 4 workgroups of two query tiles per head, half the chip; with KH = 2 the chip is full again, every staged K / V
+// tile still serves two query tiles, and the two partial dQ meet in float atomics on a zeroed dQ (two addends: the sum
+// does not depend on their order).
+template <int D, int QW, bool SPLIT, bool GEN, bool DB = false, int QT = 1, int KH = 1>
+__global__ __launch_bounds__(QW * QT * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) void mha_bwd_dq_kernel(MhaBwdParams p) {
+  static_assert(QT == 1 || SPLIT, "several query tiles per workgroup: split-key form only");
+  static_assert(KH == 1 || (SPLIT && DB), "key halves: double-buffered split-key form only");
+  constexpr int HD = D / 2, NT = D / 32, LS = D + 4, THREADS = QW * QT * kWave;
   constexpr int TILES = (DB && !SPLIT) ? QW / 2 : QW;  // DB: two stages, double buffered (see mha_fwd_kernel)
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   float *s_k = s_dyn;
   float *s_v = s_dyn + TILES * kTile * LS;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int qt = SPLIT ? w / QW : 0, ks = SPLIT ? w % QW : w;
   const int half = lane >> 5, l31 = lane & 31;
   const TileHead th = tile_head(p.xcd_map);
   const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = SPLIT ? th.tile * kTile : (th.tile * QW + w) * kTile;
-  const int my_tile = SPLIT ? w : 0;
+  const int kh = KH > 1 ? th.tile % KH : 0, qgroup = KH > 1 ? th.tile / KH : th.tile;
+  const int q0 = SPLIT ? (qgroup * QT + qt) * kTile : (th.tile * QW + w) * kTile;
+  const int my_tile = SPLIT ? ks : 0;
+  const int s_begin = KH > 1 ? kh * (p.s / KH) : 0, s_end = KH > 1 ? s_begin + p.s / KH : p.s;  // (host: S % (KH * stage) == 0)
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
@@ -883,7 +899,7 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
     lse = p.lse[static_cast<size_t>(bh) * p.l + myq] * kLog2e;  // log2 units
     if (!p.fuse_delta) delta = p.delta[static_cast<size_t>(bh) * p.l + myq];
   }
-  if (p.fuse_delta) delta = row_delta<HD>(p, gf, myq, bh, rstride, head_off, half, !SPLIT || w == 0);
+  if (p.fuse_delta) delta = row_delta<HD>(p, gf, myq, bh, rstride, head_off, half, !SPLIT || (ks == 0 && kh == 0));
   // rows past the end or without any admissible key: exp2(x - inf) = 0 without a per-element test
   const float lse_eff = (myq < p.l && lse != -INFINITY) ? lse : INFINITY;
   f32x16 dq[NT];
@@ -897,15 +913,15 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
   constexpr int FROWS = DB ? TILES * kTile : THREADS * 4 / D;
   float4 rk[NLD], rv[NLD];
   if (DB) {  // prologue: stage 0 straight into buffer 0
-    fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, 0, p.s, tid);
-    fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, 0, p.s, tid);
+    fetch_tile<D, THREADS, FROWS>(rk, kbase, kstride, s_begin, p.s, tid);
+    fetch_tile<D, THREADS, FROWS>(rv, vbase, vstride, s_begin, p.s, tid);
     store_tile<D, THREADS, FROWS>(s_k, rk, tid);
     store_tile<D, THREADS, FROWS>(s_v, rv, tid);
     __syncthreads();
   }
   int stage = 0;
-  for (int sbase = 0; sbase < p.s; sbase += kTile * TILES, ++stage) {
-    const bool more = DB && sbase + kTile * TILES < p.s;
+  for (int sbase = s_begin; sbase < s_end; sbase += kTile * TILES, ++stage) {
+    const bool more = DB && sbase + kTile * TILES < s_end;
     if (!DB) {
       __syncthreads();
       load_tile<D, THREADS, kTile * TILES>(s_k, kbase, kstride, sbase, p.s, tid);
@@ -997,17 +1013,18 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
   }
   if (SPLIT && QW > 1) {  // sum the per-wave partial dQ through LDS: [wave-1][NT*16][64 lanes]
     __syncthreads();
-    if (w > 0) {
-      float *slot = s_dyn + static_cast<size_t>(w - 1) * (NT * 16) * kWave;
+    float *sq = s_dyn + static_cast<size_t>(qt) * (QW - 1) * (NT * 16) * kWave;  // this query tile's slots
+    if (ks > 0) {
+      float *slot = sq + static_cast<size_t>(ks - 1) * (NT * 16) * kWave;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * kWave + lane] = dq[t][r];
     }
     __syncthreads();
-    if (w > 0) return;
+    if (ks > 0) return;
     for (int ww = 1; ww < QW; ++ww) {
-      const float *sl = s_dyn + static_cast<size_t>(ww - 1) * (NT * 16) * kWave;
+      const float *sl = sq + static_cast<size_t>(ww - 1) * (NT * 16) * kWave;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1020,7 +1037,10 @@ __global__ __launch_bounds__(QW * kWave, ((DB && !SPLIT && D == 64) ? 2 : 1)) vo
       const int qq = q0 + crow(r, half);
       if (qq < p.l) {
         float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + NT * l31;
-        if (NT == 2) {
+        if (KH > 1) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) unsafeAtomicAdd(row + t, dq[t][r] * p.scale);
+        } else if (NT == 2) {
           *reinterpret_cast<float2 *>(row) = make_float2(dq[0][r] * p.scale, dq[1][r] * p.scale);
         } else {
           *reinterpret_cast<float4 *>(row) = make_float4(dq[0][r] * p.scale, dq[1][r] * p.scale, dq[2 % NT][r] * p.scale,
@@ -1261,6 +1281,22 @@ bool split_double_buffered() {
   static const bool on = [] { const char *e = getenv("CODA_ATTN_SPLIT_DB"); return !e || atoi(e) != 0; }();
   return on;
 }
+// Two query tiles per workgroup in the LDS-staged split-key kernels for long key sequences: 1 when that many
+// workgroups (`pairs`) still fill the chip, 2 when they do with the keys in two halves on top (dQ only), else 0.
+// CODA_ATTN_QT=0 switches it off (A/B).
+int split_query_tiles(int pairs) {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_QT"); return !e || atoi(e) != 0; }();
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    return n;
+  }();
+  if (!on) return 0;
+  return pairs >= cus ? 1 : (2 * pairs >= cus ? 2 : 0);
+}
 // split-key kernels without LDS staging (CODA_ATTN_DIRECT = 0 off | 4 | 8 waves per workgroup; default 4)
 int split_direct() {
   static const int v = [] { const char *e = getenv("CODA_ATTN_DIRECT"); return e ? atoi(e) : 4; }();
@@ -1431,7 +1467,12 @@ int launch_fwd_g(const MhaParams &p, hipStream_t s) {
   } else {
     dim3 grid(ceil_div(p.l, kTile), p.b * p.h);
     const int direct = split_direct();
-    if (direct) {  // K / V fragments straight from L2 into registers, no staging (mha_fwd_direct_kernel)
+    if (D == 64 && p.s >= 1024 && split_query_tiles(ceil_div(p.l, 2 * kTile) * p.b * p.h) == 1) {  // K / V staged once for two query tiles
+      auto kern = mha_fwd_kernel<D, 4, true, GEN, true, 2>;
+      int st = set_lds(kern, 8 * kTileBytes);
+      if (st != CODA_OK) return st;
+      mha_launch(kern, dim3(ceil_div(p.l, 2 * kTile), p.b * p.h), dim3(8 * kWave), 8 * kTileBytes, s, p);
+    } else if (direct) {  // K / V fragments straight from L2 into registers, no staging (mha_fwd_direct_kernel)
       constexpr size_t mlds4 = sizeof(float) * 3 * (D / 32 * 16 + 2) * kWave, mlds8 = sizeof(float) * 7 * (D / 32 * 16 + 2) * kWave;
       if (direct == 8 && D == 64) {
         auto kern = mha_fwd_direct_kernel<D, 8, GEN>;
@@ -1565,7 +1606,22 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
     // on 256 x 2048; at width 64 the LDS-staged kernel below is the faster one (83 vs 93 us: 32 narrow VMEM
     // instructions per tile against 16 wide ones + LDS reads).  CODA_ATTN_DIRECT_DQ=1 forces it (A/B)
     static const bool force_dq = [] { const char *e = getenv("CODA_ATTN_DIRECT_DQ"); return e && atoi(e) != 0; }();
-    if (split_direct() && (D > 64 || force_dq)) {
+    const int share = D == 64 && p.s >= 1024 ? split_query_tiles(ceil_div(p.l, 2 * kTile) * p.b * p.h) : 0;
+    if (share == 1) {  // K / V staged once for two query tiles (see mha_fwd_kernel)
+      auto kern = mha_bwd_dq_kernel<D, 4, true, GEN, true, 2>;
+      int st = set_lds(kern, 8 * kTileBytes);
+      if (st != CODA_OK) return st;
+      mha_launch(kern, dim3(ceil_div(p.l, 2 * kTile), p.b * p.h), dim3(8 * kWave), 8 * kTileBytes, s, p);
+    } else if (share == 2 && p.s % (2 * 4 * kTile) == 0) {  // ... and the keys in two halves: dQ accumulated
+      const size_t row_bytes = sizeof(float) * p.h * D, rows = static_cast<size_t>(p.l) * p.b;
+      const hipError_t e = p.lddq == p.h * D ? hipMemsetAsync(p.dq, 0, row_bytes * rows, s)
+                                             : hipMemset2DAsync(p.dq, sizeof(float) * p.lddq, 0, row_bytes, rows, s);
+      if (e != hipSuccess) return static_cast<int>(e);
+      auto kern = mha_bwd_dq_kernel<D, 4, true, GEN, true, 2, 2>;
+      int st = set_lds(kern, 8 * kTileBytes);
+      if (st != CODA_OK) return st;
+      mha_launch(kern, dim3(2 * ceil_div(p.l, 2 * kTile), p.b * p.h), dim3(8 * kWave), 8 * kTileBytes, s, p);
+    } else if (split_direct() && (D > 64 || force_dq)) {
       constexpr size_t mlds = sizeof(float) * 3 * (D / 32 * 16) * kWave;
       auto kern = mha_bwd_dq_direct_kernel<D, 4, GEN>;
       int st = set_lds(kern, mlds);

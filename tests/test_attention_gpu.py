@@ -42,6 +42,9 @@ def make_qkv(dev, l, s, b, h, d, packed, seed):
     (256, 2048, 8, 4, 64, False, False),    # 32 batch*heads: four head groups per XCD in tile_head()
     (300, 200, 4, 4, 64, False, True),      # 16 batch*heads, ragged tiles, mask
     (96, 64, 3, 4, 64, False, False),       # 12 batch*heads: not a multiple of 8, plain grid
+    (512, 2048, 8, 4, 64, False, False),    # two query tiles per workgroup share the staged K / V (forward and dQ)
+    (544, 1280, 8, 4, 64, False, True),     # ... ragged last pair, mask
+    (300, 2048, 8, 4, 64, False, True),     # ... + the keys in two halves, dQ accumulated with atomics (as 256 x 2048 x 8 above)
 ])
 def test_forward_backward_match_torch_reference(dev, l, s, b, h, d, packed, masked):
     leaves, q, k, v = make_qkv(dev, l, s, b, h, d, packed, seed=l + s)
