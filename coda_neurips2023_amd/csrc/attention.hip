@@ -1281,22 +1281,6 @@ bool split_double_buffered() {
   static const bool on = [] { const char *e = getenv("CODA_ATTN_SPLIT_DB"); return !e || atoi(e) != 0; }();
   return on;
 }
-// Two query tiles per workgroup in the LDS-staged split-key kernels for long key sequences: 1 when that many
-// workgroups (`pairs`) still fill the chip, 2 when they do with the keys in two halves on top (dQ only), else 0.
-// CODA_ATTN_QT=0 switches it off (A/B).
-int split_query_tiles(int pairs) {
-  static const bool on = [] { const char *e = getenv("CODA_ATTN_QT"); return !e || atoi(e) != 0; }();
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    return n;
-  }();
-  if (!on) return 0;
-  return pairs >= cus ? 1 : (2 * pairs >= cus ? 2 : 0);
-}
 // split-key kernels without LDS staging (CODA_ATTN_DIRECT = 0 off | 4 | 8 waves per workgroup; default 4)
 int split_direct() {
   static const int v = [] { const char *e = getenv("CODA_ATTN_DIRECT"); return e ? atoi(e) : 4; }();

@@ -23,6 +23,8 @@
 // room for two workgroups per CU, which is what overlaps one workgroup's barrier with the other's math.
 #include "attention_common.hip.h"
 
+#include <algorithm>
+
 namespace coda {
 namespace {
 
@@ -217,8 +219,12 @@ __device__ __forceinline__ f32x16 mfma_x(const Frag<NS> &a, const Frag<NS> &b, f
 // SPLIT = false: wave w owns queries (tile*4 + w)*32 .. +31 and walks all 4 key tiles of a stage.
 // SPLIT = true:  the 4 waves share 32 queries, wave w takes key tile w of every stage; the partial
 //                (m, l, O) are merged through LDS (decoder shapes: 256 / 512 queries).
-template <int D, bool SPLIT, bool GEN, int NW = 4, int NS = 1>
-__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPLIT) ? 2 : 1)) void mha_fwd_bf16_kernel(MhaParams p) {
+// QT (SPLIT only): query tiles per workgroup -- wave (qt, ks) takes key tile ks of the stage for query tile qt, so every
+//                staged K / V tile serves QT query tiles (attention.hip, mha_fwd_kernel: the split-key launches are
+//                bound by the delivery of K / V from L2).
+template <int D, bool SPLIT, bool GEN, int NW = 4, int NS = 1, int QT = 1>
+__global__ __launch_bounds__(NW * QT * kWave, (D == 64 && NW == 4 && QT == 1 && (NS == 1 || !SPLIT) ? 2 : 1)) void mha_fwd_bf16_kernel(MhaParams p) {
+  static_assert(QT == 1 || SPLIT, "several query tiles per workgroup: split-key form only");
   using L = Lay<D>;
   // SPLIT: one key tile per wave per stage; three-piece operands: two tiles per stage keep the long-sequence
   // kernel at 55 KB of LDS (two workgroups per CU)
@@ -229,10 +235,11 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
   unsigned char *s_k = smem, *s_vt = smem + NS * IMG_K;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int qt = SPLIT ? w / NW : 0, ks = SPLIT ? w % NW : w;
   const int half = lane >> 5, l31 = lane & 31;
   const TileHead th = tile_head(p.xcd_map);
   const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = SPLIT ? th.tile * kTile : (th.tile * 4 + w) * kTile;
+  const int q0 = SPLIT ? (th.tile * QT + qt) * kTile : (th.tile * 4 + w) * kTile;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
   const bool use_drop = p.thresh16 != 0u;
   const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
 
-  Fetch<D, TILES, NW * kWave> fk, fv;
+  Fetch<D, TILES, NW * QT * kWave> fk, fv;
   fk.load(kbase, kstride, 0, p.s, tid);
   fv.load(vbase, vstride, 0, p.s, tid);
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
       fk.load(kbase, kstride, sbase + kTile * TILES, p.s, tid);
       fv.load(vbase, vstride, sbase + kTile * TILES, p.s, tid);
     }
-    for (int tile = SPLIT ? w : 0; tile < (SPLIT ? w + 1 : TILES); ++tile) {
+    for (int tile = SPLIT ? ks : 0; tile < (SPLIT ? ks + 1 : TILES); ++tile) {
       const int s0 = sbase + tile * kTile;
       if (!wave_active || s0 >= p.s) break;
       const unsigned char *tk = s_k + tile * L::ROWB, *tv = s_vt + tile * L::TRB;
@@ -335,9 +342,9 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
   lsum += __shfl_xor(lsum, 32);
   if (SPLIT) {  // merge the per-wave partial softmax states: [wave-1][NT*16 + 2][64 lanes] floats
     __syncthreads();
-    float *s_f = reinterpret_cast<float *>(smem);
-    float *slot = s_f + static_cast<size_t>(w > 0 ? w - 1 : 0) * (NT * 16 + 2) * kWave;
-    if (w > 0) {
+    float *s_f = reinterpret_cast<float *>(smem) + static_cast<size_t>(qt) * (NW - 1) * (NT * 16 + 2) * kWave;
+    float *slot = s_f + static_cast<size_t>(ks > 0 ? ks - 1 : 0) * (NT * 16 + 2) * kWave;
+    if (ks > 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
       slot[(NT * 16 + 1) * kWave + lane] = lsum;
     }
     __syncthreads();
-    if (w > 0) return;
+    if (ks > 0) return;
     float m_all = m;
     for (int ww = 1; ww < NW; ++ww) m_all = fmaxf(m_all, s_f[((ww - 1) * (NT * 16 + 2) + NT * 16) * kWave + lane]);
     const float m_ref = (m_all == -INFINITY) ? 0.f : m_all;
@@ -542,8 +549,9 @@ __global__ __launch_bounds__(kThreads, (D == 64 ? 2 : 1)) void mha_bwd_dkv_bf16_
 // ---------------------------------------------------------------------------------------------- dQ
 // A wave owns 32 queries (Q, dO fragments in registers as B operands of S^T = K Q^T and dP^T = V dO^T);
 // K comes through LDS in both images (row-major for S^T, transposed for dQ = dS K), V row-major.
-template <int D, bool SPLIT, bool GEN, int NW = 4, int NS = 1>
-__global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPLIT) ? 2 : 1)) void mha_bwd_dq_bf16_kernel(MhaBwdParams p) {
+template <int D, bool SPLIT, bool GEN, int NW = 4, int NS = 1, int QT = 1>  // QT: see mha_fwd_bf16_kernel
+__global__ __launch_bounds__(NW * QT * kWave, (D == 64 && NW == 4 && QT == 1 && (NS == 1 || !SPLIT) ? 2 : 1)) void mha_bwd_dq_bf16_kernel(MhaBwdParams p) {
+  static_assert(QT == 1 || SPLIT, "several query tiles per workgroup: split-key form only");
   using L = Lay<D>;
   // three-piece operands: one key tile per stage (41 KB of LDS: three workgroups per CU by LDS, two by registers)
   constexpr int NT = D / 32, KC = D / 16, TILES = (NS == 3 && !SPLIT) ? 1 : NW;
@@ -553,10 +561,11 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
   unsigned char *s_k = smem, *s_v = s_k + NS * IMG_R, *s_kt = s_v + NS * IMG_R;
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int qt = SPLIT ? w / NW : 0, ks = SPLIT ? w % NW : w;
   const int half = lane >> 5, l31 = lane & 31;
   const TileHead th = tile_head(p.xcd_map);
   const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
-  const int q0 = SPLIT ? th.tile * kTile : (th.tile * 4 + w) * kTile;
+  const int q0 = SPLIT ? (th.tile * QT + qt) * kTile : (th.tile * 4 + w) * kTile;
   const int myq = q0 + l31;
   const bool wave_active = q0 < p.l;
   const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
 #pragma unroll
   for (int t = 0; t < NT; ++t) dq[t] = zero16();
 
-  Fetch<D, TILES, NW * kWave> fk, fv;
+  Fetch<D, TILES, NW * QT * kWave> fk, fv;
   fk.load(kbase, kstride, 0, p.s, tid);
   fv.load(vbase, vstride, 0, p.s, tid);
   for (int sbase = 0; sbase < p.s; sbase += kTile * TILES) {
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
       fk.load(kbase, kstride, sbase + kTile * TILES, p.s, tid);
       fv.load(vbase, vstride, sbase + kTile * TILES, p.s, tid);
     }
-    for (int tile = SPLIT ? w : 0; tile < (SPLIT ? w + 1 : TILES); ++tile) {
+    for (int tile = SPLIT ? ks : 0; tile < (SPLIT ? ks + 1 : TILES); ++tile) {
       const int s0 = sbase + tile * kTile;
       if (!wave_active || s0 >= p.s) break;
       const unsigned char *tk = s_k + tile * L::ROWB, *tv = s_v + tile * L::ROWB, *tkt = s_kt + tile * L::TRB;
@@ -649,16 +658,16 @@ __global__ __launch_bounds__(NW * kWave, (D == 64 && NW == 4 && (NS == 1 || !SPL
   }
   if (SPLIT) {  // sum the per-wave partial dQ: [wave-1][NT*16][64 lanes] floats
     __syncthreads();
-    float *s_f = reinterpret_cast<float *>(smem);
-    if (w > 0) {
-      float *slot = s_f + static_cast<size_t>(w - 1) * (NT * 16) * kWave;
+    float *s_f = reinterpret_cast<float *>(smem) + static_cast<size_t>(qt) * (NW - 1) * (NT * 16) * kWave;
+    if (ks > 0) {
+      float *slot = s_f + static_cast<size_t>(ks - 1) * (NT * 16) * kWave;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * kWave + lane] = dq[t][r];
     }
     __syncthreads();
-    if (w > 0) return;
+    if (ks > 0) return;
     for (int ww = 1; ww < NW; ++ww) {
       const float *sl = s_f + static_cast<size_t>(ww - 1) * (NT * 16) * kWave;
 #pragma unroll
@@ -716,6 +725,13 @@ int fwd_launch(const MhaParams &p, hipStream_t s) {
     auto kern = mha_fwd_bf16_kernel<D, false, GEN, 4, NS>;
     if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
     mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
+  } else if (NS == 1 && D == 64 && p.s >= 1024 && split_query_tiles(ceil_div(p.l, 2 * kTile) * p.b * p.h) == 1) {
+    // two query tiles per workgroup share the staged K / V tiles (half the L2 traffic), one 8-wave workgroup per CU
+    // (the merge of the 2 x 3 partial soft-max states reuses the stage buffers and is the larger of the two)
+    const size_t lds = std::max<size_t>(4 * (L::ROWB + L::TRB), sizeof(float) * 2 * 3 * (D / 32 * 16 + 2) * kWave);
+    auto kern = mha_fwd_bf16_kernel<D, true, GEN, 4, 1, (NS == 1 && D == 64 ? 2 : 1)>;
+    if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
+    mha_launch(kern, dim3(ceil_div(p.l, 2 * kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
   } else if (NS == 1 && D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
     // at most one workgroup per CU: 8 waves / 8 key tiles per stage put twice the bytes in flight per CU
     // (measured 64 -> 53 us at 256 x 2048, but 87 -> 101 us at 512 x 2048 where two 4-wave workgroups share a CU)
@@ -764,6 +780,11 @@ int dq_launch(const MhaBwdParams &p, hipStream_t s) {
     mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(kThreads), lds, s, p);
   } else if (NS != 1) {
     return CODA_EINVAL;  // x3_takes_dq() keeps these shapes away
+  } else if (D == 64 && p.s >= 1024 && split_query_tiles(ceil_div(p.l, 2 * kTile) * p.b * p.h) == 1) {
+    const size_t lds = std::max<size_t>(4 * (2 * L::ROWB + L::TRB), sizeof(float) * 2 * 3 * (D / 32 * 16) * kWave);  // (see fwd_launch)
+    auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, 4, 1, (D == 64 ? 2 : 1)>;
+    if ((st = raise_lds(kern, lds)) != CODA_OK) return st;
+    mha_launch(kern, dim3(ceil_div(p.l, 2 * kTile), p.b * p.h), dim3(8 * kWave), lds, s, p);
   } else if (D == 64 && p.s >= 8 * kTile && ceil_div(p.l, kTile) * p.b * p.h <= 256) {
     const size_t lds = 8 * (2 * L::ROWB + L::TRB);
     auto kern = mha_bwd_dq_bf16_kernel<D, true, GEN, (D == 64 ? 8 : 4), 1>;

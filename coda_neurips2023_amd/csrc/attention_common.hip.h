@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "common.hip.h"
 
 namespace coda {
@@ -127,6 +129,23 @@ struct MhaBwdParams {
   float *ds = nullptr;  // optional (B*H, L, S) workspace: the dK/dV kernel leaves dS there and dQ = dS K becomes one GEMM
 };
 
+
+// Two query tiles per workgroup in the LDS-staged split-key kernels for long key sequences: 1 when that many
+// workgroups (`pairs`) still fill the chip, 2 when they do with the keys in two halves on top (dQ only), else 0.
+// CODA_ATTN_QT=0 switches it off (A/B).
+inline int split_query_tiles(int pairs) {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_QT"); return !e || atoi(e) != 0; }();
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    return n;
+  }();
+  if (!on) return 0;
+  return pairs >= cus ? 1 : (2 * pairs >= cus ? 2 : 0);
+}
 
 // attention_bf16.hip: the same three kernels with bf16 MFMA operands (fp32 tensors, fp32 accumulation
 // and softmax); launched by attention.hip's dispatchers inside their timing brackets.

@@ -41,6 +41,8 @@ def l2(a, b):
     (128, 128, 2, 4, 128, True, True),
     (1024, 1024, 1, 2, 128, True, False),
     (96, 64, 3, 4, 64, False, False),       # 12 batch*heads: plain grid
+    (512, 2048, 8, 4, 64, False, False),    # configs[4]'s cross-attention at full batch: two query tiles per workgroup
+    (544, 1280, 8, 4, 64, False, True),     # ... ragged last pair, mask
     (300, 700, 2, 2, 64, False, True),      # 512 <= keys < 1024: dK/dV with the keys owned per wave, ragged + mask
 ])
 def test_bf16_forward_backward_match_fp32_reference(dev, l, s, b, h, d, packed, masked):
@@ -137,6 +139,7 @@ ORACLE_OUT, ORACLE_GRAD = (2e-3, 2.5e-3), (4e-3, 3e-3)
     (100, 77, 3, 2, 64, False, True),       # ragged + mask
     (128, 128, 2, 4, 128, True, True),      # dec_dim 512
     (300, 700, 2, 2, 64, False, True),
+    (512, 2048, 8, 4, 64, False, False),    # two query tiles per workgroup (forward and dQ)
 ])
 def test_bf16_kernels_match_the_bf16_rounding_oracle(dev, l, s, b, h, d, packed, masked):
     leaves, q, k, v = make_qkv(dev, l, s, b, h, d, packed, seed=3 * l + s)
