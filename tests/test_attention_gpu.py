@@ -64,6 +64,45 @@ def test_forward_backward_match_torch_reference(dev, l, s, b, h, d, packed, mask
         assert rel(g, gr) < 1e-3
 
 
+def test_backward_into_column_slices_of_a_packed_buffer(dev):
+    """coda_mha_bwd_f32 with lddq / lddk / lddv = 3 * H * D (gradients written straight into the q | k | v column blocks of
+    one packed buffer, include/coda_attention.h) on the decoder's cross-attention launch shape, where dQ is
+    accumulated by two workgroups per query-tile pair on a ZEROED dQ: the zeroing has to follow the row pitch and leave
+    the neighbouring columns alone; results equal to the dense call bit for bit."""
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    l, s, b, h, d = 256, 2048, 8, 4, 64
+    _, q, k, v = make_qkv(dev, l, s, b, h, d, False, seed=77)
+    q, k, v = q.detach(), k.detach(), v.detach()
+    scale = d ** -0.5
+    out = torch.empty(l, b, h, d, device=dev)
+    lse = torch.empty(b, h, l, device=dev)
+    st = _lib.current_stream_handle()
+    hd = h * d
+    _lib.check(lib.coda_mha_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(), lse.data_ptr(), b, h,
+                                    l, s, d, hd, hd, hd, scale, 0.0, 0, None, st), "fwd")
+    dout = torch.randn(l, b, h, d, device=dev)
+
+    def run(lddq, lddk, lddv, dq, dk, dv):
+        delta = torch.empty(b, h, l, device=dev)
+        _lib.check(lib.coda_mha_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(), lse.data_ptr(),
+                                        dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(),
+                                        b, h, l, s, d, hd, hd, hd, lddq, lddk, lddv, scale, 0.0, 0, None, st), "bwd")
+
+    dq0, dk0, dv0 = torch.empty(l, b, hd, device=dev), torch.empty(s, b, hd, device=dev), torch.empty(s, b, hd, device=dev)
+    run(0, 0, 0, dq0, dk0, dv0)
+    pq = torch.full((l, b, 3 * hd), 7.0, device=dev)       # dQ goes to the MIDDLE block of its buffer
+    pkv = torch.full((s, b, 3 * hd), 7.0, device=dev)      # dK to the first, dV to the last block of theirs
+    run(3 * hd, 3 * hd, 3 * hd, pq[..., hd:2 * hd], pkv[..., :hd], pkv[..., 2 * hd:])
+    assert torch.equal(pq[..., hd:2 * hd], dq0)
+    assert torch.equal(pkv[..., :hd], dk0) and torch.equal(pkv[..., 2 * hd:], dv0)
+    assert bool((pq[..., :hd] == 7.0).all()) and bool((pq[..., 2 * hd:] == 7.0).all())
+    assert bool((pkv[..., hd:2 * hd] == 7.0).all())
+    ref, _ = attention_ref(q.requires_grad_(True), k, v, None, scale, 0.0, False)
+    (gq,) = torch.autograd.grad((ref * dout).sum(), (q,))
+    assert rel(dq0.view(l, b, h, d), gq) < 1e-3
+
+
 def test_need_weights_output(dev):
     _, q, k, v = make_qkv(dev, 64, 96, 2, 4, 64, False, seed=3)
     out, probs = attention_core.attention(q, k, v, None, 0.125, 0.0, True)
