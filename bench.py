@@ -476,18 +476,66 @@ def make_batch_t(bsz, n, seed, dev):
     return torch.from_numpy(pc).to(dev)[..., :3].contiguous()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here, one process per GPU, the way
+    the reference starts its own (main.py:1103-1108, torch.multiprocessing.spawn(main, nprocs=ngpus)) -- every child
+    is this same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, i.e. exactly what
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` would have started.  Rank 0's JSON line goes to
+    the inherited stdout.  The first rank that fails takes the others down and its exit code becomes ours."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=os.environ.get("MASTER_PORT") or str(_free_port()), CODA_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} of {n} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse()
+    dry = os.environ.get("CODA_BENCH_DRY") == "1"  # control-flow test on CPU, see build_dry_workload()
+    if args.gpus < 1:
+        sys.exit(f"bench.py: --gpus {args.gpus}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not dry and os.environ.get("CODA_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dry = os.environ.get("CODA_BENCH_DRY") == "1"  # control-flow test on CPU, see build_dry_workload()
+    # a rank count that differs from --gpus must never produce a line (a one-rank run labelled as N GPUs or the reverse)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure")
     assert dry or torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     # dev-only smoke mode for 1-GPU boxes: all ranks on cuda:0 over gloo (RCCL refuses two ranks per
     # device); exercises the DDP + SyncBatchNorm code path, its numbers mean nothing
     one_device = os.environ.get("CODA_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    elif not dry and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but this node shows {torch.cuda.device_count()} GPU(s): one process per GPU")
     if dry:
         dev = torch.device("cpu")
     else:
@@ -511,11 +559,14 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1 and dist.get_world_size() != args.gpus:
+        sys.exit(f"bench.py: process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
     if os.environ.get("CODA_BLAS"):  # dev A/B: "cublas" (= rocBLAS) | "cublaslt" (= hipBLASLt, torch's default here)
         torch.backends.cuda.preferred_blas_library(os.environ["CODA_BLAS"])
     mod, step_fn, desc, kind = build_workload(args.workload, dev)
+    if dry and os.environ.get("CODA_BENCH_DRY_FAIL_RANK") == str(rank):  # tests/test_bench_dry.py: a rank that dies
+        sys.exit(f"bench.py: rank {rank} fails on request")
     model = mod
     reducer = None
     if world > 1 or force_ddp:
@@ -565,8 +616,16 @@ def main():
             raw_model.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)  # batches are resident
         opt.zero_grad(set_to_none=True)
         loss = step_fn(model, pool[i % len(pool)])
-        if finite is not None:
-            finite.push(loss)  # engine.py:155-157's exit on a non-finite loss, one step late and without a host stall
+        if finite is not None or world > 1:
+            # engine.py:152-157: the exit decision is taken on the loss AVERAGED OVER THE RANKS, so that every rank takes
+            # the same one (a rank leaving alone would park the others in their next collective); one scalar
+            # all-reduce, enqueued like any kernel.  Then the check itself, one step late and without a host stall
+            seen = loss.detach().clone()
+            if world > 1:
+                dist.all_reduce(seen)
+                seen /= world
+            if finite is not None:
+                finite.push(seen)
         loss.backward()
         if reducer is not None:
             reducer.reduce()
@@ -708,7 +767,8 @@ def main():
     # Multi-GPU diagnostics (rank 0 reports, every rank takes part): the collectives of a step timed in isolation with
     # HIP events -- the two segments of the flat gradient all-reduce and one SyncBatchNorm statistics all-reduce --
     # so that the first scaling run shows where a shortfall comes from.
-    comm = None
+    # always present, so that a line measured on fewer ranks than asked for cannot pass for an N-GPU line
+    comm = {"backend": None, "rccl_ranks": 1, "launched_by": "single process"}
     if world > 1 or force_ddp:
         def timed_allreduce(t, reps):
             if not dry:
@@ -722,7 +782,13 @@ def main():
                 torch.cuda.synchronize()
             return (time.perf_counter() - t0) / reps * 1e3
 
-        comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()}
+        comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                "launched_by": ("bench.py itself (one child process per GPU, main.py:1103-1108's form)"
+                                if os.environ.get("CODA_BENCH_SPAWNED") == "1" else "an external launcher (torchrun)"),
+                "headline_collectives_per_step": "SyncBatchNorm statistics + the flat gradient all-reduce + one scalar "
+                                                 "all-reduce of the loss (engine.py:152) for the deferred finite check; "
+                                                 "reduce_dict(loss_dict) (engine.py:153, logging only) is NOT in the "
+                                                 "headline leg -- it is in value_unchanged"}
         reps = 10
         if reducer is not None:
             names = ["early", "late"] if len(reducer.segments) == 2 else [str(k) for k in range(len(reducer.segments))]
@@ -934,8 +1000,7 @@ def main():
             out["value_unchanged"] = unchanged["value"]
             out["ms_per_step_unchanged"] = unchanged["ms_per_step"]
             out["value_unchanged_caller"] = unchanged
-        if comm is not None:
-            out["comm"] = comm
+        out["comm"] = comm
         if others:
             out["roofline_others"] = others
         if world == 1 and not dry and not args.no_extras and kind == "model" and args.workload != "model40k":

@@ -45,7 +45,43 @@ def test_single_process_flow():
     # the unchanged caller's leg (engine.py:136-164 with its blocking finite check) is reported at top level
     assert out["value_unchanged"] > 0 and out["ms_per_step_unchanged"] > 0
     assert "loss.item()" in out["value_unchanged_caller"]["what"]
-    assert "comm" not in out
+    assert out["comm"]["rccl_ranks"] == 1  # always present: a one-rank line cannot pass for an N-GPU line
+
+
+@pytest.mark.timeout(300)
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's scaling command may be exactly that):
+    bench.py starts the two ranks itself, like the reference's main.py:1103-1108."""
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    _check(out, 2, 3, 1)
+    _check_multi(out, 2)
+    assert "bench.py itself" in out["comm"]["launched_by"]
+
+
+def test_rank_count_mismatch_is_fatal():
+    """a launcher that started another number of ranks than --gpus says: no line, non-zero exit"""
+    env = dict(os.environ, CODA_BENCH_DRY="1", OMP_NUM_THREADS="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "refusing to measure" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    env.pop("WORLD_SIZE"), env.pop("RANK"), env.pop("LOCAL_RANK")
+    env["WORLD_SIZE"] = "2"
+    env["RANK"] = "0"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "refusing to measure" in r.stderr
+
+
+def test_a_failing_rank_takes_the_job_down():
+    """one rank dying must not leave the others parked in a collective: the launcher stops them, exits non-zero"""
+    env = dict(os.environ, CODA_BENCH_DRY="1", OMP_NUM_THREADS="1", CODA_BENCH_DRY_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "rank 1 of 2 exited" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 @pytest.mark.timeout(300)
