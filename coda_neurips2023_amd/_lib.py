@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcoda_hip.so")
 CODA_OK = 0
 CODA_EINVAL = -1
 CODA_ENOSPC = -2
+CODA_ELOST = -3
 
 _c_void_p = ctypes.c_void_p
 _c_int = ctypes.c_int
@@ -27,6 +28,8 @@ SIGNATURES = {
     "coda_furthest_point_sampling_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
     "coda_furthest_point_sampling_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _P]),
     "coda_furthest_point_sampling_opt_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _c_int, _c_int, _P]),
+    "coda_fps_lost_partner_events": (ctypes.c_uint, [_c_int]),
+    "coda_furthest_point_sampling_dbg_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _c_int, _c_int, _P]),
     "coda_gather_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_gather_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_ball_query_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
@@ -276,4 +279,9 @@ def check(status, what):
         raise RuntimeError(f"{what}: invalid argument (CODA_EINVAL)")
     if status == CODA_ENOSPC:
         raise RuntimeError(f"{what}: workspace too small (CODA_ENOSPC)")
+    if status == CODA_ELOST:
+        word = load().coda_fps_lost_partner_events(1)  # acknowledged by raising
+        raise RuntimeError(f"{what}: an earlier two-workgroup furthest-point-sampling launch lost its partner workgroup "
+                           f"(scene {(word >> 16) & 0x7fff}, round {word & 0xffff}): the indices it returned are wrong "
+                           "(CODA_ELOST)")
     raise RuntimeError(f"{what}: HIP kernel launch failed (hipError_t={status})")

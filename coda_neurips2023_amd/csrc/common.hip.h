@@ -47,6 +47,8 @@ constexpr int kDefaultDistanceMode = 1;
 struct CallOptions {
   int distance_mode = -1;  // -1 default | 0 | 1 | 2
   int fps_waves = 0;       // 0 default | 8 | 16
+  int fps_spin_limit = 0;  // coda_furthest_point_sampling_dbg_f32 only: polls before a partner counts as lost (0: default)
+  int fps_drop_half = -1;  // coda_furthest_point_sampling_dbg_f32 only: the workgroup of the pair that exits at once
   int bq_route = 0;        // 0 auto | 1 grid | 2 scan
   int mfma_dtype = -1;     // -1 default | 0 fp32 | 1 bf16 | 2 bf16x3
   void *attn_ds_ws = nullptr;  // coda_mha_bwd_ws_f32: the caller's dS workspace (coda_attention.h)

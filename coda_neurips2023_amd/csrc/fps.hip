@@ -24,6 +24,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace coda {
@@ -490,7 +491,45 @@ struct FpsMailbox {
   unsigned long long kk;
   unsigned long long pad_[7];  // one 64-byte line per mailbox
 };
-constexpr int kFpsSpinLimit = 1 << 22;  // ~ a second of polling: a lost partner ends the wait, not the device
+constexpr int kFpsSpinLimit = 1 << 22;  // ~ seconds of polling: a lost partner ends the wait, not the device
+
+// A workgroup of the pair that gave up waiting has produced WRONG indices from that round on.  That must not be
+// silent (the reference's single block per scene, sampling_gpu.cu:72-176, has no such failure mode): the wave that
+// gives up writes a diagnostic word (bit 31 | scene << 16 | round) to pinned host memory -- visible to the host without any synchronisation --
+// and stops polling for good (one bounded wait per launch, not one per round).  Every later
+// coda_furthest_point_sampling* call returns CODA_ELOST while that word is non-zero and has not been read with
+// coda_fps_lost_partner_events(reset = 1).  The word is allocated at the first two-workgroup launch of the process
+// (the only allocation the library ever makes on this path; mapped + portable, so every device sees it).
+struct FpsStatusWord {
+  unsigned int *host = nullptr;
+  int err = 0;
+};
+const FpsStatusWord &fps_status_word(bool create) {
+  static std::atomic<bool> ready{false};
+  static std::mutex mu;
+  static FpsStatusWord word;
+  if (!ready.load(std::memory_order_acquire) && create) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!ready.load(std::memory_order_relaxed)) {
+      void *p = nullptr;
+      const hipError_t e = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent);
+      if (e == hipSuccess) {
+        word.host = static_cast<unsigned int *>(p);
+        __atomic_store_n(word.host, 0u, __ATOMIC_RELAXED);
+      } else {
+        word.err = static_cast<int>(e);
+        (void)hipGetLastError();
+      }
+      ready.store(true, std::memory_order_release);
+    }
+  }
+  return word;  // (host == nullptr before the first two-workgroup launch: nothing can have been lost)
+}
+unsigned int fps_lost_events(bool reset) {
+  const FpsStatusWord &w = fps_status_word(false);
+  if (!w.host) return 0u;
+  return reset ? __atomic_exchange_n(w.host, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(w.host, __ATOMIC_ACQUIRE);
+}
 
 // -DCODA_FPS_PROF (tools/fps_prof.py builds a private copy of this file with it): shader-clock sums of the phases
 // of a round per (scene, wave), read back with coda_fps_prof_read.  Compiles to nothing in the library.
@@ -521,7 +560,13 @@ __device__ unsigned long long g_fps_prof[64][16][8];
 template <int SL, int DM, int NWG = 1, int W = kBucketWaves>
 __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(const float *__restrict__ xyz, int n, int m, int log2T,
                                                             float4 *__restrict__ sorted, int32_t *__restrict__ idx,
-                                                            FpsMailbox *__restrict__ mail) {
+                                                            FpsMailbox *__restrict__ mail,
+                                                            unsigned int *__restrict__ lost_events, int spin_limit,
+                                                            int drop_half) {
+  if constexpr (NWG == 2) {
+    // test hook (coda_furthest_point_sampling_dbg_f32): the workgroup that never shows up
+    if (static_cast<int>(blockIdx.y) == drop_half) return;
+  }
   constexpr int TH = 64 * W;                       // threads
   constexpr int PER = kMortonCells / TH;           // histogram counters per thread in the scan
   constexpr int KB = NWG == 1 ? 15 : 16;           // bits of the point index inside the tie-break key
@@ -538,9 +583,20 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(const float *__restr
 
   const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const float *__restrict__ pts = xyz + static_cast<size_t>(blockIdx.x) * n * 3;
-  float4 *__restrict__ rec = sorted + (static_cast<size_t>(half) * gridDim.x + blockIdx.x) * n;  // own copy per workgroup
+  float4 *__restrict__ rec = sorted + static_cast<size_t>(blockIdx.x) * n;  // one record array per scene
   int32_t *__restrict__ out = idx + static_cast<size_t>(blockIdx.x) * m;
 
+  unsigned int nvalid = 0u;
+  bool partner_lost = false;  // NWG = 2: this wave gave up waiting for the other workgroup once; wave-uniform
+  // NWG = 2: ONE Morton order per scene.  Workgroup 0 sorts; workgroup 1 waits for it and reads the same records.
+  // (Until round 5 both sorted redundantly into copies of their own.  The scatter takes its positions from LDS
+  // atomics, so the order of the points INSIDE a cell is whatever order the atomics happened in -- and the two
+  // workgroups split the record array by POSITION: a point of the cell the split runs through could be in the first
+  // half of one order and in the second half of the other, i.e. owned by both, and another point of that cell by
+  // NEITHER, which then never became a sample.  The two orders agree almost always (same code, same timing on two
+  // idle CUs), so the indices were wrong about once in a hundred launches, more often next to other kernels: the
+  // unexplained whole-step failure of round 4.  tests/test_ops_gpu.py::test_fps_two_workgroups_under_cotenancy_stress.)
+  if (NWG == 1 || half == 0) {
   // ---- prologue 1: bounding box of the participating points
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int k = tid; k < n; k += TH) {
@@ -610,7 +666,6 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(const float *__restr
     }
   }
   __syncthreads();
-  unsigned int nvalid = 0u;
   for (int q = 0; q < W; ++q) nvalid += s_wsum[q];
   for (int k = tid; k < n; k += TH) {
     const float x = pts[k * 3], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
@@ -619,8 +674,41 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(const float *__restr
       rec[pos] = make_float4(x, y, z, __uint_as_float(static_cast<uint32_t>(k)));
     }
   }
-  __threadfence_block();
-  __syncthreads();
+  if constexpr (NWG == 2) {
+    // hand the records over: every thread makes its record stores visible at agent scope (a write-back of this XCD's
+    // L2 -- once per launch, not per round), then ONE flag word carries the record count to the partner
+    __threadfence();
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(&mail[static_cast<size_t>(gridDim.x) * 4 + blockIdx.x].kk,
+                         (static_cast<unsigned long long>(nvalid) << 1) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __threadfence_block();
+    __syncthreads();
+  }
+  } else {
+    // workgroup 1 of the pair: wait for the sorted records (the same bounded wait as the rounds' below)
+    if (tid < 3) s_slot[tid] = 0ull;
+    unsigned long long word = 0ull;
+    int gave_up = 0;
+    if (lane == 0) {
+      int spins = 0;
+      do {
+        word = __hip_atomic_load(&mail[static_cast<size_t>(gridDim.x) * 4 + blockIdx.x].kk, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      } while (word == 0ull && ++spins < spin_limit);
+      if (word == 0ull) {
+        gave_up = 1;
+        __hip_atomic_store(lost_events, 0x80000000u | ((blockIdx.x & 0x7fffu) << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    word = __shfl(word, 0, kWave);
+    partner_lost = __shfl(gave_up, 0, kWave) != 0;
+    nvalid = static_cast<unsigned int>(word >> 1);  // (0 when the partner was lost: this workgroup owns nothing)
+    __threadfence();  // acquire: nothing of an earlier launch's records may be served from this XCD's caches
+    __syncthreads();
+  }
 
   // ---- prologue 3: buckets into registers; bucket b -> wave b % W, slot b / W
   Slots<SL> px, py, pz, t;
@@ -753,13 +841,27 @@ __global__ __launch_bounds__(64 * W) void fps_bucket_kernel(const float *__restr
       if (tid == 0) __hip_atomic_store(&mine->kk, (kk & ~kSeqMask) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // every wave polls for itself (lane 0) and broadcasts: no second barrier in the round
       unsigned long long pkk = 0ull;
-      if (lane == 0) {
-        int spins = 0;
-        do {
-          pkk = __hip_atomic_load(&theirs->kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((pkk & kSeqMask) != seq && ++spins < kFpsSpinLimit);
+      if (!partner_lost) {
+        int gave_up = 0;
+        if (lane == 0) {
+          int spins = 0;
+          do {
+            pkk = __hip_atomic_load(&theirs->kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((pkk & kSeqMask) != seq && ++spins < spin_limit);
+          if ((pkk & kSeqMask) != seq) {
+            // the partner did not answer within the limit: from here on the indices are wrong.  Say so where the host
+            // sees it, and never wait again (a wait per round would keep the device busy for m x the limit)
+            gave_up = 1;
+            pkk = 0ull;
+            // (a plain system-scope store, not a read-modify-write: no PCIe atomics needed; the last writer's
+            // diagnostic stays: bit 31 | scene << 16 | round)
+            __hip_atomic_store(lost_events, 0x80000000u | ((blockIdx.x & 0x7fffu) << 16) | (static_cast<unsigned>(j) & 0xffffu),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        pkk = __shfl(pkk, 0, kWave);
+        partner_lost = __shfl(gave_up, 0, kWave) != 0;
       }
-      pkk = __shfl(pkk, 0, kWave);
       if ((pkk & ~kSeqMask) > (kk & ~kSeqMask)) {  // the partner's candidate wins (larger distance, then smaller key)
         kk = pkk;
         const uint32_t k = (~(static_cast<uint32_t>(pkk) >> IDB)) & ((1u << KB) - 1u);
@@ -796,7 +898,7 @@ int launch_bucket(const float *xyz, int b, int n, int m, int log2T, float4 *ws, 
     st = raise_dynamic_lds(kern, lds, 20 * 1024);  // static + dynamic LDS exceeds the 64 KB default
     if (st == CODA_OK)
       hipLaunchKernelGGL(kern, dim3(b), dim3(64 * W), lds, s, xyz, n, m, log2T, ws, idx,
-                         static_cast<FpsMailbox *>(nullptr));
+                         static_cast<FpsMailbox *>(nullptr), static_cast<unsigned int *>(nullptr), 0, -1);
   });
   return st;
 }
@@ -845,20 +947,29 @@ bool bucket2_eligible(int n, int m) {
   return n >= bucket2_min_points() && n >= 2 * kBucketMinPoints && n <= 2 * kBucketMaxPoints && m >= kBucketMinSamples;
 }
 size_t bucket2_mail_offset(int b, int n) { return (sizeof(float4) * 2 * static_cast<size_t>(b) * n + 255) & ~static_cast<size_t>(255); }
-size_t bucket2_workspace_bytes(int b, int n) { return bucket2_mail_offset(b, n) + sizeof(FpsMailbox) * 4 * static_cast<size_t>(b); }
+// per scene: 2 round parities x 2 workgroups of candidate mailboxes, then (after all of those) one hand-over word
+constexpr int kMailboxesPerScene = 5;
+size_t bucket2_workspace_bytes(int b, int n) {
+  return bucket2_mail_offset(b, n) + sizeof(FpsMailbox) * kMailboxesPerScene * static_cast<size_t>(b);
+}
 
 template <int SL, int W = kBucketWaves>
 int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, int32_t *idx, hipStream_t s) {
   constexpr size_t lds = sizeof(uint32_t) * SL * 64 * W;
   FpsMailbox *mail = reinterpret_cast<FpsMailbox *>(static_cast<char *>(ws) + bucket2_mail_offset(b, n));
-  hipError_t e = hipMemsetAsync(mail, 0, sizeof(FpsMailbox) * 4 * static_cast<size_t>(b), s);  // round numbers start at 1
+  const FpsStatusWord &status = fps_status_word(true);
+  if (!status.host) return status.err ? status.err : CODA_ENOSPC;  // no way to report a lost partner: do not launch
+  const CallOptions &o = call_options();
+  const int spin_limit = o.fps_spin_limit > 0 ? o.fps_spin_limit : kFpsSpinLimit;
+  hipError_t e = hipMemsetAsync(mail, 0, sizeof(FpsMailbox) * kMailboxesPerScene * static_cast<size_t>(b), s);  // round numbers start at 1
   if (e != hipSuccess) return static_cast<int>(e);
   int st = CODA_OK;
   CODA_DISPATCH_DM(distance_mode(), {
     auto kern = fps_bucket_kernel<SL, DM, 2, W>;
     st = raise_dynamic_lds(kern, lds, 20 * 1024);
     if (st == CODA_OK)
-      hipLaunchKernelGGL(kern, dim3(b, 2), dim3(64 * W), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail);
+      hipLaunchKernelGGL(kern, dim3(b, 2), dim3(64 * W), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail,
+                         status.host, spin_limit, o.fps_drop_half);
   });
   return st;
 }
@@ -993,6 +1104,9 @@ CODA_API int coda_furthest_point_sampling_f32(const float *xyz, int b, int n, in
   if (b == 0 || m == 0) return CODA_OK;  // sampling_gpu.cu:75
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int log2T = reference_block_log2(n);
+  // an EARLIER two-workgroup launch of this process gave up waiting for its partner workgroup: its indices are wrong.
+  // Sticky until read with coda_fps_lost_partner_events(1) -- nothing is launched on top of an unacknowledged loss
+  if (fps_lost_events(false) != 0u) return CODA_ELOST;
 
   (void)hipGetLastError();  // drop stale sticky errors of earlier, unrelated HIP calls
   // variant 0 (default): bucketed kernel (needs the workspace), else v2 where it applies;
@@ -1042,6 +1156,18 @@ CODA_API int coda_furthest_point_sampling_opt_f32(const float *xyz, int b, int n
   coda::CallOptions o = coda::call_options();
   o.distance_mode = distance_mode;
   o.fps_waves = waves;
+  coda::ScopedCallOptions scope(o);
+  return coda_furthest_point_sampling_f32(xyz, b, n, m, idx, workspace, workspace_bytes, stream);
+}
+
+CODA_API unsigned int coda_fps_lost_partner_events(int reset) { return coda::fps_lost_events(reset != 0); }
+
+CODA_API int coda_furthest_point_sampling_dbg_f32(const float *xyz, int b, int n, int m, int32_t *idx, void *workspace,
+                                                  size_t workspace_bytes, int spin_limit, int drop_half, void *stream) {
+  if (spin_limit < 0 || drop_half < -1 || drop_half > 1) return CODA_EINVAL;
+  coda::CallOptions o = coda::call_options();
+  o.fps_spin_limit = spin_limit;
+  o.fps_drop_half = drop_half;
   coda::ScopedCallOptions scope(o);
   return coda_furthest_point_sampling_f32(xyz, b, n, m, idx, workspace, workspace_bytes, stream);
 }

@@ -89,8 +89,19 @@ def set_fps_waves(waves=0):
     _lib.set_option("fps_waves", waves)
 
 
-def furthest_point_sampling(points, nsamples):
-    """(B,N,3) f32 -> (B,nsamples) i32.  sampling.cpp:67-88."""
+def check_sampling_status():
+    """Raises if a two-workgroup furthest-point-sampling launch of this process lost its partner workgroup (its indices
+    are wrong; include/coda_pointnet2.h, CODA_ELOST).  One read of a pinned host word: free to call anywhere; it speaks
+    for every launch whose stream has been synchronised.  ``furthest_point_sampling`` itself refuses to launch on top
+    of an unacknowledged loss, and ``SamplingPrefetcher.take`` calls this when it hands a finished sampling over."""
+    lib = _lib.load()
+    if lib.coda_fps_lost_partner_events(0):
+        _lib.check(_lib.CODA_ELOST, "furthest_point_sampling")
+
+
+def furthest_point_sampling(points, nsamples, _dbg=None):
+    """(B,N,3) f32 -> (B,nsamples) i32.  sampling.cpp:67-88.  (``_dbg = (spin_limit, drop_half)``: the test hook
+    coda_furthest_point_sampling_dbg_f32 that makes the two-workgroup kernel lose its partner.)"""
     _check_contiguous(points, "points")
     _check_float(points, "points")
     _check_device(points)
@@ -100,8 +111,12 @@ def furthest_point_sampling(points, nsamples):
     ws_bytes = lib.coda_furthest_point_sampling_workspace_bytes(b, n, nsamples)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=points.device) if ws_bytes else None
     with torch.cuda.device(points.device), _timed("furthest_point_sampling"):
-        st = lib.coda_furthest_point_sampling_opt_f32(_ptr(points), b, n, nsamples, _ptr(out), _ptr(ws), ws_bytes,
-                                                      _lib.opt("distance_mode"), _lib.opt("fps_waves"), _stream())
+        if _dbg is not None:
+            st = lib.coda_furthest_point_sampling_dbg_f32(_ptr(points), b, n, nsamples, _ptr(out), _ptr(ws), ws_bytes,
+                                                          int(_dbg[0]), int(_dbg[1]), _stream())
+        else:
+            st = lib.coda_furthest_point_sampling_opt_f32(_ptr(points), b, n, nsamples, _ptr(out), _ptr(ws), ws_bytes,
+                                                          _lib.opt("distance_mode"), _lib.opt("fps_waves"), _stream())
     _lib.check(st, "furthest_point_sampling")
     return out
 

@@ -105,13 +105,19 @@ class SamplingPrefetcher:
         for k, (pc, version, prepared, done) in enumerate(self._pending):
             if pc is point_clouds and version == point_clouds._version:
                 del self._pending[k]
+                finished = False
                 if self.wait_for_counts:
                     done.synchronize()
+                    finished = True
                 elif not done.query():
                     # the side stream is still busy (its workgroups need whole CUs and may have been
                     # starved): do not stall the host for the row count -- drop it (the shared MLP then
                     # runs on all rows) and let the compute stream wait on the device side
                     prepared = dict(prepared, total_host=None)
+                else:
+                    finished = True
+                if finished:
+                    _ext.check_sampling_status()  # a sampling kernel that lost its partner workgroup is fatal
                 cur = torch.cuda.current_stream(point_clouds.device)
                 cur.wait_event(done)
                 for v in prepared.values():

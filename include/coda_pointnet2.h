@@ -37,6 +37,7 @@ extern "C" {
 #define CODA_OK 0
 #define CODA_EINVAL (-1)
 #define CODA_ENOSPC (-2)
+#define CODA_ELOST (-3) /* an earlier two-workgroup sampling launch lost its partner workgroup: see below */
 
 /* Library identification: returns "coda_hip gfx950 <abi-version>". */
 const char *coda_version(void);
@@ -78,7 +79,8 @@ int coda_get_distance_mode(void);
  * the buckets each, exchanging their candidate every round through a mailbox in
  * `workspace` (one relaxed 64-bit atomic each way; the pair is co-resident on any
  * device with more than 2*B CUs; a wait of ~2^22 polls without an answer is
- * abandoned rather than hanging the device); otherwise the running distances live
+ * abandoned rather than hanging the device -- LOUDLY: see
+ * coda_fps_lost_partner_events below); otherwise the running distances live
  * in registers (N <= 24576), LDS (N <= ~40000) or `workspace` (B*N floats, the
  * reference's `tmp` tensor, sampling.cpp:75-77).  coda_..._workspace_bytes()
  * gives the size the chosen kernel needs (Morton records, mailboxes, distances;
@@ -96,6 +98,25 @@ int coda_furthest_point_sampling_opt_f32(const float *xyz, int b, int n, int m,
                                          int32_t *idx, void *workspace,
                                          size_t workspace_bytes, int distance_mode,
                                          int waves, void *stream);
+
+/* The two-workgroup kernel's only failure mode that the reference's single block per
+ * scene (sampling_gpu.cu:72-176) does not have: a workgroup whose partner never
+ * answers gives up after the poll limit, and the indices of that launch are WRONG
+ * from that round on.  The wave that gives up writes a diagnostic word
+ * (bit 31 | scene << 16 | round) to pinned host memory and never waits again, so the
+ * launch still ends promptly.  Reporting, since a launch is asynchronous:
+ *  - every later coda_furthest_point_sampling*_f32 call of the process returns
+ *    CODA_ELOST (and launches nothing) until the word has been read with reset = 1;
+ *  - coda_fps_lost_partner_events(reset) returns the word (0 = nothing lost); after
+ *    the launch's stream has been synchronised it speaks for that launch.
+ * coda_furthest_point_sampling_dbg_f32 is the test hook that produces the event:
+ * spin_limit (> 0: polls before giving up, 0: default) and drop_half (0 | 1: that
+ * workgroup of every pair exits at once; -1: none).  tests/test_ops_gpu.py.        */
+unsigned int coda_fps_lost_partner_events(int reset);
+int coda_furthest_point_sampling_dbg_f32(const float *xyz, int b, int n, int m,
+                                         int32_t *idx, void *workspace,
+                                         size_t workspace_bytes, int spin_limit,
+                                         int drop_half, void *stream);
 
 /* ---- gather_points / gather_points_grad --------------------------------------
  * out[b,c,j] = points[b,c,idx[b,j]]            src/sampling_gpu.cu:11-33

@@ -15,6 +15,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    """Keep what a failing test printed.  A failure of a parity test that cannot be reproduced on demand (DESIGN.md:
+    the one unexplained failure of the whole-step test in round 4, output not kept) is lost otherwise: the failing
+    assertion, its message (which quantity, which numbers) and everything the test printed up to there (the whole-step
+    tests print loss, loss terms, assignments and the worst gradients before they assert) go to
+    gpurun_out/failures/<test>.txt, which travels back from the GPU box."""
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == "call" and rep.failed:
+        try:
+            d = os.path.join(ROOT, "gpurun_out", "failures")
+            os.makedirs(d, exist_ok=True)
+            name = "".join(c if c.isalnum() or c in "-_.[]" else "_" for c in item.nodeid)[-180:]
+            with open(os.path.join(d, name + ".txt"), "a") as f:
+                f.write(f"==== {item.nodeid}\n{rep.longreprtext}\n---- captured stdout\n{rep.capstdout}\n"
+                        f"---- captured stderr\n{rep.capstderr}\n")
+        except OSError:
+            pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """CPU oracle (oracle/pointnet2_oracle.c) -- the checker, never the product."""

@@ -147,6 +147,83 @@ def test_fps_two_workgroups_per_scene(dev, oracle, fps_waves, n, m):
     assert np.array_equal(got, oracle.furthest_point_sampling(dup, min(m, 300)))
 
 
+def test_fps_pair_that_loses_its_partner_is_loud(dev, oracle, distance_mode):
+    """The two-workgroup kernel's one failure mode the reference's single block per scene (sampling_gpu.cu:72-176) does
+    not have: the partner never answers.  Forced through the test hook (workgroup 1 of every pair exits at once, the
+    poll limit lowered): the launch must END (no wait per round), the loss must reach the host (a word in pinned
+    memory), the NEXT sampling call must refuse with a RuntimeError, and after that acknowledgement the operator must
+    work -- and be bit-exact -- again."""
+    import time
+    from coda_neurips2023_amd import _lib
+    if distance_mode != 1:
+        pytest.skip("one arithmetic mode is enough for the failure path")
+    lib = _lib.load()
+    lib.coda_fps_lost_partner_events(1)
+    pc, _, _ = make_batch(2, 40000, seed=77)
+    x = cu(pc, dev)
+    ref = oracle.furthest_point_sampling(pc, 300)
+    assert np.array_equal(_ext.furthest_point_sampling(x, 300).cpu().numpy(), ref)
+    assert lib.coda_fps_lost_partner_events(0) == 0
+    _ext.check_sampling_status()
+    t0 = time.perf_counter()
+    wrong = _ext.furthest_point_sampling(x, 300, _dbg=(4000, 1))   # asynchronous: the call itself cannot know yet
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 2.0, "a lost partner must cost ONE bounded wait, not one per round"
+    word = lib.coda_fps_lost_partner_events(0)
+    assert word & 0x80000000 and (word & 0xffff) == 1, hex(word)   # given up in round 1
+    w = wrong.cpu().numpy()
+    assert w.min() >= 0 and w.max() < 40000                         # wrong, but never out of range
+    assert not np.array_equal(w, ref)
+    with pytest.raises(RuntimeError, match="lost its partner"):
+        _ext.check_sampling_status()                                # acknowledges
+    wrong = _ext.furthest_point_sampling(x, 300, _dbg=(4000, 1))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="lost its partner"):
+        _ext.furthest_point_sampling(x, 300)                        # refuses to launch on top of the loss; acknowledges
+    assert lib.coda_fps_lost_partner_events(0) == 0
+    assert np.array_equal(_ext.furthest_point_sampling(x, 300).cpu().numpy(), ref)
+    # a SLOW partner is not a lost one: with the default limit a chip-filling neighbour changes nothing
+    assert lib.coda_fps_lost_partner_events(0) == 0
+
+
+def test_fps_two_workgroups_under_cotenancy_stress(dev, oracle, distance_mode):
+    """500 launches of the two-workgroup kernel at the ScanNet size (8 x 40 000 -> 2048) while another stream keeps
+    the chip full (large GEMMs back to back, so the pair's workgroups are dispatched late and at different times),
+    interleaved with launches on a second stream of its own: every result bit-equal to the oracle's, no lost-partner
+    event.  (the pair's co-residency is not guaranteed by a plain launch; this is the evidence that a
+    delayed partner is waited for, and test_fps_pair_that_loses_its_partner_is_loud that a missing one is loud.)"""
+    import os
+    from coda_neurips2023_amd import _lib
+    if distance_mode != 1:
+        pytest.skip("one arithmetic mode is enough for the stress loop")
+    reps = int(os.environ.get("CODA_STRESS_REPS", "500"))
+    lib = _lib.load()
+    lib.coda_fps_lost_partner_events(1)
+    pc, _, _ = make_batch(8, 40000, seed=4040)
+    x = cu(pc, dev)
+    ref = torch.from_numpy(oracle.furthest_point_sampling(pc, 2048)).to(dev)
+    a = torch.randn(8192, 8192, device=dev)
+    filler, second = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    for i in range(reps):
+        if i % 4 == 0:
+            with torch.cuda.stream(filler):
+                for _ in range(3):
+                    a @ a                                         # ~10 ms of a full chip each
+        if i % 5 == 4:                                            # two pairs of streams in flight at once
+            second.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(second):
+                got2 = _ext.furthest_point_sampling(x, 2048)
+                bad += (got2 != ref).sum()
+            torch.cuda.current_stream().wait_stream(second)
+        got = _ext.furthest_point_sampling(x, 2048)
+        bad += (got != ref).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, f"{int(bad)} wrong indices in {reps} launches"
+    assert lib.coda_fps_lost_partner_events(0) == 0
+
+
 @pytest.mark.parametrize("n,m", [(30000, 300), (50000, 200), (30000, 100)])
 def test_fps_streaming_paths(dev, oracle, n, m):
     """n > 24576 with few samples, or n > 40 960: running distances in LDS (<= ~40000) or in the workspace."""

@@ -43,6 +43,12 @@ LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-3, 1e-3, 2e-3
 
 def run_product(dev, case, z):
     """The product's step on `dev` with the fixture's inputs -> (loss, loss_dict, captured, outputs, model)."""
+    return build_product(dev, case, z)()
+
+
+def build_product(dev, case, z):
+    """-> step(): one forward + criterion + backward of the product on the fixture's inputs; every call starts from
+    zeroed gradients and returns (loss, loss_dict, captured, outputs, model)."""
     batch, seam = SI.build(case)
     args = SI.recipe(case)
     cfg = HotPathDatasetConfig()
@@ -78,13 +84,18 @@ def run_product(dev, case, z):
         return res
 
     crit.matcher.solve = spy
-    hook = model.pre_encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("sa_inds", o[2].detach().cpu()))
+    model.pre_encoder.register_forward_hook(lambda m, i, o: captured.__setitem__("sa_inds", o[2].detach().cpu()))
     dbatch = {k: v.to(dev) for k, v in batch.items()}
-    pred = model(dbatch, curr_epoch=0)
-    loss, loss_dict = crit(pred, dbatch)
-    loss.backward()
-    hook.remove()
-    return loss, loss_dict, captured, pred["outputs"], model
+
+    def step():
+        captured["inds"], captured["mask"] = [], []
+        model.zero_grad(set_to_none=True)
+        pred = model(dbatch, curr_epoch=0)
+        loss, loss_dict = crit(pred, dbatch)
+        loss.backward()
+        return loss, loss_dict, captured, pred["outputs"], model
+
+    return step
 
 
 def compare(loss, loss_dict, captured, outputs, model, z, grad_tol=GRAD_TOL, few_tokens=False):
@@ -153,6 +164,43 @@ def test_whole_step_equals_the_reference_modules_at_full_size(dev, case):
     loss, loss_dict, captured, outputs, model = run_product(dev, case, z)
     torch.cuda.synchronize()
     compare(loss, loss_dict, captured, outputs, model, z, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["configs4_fp32"])
+def test_whole_step_repeated_in_one_process(dev, case):
+    """The open item of round 4: this case failed ONCE (output not kept) and never again.  The case is the only one on
+    the two-workgroup sampling kernel and the 512-query attention shapes, so: the same step CODA_STRESS_STEP_REPS times
+    (default 200) in one process on one model -- the first run held against the reference's fixture as above, every
+    later run held against the first ON THE DEVICE: sampling indices bit-equal, the 64 assignments identical, loss and
+    every gradient tensor within 1e-5 (relative L2; the step's only run-to-run freedom is the order of a few fp64 /
+    two-addend atomics).  Any failure leaves the failing quantity in gpurun_out/failures/ (tests/conftest.py)."""
+    reps = int(os.environ.get("CODA_STRESS_STEP_REPS", "200"))
+    z = np.load(GOLDEN % case)
+    step = build_product(dev, case, z)
+    loss, loss_dict, captured, outputs, model = step()
+    torch.cuda.synchronize()
+    compare(loss, loss_dict, captured, outputs, model, z, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
+    first = {"loss": loss.detach().double(), "inds": captured["sa_inds"].clone(),
+             "assign": torch.cat([t.reshape(-1) for t in captured["inds"]]).clone(),
+             "grads": {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}}
+    norms = {n: g.double().norm().clamp_min(1e-30) for n, g in first["grads"].items()}
+    scale = max(float(v) for v in norms.values())
+    for rep in range(1, reps):
+        loss_r, _, cap_r, _, model_r = step()   # same model, same inputs, gradients from zero
+        torch.cuda.synchronize()
+        assert torch.equal(cap_r["sa_inds"], first["inds"]), f"run {rep}: sampling indices changed"
+        assert torch.equal(torch.cat([t.reshape(-1) for t in cap_r["inds"]]), first["assign"]), f"run {rep}: assignments"
+        e = abs(float(loss_r.detach().double() - first["loss"]) / float(first["loss"]))
+        assert e < 1e-6, f"run {rep}: loss moved by {e:.2e}"
+        worst = (0.0, "")
+        for n, p in model_r.named_parameters():
+            if p.grad is None:
+                continue
+            d = float((p.grad.double() - first["grads"][n].double()).norm() / max(float(norms[n]), 1e-6 * scale))
+            worst = max(worst, (d, n))
+        assert worst[0] < 1e-5, f"run {rep}: gradient {worst[1]} moved by {worst[0]:.2e}"
+        del loss_r
 
 
 @pytest.mark.parametrize("case", list(SI.CASES))
