@@ -55,6 +55,7 @@ RADIUS = 0.2
 BQ_GROUP_BYTES_PER_SCENE = (12 * N_POINTS + 12 * M_CENTRES + 4 * M_CENTRES * NSAMPLE) + \
                            (4 * M_CENTRES * NSAMPLE + 12 * N_POINTS + 12 * M_CENTRES * NSAMPLE)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+BQ_TRAFFIC_PMC = int((1089.0 * 2 + 3012.2 + 2666.0 * 2 + 16384.0) * 1024)  # profiles/r05_pmc_ball_query.md, B = 8
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 # MFMA flops of one attention kernel per (query, key, model-channel) triple: forward QK^T + PV;
@@ -838,7 +839,7 @@ def main():
         if ev:
             ms64 = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
             by = BQ_GROUP_BYTES_PER_SCENE * 64
-            bq64 = {"kernel": "grid_build_kernel + grid_query_kernel, B = 64 scenes in one call (the global batch on one "
+            bq64 = {"kernel": "grid_build_kernel + grid_query8_kernel, B = 64 scenes in one call (the global batch on one "
                               "GPU), GPU otherwise idle",
                     "timing": "HIP events around each call", "bound": "hbm", "achieved": round(by / (ms64 * 1e-3) / 1e9, 3),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -854,7 +855,7 @@ def main():
         bytes_per_launch = BQ_GROUP_BYTES_PER_SCENE * B_PER_GPU
         achieved = bytes_per_launch / (bq_ms * 1e-3) / 1e9 if bq_ms else None
         bq_roofline = {
-            "kernel": "grid_build_kernel + grid_query_kernel (cell-binned ball_query fused with xyz grouping, "
+            "kernel": "grid_build_kernel + grid_query8_kernel (cell-binned ball_query fused with xyz grouping, "
                       "one coda_query_and_group_xyz_f32 call)",
             "timing": ("HIP events around each call inside the timed region"
                        + (" (side stream, concurrent with the step's kernels)" if prefetch else "")),
@@ -863,10 +864,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-            # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate
-            # rocprofv3 --pmc passes of tools/bench_ops.py: profiles/r03_pmc_ball_query.md (not collected in this run)
-            "traffic": 25585664,
-            "traffic_source": "profiles/r03_pmc_ball_query.md",
+            # HBM bytes per launch from PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate rocprofv3 --pmc passes
+            # of tools/bench_ops.py on THIS round's kernels (tools/pmc_bq.sh): build 1089.0 KB x2 + 3012.2 KB, query
+            # 2666.0 KB x2 + 16384.0 KB -- profiles/r05_pmc_ball_query.md (not collected in this run)
+            "traffic": BQ_TRAFFIC_PMC,
+            "traffic_source": "profiles/r05_pmc_ball_query.md",
             "bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(bq_ms, 5) if bq_ms else None,
             # same operator, same inputs, GPU otherwise idle (only reported when the timed region ran it

@@ -59,7 +59,7 @@ def main():
     if "bq" in which:
         nbytes = 8 * (12 * 20000 + 12 * 2048 + 4 * 2048 * 64)
         gbytes = 8 * 3126016
-        for alg in ("scan", "grid", "tile"):
+        for alg in ("scan", "grid"):
             if alg == "scan" and "quick" in which:
                 continue
             med, mn = timeit(lambda: _ext.ball_query(new_xyz, xyz, 0.2, 64, algorithm=alg))
@@ -76,14 +76,14 @@ def main():
         xyz64 = torch.from_numpy(np.concatenate(pcs)).to(dev)
         inds64 = _ext.furthest_point_sampling(xyz64, 2048)
         new64 = torch.gather(xyz64, 1, inds64.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-        for alg in ("grid", "tile"):
+        for alg in ("grid",):
             med, mn = timeit(lambda: _ext.query_and_group_xyz(new64, xyz64, 0.2, 64, True, algorithm=alg, channels_last=True))
             print(f"query_and_group_xyz {alg} B=64: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us  "
                   f"({8 * gbytes / med / 1e6:.1f} GB/s = {8 * gbytes / med / 1e6 / 8000:.3f} of 8 TB/s)")
         pc40, _, _ = make_batch(8, 40000, seed=77)
         xyz40 = torch.from_numpy(pc40).to(dev)
         new40 = torch.gather(xyz40, 1, _ext.furthest_point_sampling(xyz40, 2048).long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-        for alg in ("grid", "tile"):
+        for alg in ("grid",):
             med, mn = timeit(lambda: _ext.query_and_group_xyz(new40, xyz40, 0.2, 64, True, algorithm=alg, channels_last=True))
             print(f"query_and_group_xyz {alg} N=40000: median {med * 1e3:.1f} us  min {mn * 1e3:.1f} us")
     if "group" in which:
