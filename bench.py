@@ -28,6 +28,7 @@ DDP gradient all-reduce (+ SyncBatchNorm statistics), as in the reference
 (main.py:993-996).
 """
 import argparse
+import contextlib
 import gc
 import json
 import math
@@ -111,8 +112,6 @@ def build_workload(kind, dev):
     if kind in ("auto", "model"):
         return build_model_workload(dev)
     if kind == "model40k":  # profiling aid: the configs[4] share as the main workload (bf16 attention, 512 queries)
-        from coda_neurips2023_amd import attention_core
-        attention_core.set_mfma_dtype("bf16")
         return build_model_workload(dev, nq=512, config_tag="configs[4], one GPU's share", attn="bf16")
     torch.manual_seed(0)
     mod = pointnet2_modules.PointnetSAModuleVotes(radius=RADIUS, nsample=NSAMPLE, npoint=M_CENTRES,
@@ -260,11 +259,16 @@ def build_model_workload(dev, nq=256, config_tag="configs[2]", attn="fp32", imag
     crit = crit.to(dev)
     tgt_gen = torch.Generator().manual_seed(2)
 
+    from coda_neurips2023_amd import attention_core
+
     def step(m, batch, pre_encoded=None, with_dict=False):
         if "gt_box_present" not in batch:  # ground truth travels with the batch (engine.py:137-148); made once
             batch.update(synthetic_targets(batch, tgt_gen))
-        pred = m(batch, curr_epoch=0, pre_encoded=pre_encoded) if pre_encoded is not None else m(batch, curr_epoch=0)
-        loss, loss_dict = crit(pred, batch)
+        # the MFMA operand type of the attention core is a per-call option: a scope around the forward pass, which the
+        # backward of the same graph inherits (attention_core.mfma_dtype)
+        with attention_core.mfma_dtype(attn) if dev.type == "cuda" else contextlib.nullcontext():
+            pred = m(batch, curr_epoch=0, pre_encoded=pre_encoded) if pre_encoded is not None else m(batch, curr_epoch=0)
+            loss, loss_dict = crit(pred, batch)
         return (loss, loss_dict) if with_dict else loss
 
     desc = (f"{config_tag}: full model_3detr (SA {'40000' if nq == 512 else '20000'}->2048 r=0.2 ns=64, enc 3L d=256 "
@@ -326,11 +330,10 @@ def run_extra(kind, dev, steps, warmup):
                  "random-init), models/model_3detr.py:902-1086")
         prefetch = True
     else:
-        attention_core.set_mfma_dtype("bf16")
         n_points = 40000
         mod, step_fn, desc, _ = build_model_workload(dev, nq=512, config_tag="configs[4], one GPU's share", attn="bf16")
         prefetch = True
-    try:
+    if True:
         pool = []
         for i in range(3):
             pc, mn, mx = make_batch(B_PER_GPU, n_points, seed=4321 + i)
@@ -362,8 +365,6 @@ def run_extra(kind, dev, steps, warmup):
         if kind == "model40k":
             attn_ms = attention_core.collect_kernel_timing()
             attention_core.disable_kernel_timing()
-    finally:
-        attention_core.set_mfma_dtype("fp32")
     out = {"metric": "scenes/sec fwd+bwd", "value": round(B_PER_GPU * steps / dt, 3), "unit": "scenes/s", "n_gpus": 1,
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
            "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": n_points,

@@ -29,18 +29,19 @@ def _dtype_code(dtype):
     return _DTYPE_CODES[str(dtype).replace("torch.", "")]
 
 
-def set_mfma_dtype(dtype):
-    """'fp32', 'bf16', 'bf16x3' or 'default': operand type of the matrix-core products inside the fused attention kernels
-    for the calls of THIS thread from now on (a per-call argument of coda_mha_*_opt_f32, include/coda_attention.h --
-    the library itself keeps no switch).  Tensors stay float32 in every mode; 'bf16x3' carries each fp32 operand as
-    three bf16 pieces and gives fp32-level results on the bf16 matrix cores.  Prefer the scoped form ``mfma_dtype``."""
-    _lib.set_option("mfma_dtype", _dtype_code(dtype))
-
-
 def mfma_dtype(dtype):
-    """``with attention_core.mfma_dtype("bf16"): loss = model(batch)...; loss.backward()`` -- the forward passes issued
-    inside the block (and their backward passes, whenever they run) use that operand type; other threads and the code
-    outside the block are unaffected."""
+    """'fp32', 'bf16', 'bf16x3' or 'default': operand type of the matrix-core products inside the fused attention
+    kernels -- a per-call argument of coda_mha_*_opt_f32 (include/coda_attention.h; the library keeps no switch), and on
+    this side a SCOPE, the only form there is (no setter: round 5):
+
+        with attention_core.mfma_dtype("bf16"):
+            loss = criterion(model(batch), batch)
+        loss.backward()
+
+    The forward passes issued inside the block use that operand type, and so do their backward passes whenever they run
+    (the autograd node keeps the code it was issued with); other threads and the code outside the block are unaffected.
+    Tensors stay float32 in every mode; 'bf16x3' carries each fp32 operand as three bf16 pieces and gives fp32-level
+    results on the bf16 matrix cores."""
     return _lib.options(mfma_dtype=_dtype_code(dtype))
 
 

@@ -1275,7 +1275,9 @@ CODA_API int coda_sa_mfma_supported(int c1, int c2, int c3, int s_len) {
 CODA_API int coda_sa_pack_groups_f32(const float *grouped, const int32_t *idx, int dedup, float *x, float *row_weight,
                                      int32_t *group_offsets, int32_t *row_group, double *moments, int32_t *counts,
                                      double *zero, int nzero, long long groups, int s_len, void *stream) {
-  if (groups < 0 || s_len <= 0 || nzero < 0 || groups * s_len > 0x7fffffffLL) return CODA_EINVAL;
+  // row_group packs (group << 6) | row-in-group into an int32: at most 2^25 groups of at most 64 rows
+  if (groups < 0 || groups >= (1LL << 25) || s_len <= 0 || s_len > kRows || nzero < 0 || groups * s_len > 0x7fffffffLL)
+    return CODA_EINVAL;
   if (!group_offsets || !moments || (nzero > 0 && !zero)) return CODA_EINVAL;
   if (groups > 0 && (!grouped || !idx || !x || !row_weight || !row_group || !counts)) return CODA_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);

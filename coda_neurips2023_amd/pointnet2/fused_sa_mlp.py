@@ -324,8 +324,12 @@ def pack_groups(idx, grouped_cl, widths, dedup=True):
     """The parameter-free front of the MFMA path (``coda_sa_pack_groups_f32``; the sampling prefetcher runs it on
     its side stream): the distinct rows of every ball-query group packed back to back, with their multiplicity,
     group offsets, (group, row-in-group) words and the 3x3 moments of the packed xyz -- all on the device, no row
-    count travels to the host.  Also zeroes the statistics accumulators of the two MFMA layers.
-    idx (B,M,S) int32, grouped_cl (B,M,S,3) / (B*M*S,3) float32 -> tuple of tensors."""
+    count travels to the host.  Also zeroes the statistics accumulators of the two MFMA layers -- ONCE: the last element
+    of the result is a use counter, and a second forward on the same tuple (a prefetched front used twice, an
+    activation-checkpoint recompute) zeroes them itself instead of adding into the first pass's -- possibly already
+    all-reduced -- sums.  idx (B,M,S) int32, grouped_cl (B,M,S,3) / (B*M*S,3) float32 -> tuple of tensors + counter.
+    Capacity note: x / y2 / y3 of the forward are sized for B*M*S rows (the packed count is not known on the host):
+    1.5 GB at 8 x 2048 x 64, of which the de-duplicated rows (30 % on the bench scenes) are touched."""
     b, m, s = idx.shape
     g = b * m
     dev = idx.device
@@ -343,7 +347,7 @@ def pack_groups(idx, grouped_cl, widths, dedup=True):
     src = grouped_cl if grouped_cl.is_contiguous() else grouped_cl.contiguous()
     _call("coda_sa_pack_groups_f32", _p(src), _p(idx.contiguous()), 1 if dedup else 0, _p(x), _p(roww), _p(goff), _p(grow),
           _p(mom), _p(counts), _p(zero), zero.numel(), g, s)
-    return x, roww, goff, grow, mom, sums
+    return x, roww, goff, grow, mom, sums, {"uses": 0}
 
 
 class _MfmaMlpPool(torch.autograd.Function):
@@ -353,9 +357,13 @@ class _MfmaMlpPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packed, groups, nsample, bns, training, *params):
         lib = _lib.load()
-        x, roww, goff, grow, mom, sums = packed
+        x, roww, goff, grow, mom, sums, state = packed
         dev = x.device
         cap = x.shape[0]
+        c_first = params[0].shape[0]
+        if state["uses"] > 0:  # the accumulators hold an earlier pass's sums: this pass starts from zero like the first
+            sums[2 * c_first:].zero_()
+        state["uses"] += 1
         ws = [params[3 * i].reshape(params[3 * i].shape[0], -1).contiguous() for i in range(3)]
         gammas = [params[3 * i + 1] for i in range(3)]
         betas = [params[3 * i + 2] for i in range(3)]

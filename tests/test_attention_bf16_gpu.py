@@ -1,4 +1,4 @@
-"""bf16-MFMA mode of the fused attention core (coda_mha_set_mfma_dtype(1), csrc/attention_bf16.hip;
+"""bf16-MFMA mode of the fused attention core (mfma_dtype = 1 of coda_mha_*_opt_f32, csrc/attention_bf16.hip;
 BASELINE.json configs[4]) against the plain torch fp32 reference of the same op.
 
 Tolerance: bf16 operands carry 8 significand bits (unit round-off 2^-9 = 2e-3); with fp32
@@ -18,10 +18,10 @@ TOL_MAX, TOL_L2 = 2e-2, 1e-2
 
 @pytest.fixture(autouse=True)
 def bf16_mode():
-    attention_core.set_mfma_dtype("bf16")
-    assert attention_core.get_mfma_dtype() == "bf16"
-    yield
-    attention_core.set_mfma_dtype("fp32")
+    with attention_core.mfma_dtype("bf16"):
+        assert attention_core.get_mfma_dtype() == "bf16"
+        yield
+    assert attention_core.get_mfma_dtype() == "fp32"
 
 
 def l2(a, b):
@@ -72,10 +72,9 @@ def test_bf16_dropout_mask_is_the_fp32_modes(dev):
     eye = eye.to(dev)
     torch.manual_seed(5)
     a_bf16, _ = attention_core.attention(q, k, eye, None, d ** -0.5, p, False)
-    attention_core.set_mfma_dtype("fp32")
     torch.manual_seed(5)
-    a_fp32, _ = attention_core.attention(q, k, eye, None, d ** -0.5, p, False)
-    attention_core.set_mfma_dtype("bf16")
+    with attention_core.mfma_dtype("fp32"):
+        a_fp32, _ = attention_core.attention(q, k, eye, None, d ** -0.5, p, False)
     assert torch.equal(a_bf16 != 0, a_fp32 != 0)
     assert rel(a_bf16, a_fp32) < TOL_MAX
 

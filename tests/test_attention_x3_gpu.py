@@ -1,4 +1,4 @@
-"""Three-piece mode of the fused attention core (coda_mha_set_mfma_dtype(2), csrc/attention_bf16.hip with NS = 3):
+"""Three-piece mode of the fused attention core (mfma_dtype = 2 of coda_mha_*_opt_f32, csrc/attention_bf16.hip with NS = 3):
 every fp32 operand as hi + mid + lo bf16 pieces, six piece products per product, fp32 accumulation.
 
 The claim to check is "fp32-level results": on the same inputs the error against a FLOAT64 evaluation of the op
@@ -15,17 +15,12 @@ from tests.test_attention_gpu import make_qkv, rel
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def restore_mode():
-    yield
-    attention_core.set_mfma_dtype("fp32")
-
-
 def run(mode, q, k, v, leaves, mask, scale, gw, p=0.0):
-    attention_core.set_mfma_dtype(mode)
-    assert attention_core.get_mfma_dtype() == mode
-    torch.manual_seed(77)
-    out, _ = attention_core.attention(q, k, v, mask, scale, p, False)
+    with attention_core.mfma_dtype(mode):
+        assert attention_core.get_mfma_dtype() == mode
+        torch.manual_seed(77)
+        out, _ = attention_core.attention(q, k, v, mask, scale, p, False)
+    assert attention_core.get_mfma_dtype() == "fp32"          # the scope is gone, the backward still runs in `mode`
     grads = torch.autograd.grad((out * gw).sum(), leaves)
     return [out.detach()] + [g.detach() for g in grads]
 
@@ -69,8 +64,8 @@ def test_x3_dropout_masks_are_the_fp32_modes(dev):
     eye = torch.eye(s, d).view(s, 1, 1, d).expand(s, b, h, d).contiguous().to(dev)
     masks = {}
     for mode in ("fp32", "bf16x3"):
-        attention_core.set_mfma_dtype(mode)
         torch.manual_seed(123)
-        a, _ = attention_core.attention(q, k, eye, None, d ** -0.5, p, False)
+        with attention_core.mfma_dtype(mode):
+            a, _ = attention_core.attention(q, k, eye, None, d ** -0.5, p, False)
         masks[mode] = a != 0
     assert torch.equal(masks["fp32"], masks["bf16x3"])

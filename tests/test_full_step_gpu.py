@@ -8,7 +8,7 @@ configs of BASELINE.json name:
 * ``configs[2]``     20 000 points, 256 queries, d_dec 256, fp32, stage-2 loss set (both alignment terms);
 * ``configs[3]``     the stage-1 recipe of scripts/coda_sunrgbd_stage1.sh:7-27 at its own shape: d_dec 512
                      (head width 128), 128 queries, L1 alignment term only;
-* ``configs[4]``     40 000 points, 512 queries, bf16-MFMA attention (``set_mfma_dtype("bf16")``).
+* ``configs[4]``     40 000 points, 512 queries, bf16-MFMA attention (``with attention_core.mfma_dtype("bf16")``).
 
 Checker: the CPU port (oracle/cpu_port.py: the same host-side module graph with the C oracle ops and plain torch
 attention in the kernel seams, C gIoU, scipy assignment = the reference's host route), run twice: in float32 (what
@@ -163,13 +163,9 @@ def test_whole_step_forward_criterion_backward(dev, case):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     with cpu_port.patched(attention=attn):
         r_loss, r_dict, r_cap, r_pred = _step(ref_model, ref_crit, cpu_batch)
-    if attn == "bf16":
-        attention_core.set_mfma_dtype("bf16")
-    try:
+    with attention_core.mfma_dtype(attn):  # a scope around forward + criterion; the backward inside _step inherits it
         g_loss, g_dict, g_cap, g_pred = _step(gpu_model, gpu_crit, gpu_batch)
         torch.cuda.synchronize()
-    finally:
-        attention_core.set_mfma_dtype("fp32")
 
     # ---- furthest point sampling of the set-abstraction stage (20 000 / 40 000 -> 2048): bit-exact ----------------
     assert torch.equal(g_cap["sa_inds"], r_cap["sa_inds"]), "FPS indices of the pre-encoder differ from the oracle's"
@@ -233,12 +229,9 @@ def test_whole_step_forward_criterion_backward(dev, case):
         # (bf16 only) a different assignment moves whole matched-box terms from one proposal to another: to compare
         # ARITHMETIC, the GPU step is repeated with the reference's assignments (the matcher itself was checked above)
         gpu_model.zero_grad(set_to_none=True)
-        attention_core.set_mfma_dtype(attn)
-        try:
+        with attention_core.mfma_dtype(attn):
             g_loss, g_dict, _, g_pred = _step(gpu_model, gpu_crit, gpu_batch, forced=(r_cap["inds"], r_cap["mask"]))
             torch.cuda.synchronize()
-        finally:
-            attention_core.set_mfma_dtype("fp32")
         rel = abs(float(g_loss) - float(r_loss)) / abs(float(r_loss))
         print(f"{case}: with the reference's assignments: loss gpu {float(g_loss):.6f} rel {rel:.2e}")
         assert rel < tol["loss"]

@@ -71,7 +71,7 @@ def _row_maps(cnt, s, dedup=True):
 def test_pack_groups(dev, dedup):
     g, s = 37, 64
     idx, grouped, cnt = _groups(dev, g, s, seed=1)
-    x, roww, goff, grow, mom, sums = _pack(idx, grouped, dedup)
+    x, roww, goff, grow, mom, sums, _ = _pack(idx, grouped, dedup)
     g_of, rin, w = _row_maps(cnt, s, dedup)
     total = g_of.numel()
     assert int(goff[-1]) == total
@@ -110,7 +110,7 @@ def _l1(x, w1, st1):
 def test_forward_layer2_from_xyz(dev, nblk):
     g, s = 41, 64
     idx, grouped, cnt = _groups(dev, g, s, seed=2)
-    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    x, roww, goff, grow, mom, sums, _ = _pack(idx, grouped)
     total = int(goff[-1])
     gen = torch.Generator().manual_seed(3)
     w1 = torch.randn(C1, 3, generator=gen).to(dev)
@@ -155,7 +155,7 @@ def _pool_ref(y3, g_of, rin, gamma, ngroups):
 def test_forward_layer3_with_pooling(dev, nblk):
     g, s = 45, 64
     idx, grouped, cnt = _groups(dev, g, s, seed=5)
-    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    x, roww, goff, grow, mom, sums, _ = _pack(idx, grouped)
     total = int(goff[-1])
     g_of, rin, w = _row_maps(cnt, s)
     gen = torch.Generator().manual_seed(6)
@@ -212,7 +212,7 @@ def _dy_ref(y, dsel, w, coef):
 def test_backward_last_layer(dev, nblk):
     g, s = 39, 64
     idx, grouped, cnt = _groups(dev, g, s, seed=9)
-    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    x, roww, goff, grow, mom, sums, _ = _pack(idx, grouped)
     total = int(goff[-1])
     g_of, rin, w = _row_maps(cnt, s)
     gen = torch.Generator().manual_seed(10)
@@ -250,7 +250,7 @@ def test_backward_last_layer(dev, nblk):
 def test_backward_hidden_layer_and_layer1_closed_form(dev, nblk):
     g, s = 39, 64
     idx, grouped, cnt = _groups(dev, g, s, seed=13)
-    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    x, roww, goff, grow, mom, sums, _ = _pack(idx, grouped)
     total = int(goff[-1])
     g_of, rin, w = _row_maps(cnt, s)
     gen = torch.Generator().manual_seed(14)
@@ -295,7 +295,7 @@ def test_empty_and_tiny_inputs(dev):
     idx = torch.zeros(1, 64, dtype=torch.int32, device=dev)  # an empty ball: all zeros = one distinct row
     grouped = torch.randn(1, 64, 3, device=dev)
     grouped[:] = grouped[:, :1]
-    x, roww, goff, grow, mom, sums = _pack(idx, grouped)
+    x, roww, goff, grow, mom, sums, _ = _pack(idx, grouped)
     assert int(goff[-1]) == 1 and float(roww[0]) == 64.0
     gen = torch.Generator().manual_seed(0)
     w1, w2 = torch.randn(C1, 3, generator=gen).to(dev), torch.randn(C2, C1, generator=gen).to(dev)

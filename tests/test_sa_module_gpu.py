@@ -95,6 +95,25 @@ def test_pre_encoder_widths_match_reference_through_the_mfma_pipeline(dev, monke
     _close(new_feat_eval, g["new_feat_eval"], "eval-mode features")
 
 
+def test_a_prepared_front_can_be_used_twice(dev):
+    """The packed front carries the statistics accumulators of the two MFMA layers, zeroed by the packing kernel.  A
+    second forward on the same front (a prefetched batch used twice, an activation-checkpoint recompute) must not add
+    into the first pass's sums: same features both times."""
+    from coda_neurips2023_amd.synthetic_scenes import make_batch
+    pc, _, _ = make_batch(2, 5000, seed=8)
+    xyz = torch.from_numpy(pc).to(dev)
+    torch.manual_seed(2)
+    mod = pointnet2_modules.PointnetSAModuleVotes(mlp=[0, 64, 128, 256], npoint=128, radius=0.2, nsample=64,
+                                                  normalize_xyz=True).to(dev).train()
+    front = mod.prepare(xyz)
+    assert "packed" in front
+    with torch.no_grad():
+        a = mod(xyz, prepared=front)[1].clone()
+        b = mod(xyz, prepared=front)[1].clone()
+    # (equal up to the order of the fp64 statistics atomics; doubled sums would change the features by tens of percent)
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
 def test_prepared_front_equals_the_inline_forward(dev):
     """forward(xyz, prepared=prepare(xyz)) -- the sampling prefetcher's route through the MFMA pipeline -- equals
     forward(xyz): same indices, features, parameter gradients and running statistics (a quarter of the BatchNorm

@@ -47,11 +47,10 @@ def run(l, s, b=8, h=4, d=64, p=0.1, reps=20):
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 p = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 for dt in (["fp32", "bf16", "bf16x3"] if which == "both" else [which]):
-    core.set_mfma_dtype(dt)
     print(f"--- MFMA operands: {dt}")
-    for shape in [(2048, 2048), (256, 2048), (256, 256), (512, 2048), (512, 512)]:
-        run(*shape, p=p)
-    run(256, 2048, d=128, h=4, p=p)
-    run(128, 2048, d=128, h=4, p=p)   # the scripts' variant: dec_dim 512, 128 queries
-    run(128, 128, d=128, h=4, p=p)
-core.set_mfma_dtype("fp32")
+    with core.mfma_dtype(dt):
+        for shape in [(2048, 2048), (256, 2048), (256, 256), (512, 2048), (512, 512)]:
+            run(*shape, p=p)
+        run(256, 2048, d=128, h=4, p=p)
+        run(128, 2048, d=128, h=4, p=p)   # the scripts' variant: dec_dim 512, 128 queries
+        run(128, 128, d=128, h=4, p=p)

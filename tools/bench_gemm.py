@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Own fp32-MFMA GEMM kernels (coda_sgemm_f32, coda_gemm_tn_f32) vs the library path (coda_gemm_f32 = hipBLASLt)
+"""Own fp32-MFMA GEMM kernel (coda_sgemm_f32) vs the library path (coda_gemm_f32 = hipBLASLt)
 on the shapes a training step issues (tools/gemm_shapes.py): device time (HIP events over a queued batch of
 launches) and host time per call.  Dev tool."""
 import os
@@ -65,9 +65,8 @@ for (rows, co, ci) in [(2048, 256, 256), (2048, 512, 256), (16384, 256, 256), (1
     dy = torch.randn(rows, co, device=dev)
     x = torch.randn(rows, ci, device=dev)
     ref = (dy.double().t() @ x.double()).float()
-    e = float((gemm.mm_tn(dy, x, kernel=True) - ref).abs().max() / ref.abs().max())
-    t_k, h_k = timeit(lambda: gemm.mm_tn(dy, x, kernel=True))
-    t_l, h_l = timeit(lambda: gemm.mm_tn(dy, x, kernel=False))
+    e = float((gemm.mm_tn(dy, x) - ref).abs().max() / ref.abs().max())
+    t_l, h_l = timeit(lambda: gemm.mm_tn(dy, x))  # one library GEMM (the own TN kernel was removed in round 4)
     from coda_neurips2023_amd.linear_fn import tn_gemm
-    t_c, h_c = timeit(lambda: tn_gemm(dy, x))
-    print(f"{rows:6d} {co:4d}x{ci:4d}  tn kernel {t_k:7.1f} us  lib {t_l:7.1f} us  linear_fn.tn_gemm {t_c:7.1f} us | host {h_k:4.1f} {h_l:4.1f} {h_c:4.1f} | err {e:.1e}")
+    t_c, h_c = timeit(lambda: tn_gemm(dy, x))     # row chunks + a sum: what the step uses for long reductions
+    print(f"{rows:6d} {co:4d}x{ci:4d}  gemm.mm_tn {t_l:7.1f} us  linear_fn.tn_gemm {t_c:7.1f} us | host {h_l:4.1f} {h_c:4.1f} | err {e:.1e}")
