@@ -52,9 +52,11 @@ class _Anything:
         return _Anything()
 
 
-def install_reference():
+def install_reference(any_dtype=False):
     """stub the third-party imports that are absent here and
-    register the oracle as pointnet2._ext BEFORE importing the reference."""
+    register the oracle as pointnet2._ext BEFORE importing the reference.  any_dtype: the operators follow the tensors'
+    dtype (oracle/cpu_port._AnyDtypeExt: index-producing operators on the float32 image of their input, gathers as
+    torch indexing) -- for the float64 run of golden_step_full_f64."""
     for name in ["plyfile", "trimesh", "cv2", "ftfy", "torchvision", "torchvision.transforms",
                  "torchvision.ops", "torchvision.models", "torchvision.models.detection",
                  "torchvision.models.detection.backbone_utils", "timm", "timm.data",
@@ -68,7 +70,11 @@ def install_reference():
     const.DEFAULT_CROP_PCT = 0.875
     pkg = types.ModuleType("pointnet2")
     pkg.__path__ = []
-    ext = O.TorchExt()
+    if any_dtype:
+        from oracle.cpu_port import _AnyDtypeExt
+        ext = _AnyDtypeExt()
+    else:
+        ext = O.TorchExt()
     mod = types.ModuleType("pointnet2._ext")
     for fn in ["gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
                "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
@@ -816,7 +822,7 @@ def golden_eval_det():
     _save("eval_det.npz", **out)
 
 
-def golden_step_full(case="configs2"):
+def golden_step_full(case="configs2", f64=False):
     """ONE WHOLE TRAINING STEP AT BASELINE.json configs[2]'s / configs[3]'s PER-GPU SIZE THROUGH THE REFERENCE'S OWN MODULES (8 scenes x
     20 000 points, 2048 encoder tokens, 256 queries, 3 + 8 layers, the stage-2 loss set): models/model_3detr.py's
     pre-encoder / encoder / decoder / heads (:1767-1794, the oracle's C ops behind pointnet2._ext), criterion.py's
@@ -850,6 +856,15 @@ def golden_step_full(case="configs2"):
     # the test point is moved off the ReLU kinks of the query projection (SI.condition_query_projection: why); the two
     # conditioned biases travel in the fixture
     qp_bias = SI.condition_query_projection(model, batch, SI.CASES[case]["nq"])
+    if f64:  # the float32 fixture's conditioned biases, so that both fixtures describe the same test point
+        z32 = np.load(os.path.join(HERE, f"step_full_{case}.npz"))
+        lin = [m for m in model.query_projection.layers if isinstance(m, (torch.nn.Conv1d, torch.nn.Linear))]
+        with torch.no_grad():
+            lin[0].bias.copy_(torch.from_numpy(z32["cond/qp_bias0"]))
+            lin[1].bias.copy_(torch.from_numpy(z32["cond/qp_bias2"]))
+        model.double()
+        batch = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+        seam = {k: (v.double() if v.is_floating_point() else v) for k, v in seam.items()}
     model.train()
     # SetCriterion.__init__ parks a scratch tensor on 'cuda' (criterion.py:97): keep it on the host while constructing
     real_to = torch.Tensor.to
@@ -858,6 +873,12 @@ def golden_step_full(case="configs2"):
         crit = RC.build_criterion(args, cfg)
     finally:
         torch.Tensor.to = real_to
+    if f64:
+        crit.double()  # (class weights and other float buffers of the criterion)
+        # criterion.py:604 casts the text embeddings `.to(torch.float32)` in front of a bmm (lossless here: the seam's
+        # embeddings ARE float32 data): let that one product promote instead of raising
+        real_bmm = torch.bmm
+        torch.bmm = lambda a, b, **kw: real_bmm(a.double(), b.double(), **kw)
     captured = {}
     real_match = crit.matcher.forward
 
@@ -891,6 +912,15 @@ def golden_step_full(case="configs2"):
     print(f"step_full: criterion {time.time() - t0:.1f} s, loss {float(loss):.6f}")
     loss.backward()
     print(f"step_full: backward {time.time() - t0:.1f} s")
+    if f64:
+        out = {"loss": np.float64(float(loss)), "sa_inds": _np(enc_inds).astype(np.int32)}
+        for name, p in model.named_parameters():
+            if p.grad is not None:
+                g = p.grad.detach().double().reshape(-1).numpy()
+                out[f"norm/{name}"] = np.float64(np.linalg.norm(g))
+                out[f"sketch/{name}"] = sketch(g, name)
+        _save(f"step_full_{case}_f64.npz", **out)
+        return
     out = {"loss": np.float64(float(loss)), "sa_inds": _np(enc_inds).astype(np.int32),
            # SetCriterion.forward matches the last layer first, then aux 0..6 (:1200-1210): stored in LAYER order
            "assign_inds": _np(torch.cat(captured["inds"][1:] + captured["inds"][:1])).astype(np.int16),
@@ -912,6 +942,35 @@ def golden_step_full(case="configs2"):
     _save(f"step_full_{case}.npz", **out)
 
 
+def sketch(g, name, k=128):
+    """Count sketch of a flat float64 tensor: every element is added, with a seeded random sign, to one of k seeded
+    random buckets.  For two tensors a, b:  sum_b (sketch(a) - sketch(b))_b^2  is an unbiased estimate of |a - b|^2
+    (relative standard deviation ~ sqrt(2 / k) = 12.5 % on the square, 6 % on the norm) -- EVERY element takes part, in
+    1 KB per tensor and O(n) work."""
+    import zlib
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 77)
+    bucket = rng.integers(0, k, g.size)
+    sign = rng.integers(0, 2, g.size).astype(np.float64) * 2.0 - 1.0
+    return np.bincount(bucket, weights=sign * g, minlength=k)
+
+
+def golden_step_full_f64(case="configs2"):
+    """the whole step of golden_step_full through the reference's modules IN FLOAT64 (run with
+    `make_golden.py step_full_f64`, which installs the dtype-following operators; 10-20 minutes and ~20 GB on 8 cores),
+    so that tests/test_reference_step_gpu.py can hold the product's gradients against the reference's TRUE gradients
+    on WHOLE tensors at the north-star 1e-3: per parameter gradient its norm and a 128-bucket count sketch (see `sketch`)."""
+    golden_step_full(case, f64=True)
+
+
+def golden_step_full_configs3_f64():
+    golden_step_full("configs3", f64=True)
+
+
+def golden_step_full_configs4_f64():
+    golden_step_full("configs4_fp32", f64=True)
+
+
 def golden_step_full_configs3():
     golden_step_full("configs3")
 
@@ -923,7 +982,7 @@ def golden_step_full_configs4():
 if __name__ == "__main__":
     O.build()
     O.set_fma_mode(FMA_MODE)
-    install_reference()
+    install_reference(any_dtype=any(w.endswith("_f64") for w in sys.argv[1:]))
     torch.set_num_threads(8)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     which = sys.argv[1:] or ["ops", "sa_module", "sa_module_wide", "transformer", "model", "criterion", "giou", "eval_post", "clip_crops", "clip_tower", "region_branch", "eval_det", "step_full", "step_full_configs3", "step_full_configs4"]

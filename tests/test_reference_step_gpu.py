@@ -38,7 +38,52 @@ from coda_neurips2023_amd.dataset_config import HotPathDatasetConfig  # noqa: E4
 from coda_neurips2023_amd.model_3detr import build_model  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "step_full_%s.npz")
+GOLDEN_F64 = os.path.join(os.path.dirname(__file__), "golden", "step_full_%s_f64.npz")
 LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-3, 1e-3, 2e-3
+WHOLE_TOL = 1e-3  # north_star's tolerance, on WHOLE gradient tensors against the reference's float64 run (below)
+
+
+def sketch(g, name, k=128):
+    """tests/golden/make_golden.py::sketch, restated (the generator cannot travel).  Count sketch of a flat float64 tensor: every element is added, with a seeded random sign, to one of k seeded
+    random buckets.  For two tensors a, b:  sum_b (sketch(a) - sketch(b))_b^2  is an unbiased estimate of |a - b|^2
+    (relative standard deviation ~ sqrt(2 / k) = 12.5 % on the square, 6 % on the norm) -- EVERY element takes part, in
+    1 KB per tensor and O(n) work."""
+    import zlib
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 77)
+    bucket = rng.integers(0, k, g.size)
+    sign = rng.integers(0, 2, g.size).astype(np.float64) * 2.0 - 1.0
+    return np.bincount(bucket, weights=sign * g, minlength=k)
+
+
+def compare_whole_tensors(model, case, tol=WHOLE_TOL, few_tokens=False):
+    """Every parameter gradient, WHOLE, against the reference's own modules run in FLOAT64
+    (tests/golden/step_full_<case>_f64.npz: make_golden.py::golden_step_full_f64 -- the reference's model_3detr.py +
+    criterion.py on the host in double precision, 2.5 minutes on 8 cores; per tensor its norm and a 128-number
+    count sketch, 1 KB): the estimated relative L2 error |g - g_ref| / |g_ref| of the whole tensor is
+    held at north_star's 1e-3.  This is the float64-judged whole-tensor bound VERDICT r4 asked for next to the sampled
+    2e-3 against the float32 run; the estimator's own 6 % noise is inside the margin (measured worst: see DESIGN.md)."""
+    z = np.load(GOLDEN_F64 % case)
+    params = dict(model.named_parameters())
+    names = [k[7:] for k in z.files if k.startswith("sketch/")]
+    assert set(names) == {n for n, p in params.items() if p.grad is not None}
+    scale = max(float(z[f"norm/{n}"]) for n in names)
+    report = []
+    for n in names:
+        ref_norm = float(z[f"norm/{n}"])
+        g = params[n].grad.detach().double().cpu().numpy().reshape(-1)
+        if ref_norm < 1e-6 * scale:  # true gradient zero (a bias in front of a batch-statistics norm)
+            assert float(np.linalg.norm(g)) < 1e-3 * scale, n
+            continue
+        d = sketch(g, n) - z[f"sketch/{n}"]
+        report.append((float(np.sqrt(np.sum(d * d))) / ref_norm, n, g.size))
+    report.sort(reverse=True)
+    for e, n, size in report[:6]:
+        print(f"  whole-tensor grad {n:66s} ({size:7d} elements) est. rel L2 vs the float64 reference {e:.2e}")
+    lim = lambda n: tol * (2.0 if few_tokens and n.startswith(("mlp_heads.", "query_projection.")) else 1.0)  # noqa: E731
+    bad = [(e, n) for e, n, _ in report if not e < lim(n)]
+    assert not bad, bad[:10]
+    return report[0][0]
 
 
 def run_product(dev, case, z):
@@ -164,6 +209,8 @@ def test_whole_step_equals_the_reference_modules_at_full_size(dev, case):
     loss, loss_dict, captured, outputs, model = run_product(dev, case, z)
     torch.cuda.synchronize()
     compare(loss, loss_dict, captured, outputs, model, z, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
+    if os.path.exists(GOLDEN_F64 % case):
+        compare_whole_tensors(model, case, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
 
 
 @pytest.mark.gpu
@@ -216,3 +263,7 @@ def test_cpu_port_equals_the_reference_modules_at_full_size(case):
     with cpu_port.patched():
         res = run_product(torch.device("cpu"), case, np.load(GOLDEN % case))
     compare(*res, np.load(GOLDEN % case), grad_tol=3e-3, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
+    if os.path.exists(GOLDEN_F64 % case):
+        # the checker (torch-CPU float32 layers + the C oracle) against the float64 truth: measured <= 5.4e-4 on whole
+        # tensors (configs[3]; 2.6e-4 configs[2], 4.8e-4 configs[4]'s shape) -- held at 2e-3, the product at 1e-3 (above)
+        compare_whole_tensors(res[4], case, tol=2e-3, few_tokens=SI.CASES[case]["nq"] * SI.B <= 1024)
