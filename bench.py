@@ -356,6 +356,11 @@ def run_extra(kind, dev, steps, warmup):
         attn_ms = {}
         if kind == "model40k":
             attention_core.enable_kernel_timing(0)
+        # as in the headline loop: a full pass of Python's cyclic collector over the long-lived objects of torch + the
+        # models built so far costs 40-90 ms -- inside ten timed steps that is +4..9 ms per step (seen once in round 5:
+        # 24.5 instead of 16.9 ms per step on this configuration with identical kernel times)
+        gc.collect()
+        gc.freeze()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
