@@ -263,6 +263,103 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float *
 #undef BQ_PROF_BASE
 }
 
+// ---- build, one workgroup per scene (round 5; large batches) -------------------------------------------------------
+// The slab build above classifies every point in every one of a scene's 8 workgroups: 8x the work for 8x the CUs, which
+// pays while there are fewer scenes than CUs / 8.  At the global batch (64 scenes = 512 slab workgroups = two rounds of
+// the chip, 28 us) the redundancy is what the time is made of; here ONE 1024-thread workgroup per scene keeps the whole
+// 16 384-counter table in LDS (64 KB) and every point is classified once per pass: count (LDS atomics), scan (16
+// counters per thread), scatter (returning LDS atomics) -- the same table and records as the slab build (the order
+// inside a cell is arbitrary in both; the query ranks by index).
+constexpr int kBuild1Threads = 1024;
+constexpr int kBuild1PerThread = kCells / kBuild1Threads;  // 16 counters per thread in the scan
+
+template <int G>
+__global__ __launch_bounds__(kBuild1Threads) void grid_build1_kernel(const float *__restrict__ xyz, int n, float inv_cell,
+                                                                    unsigned char *__restrict__ ws, size_t scene_stride,
+                                                                    int vec) {
+  __shared__ __attribute__((aligned(16))) int s_cnt[kCells];
+  __shared__ int s_wsum[kBuild1Threads / kWave];
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const int scene = blockIdx.x;
+  const float *__restrict__ pts = xyz + static_cast<size_t>(scene) * n * 3;
+  const SceneWs w = scene_ws(ws, scene_stride, scene);
+  const int ngroups = (n + 3) / 4;
+
+  for (int c = tid; c < kCells; c += kBuild1Threads) s_cnt[c] = 0;
+  constexpr int GG = G > 0 ? G : 1;
+  Quad q[GG];
+  if (G > 0) {
+#pragma unroll
+    for (int i = 0; i < GG; ++i) q[i] = load_quad(pts, tid + i * kBuild1Threads, n, vec != 0);
+  }
+  __syncthreads();
+  auto count_quad = [&](const Quad &qq, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * g + j < n) atomicAdd(&s_cnt[cell_of(qq.v[3 * j], qq.v[3 * j + 1], qq.v[3 * j + 2], inv_cell)], 1);
+  };
+  if (G > 0) {
+#pragma unroll
+    for (int i = 0; i < GG; ++i) count_quad(q[i], tid + i * kBuild1Threads);
+    for (int g = tid + GG * kBuild1Threads; g < ngroups; g += kBuild1Threads) count_quad(load_quad(pts, g, n, vec != 0), g);
+  } else {
+    for (int g = tid; g < ngroups; g += kBuild1Threads) count_quad(load_quad(pts, g, n, vec != 0), g);
+  }
+  __syncthreads();
+  // exclusive scan of the 16 384 counters: 16 consecutive ones per thread (read twice from LDS rather than kept: the
+  // resident points need the registers)
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < kBuild1PerThread / 4; ++i) {
+    const int4 c4 = *reinterpret_cast<const int4 *>(s_cnt + tid * kBuild1PerThread + 4 * i);
+    sum += c4.x + c4.y + c4.z + c4.w;
+  }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  if (lane == kWave - 1) s_wsum[wv] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int i = 0; i < wv; ++i) run += s_wsum[i];
+#pragma unroll
+  for (int i = 0; i < kBuild1PerThread / 4; ++i) {
+    const int4 c4 = *reinterpret_cast<const int4 *>(s_cnt + tid * kBuild1PerThread + 4 * i);
+    int4 st;
+    st.x = run; run += c4.x;
+    st.y = run; run += c4.y;
+    st.z = run; run += c4.z;
+    st.w = run; run += c4.w;
+    *reinterpret_cast<int4 *>(s_cnt + tid * kBuild1PerThread + 4 * i) = st;                 // scatter cursors
+    *reinterpret_cast<int4 *>(w.cell_start + tid * kBuild1PerThread + 4 * i) = st;
+  }
+  if (tid == kBuild1Threads - 1) w.cell_start[kCells] = run;
+  __syncthreads();
+  auto scatter_quad = [&](const Quad &qq, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = qq.v[3 * j], y = qq.v[3 * j + 1], z = qq.v[3 * j + 2];
+      if (4 * g + j < n) {
+        const int pos = atomicAdd(&s_cnt[cell_of(x, y, z, inv_cell)], 1);
+        w.records[pos] = make_float4(x, y, z, __int_as_float(4 * g + j));
+      }
+    }
+  };
+  if (G > 0) {
+#pragma unroll
+    for (int i = 0; i < GG; ++i) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) asm volatile("" : "+v"(q[i].v[e]));  // (the cell index is recomputed, not carried)
+      scatter_quad(q[i], tid + i * kBuild1Threads);
+    }
+    for (int g = tid + GG * kBuild1Threads; g < ngroups; g += kBuild1Threads) scatter_quad(load_quad(pts, g, n, vec != 0), g);
+  } else {
+    for (int g = tid; g < ngroups; g += kBuild1Threads) scatter_quad(load_quad(pts, g, n, vec != 0), g);
+  }
+}
+
 // Keep only the `keep` smallest-index records of buf[0..h): all-pairs rank in LDS.
 // Each lane owns records lane, lane+64, ...; returns the new count.
 template <int kSlots>
@@ -802,7 +899,17 @@ int ball_query_grid(const float *new_xyz, const float *xyz, int32_t *idx, float 
   // CODA_BQ_KEEP=0|2|6|8|12 forces an instantiation (A/B).
   static const int force = [] { const char *e = getenv("CODA_BQ_KEEP"); return e ? atoi(e) : -1; }();
   const int keep = force >= 0 ? force : (per <= 2 ? 2 : (per <= 6 ? 6 : 8));
-  if (keep == 2) hipLaunchKernelGGL(grid_build_kernel<2>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
+  // From CODA_BQ_BUILD1 scenes on (default 24: where the slab build's b * 8 workgroups stop fitting the chip in one
+  // round at two per CU... measured: see profiles/r05_pmc_ball_query.md) ONE workgroup per scene builds the whole table.
+  static const int build1_from = [] { const char *e = getenv("CODA_BQ_BUILD1"); return e ? atoi(e) : 24; }();
+  if (b >= build1_from) {
+    const int q1 = ceil_div(ceil_div(n, 4), kBuild1Threads);  // quads per thread
+    const dim3 g1(b), b1(kBuild1Threads);
+    // four quads per thread stay in registers across the two passes (128 VGPRs per thread at 1024 threads: five spill),
+    // the rest of the cloud is read again from L2 in the second pass
+    (void)q1;
+    hipLaunchKernelGGL(grid_build1_kernel<4>, g1, b1, 0, s, xyz, n, inv_cell, ws, stride, vec);
+  } else if (keep == 2) hipLaunchKernelGGL(grid_build_kernel<2>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
   else if (keep == 6) hipLaunchKernelGGL(grid_build_kernel<6>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
   else if (keep == 8) hipLaunchKernelGGL(grid_build_kernel<8>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
   else if (keep == 12) hipLaunchKernelGGL(grid_build_kernel<kKeepMax>, bgrid, dim3(kBuildThreads), 0, s, xyz, n, inv_cell, ws, stride, vec, b);
