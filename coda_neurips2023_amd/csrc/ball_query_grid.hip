@@ -24,11 +24,13 @@
 // Round 1's build was one workgroup per scene reading the cloud three times (bounding box, histogram,
 // scatter) and scanning 32768 counters: 44-65 us on 8 of 256 CUs.
 // Workspace per scene: cell_start[16385] | pad | records[N] (float4).
-// Query (one wave per centre): lanes 0..8 fetch the nine x-contiguous cell ranges
-//   (18 half-ranges when the three x cells wrap around the torus), a wave prefix sum
-//   flattens them into one candidate list so that every lane of every 64-wide chunk has
-//   work, hits are compacted with ballot/mbcnt into an LDS buffer, ranked, and written as
-//   one 256-B row (+ the centred / normalised xyz of the fused QueryAndGroup path).
+// Query, nsample <= 64 (round 5, grid_query8_kernel): a wave serves eight centres, eight lanes each, on a flattened
+//   candidate list, and a DPP bitonic sorting network produces "the first nsample in index order"; see the kernel.
+// Query, larger nsample (rounds 2-4, grid_query_kernel: one wave per centre): lanes 0..8 fetch the nine x-contiguous
+//   cell ranges (18 half-ranges when the three x cells wrap around the torus), a wave prefix sum flattens them into one
+//   candidate list so that every lane of every 64-wide chunk has work, hits are compacted with ballot/mbcnt into an LDS
+//   buffer, ranked, and written as one 256-B row (+ the centred / normalised xyz of the fused QueryAndGroup path).
+// Build at 24+ scenes: one 1024-thread workgroup per scene with the whole table in LDS (grid_build1_kernel).
 #include "common.hip.h"
 
 #include <cstdlib>
