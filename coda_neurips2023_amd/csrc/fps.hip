@@ -1089,7 +1089,7 @@ constexpr size_t kStreamKeyBytes = sizeof(uint2) * 2 * (kStreamThreads / kWave);
 
 CODA_API size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
   if (b <= 0 || n <= 0) return 0;
-  if (coda::bucket2_eligible(n, m)) return coda::bucket2_workspace_bytes(b, n);  // two copies + the mailboxes
+  if (coda::bucket2_eligible(n, m)) return coda::bucket2_workspace_bytes(b, n);  // records (sized for two copies: round 5 uses one) + the mailboxes
   if (coda::bucket_eligible(n, m)) return sizeof(float4) * static_cast<size_t>(b) * n;  // Morton-sorted records
   const size_t lds_need = coda::kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
   if (n <= 1024 * 24 || lds_need <= coda::kLdsBudget) return 0;
