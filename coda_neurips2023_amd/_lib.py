@@ -32,6 +32,9 @@ SIGNATURES = {
     "coda_furthest_point_sampling_dbg_f32": (_c_int, [_P, _c_int, _c_int, _c_int, _P, _P, _c_size_t, _c_int, _c_int, _P]),
     "coda_gather_points_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_gather_points_grad_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P]),
+    "coda_scatter_add_det_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int]),
+    "coda_gather_points_grad_det_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P, _c_size_t, _P]),
+    "coda_group_points_grad_det_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _c_size_t, _P]),
     "coda_ball_query_workspace_bytes": (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "coda_ball_query_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _P, _c_size_t, _P]),
     "coda_ball_query_opt_f32": (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_float, _c_int, _P, _c_size_t, _c_int, _c_int, _P]),

@@ -8,6 +8,9 @@
 // writes CH coalesced output streams.  All four are HBM/L2-bound byte movers.
 #include "common.hip.h"
 
+#include <algorithm>
+#include <cmath>
+
 namespace coda {
 namespace {
 
@@ -74,8 +77,128 @@ int scatter_add_rows(const float *grad_out, const int32_t *idx, float *grad_poin
   return launch_status();
 }
 
+// ---- deterministic scatter-add (round 5) -----------------------------------------------------------------------------
+// The adjoints above sum colliding gradients with hardware float atomics: like the reference's atomicAdd
+// (group_points_gpu.cu:46-67, sampling_gpu.cu:37-60) the result depends on the order the atomics happen in, i.e. it is
+// not reproducible from run to run.  Integer addition is associative: every addend is converted to 64-bit fixed point
+// at a scale taken from the tensor's largest magnitude (so that the worst-case sum of all e_count addends still fits),
+// accumulated with 64-bit integer atomics -- ANY order gives the same bits -- and converted back once.  The fixed-point
+// grid has 62 - ceil(log2(e_count + 1)) bits below the largest magnitude (47 at 32 768 entries per scene, never fewer
+// than 31): finer than the float32 roundings of a float accumulation.  Three passes (largest magnitude, scatter,
+// convert) and 8 bytes of workspace per output element.  A non-finite gradient anywhere makes the whole result NaN
+// (the float atomics would have poisoned only the targets it reaches; a training step is lost either way).
+struct DetHeader {
+  unsigned int absmax_bits;  // float bits of the largest |x| (non-negative floats order like their bit patterns)
+  unsigned int pad_[63];
+};
+static_assert(sizeof(DetHeader) == 256, "header = one aligned block in front of the accumulators");
+
+__global__ __launch_bounds__(kThreads) void det_absmax_kernel(const float *__restrict__ x, size_t total, DetHeader *hdr) {
+  unsigned int m = 0u;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * kThreads)
+    m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), off)));
+  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0u) atomicMax(&hdr->absmax_bits, m);
+}
+// 2^k with  max |x| * 2^k < 2^(62 - count_bits):  k = 62 - count_bits - (exponent of max + 1)
+__device__ __forceinline__ double det_scale(unsigned int absmax_bits, int count_bits) {
+  if (absmax_bits == 0u) return 1.0;
+  const int e = static_cast<int>(absmax_bits >> 23) - 127;  // max < 2^(e + 1)  (denormals: e = -127, still an upper bound)
+  return ldexp(1.0, 62 - count_bits - (e + 1));
+}
+__global__ __launch_bounds__(kThreads) void det_scatter_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+                                                               const DetHeader *__restrict__ hdr,
+                                                               unsigned long long *__restrict__ acc, int c, int n, int e_count,
+                                                               int count_bits) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= e_count) return;
+  const unsigned int mb = hdr->absmax_bits;
+  if (mb >= 0x7f800000u) return;  // non-finite input: the convert pass writes NaN
+  const double scale = det_scale(mb, count_bits);
+  const int bi = blockIdx.z;
+  const int c0 = blockIdx.y * kCh;
+  const int a = idx[static_cast<size_t>(bi) * e_count + e];
+  const float *__restrict__ src = grad_out + (static_cast<size_t>(bi) * c + c0) * e_count + e;
+  unsigned long long *__restrict__ dst = acc + (static_cast<size_t>(bi) * c + c0) * n + a;
+#pragma unroll
+  for (int l = 0; l < kCh; ++l)
+    if (c0 + l < c) {
+      const long long q = __double2ll_rn(static_cast<double>(src[static_cast<size_t>(l) * e_count]) * scale);
+      if (q != 0) atomicAdd(dst + static_cast<size_t>(l) * n, static_cast<unsigned long long>(q));  // two's complement
+    }
+}
+__global__ __launch_bounds__(kThreads) void det_convert_kernel(const unsigned long long *__restrict__ acc,
+                                                               const DetHeader *__restrict__ hdr, float *__restrict__ out,
+                                                               size_t total, int count_bits) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const unsigned int mb = hdr->absmax_bits;
+  if (mb >= 0x7f800000u) {
+    out[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
+  out[i] = static_cast<float>(static_cast<double>(static_cast<long long>(acc[i])) / det_scale(mb, count_bits));
+}
+
+size_t det_workspace_bytes(int b, int c, int n) {
+  return sizeof(DetHeader) + sizeof(unsigned long long) * static_cast<size_t>(b) * c * n;
+}
+
+int scatter_add_rows_det(const float *grad_out, const int32_t *idx, float *grad_points, int b, int c, int n, long long e_count,
+                         void *workspace, size_t workspace_bytes, hipStream_t s) {
+  if (e_count > 0x7fffffffLL) return CODA_EINVAL;
+  const size_t out_total = static_cast<size_t>(b) * c * n;
+  if (e_count == 0) {
+    const hipError_t e0 = hipMemsetAsync(grad_points, 0, sizeof(float) * out_total, s);
+    return e0 == hipSuccess ? CODA_OK : static_cast<int>(e0);
+  }
+  if (!workspace || workspace_bytes < det_workspace_bytes(b, c, n) || (reinterpret_cast<uintptr_t>(workspace) & 7) != 0)
+    return CODA_ENOSPC;
+  DetHeader *hdr = static_cast<DetHeader *>(workspace);
+  unsigned long long *acc = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + sizeof(DetHeader));
+  const hipError_t e = hipMemsetAsync(workspace, 0, det_workspace_bytes(b, c, n), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  int count_bits = 1;
+  while ((1LL << count_bits) <= e_count) ++count_bits;  // ceil(log2(e_count + 1))
+  const size_t in_total = static_cast<size_t>(b) * c * static_cast<size_t>(e_count);
+  clear_sticky_error();
+  const unsigned int rblocks = static_cast<unsigned int>(std::min<size_t>((in_total + kThreads - 1) / kThreads, 4096));
+  hipLaunchKernelGGL(det_absmax_kernel, dim3(rblocks), dim3(kThreads), 0, s, grad_out, in_total, hdr);
+  dim3 grid(ceil_div(static_cast<int>(e_count), kThreads), ceil_div(c, kCh), b);
+  hipLaunchKernelGGL(det_scatter_kernel, grid, dim3(kThreads), 0, s, grad_out, idx, hdr, acc, c, n, static_cast<int>(e_count),
+                     count_bits);
+  hipLaunchKernelGGL(det_convert_kernel, dim3(static_cast<unsigned int>((out_total + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                     acc, hdr, grad_points, out_total, count_bits);
+  return launch_status();
+}
+
 }  // namespace
 }  // namespace coda
+
+CODA_API size_t coda_scatter_add_det_workspace_bytes(int b, int c, int n) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  return coda::det_workspace_bytes(b, c, n);
+}
+
+CODA_API int coda_gather_points_grad_det_f32(const float *grad_out, const int32_t *idx, float *grad_points, int b, int c, int n,
+                                             int m, void *workspace, size_t workspace_bytes, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || m < 0) return CODA_EINVAL;
+  if (b == 0 || c == 0 || n == 0) return CODA_OK;
+  if (!grad_points || (m > 0 && (!grad_out || !idx))) return CODA_EINVAL;
+  return coda::scatter_add_rows_det(grad_out, idx, grad_points, b, c, n, m, workspace, workspace_bytes,
+                                    static_cast<hipStream_t>(stream));
+}
+
+CODA_API int coda_group_points_grad_det_f32(const float *grad_out, const int32_t *idx, float *grad_points, int b, int c, int n,
+                                            int npoints, int nsample, void *workspace, size_t workspace_bytes, void *stream) {
+  if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return CODA_EINVAL;
+  if (b == 0 || c == 0 || n == 0) return CODA_OK;
+  const long long e_count = static_cast<long long>(npoints) * nsample;
+  if (!grad_points || (e_count > 0 && (!grad_out || !idx))) return CODA_EINVAL;
+  return coda::scatter_add_rows_det(grad_out, idx, grad_points, b, c, n, e_count, workspace, workspace_bytes,
+                                    static_cast<hipStream_t>(stream));
+}
 
 CODA_API int coda_gather_points_f32(const float *points, const int32_t *idx, float *out, int b,
                                     int c, int n, int m, void *stream) {

@@ -138,6 +138,17 @@ def gather_points(points, idx):
     return out
 
 
+# The two scatter-add adjoints: deterministic by default (64-bit fixed-point accumulation: reproducible bit for bit,
+# include/coda_pointnet2.h); CODA_SCATTER=atomic selects the float atomics of the plain entry points -- the reference's
+# own, order-dependent form.
+_SCATTER_ATOMIC = __import__("os").environ.get("CODA_SCATTER", "det") == "atomic"
+
+
+def _det_workspace(lib, b, c, n, device):
+    nbytes = lib.coda_scatter_add_det_workspace_bytes(b, c, n)
+    return (torch.empty(nbytes // 8 + 1, dtype=torch.int64, device=device), nbytes) if nbytes else (None, 0)
+
+
 def gather_points_grad(grad_out, idx, n):
     """(B,C,M) f32, (B,M) i32, n -> (B,C,n).  sampling.cpp:43-66."""
     _check_contiguous(grad_out, "grad_out")
@@ -149,8 +160,12 @@ def gather_points_grad(grad_out, idx, n):
     b, c, m = grad_out.shape
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device), _timed("gather_points_grad"):
-        st = lib.coda_gather_points_grad_f32(_ptr(grad_out), _ptr(idx), _ptr(out), b, c, n, m,
-                                             _stream())
+        if _SCATTER_ATOMIC:
+            st = lib.coda_gather_points_grad_f32(_ptr(grad_out), _ptr(idx), _ptr(out), b, c, n, m, _stream())
+        else:
+            ws, ws_bytes = _det_workspace(lib, b, c, n, grad_out.device)
+            st = lib.coda_gather_points_grad_det_f32(_ptr(grad_out), _ptr(idx), _ptr(out), b, c, n, m, _ptr(ws), ws_bytes,
+                                                     _stream())
     _lib.check(st, "gather_points_grad")
     return out
 
@@ -228,8 +243,12 @@ def group_points_grad(grad_out, idx, n):
     npoints, nsample = idx.size(1), idx.size(2)
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device), _timed("group_points_grad"):
-        st = lib.coda_group_points_grad_f32(_ptr(grad_out), _ptr(idx), _ptr(out), b, c, n,
-                                            npoints, nsample, _stream())
+        if _SCATTER_ATOMIC:
+            st = lib.coda_group_points_grad_f32(_ptr(grad_out), _ptr(idx), _ptr(out), b, c, n, npoints, nsample, _stream())
+        else:
+            ws, ws_bytes = _det_workspace(lib, b, c, n, grad_out.device)
+            st = lib.coda_group_points_grad_det_f32(_ptr(grad_out), _ptr(idx), _ptr(out), b, c, n, npoints, nsample,
+                                                    _ptr(ws), ws_bytes, _stream())
     _lib.check(st, "group_points_grad")
     return out
 

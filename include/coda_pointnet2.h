@@ -129,6 +129,24 @@ int coda_gather_points_grad_f32(const float *grad_out, const int32_t *idx,
                                 float *grad_points, int b, int c, int n, int m,
                                 void *stream);
 
+/* Deterministic forms of the two scatter-add adjoints (gather_points_grad here, group_points_grad below): the same
+ * sums, but reproducible bit for bit from run to run.  The float atomics of the plain entry points -- and of the
+ * reference, sampling_gpu.cu:37-60 / group_points_gpu.cu:46-67 -- add colliding gradients in whatever order the
+ * hardware serves them.  Here every addend goes to 64-bit fixed point at a scale taken from the tensor's largest
+ * magnitude (62 - ceil(log2(entries + 1)) bits below it: 47 at 32 768 entries per scene, never fewer than 31, i.e. finer
+ * than float32), is accumulated with integer atomics (associative: any order, same bits) and converted back once.
+ * `workspace`: device memory, 8-byte aligned, >= coda_scatter_add_det_workspace_bytes(b, c, n) (8 bytes per output
+ * element + 256); CODA_ENOSPC otherwise.  A non-finite gradient anywhere makes the whole result NaN.
+ * The Python binding uses these by default (CODA_SCATTER=atomic: the plain ones).                                  */
+size_t coda_scatter_add_det_workspace_bytes(int b, int c, int n);
+int coda_gather_points_grad_det_f32(const float *grad_out, const int32_t *idx,
+                                    float *grad_points, int b, int c, int n, int m,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+int coda_group_points_grad_det_f32(const float *grad_out, const int32_t *idx,
+                                   float *grad_points, int b, int c, int n, int npoints,
+                                   int nsample, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+
 /* ---- ball_query ---------------------------------------------------------------
  * Replaces ball_query(new_xyz (B,M,3), xyz (B,N,3), radius, nsample) -> (B,M,S) i32
  *   wrapper src/ball_query.cpp:11-35, kernel src/ball_query_gpu.cu:12-57.

@@ -378,6 +378,59 @@ def test_scatter_add_grads(dev, oracle, b, c, n, m, s):
     assert np.array_equal(got, oracle.gather_points_grad(go1, perm, n))
 
 
+def test_scatter_add_grads_are_deterministic_and_accurate(dev, distance_mode):
+    """The default adjoints of gather / group accumulate in 64-bit fixed point (include/coda_pointnet2.h): the same bits
+    from run to run under heavy collisions (the masked encoder's shape, 32 768 entries onto 2048 targets per scene and
+    channel; and the worst case, every entry onto ONE target), closer to the float64 sum than the float atomics are,
+    and NaN everywhere for a non-finite input.  (The reference's atomicAdd form, CODA_SCATTER=atomic, is neither.)"""
+    if distance_mode != 1:
+        pytest.skip("no distance arithmetic in this operator")
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    b, c, n, m, s = 2, 64, 2048, 1024, 32
+    idx = rng.integers(0, n, (b, m, s)).astype(np.int32)
+    idx[1] = 7                                                   # scene 1: every entry collides on target 7
+    go = (rng.standard_normal((b, c, m, s)) * np.exp(rng.uniform(-8, 8, (b, c, 1, 1)))).astype(np.float32)
+    d_go, d_idx = cu(go, dev), cu(idx, dev)
+    first = _ext.group_points_grad(d_go, d_idx, n)
+    for _ in range(5):
+        assert torch.equal(_ext.group_points_grad(d_go, d_idx, n), first), "not reproducible"
+    exact = np.zeros((b, c, n), np.float64)
+    for bi in range(b):
+        np.add.at(exact[bi].T, idx[bi].reshape(-1), go[bi].reshape(c, -1).T.astype(np.float64))
+    got = first.cpu().numpy().astype(np.float64)
+    scale = np.abs(go).max()
+    err_det = np.abs(got - exact).max() / scale
+    atomic = torch.empty_like(first)
+    st = lib.coda_group_points_grad_f32(d_go.data_ptr(), d_idx.data_ptr(), atomic.data_ptr(), b, c, n, m, s,
+                                        _lib.current_stream_handle())
+    assert st == 0
+    err_atomic = np.abs(atomic.cpu().numpy().astype(np.float64) - exact).max() / scale
+    print(f"max error / max |g|: fixed point {err_det:.2e}, float atomics {err_atomic:.2e}")
+    assert err_det <= 2.0 ** -23 * 1.01 * np.abs(exact).max() / scale + 1e-12   # one float32 rounding of the result
+    assert err_det <= err_atomic + 1e-12
+    # gather_points_grad: the same code with one entry per row
+    idx1 = rng.integers(0, 16, (b, m)).astype(np.int32)
+    go1 = rng.standard_normal((b, c, m)).astype(np.float32)
+    g1 = _ext.gather_points_grad(cu(go1, dev), cu(idx1, dev), n)
+    assert torch.equal(_ext.gather_points_grad(cu(go1, dev), cu(idx1, dev), n), g1)
+    ref1 = np.zeros((b, c, n), np.float64)
+    for bi in range(b):
+        np.add.at(ref1[bi].T, idx1[bi], go1[bi].T.astype(np.float64))
+    np.testing.assert_allclose(g1.cpu().numpy(), ref1, rtol=2e-7, atol=1e-7)
+    # a non-finite gradient: NaN everywhere (stated in the header), all-zero gradients: zeros
+    bad = d_go.clone()
+    bad[0, 3, 5, 1] = float("inf")
+    assert torch.isnan(_ext.group_points_grad(bad, d_idx, n)).all()
+    assert not _ext.group_points_grad(torch.zeros_like(d_go), d_idx, n).any()
+    # too small a workspace is refused
+    out = torch.empty((b, c, n), device=dev)
+    ws = torch.empty(64, dtype=torch.int64, device=dev)
+    assert lib.coda_group_points_grad_det_f32(d_go.data_ptr(), d_idx.data_ptr(), out.data_ptr(), b, c, n, m, s, ws.data_ptr(),
+                                              ws.numel() * 8, _lib.current_stream_handle()) == _lib.CODA_ENOSPC
+
+
 # ----------------------------------------------------------- three_nn / interpolate
 @pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 50, 2), (2, 50, 30), (2, 1024, 128), (1, 3000, 1500)])
 def test_three_nn_matches_oracle(dev, oracle, b, n, m):
