@@ -317,8 +317,21 @@ def run_extra(kind, dev, steps, warmup):
     from coda_neurips2023_amd import attention_core
     n_points = N_POINTS
     prefetch = False
-    if kind == "sa":
+    sa_prefetcher = None
+    if kind in ("sa", "sa_prefetch"):
         mod, step_fn, desc, _ = build_workload("sa", dev)
+        if kind == "sa_prefetch":
+            # the module's own split: prepare(xyz) = the parameter-free front (FPS, centre gather, ball query + grouping,
+            # packing) of batch i + 1 on the sampling side stream during step i, forward(xyz, prepared=...) continues
+            # from it -- what the full model's prefetch_sampling does for its pre-encoder
+            from coda_neurips2023_amd.pointnet2.pointnet2_utils import SamplingPrefetcher
+            sa_prefetcher = SamplingPrefetcher()
+
+            def step_fn(model, batch, _inner=None):  # noqa: F811
+                pc = batch["point_clouds"]
+                front = sa_prefetcher.take(pc)
+                _, feat, _ = model(pc if front is None else front["xyz"], prepared=front)
+                return feat.square().mean()
     elif kind == "scripts":
         mod, step_fn, desc, _ = build_model_workload(dev, nq=128, dec_dim=512,
                                                      config_tag="the scripts' variant (scripts/coda_sunrgbd_stage1.sh: "
@@ -346,6 +359,8 @@ def run_extra(kind, dev, steps, warmup):
         def one(i):
             if prefetch:
                 mod.prefetch_sampling(pool[(i + 1) % len(pool)], wait_for=None)
+            if sa_prefetcher is not None:
+                sa_prefetcher.submit(pool[(i + 1) % len(pool)]["point_clouds"], mod, wait_for=None)
             opt.zero_grad(set_to_none=True)
             step_fn(mod, pool[i % len(pool)]).backward()
             clip()
@@ -373,7 +388,8 @@ def run_extra(kind, dev, steps, warmup):
     out = {"metric": "scenes/sec fwd+bwd", "value": round(B_PER_GPU * steps / dt, 3), "unit": "scenes/s", "n_gpus": 1,
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
            "config": {"workload": desc, "scenes_per_gpu": B_PER_GPU, "points": n_points,
-                      "sampling": "FPS + ball query of batch i+1 on a side stream during step i" if prefetch else "in line"}}
+                      "sampling": "FPS + ball query of batch i+1 on a side stream during step i"
+                                  if (prefetch or sa_prefetcher is not None) else "in line"}}
     if attn_ms:
         # bf16 MFMA: executed flops over the dense bf16 peak; these kernels are bound by the softmax VALU work and
         # by K/V delivery, not by the matrix cores
@@ -1027,6 +1043,7 @@ def main():
             # secondary lines; the headline's timed region above is untouched by them)
             ex_steps, ex_warm = max(5, min(args.steps, 10)), 3
             out["extra_configs"] = {"configs[1]_sa_only": run_extra("sa", dev, ex_steps, ex_warm),
+                                    "configs[1]_sa_only_sampling_ahead": run_extra("sa_prefetch", dev, ex_steps, ex_warm),
                                     "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm),
                                     "scripts_variant_dec512_128q": run_extra("scripts", dev, ex_steps, ex_warm),
                                     "clip_image_tower": run_image_tower(dev, ex_steps, ex_warm),
