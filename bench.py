@@ -643,8 +643,9 @@ def main():
             # engine.py:152-157: the exit decision is taken on the loss AVERAGED OVER THE RANKS, so that every rank takes
             # the same one (a rank leaving alone would park the others in their next collective); one scalar
             # all-reduce, enqueued like any kernel.  Then the check itself, one step late and without a host stall
-            seen = loss.detach().clone()
+            seen = loss.detach()
             if world > 1:
+                seen = seen.clone()
                 dist.all_reduce(seen)
                 seen /= world
             if finite is not None:
