@@ -9,8 +9,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o attn -- python $R/tools/bench_attn.py fp32 > /dev/null 2>&1
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
-  mkdir -p $R/gpurun_out/r3_pmc
-  cp "$f" $R/gpurun_out/r3_pmc/attn_$c.csv
+  mkdir -p $R/gpurun_out/${PMC_TAG:-r05}_pmc
+  cp "$f" $R/gpurun_out/${PMC_TAG:-r05}_pmc/attn_$c.csv
   echo "== $c"
   python $R/tools/pmc_medians.py "$f" mha_
 done
