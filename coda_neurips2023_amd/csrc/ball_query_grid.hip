@@ -817,24 +817,32 @@ __global__ __launch_bounds__(kQ8Waves *kWave, 3) void grid_query8_kernel(
     float *stage = reinterpret_cast<float *>(list);
 #pragma unroll
     for (int it = 0; it < kQ8MaxSample / (4 * kQ8Lanes); ++it) {
+      if (it * 4 * kQ8Lanes >= nsample) break;  // (uniform: the whole pass lies past the row)
       const int s4 = 4 * k + it * 4 * kQ8Lanes;
-      if (s4 >= nsample) break;
+      // A lane whose four samples lie past the row (nsample = 4, 8, 16, 24, 48 ...) has nothing of its own but STAYS in
+      // the pass: the channels-last store below is cooperative (lane k writes pieces k, k + 8, k + 16 of the group's
+      // staged rows).  Round 5 left the loop here instead, and pieces 4..7 of a 16-sample row were never written.
+      const bool mine = s4 < nsample;
       const int4 raw = raws[it];
       const int i4[4] = {s4 < nh ? raw.x : head, s4 + 1 < nh ? raw.y : head, s4 + 2 < nh ? raw.z : head,
                          s4 + 3 < nh ? raw.w : head};
-      *reinterpret_cast<int4 *>(idx + row_off + s4) = make_int4(i4[0], i4[1], i4[2], i4[3]);
+      if (mine) *reinterpret_cast<int4 *>(idx + row_off + s4) = make_int4(i4[0], i4[1], i4[2], i4[3]);
       if (grouped) {
-        float gx[4], gy[4], gz[4];
+        float gx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gy[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (mine) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) centred(i4[q], gx[q], gy[q], gz[q]);
+          for (int q = 0; q < 4; ++q) centred(i4[q], gx[q], gy[q], gz[q]);
+        }
         if (normalize & 2) {  // channels-last (B,M,S,3): 12 consecutive floats per lane, 96 per group and pass
           // Through LDS, so that every store instruction writes whole lines: lane k's three 16-byte pieces are 48 bytes
           // apart -- stored directly, each instruction wrote every third 16-byte piece of its lines (PMC: 22.0 MB
           // written and 7 MB fetched back for 16.8 MB of rows).  Transposed, lane k writes pieces k, k + 8, k + 16.
-          float4 *st = reinterpret_cast<float4 *>(stage + 3 * s4);
-          st[0] = make_float4(gx[0], gy[0], gz[0], gx[1]);
-          st[1] = make_float4(gy[1], gz[1], gx[2], gy[2]);
-          st[2] = make_float4(gz[2], gx[3], gy[3], gz[3]);
+          if (mine) {
+            float4 *st = reinterpret_cast<float4 *>(stage + 3 * s4);
+            st[0] = make_float4(gx[0], gy[0], gz[0], gx[1]);
+            st[1] = make_float4(gy[1], gz[1], gx[2], gy[2]);
+            st[2] = make_float4(gz[2], gx[3], gy[3], gz[3]);
+          }
           __builtin_amdgcn_wave_barrier();
           const int base4 = it * 3 * kQ8Lanes;  // 16-byte pieces of this pass start here
           const float4 *rd = reinterpret_cast<const float4 *>(stage);
@@ -845,7 +853,7 @@ __global__ __launch_bounds__(kQ8Waves *kWave, 3) void grid_query8_kernel(
             const int pc4 = k + kQ8Lanes * r;
             if (pc4 < npieces) o[base4 + pc4] = rd[base4 + pc4];
           }
-        } else {
+        } else if (mine) {
           float *o = grouped + static_cast<size_t>(bi) * 3 * plane + static_cast<size_t>(j) * nsample + s4;
           *reinterpret_cast<float4 *>(o) = make_float4(gx[0], gx[1], gx[2], gx[3]);
           *reinterpret_cast<float4 *>(o + plane) = make_float4(gy[0], gy[1], gy[2], gy[3]);

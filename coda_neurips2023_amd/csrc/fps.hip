@@ -946,9 +946,11 @@ int bucket2_min_points() {
 bool bucket2_eligible(int n, int m) {
   return n >= bucket2_min_points() && n >= 2 * kBucketMinPoints && n <= 2 * kBucketMaxPoints && m >= kBucketMinSamples;
 }
-size_t bucket2_mail_offset(int b, int n) { return (sizeof(float4) * 2 * static_cast<size_t>(b) * n + 255) & ~static_cast<size_t>(255); }
+// one Morton-ordered record array per scene (round 5 on: workgroup 0 sorts, workgroup 1 reads the same records), then the mailboxes
+size_t bucket2_mail_offset(int b, int n) { return (sizeof(float4) * static_cast<size_t>(b) * n + 255) & ~static_cast<size_t>(255); }
 // per scene: 2 round parities x 2 workgroups of candidate mailboxes, then (after all of those) one hand-over word
 constexpr int kMailboxesPerScene = 5;
+constexpr int kPairScenesPerLaunch = 64;  // see launch_bucket2
 size_t bucket2_workspace_bytes(int b, int n) {
   return bucket2_mail_offset(b, n) + sizeof(FpsMailbox) * kMailboxesPerScene * static_cast<size_t>(b);
 }
@@ -964,12 +966,22 @@ int launch_bucket2(const float *xyz, int b, int n, int m, int log2T, void *ws, i
   hipError_t e = hipMemsetAsync(mail, 0, sizeof(FpsMailbox) * kMailboxesPerScene * static_cast<size_t>(b), s);  // round numbers start at 1
   if (e != hipSuccess) return static_cast<int>(e);
   int st = CODA_OK;
+  // LAUNCH-SHAPE PRECONDITION of the pair: workgroups (s, 0) and (s, 1) wait for each other, so both must be resident
+  // at the same time.  The grid is (scenes, 2) with x fastest -- the (s, 0) of ALL scenes are dispatched first, and
+  // with more scenes than the chip has workgroup slots (one per CU at this LDS / register footprint: 256) every
+  // resident workgroup would be an (s, 0) spinning for an (s, 1) that cannot start (loud since
+  // round 5 -- CODA_ELOST -- but a precondition nothing checked).  So: at most kPairScenesPerLaunch scenes per
+  // launch (2 x 64 workgroups = half the chip; a multiple of 8, so that (s, 0) and (s, 1) = linear ids s and
+  // s + scenes still share an XCD), more scenes = more launches on the same stream.
   CODA_DISPATCH_DM(distance_mode(), {
     auto kern = fps_bucket_kernel<SL, DM, 2, W>;
     st = raise_dynamic_lds(kern, lds, 20 * 1024);
-    if (st == CODA_OK)
-      hipLaunchKernelGGL(kern, dim3(b, 2), dim3(64 * W), lds, s, xyz, n, m, log2T, static_cast<float4 *>(ws), idx, mail,
-                         status.host, spin_limit, o.fps_drop_half);
+    for (int s0 = 0; st == CODA_OK && s0 < b; s0 += kPairScenesPerLaunch) {
+      const int nb = b - s0 < kPairScenesPerLaunch ? b - s0 : kPairScenesPerLaunch;
+      hipLaunchKernelGGL(kern, dim3(nb, 2), dim3(64 * W), lds, s, xyz + static_cast<size_t>(s0) * n * 3, n, m, log2T,
+                         static_cast<float4 *>(ws) + static_cast<size_t>(s0) * n, idx + static_cast<size_t>(s0) * m,
+                         mail + static_cast<size_t>(s0) * kMailboxesPerScene, status.host, spin_limit, o.fps_drop_half);
+    }
   });
   return st;
 }
@@ -1089,7 +1101,7 @@ constexpr size_t kStreamKeyBytes = sizeof(uint2) * 2 * (kStreamThreads / kWave);
 
 CODA_API size_t coda_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
   if (b <= 0 || n <= 0) return 0;
-  if (coda::bucket2_eligible(n, m)) return coda::bucket2_workspace_bytes(b, n);  // records (sized for two copies: round 5 uses one) + the mailboxes
+  if (coda::bucket2_eligible(n, m)) return coda::bucket2_workspace_bytes(b, n);  // one record array per scene + the mailboxes
   if (coda::bucket_eligible(n, m)) return sizeof(float4) * static_cast<size_t>(b) * n;  // Morton-sorted records
   const size_t lds_need = coda::kStreamKeyBytes + sizeof(float) * static_cast<size_t>(n);
   if (n <= 1024 * 24 || lds_need <= coda::kLdsBudget) return 0;

@@ -70,11 +70,22 @@ class SamplingPrefetcher:
         self._pending = []
         self._max = max_pending
         self.wait_for_counts = wait_for_counts
+        self._unchecked = []  # completion events of fronts handed out before the side stream had finished
+
+    def _check_finished(self):
+        """A front taken while the side stream was still running was handed to the step UNCHECKED (the host must not
+        stall for it).  Its sampling status is read here, at the next submit / take -- one step later at most, and with
+        the event known to be complete: a launch that lost its partner workgroup (``CODA_ELOST``) raises now, so the
+        step trained on wrong indices is attributed to the batch before this one and can be discarded by the caller."""
+        if self._unchecked and all(ev.query() for ev in self._unchecked):
+            self._unchecked.clear()
+            _ext.check_sampling_status()
 
     def submit(self, point_clouds, module, wait_for="current", after=None):
         """``after(prepared)``: more work for the side stream that only needs the prepared front (it may add
         entries to the dict), run before the completion event is recorded."""
         dev = point_clouds.device
+        self._check_finished()
         if self._stream is None or self._stream.device != dev:
             # A HIGH-PRIORITY stream: it gets a hardware queue of its own.  Streams of equal priority are dealt onto a
             # few hardware queues round-robin, and once a communication library has created its streams the sampling
@@ -102,6 +113,7 @@ class SamplingPrefetcher:
 
     def take(self, point_clouds):
         """The prepared front of this very tensor (see ``PointnetSAModuleVotes.prepare``), or None."""
+        self._check_finished()
         for k, (pc, version, prepared, done) in enumerate(self._pending):
             if pc is point_clouds and version == point_clouds._version:
                 del self._pending[k]
@@ -114,6 +126,7 @@ class SamplingPrefetcher:
                     # starved): do not stall the host for the row count -- drop it (the shared MLP then
                     # runs on all rows) and let the compute stream wait on the device side
                     prepared = dict(prepared, total_host=None)
+                    self._unchecked.append(done)  # status read once the event has completed: _check_finished()
                 else:
                     finished = True
                 if finished:

@@ -77,8 +77,12 @@ int coda_get_distance_mode(void);
  * scene, the Morton-sorted cloud in its registers, only the buckets a new sample
  * can reach are updated; 20480 < N <= 40960: TWO workgroups per scene, half of
  * the buckets each, exchanging their candidate every round through a mailbox in
- * `workspace` (one relaxed 64-bit atomic each way; the pair is co-resident on any
- * device with more than 2*B CUs; a wait of ~2^22 polls without an answer is
+ * `workspace` (one relaxed 64-bit atomic each way).  LAUNCH PRECONDITION of the
+ * pair, kept by the library itself: both workgroups of a scene must be resident
+ * together, so a call is issued as launches of at most 64 scenes (128 workgroups,
+ * half of the 256 CUs) on the caller's stream -- any B is accepted.  What the
+ * library cannot see is OTHER work of the caller that fills the device with
+ * workgroups that never retire; a wait of ~2^22 polls without an answer is
  * abandoned rather than hanging the device -- LOUDLY: see
  * coda_fps_lost_partner_events below); otherwise the running distances live
  * in registers (N <= 24576), LDS (N <= ~40000) or `workspace` (B*N floats, the
@@ -109,6 +113,14 @@ int coda_furthest_point_sampling_opt_f32(const float *xyz, int b, int n, int m,
  *    CODA_ELOST (and launches nothing) until the word has been read with reset = 1;
  *  - coda_fps_lost_partner_events(reset) returns the word (0 = nothing lost); after
  *    the launch's stream has been synchronised it speaks for that launch.
+ * SCOPE: this latch is the one piece of mutable state behind this header, and it is
+ * PROCESS-wide (one pinned host word per process, shared by every device, stream and
+ * thread).  Two independent callers in one process share it: a loss in one caller's
+ * launch makes the other caller's next sampling call return CODA_ELOST, and whoever
+ * reads with reset = 1 acknowledges for both -- it is a fault latch ("some sampling
+ * result of this process is wrong"), not a per-call status.  A caller that must
+ * attribute the loss synchronises its own stream and reads the word (reset = 0)
+ * before anyone resets it; bits 16..30 name the scene, bits 0..15 the round.
  * coda_furthest_point_sampling_dbg_f32 is the test hook that produces the event:
  * spin_limit (> 0: polls before giving up, 0: default) and drop_half (0 | 1: that
  * workgroup of every pair exits at once; -1: none).  tests/test_ops_gpu.py.        */

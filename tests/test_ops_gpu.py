@@ -266,7 +266,11 @@ def test_ball_query_matches_oracle(dev, oracle, b, n, m, r, s):
 @pytest.mark.parametrize("algorithm", ["scan", "grid"])
 @pytest.mark.parametrize("n,m,r,s", [(1024, 100, 0.3, 16), (3000, 130, 0.25, 64), (20000, 500, 0.2, 64),
                                      (20000, 300, 0.4, 32), (5000, 64, 1.5, 128), (40000, 256, 0.2, 64),
-                                     (20001, 2048, 0.2, 64), (12345, 1000, 0.05, 8)])
+                                     (20001, 2048, 0.2, 64), (12345, 1000, 0.05, 8),
+                                     # rows shorter than one 32-sample pass of the eight-lane query kernel's vectorised
+                                     # output (the channels-last store is cooperative across the 8 lanes)
+                                     (4096, 257, 0.3, 4), (4096, 257, 0.3, 24), (20000, 300, 0.3, 48),
+                                     (4096, 64, 0.3, 6), (4096, 64, 0.3, 63)])
 def test_ball_query_scan_and_grid_paths(dev, oracle, algorithm, n, m, r, s):
     pc, _, _ = make_batch(2, n, seed=n + m)
     rng = np.random.default_rng(s)
@@ -281,8 +285,18 @@ def test_ball_query_scan_and_grid_paths(dev, oracle, algorithm, n, m, r, s):
     idx, grouped = _ext.query_and_group_xyz(d_new, d_pc, r, s, True, algorithm=algorithm)
     assert np.array_equal(idx.cpu().numpy(), ref)
     exp = np.take_along_axis(pc, ref.reshape(2, -1, 1).astype(np.int64).repeat(3, -1), 1).reshape(2, m, s, 3)
-    exp = (exp - new[:, :, None, :]) * (np.float32(1.0) / np.float32(r))
+    exp_raw = exp - new[:, :, None, :]
+    exp = exp_raw * (np.float32(1.0) / np.float32(r))
     np.testing.assert_array_equal(grouped.cpu().numpy(), exp.transpose(0, 3, 1, 2))
+    # channels-last (B,M,S,3) rows -- what the fused set-abstraction front consumes -- on poisoned memory
+    # (torch.empty hands back recycled blocks: a piece the kernel skips would otherwise often LOOK right)
+    poison = [torch.full((2, m, s), -7, dtype=torch.int32, device=dev), torch.full((2, m, s, 3), float("nan"), device=dev)]
+    del poison
+    idx_cl, grouped_cl = _ext.query_and_group_xyz(d_new, d_pc, r, s, True, algorithm=algorithm, channels_last=True)
+    assert np.array_equal(idx_cl.cpu().numpy(), ref)
+    np.testing.assert_array_equal(grouped_cl.cpu().numpy(), exp)
+    _, raw_cl = _ext.query_and_group_xyz(d_new, d_pc, r, s, False, algorithm=algorithm, channels_last=True)
+    np.testing.assert_array_equal(raw_cl.cpu().numpy(), exp_raw)
 
 
 def test_ball_query_grid_stress(dev, oracle):
