@@ -37,7 +37,144 @@ _OWN_SMALL = os.environ.get("CODA_SGEMM", "1") != "0"
 _OWN_MAX_MN = 2048 * 256
 
 
+# ---- the large token-wise products on the bf16 matrix cores (csrc/gemm_x3.hip) -------------------------------------
+# y = x W^T + b and dx = dy W with >= _X3_MIN_ROWS token rows: every fp32 operand as three bf16 pieces, six piece
+# products, fp32 accumulation -- error against float64 within 2x of the native fp32 GEMM (tests/test_gemm_x3_gpu.py).
+# The WEIGHT's pieces are kept per weight (both orientations) and refreshed once per optimizer step in one launch;
+# CODA_GEMM_X3=0 sends everything back to the library (A/B switch, and the reference point of the parity tests).
+_X3 = os.environ.get("CODA_GEMM_X3", "1") != "0"
+_X3_MIN_ROWS = 4096
+
+
+def set_x3(on):
+    """Development / test switch (tools/bench_gemm_x3.py, tests): route eligible products through the x3 kernels."""
+    global _X3
+    _X3 = bool(on)
+
+
+class _Planes:
+    __slots__ = ("base", "version", "epoch", "used", "nt", "nn")
+
+
+_planes = {}          # (data_ptr, rows, cols, stride) of the BASE weight -> _Planes (holds the base: its storage stays alive)
+_planes_epoch = 0
+
+
+def _weight_base(w):
+    """(base, first row, rows) when ``w`` is a weight -- a leaf that requires grad / an nn.Parameter -- or a row slice
+    of one (in_proj_weight[e:2 * e]); None for anything else (activations never enter the cache: their storage is
+    recycled by the allocator, and a cache keyed by address would serve another tensor's pieces)."""
+    base = w._base if w._base is not None else w
+    if not (base.requires_grad or isinstance(base, torch.nn.Parameter)) or not base.is_leaf:
+        return None
+    if base.dim() != 2 or base.stride(1) != 1 or base.dtype != torch.float32:
+        return None
+    if base is w:
+        return base, 0, w.shape[0]
+    if w.shape[1] != base.shape[1] or w.stride() != base.stride():
+        return None
+    off = (w.data_ptr() - base.data_ptr()) // 4
+    if off % base.stride(0):
+        return None
+    return base, off // base.stride(0), w.shape[0]
+
+
+def _split_items(entries):
+    import numpy as np
+    table = np.zeros((len(entries), 5), dtype=np.int64)  # the CodaX3SplitItem layout: src, nt, nn, (rows, cols), ld
+    for i, e in enumerate(entries):
+        r, c = e.base.shape
+        table[i] = (e.base.data_ptr(), e.nt.data_ptr(), e.nn.data_ptr(), r | (c << 32), e.base.stride(0))
+    st = _lib.load().coda_gemm_x3_split_f32(table.ctypes.data, len(entries), _lib.current_stream_handle())
+    _lib.check(st, "coda_gemm_x3_split_f32")
+
+
+def _weight_planes(base):
+    key = (base.data_ptr(), base.shape[0], base.shape[1], base.stride(0))
+    e = _planes.get(key)
+    if e is None or e.base.device != base.device:
+        e = _Planes()
+        r, c = base.shape
+        e.nt = torch.empty((3, r, c), dtype=torch.bfloat16, device=base.device)
+        e.nn = torch.empty((3, c, r), dtype=torch.bfloat16, device=base.device)
+        e.version, e.epoch, e.used, e.base = -1, -1, -1, None
+        _planes[key] = e
+    if e.version != base._version or e.epoch != _planes_epoch or e.base is None:
+        e.base = base
+        with torch.cuda.device(base.device):
+            _split_items([e])
+        e.version, e.epoch = base._version, _planes_epoch
+    e.used = _planes_epoch
+    return e
+
+
+def refresh_weight_planes():
+    """The weights have changed behind the version counters (this package's optimizer writes through raw pointers;
+    so do checkpoint loaders that assign through ``p.data``): every cached set of pieces that was used since the last
+    refresh is recomputed NOW, all of them in one launch on the current stream; the others are dropped.  Called by
+    ``optim.step`` and -- through torch's global post-step hook -- after every torch optimizer step."""
+    global _planes_epoch
+    live = []
+    for key, e in list(_planes.items()):
+        if e.used == _planes_epoch and e.base is not None and e.base.is_cuda:
+            live.append(e)
+        else:
+            del _planes[key]
+    _planes_epoch += 1
+    by_dev = {}
+    for e in live:
+        by_dev.setdefault(e.base.device, []).append(e)
+    for dev, group in by_dev.items():
+        with torch.cuda.device(dev):
+            _split_items(group)
+        for e in group:
+            e.version, e.epoch = e.base._version, _planes_epoch
+            e.used = _planes_epoch - 1   # "not yet used in the new epoch": dropped at the next refresh unless used
+
+
+try:  # torch optimizers bump the version counters themselves; the hook only turns ~25 one-weight launches into one
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
+    _reg_post(lambda *_a, **_k: refresh_weight_planes() if _planes else None)
+except Exception:  # pragma: no cover
+    pass
+
+
+def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
+    """The product through coda_gemm_x3_nt_f32 when it is one of the large token-wise ones with a weight as B;
+    returns ``out`` or None ("not this route")."""
+    if transa or m < _X3_MIN_ROWS or m % 64 or n % 64 or k % 32 or a.stride(0) % 4 or a.data_ptr() % 16:
+        return None
+    wb = _weight_base(b)
+    if wb is None:
+        return None
+    base, r0, nrows = wb
+    if base.shape[0] % 8 or base.shape[1] % 8:
+        return None
+    e = _weight_planes(base)
+    rows, cols = base.shape
+    if transb:   # y = x W^T: W (n x k) = rows r0.. of the base -> a row slice of nt
+        w_ptr, ldw = e.nt.data_ptr() + 2 * r0 * cols, cols
+    else:        # dx = dy W: W (k x n) = rows r0.. of the base -> a column slice of nn ([cols][rows])
+        w_ptr, ldw = e.nn.data_ptr() + 2 * r0, rows
+    if w_ptr % 16:
+        return None
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    st = _lib.load().coda_gemm_x3_nt_f32(m, n, k, a.data_ptr(), a.stride(0), w_ptr, ldw, rows * cols, out.data_ptr(),
+                                         out.stride(0), bias.data_ptr() if bias is not None else None,
+                                         1 if accumulate else 0, _lib.current_stream_handle())
+    if st == _lib.CODA_ENOSPC:
+        return None
+    if st != 0:
+        raise RuntimeError(f"coda_gemm_x3_nt_f32 failed ({st}) for transb={transb} m={m} n={n} k={k}")
+    return out
+
+
 def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
+    if _X3:
+        r = _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate)
+        if r is not None:
+            return r
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if _OWN_SMALL and not transa and m * n <= _OWN_MAX_MN and m % 64 == 0 and n % 64 == 0 and k % 128 == 0:

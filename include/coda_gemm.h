@@ -81,6 +81,34 @@ typedef struct CodaTnProblem {
 
 int coda_grouped_gemm_tn_f32(const CodaTnProblem *problems, int count, void *stream);
 
+/* ---- fp32-accurate GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) ------------------------------------------
+ * Same products as coda_gemm_f32 for the token-wise linear layers (models/helpers.py:45-112,
+ * models/transformer.py:461-479, 556-580, models/model_3detr.py:409-419, 475-511), computed with every fp32 operand
+ * carried as three bf16 pieces (x = hi + mid + lo exactly) and the six piece products of order <= 2 accumulated in
+ * fp32: error against float64 within 2x of the native fp32 GEMM (tests/test_gemm_x3_gpu.py), 6/16 of its matrix time.
+ *
+ * The WEIGHT operand is split ahead of time, once per optimizer step:
+ *   coda_gemm_x3_split_f32: for every item, src (rows x cols fp32, row stride ld) -> nt = three bf16 planes
+ *   [3][rows][cols] and / or nn = three bf16 planes of the TRANSPOSE [3][cols][rows] (either may be NULL).  `items` is
+ *   HOST memory read during the call; all items go in one launch (48 per launch).
+ * The product:
+ *   coda_gemm_x3_nt_f32: C (m x n, row stride ldc) [+]= A (m x k fp32, row stride lda) . W^T [+ bias], W given as its
+ *   planes: plane q at w_planes + q * plane_stride, row r (of n) at + r * ldw, bf16 ELEMENTS.  y = x W^T + b takes the
+ *   `nt` planes of W (n x k); dx = dy W takes the `nn` planes (k_in x n_out: again "row = output column") -- a row
+ *   slice of W is a row slice of nt and a COLUMN slice of nn (ldw stays the full row length).
+ *   Constraints: m, n multiples of 64, k a multiple of 32, lda a multiple of 4, ldw and plane_stride multiples of 8,
+ *   a and w_planes 16-byte aligned; CODA_ENOSPC otherwise ("not this kernel's shape": use coda_gemm_f32). */
+typedef struct CodaX3SplitItem {
+  const float *src;
+  void *nt;
+  void *nn;
+  int rows, cols;
+  long long ld;
+} CodaX3SplitItem;
+int coda_gemm_x3_split_f32(const CodaX3SplitItem *items, int count, void *stream);
+int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long lda, const void *w_planes, long long ldw,
+                        long long plane_stride, float *c, long long ldc, const float *bias, int accumulate, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
