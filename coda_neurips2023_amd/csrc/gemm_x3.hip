@@ -23,13 +23,14 @@
 //
 //   C (M x N, row stride ldc) [+]= A (M x K fp32, row stride lda) . W^T [+ bias],   W as three bf16 planes [3][N][K]
 //
-// Shape: 256 threads = 2 x 2 waves on a BM x BN tile of C (128 x 128, 64 x 128, 64 x 64), K walked in steps of 32 through
-// one LDS stage ([row][32 k] bf16 per plane, row stride 80 B: conflict-free ds_read_b128 fragments), the global loads of
-// step i + 1 in flight during the MFMAs of step i, two workgroups per CU.
+// Shape: 128 x 128 (or 128 x 64) tiles of C, K walked in stages of 32 ([row][32 k] bf16 per plane in LDS, row stride
+// 80 B: conflict-free ds_read_b128 fragments); see x3_nt_pipe_kernel for the pipeline and for the accumulator scheme
+// that removes the matrix core's rounding bias.
 #include "coda_gemm.h"
 #include "common.hip.h"
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace coda {
 namespace {
@@ -54,6 +55,7 @@ struct X3NtParams {
   int accumulate;
   int tiles_m, tiles_n;
   int xcd_map;         // tiles of one A row block on one XCD
+  int dbg;             // development probes (CODA_X3_DBG): parts of the pipelined kernel switched off
 };
 
 struct Pieces4 {
@@ -72,127 +74,233 @@ __device__ __forceinline__ Pieces4 split4(f32x4v x) {
 
 __device__ __forceinline__ int crow_x3(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(kX3Threads, 2) void x3_nt_kernel(const X3NtParams p) {
-  constexpr int TM = BM / 64, TN = BN / 64;          // 32 x 32 MFMA tiles per wave in each direction
+// ---- the kernel: persistent workgroups, producer and consumer waves -----------------------------------------------------
+// A first form (256 threads, every wave loads, splits, stores and multiplies; two barriers per 32-k stage, two workgroups
+// per CU) reached 38 % of the six-product MFMA pace: whatever a wave does besides MFMAs -- waiting for its loads,
+// splitting the activations, writing LDS -- it does INSTEAD of issuing MFMAs.  Measured with the parts switched off one
+// at a time, MFMAs + fragment reads alone, loads alone and split + LDS stores alone ADD UP to the kernel's time (a
+// one-wave-per-SIMD variant with everything in one instruction stream: 102 us = 49 + 22 epilogue + 24 + 15 on
+// 98 304 x 256 x 256), i.e. nothing overlapped.  So the roles are separated (8 waves, two per SIMD, one workgroup per CU):
+//   waves 0-3 (consumers, a 64 x 64 quarter of the 128 x 128 tile each): fragment reads + 48 MFMAs per stage, the epilogue;
+//   waves 4-7 (producers): global loads P stages ahead into a register ring, activation split, LDS stores.
+// A workgroup walks a LIST of tiles as one flat sequence of stages, two LDS buffers, ONE barrier per stage:
+//   stage s:  consumers on buffer s & 1  ||  producers: stage s + 1 registers -> buffer (s + 1) & 1, loads of stage s + 1 + P
+// The two instruction streams of a SIMD interleave in hardware; a tile's epilogue runs under the producers' work for the
+// next tile, and the first-load latency is paid once per workgroup instead of once per tile.
+constexpr int kX3PipeThreads = 512;
+template <int BN, int P>
+__global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3NtParams p, int total_tiles, int nk) {
+  constexpr int BM = 128;
+  constexpr int TM = 2, TN = BN / 64;
   constexpr int IMG_A = BM * kX3Row, IMG_W = BN * kX3Row;
-  constexpr int NA = BM * kX3BK / 4 / kX3Threads;    // float4 pieces of A per thread and stage
-  constexpr int NW = 3 * BN * 4 / kX3Threads;        // 16-byte pieces of the W planes per thread and stage
-  static_assert(NA >= 1 && NW >= 1 && 3 * BN * 4 % kX3Threads == 0, "tile shape");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * IMG_A + 3 * IMG_W];
-  unsigned char *s_a = smem, *s_w = smem + 3 * IMG_A;
+  constexpr int BUF = 3 * IMG_A + 3 * IMG_W;
+  constexpr int NA = BM * kX3BK / 4 / 256;         // 4 float4 pieces of A per producer thread and stage
+  constexpr int NW = 3 * BN * 4 / 256;             // 6 | 3 16-byte pieces of the W planes
+  constexpr int U = (P % 2 == 0) ? P : 2 * P;      // stages per trip of the unrolled loop: ring slot and LDS buffer static
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
 
-  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const int half = lane >> 5, l31 = lane & 31;
-  int tm, tn;
-  {
-    const int b = static_cast<int>(blockIdx.x);
+  const int lane = lane_id(), w = wave_id();
+  const bool consumer = w < 4;                     // wave-uniform
+  const int nwg = static_cast<int>(gridDim.x), b = static_cast<int>(blockIdx.x);
+  // this workgroup's tiles: with the XCD map, XCD x owns the row blocks tm = x (mod 8) and its nwg / 8 workgroups take
+  // that list's tiles (n fastest) round-robin, so the tiles_n tiles of a row block run on one L2 at about the same time
+  const int xcd = b & 7, slot = b >> 3, per_xcd = nwg >> 3, t8 = total_tiles >> 3;
+  const int my_tiles = p.xcd_map ? (t8 > slot ? (t8 - slot + per_xcd - 1) / per_xcd : 0)
+                                 : (total_tiles > b ? (total_tiles - b + nwg - 1) / nwg : 0);
+  if (my_tiles == 0) return;
+  auto coords = [&](int i, int &m0, int &n0) {
+    int tm, tn;
     if (p.xcd_map) {
-      // workgroups are dealt round-robin over the 8 XCDs: the tiles_n tiles that share an A row block take
-      // consecutive slots of ONE XCD, so the block is fetched from HBM once and served from that L2 afterwards
-      const int xcd = b & 7, slot = b >> 3;
-      tm = (slot / p.tiles_n) * 8 + xcd;
-      tn = slot % p.tiles_n;
+      const int g = slot + i * per_xcd;
+      tm = (g / p.tiles_n) * 8 + xcd;
+      tn = g % p.tiles_n;
     } else {
-      tm = b / p.tiles_n;
-      tn = b % p.tiles_n;
+      const int t = b + i * nwg;
+      tm = t / p.tiles_n;
+      tn = t % p.tiles_n;
     }
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (BN / 2);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  const int total = my_tiles * nk;  // stages of this workgroup
 
-  f32x16 acc[TM][TN];
+  if (!consumer) {
+    // ================================================= producers =================================================
+    const int tid = static_cast<int>(threadIdx.x) - 256;
+    int a_row[NA], a_c4[NA], w_q[NW], w_row[NW], w_c[NW];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int i = tid + u * 256;
+      a_row[u] = i >> 3;
+      a_c4[u] = i & 7;
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int i = tid + u * 256, rem = i % (BN * 4);
+      w_q[u] = i / (BN * 4);
+      w_row[u] = rem >> 2;
+      w_c[u] = rem & 3;
+    }
+    f32x4v ra[P][NA];
+    u32x4v rw[P][NW];
+    // SIGN PATTERN (see the consumers): the activation pieces of row r, 16-k block b go to LDS multiplied by
+    // (-1)^(r + b).  Row and block parity are the same for all of a thread's pieces: one constant mask.
+    const unsigned int flip = ((((tid >> 3) ^ ((tid & 7) >> 2)) & 1) != 0) ? 0x80000000u : 0u;
+    // fetch stream: (tile f_i, k-step f_k); past the end it keeps re-reading the last stage (unconditional loads keep
+    // the compiler's counted waits exact; the extra stages come from L2)
+    int f_i = 0, f_k = 0, f_m0, f_n0;
+    coords(0, f_m0, f_n0);
+#define X3P_FETCH(SLOT)                                                                                               \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NA; ++u)                                                                    \
+      ra[SLOT][u] = *reinterpret_cast<const f32x4v *>(p.a + static_cast<size_t>(f_m0 + a_row[u]) * p.lda +            \
+                                                      kX3BK * f_k + 4 * a_c4[u]);                                     \
+    _Pragma("unroll") for (int u = 0; u < NW; ++u)                                                                    \
+      rw[SLOT][u] = *reinterpret_cast<const u32x4v *>(p.w + static_cast<size_t>(w_q[u]) * p.wplane +                  \
+                                                      static_cast<size_t>(f_n0 + w_row[u]) * p.ldw + kX3BK * f_k +    \
+                                                      8 * w_c[u]);                                                    \
+    if (f_k + 1 < nk) ++f_k;                                                                                          \
+    else if (f_i + 1 < my_tiles) {                                                                                    \
+      f_k = 0;                                                                                                        \
+      ++f_i;                                                                                                          \
+      coords(f_i, f_m0, f_n0);                                                                                        \
+    }                                                                                                                 \
+  }
+#define X3P_STORE(SLOT, BUFI)                                                                                         \
+  {                                                                                                                   \
+    unsigned char *sa_ = x3_smem + (BUFI) * BUF, *sw_ = sa_ + 3 * IMG_A;                                              \
+    _Pragma("unroll") for (int u = 0; u < NA; ++u) {                                                                  \
+      const u32x4v bits_ = __builtin_bit_cast(u32x4v, ra[SLOT][u]) ^ flip;                                            \
+      const Pieces4 sp = split4(__builtin_bit_cast(f32x4v, bits_));                                                   \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                                   \
+        *reinterpret_cast<bf16x4 *>(sa_ + q * IMG_A + a_row[u] * kX3Row + 8 * a_c4[u]) = sp.p[q];                     \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < NW; ++u)                                                                    \
+      *reinterpret_cast<u32x4v *>(sw_ + w_q[u] * IMG_W + w_row[u] * kX3Row + 16 * w_c[u]) = rw[SLOT][u];              \
+  }
+    // prologue: P stages in flight, stage 0 into buffer 0
+#pragma unroll
+    for (int d = 0; d < P; ++d) X3P_FETCH(d);
+    X3P_STORE(0, 0);
+    X3P_FETCH(0);
+    __syncthreads();
+    for (int s = 0; s < total;) {
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (s >= total) break;
+        // stage s + 1 (ring slot (s + 1) % P) -> the other buffer (its last readers passed the barrier at the end of
+        // stage s - 1), then the freed register set takes stage s + 1 + P.  (Past the end the last stage is stored
+        // again: harmless.)
+        if (!(p.dbg & 1)) {
+          X3P_STORE((uu + 1) % P, (uu & 1) ^ 1);
+          X3P_FETCH((uu + 1) % P);
+        }
+        __syncthreads();
+        ++s;
+      }
+    }
+#undef X3P_FETCH
+#undef X3P_STORE
+    return;
+  }
+  // ================================================= consumers =================================================
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (BN / 2);
+  // THE MATRIX CORE'S ACCUMULATION IS BIASED: v_mfma_f32_32x32x16_bf16 truncates the aligned addends toward minus
+  // infinity (measured, tools/x3_bias.py: mean signed error -2e-11 * K * mean|y| whatever the sign of y, where the fp32
+  // MFMA and the library GEMM are unbiased).  Per element that is far below the rounding noise -- the RMS error of this
+  // kernel is 0.6x the library's -- but it has ONE sign, so a sum over the 16 384 token rows of an output column (every
+  // bias and LayerNorm gradient of the step is such a sum, and they cancel heavily) collects it 16 384-fold where
+  // random errors collect 128-fold: whole-step gradients moved by 1.2e-3 against float64 (0.36e-3 with the library).
+  // Cure: two accumulators, X for the even and Y for the odd 16-k blocks, with the activations' sign alternating over
+  // rows AND blocks (the producers store (-1)^(row + block) * a), so that
+  //   X[r] = s_r * (sum over even blocks),  Y[r] = -s_r * (sum over odd blocks),  y[r] = s_r * (X[r] - Y[r]),  s_r = (-1)^r:
+  // both accumulators carry the same negative bias, the difference keeps only its row-to-row fluctuation, and what is
+  // left changes sign from one row to the next -- column sums see noise again, not a drift.
+  f32x16 acc[TM][TN], acs[TM][TN];  // X and Y
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // (no lambdas around the staging registers: captured by reference, hipcc kept `rw` in SCRATCH memory -- every
-  // prefetched piece was waited for at once, stored to scratch and read back before its LDS write)
-  f32x4v ra[NA];
-  u32x4v rw[NW];
-#define X3_FETCH(K0)                                                                                                   \
-  {                                                                                                                    \
-    _Pragma("unroll") for (int u = 0; u < NA; ++u) {                                                                   \
-      const int i_ = tid + u * kX3Threads, row_ = i_ >> 3, c4_ = i_ & 7;                                               \
-      ra[u] = *reinterpret_cast<const f32x4v *>(p.a + static_cast<size_t>(m0 + row_) * p.lda + (K0) + 4 * c4_);        \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                                                   \
-      const int i_ = tid + u * kX3Threads, q_ = i_ / (BN * 4), rem_ = i_ % (BN * 4), row_ = rem_ >> 2, c_ = rem_ & 3;  \
-      rw[u] = *reinterpret_cast<const u32x4v *>(p.w + static_cast<size_t>(q_) * p.wplane +                              \
-                                               static_cast<size_t>(n0 + row_) * p.ldw + (K0) + 8 * c_);                \
-    }                                                                                                                  \
-  }
-
-  X3_FETCH(0);
-  for (int k0 = 0; k0 < p.k; k0 += kX3BK) {
-    __syncthreads();  // everyone is done reading the previous stage
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acs[i][j][r] = 0.f;
+  int c_i = 0, c_k = 0, c_m0, c_n0;
+  coords(0, c_m0, c_n0);
+  __syncthreads();  // (the producers' prologue barrier)
+  for (int s = 0; s < total;) {
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
-      const int i = tid + u * kX3Threads, row = i >> 3, c4 = i & 7;
-      const Pieces4 sp = split4(ra[u]);
+    for (int uu = 0; uu < 2; ++uu) {
+      if (s >= total) break;
+      const unsigned char *sa = x3_smem + uu * BUF, *sw = sa + 3 * IMG_A;
+      if (!(p.dbg & 2))
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4 *>(s_a + q * IMG_A + row * kX3Row + 8 * c4) = sp.p[q];
-    }
-#pragma unroll
-    for (int u = 0; u < NW; ++u) {
-      const int i = tid + u * kX3Threads, q = i / (BN * 4), rem = i % (BN * 4), row = rem >> 2, c = rem & 3;
-      *reinterpret_cast<u32x4v *>(s_w + q * IMG_W + row * kX3Row + 16 * c) = rw[u];
-    }
-    __syncthreads();
-    {
-      // the next stage's loads, in flight during this stage's MFMAs (the last iteration fetches its own tile again:
-      // unconditional loads keep the waits in front of the LDS writes exact)
-      const int kn = k0 + kX3BK < p.k ? k0 + kX3BK : k0;
-      X3_FETCH(kn);
-    }
-#pragma unroll
-    for (int kk = 0; kk < kX3BK / 16; ++kk) {
-      bf16x8 fa[TM][3], fb[TN][3];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          fa[i][q] = *reinterpret_cast<const bf16x8 *>(s_a + q * IMG_A + (wm + 32 * i + l31) * kX3Row + 32 * kk + 16 * half);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          fb[j][q] = *reinterpret_cast<const bf16x8 *>(s_w + q * IMG_W + (wn + 32 * j + l31) * kX3Row + 32 * kk + 16 * half);
-      // six piece products of order <= 2, smallest first; the (i, j) tiles interleave so that consecutive MFMAs are
-      // independent
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        constexpr int qa_of[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int qb_of[6] = {0, 2, 1, 0, 1, 0};
-        const int qa = qa_of[t], qb = qb_of[t];
+      for (int kk = 0; kk < kX3BK / 16; ++kk) {
+        bf16x8 fa[TM][3], fb[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+          for (int q = 0; q < 3; ++q)
+            fa[i][q] = *reinterpret_cast<const bf16x8 *>(sa + q * IMG_A + (wm + 32 * i + l31) * kX3Row + 32 * kk + 16 * half);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            fb[j][q] = *reinterpret_cast<const bf16x8 *>(sw + q * IMG_W + (wn + 32 * j + l31) * kX3Row + 32 * kk + 16 * half);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          constexpr int qa_of[6] = {2, 0, 1, 1, 0, 0};
+          constexpr int qb_of[6] = {0, 2, 1, 0, 1, 0};
+          const int qa = qa_of[t], qb = qb_of[t];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (kk & 1) acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acs[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+            }
+        }
       }
+      if (c_k + 1 == nk && (p.dbg & 4)) {
+        c_k = 0;
+        ++c_i;
+        if (c_i < my_tiles) coords(c_i, c_m0, c_n0);
+      } else if (c_k + 1 == nk) {
+        // tile done: plain stores (2 rows x 128 contiguous bytes per instruction), running under the producers' work
+        // for the next tile
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = c_n0 + wn + 32 * j + l31;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+            float *dst0 = p.c + static_cast<size_t>(c_m0 + wm + 32 * i + 4 * half) * p.ldc + col;
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)  // row = (r & 3) + 8 (r >> 2) + 4 half (+ even offsets): its parity is r & 1
+              y[r] = (r & 1) ? acs[i][j][r] - acc[i][j][r] : acc[i][j][r] - acs[i][j][r];
+            if (p.accumulate) {  // (hoisted: inside the element loop the compiler branched and waited per element)
+              float old[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) old[r] = dst0[static_cast<size_t>(crow_x3(r, 0)) * p.ldc];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) y[r] += old[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              dst0[static_cast<size_t>(crow_x3(r, 0)) * p.ldc] = y[r] + bias;
+              acc[i][j][r] = acs[i][j][r] = 0.f;
+            }
+          }
+        c_k = 0;
+        ++c_i;
+        if (c_i < my_tiles) coords(c_i, c_m0, c_n0);
+      } else {
+        ++c_k;
+      }
+      __syncthreads();
+      ++s;
     }
   }
-#undef X3_FETCH
-  // epilogue: a store instruction writes 2 rows x 128 contiguous bytes
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn + 32 * j + l31;
-      const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + 32 * i + crow_x3(r, half);
-        float *dst = p.c + static_cast<size_t>(row) * p.ldc + col;
-        float v = acc[i][j][r] + bias;
-        if (p.accumulate) v += *dst;
-        *dst = v;
-      }
-    }
 }
 
 // ---- the weights' pieces: every weight of a step in one launch ---------------------------------------------------------
@@ -259,12 +367,31 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const X3SplitTable t) {
   }
 }
 
-template <int BM, int BN>
-int launch_x3_nt(X3NtParams p, hipStream_t s) {
-  p.tiles_m = p.m / BM;
+template <int BN>
+int launch_x3_pipe(X3NtParams p, hipStream_t s) {
+  constexpr int P = 3;
+  constexpr size_t lds = 2 * (3 * 128 * kX3Row + 3 * BN * kX3Row);
+  p.tiles_m = p.m / 128;
   p.tiles_n = p.n / BN;
-  p.xcd_map = (p.tiles_m % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((x3_nt_kernel<BM, BN>), dim3(static_cast<unsigned>(p.tiles_m) * p.tiles_n), dim3(kX3Threads), 0, s, p);
+  const int tiles = p.tiles_m * p.tiles_n;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    static int cached[64] = {0};
+    if (dev >= 0 && dev < 64) {
+      if (!cached[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cached[dev] = v;
+        else cached[dev] = 256;
+      }
+      cus = cached[dev];
+    }
+  }
+  int nwg = tiles < cus ? tiles : cus;
+  p.xcd_map = (p.tiles_m % 8 == 0 && nwg % 8 == 0 && nwg >= 8) ? 1 : 0;
+  auto kern = x3_nt_pipe_kernel<BN, P>;
+  const int st = raise_dynamic_lds(kern, lds);
+  if (st != CODA_OK) return st;
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nwg)), dim3(kX3PipeThreads), lds, s, p, tiles, p.k / kX3BK);
   return launch_status();
 }
 
@@ -307,17 +434,13 @@ CODA_API int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long 
   if (m == 0 || n == 0) return CODA_OK;
   if (!a || !w_planes || !c || k == 0) return CODA_EINVAL;
   // shapes / alignments this kernel takes (everything else: coda_gemm_f32)
-  if (m % 64 || n % 64 || k % kX3BK || lda % 4 || ldw % 8 || plane_stride % 8 ||
+  if (m % 128 || n % 64 || k % kX3BK || lda % 4 || ldw % 8 || plane_stride % 8 ||
       (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_planes)) % 16 ||
       reinterpret_cast<uintptr_t>(c) % 4)
     return CODA_ENOSPC;
   hipStream_t s = static_cast<hipStream_t>(stream);
   clear_sticky_error();
-  X3NtParams p{a, static_cast<const __bf16 *>(w_planes), bias, c, lda, ldw, plane_stride, ldc, m, n, k, accumulate, 0, 0, 0};
-  // tile choice: the largest tile that still gives every CU two workgroups
-  const long long t128 = (m % 128 == 0 && n % 128 == 0) ? static_cast<long long>(m / 128) * (n / 128) : 0;
-  const long long t64x128 = (n % 128 == 0) ? static_cast<long long>(m / 64) * (n / 128) : 0;
-  if (t128 >= 512) return launch_x3_nt<128, 128>(p, s);
-  if (t64x128 >= 256) return launch_x3_nt<64, 128>(p, s);
-  return launch_x3_nt<64, 64>(p, s);
+  static const int dbg = [] { const char *e = getenv("CODA_X3_DBG"); return e ? atoi(e) : 0; }();
+  X3NtParams p{a, static_cast<const __bf16 *>(w_planes), bias, c, lda, ldw, plane_stride, ldc, m, n, k, accumulate, 0, 0, 0, dbg};
+  return (n % 128 == 0) ? launch_x3_pipe<128>(p, s) : launch_x3_pipe<64>(p, s);
 }

@@ -282,6 +282,8 @@ class _DecoderStack(torch.autograd.Function):
         mp2 = mem2 if pos is None else (memory + pos).reshape(-1, e)
         wk_all = torch.cat([lp[8][e:2 * e] for lp in layers])          # in_proj rows of the keys   (nl*E, E)
         wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
+        gemm.declare_weight(wk_all)   # (built per step from the layers' parameters: gemm.py, x3 route)
+        gemm.declare_weight(wv_all)
         bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
         bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
         k_all = gemm.linear(mp2, wk_all, bk_all, out=_kv_buffer(mp2.shape[0], nl * e, dev))   # (S*B, nl*E)
@@ -473,6 +475,8 @@ class _DecoderStackC(torch.autograd.Function):
         mp2 = mem2 if pos is None else (memory + pos).reshape(-1, e)
         wk_all = torch.cat([lp[8][e:2 * e] for lp in layers])
         wv_all = torch.cat([lp[8][2 * e:] for lp in layers])
+        gemm.declare_weight(wk_all)   # (built per step from the layers' parameters: gemm.py, x3 route)
+        gemm.declare_weight(wv_all)
         bk_all = torch.cat([lp[9][e:2 * e] for lp in layers])
         bv_all = torch.cat([lp[9][2 * e:] for lp in layers])
         k_all = gemm.linear(mp2, wk_all, bk_all, out=_kv_buffer(mp2.shape[0], nl * e, dev))

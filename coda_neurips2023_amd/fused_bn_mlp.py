@@ -171,9 +171,11 @@ class _HiddenStack(torch.autograd.Function):
             c = ws[i].shape[1]
             if cur is None:
                 if groups == 1:
-                    z = torch.mm(x, ws[i][0].t()).unsqueeze(0)
+                    z = gemm.linear(x, ws[i][0]).unsqueeze(0)
                 else:  # one batched GEMM over the heads; x is broadcast with batch stride 0
                     z = torch.bmm(x.unsqueeze(0).expand(groups, -1, -1), ws[i].transpose(1, 2))
+            elif groups == 1:
+                z = gemm.linear(cur[0], ws[i][0]).unsqueeze(0)
             else:
                 z = torch.bmm(cur, ws[i].transpose(1, 2))
             # one partial sum per row block; the finalize kernel adds them (no atomics, no memset)
@@ -312,12 +314,12 @@ class _HiddenStack(torch.autograd.Function):
             # weight gradients (split-K) and the gradient of the block input
             if i > 0:
                 dw = _split_k_tn(dz, acts[i - 1], defer)
-                da = torch.bmm(dz, ws[i])
+                da = gemm.mm(dz[0], ws[i][0]).unsqueeze(0) if groups == 1 else torch.bmm(dz, ws[i])
             else:
                 xs = x.unsqueeze(0)
                 if groups == 1:
                     dw = _split_k_tn(dz, xs, defer)
-                    dx = torch.mm(dz[0], ws[0][0]) if ctx.needs_input_grad[0] else None
+                    dx = gemm.mm(dz[0], ws[0][0]) if ctx.needs_input_grad[0] else None
                 else:
                     dw = torch.empty((groups, dz.shape[2], xs.shape[2]), dtype=torch.float32, device=dev)
                     for g in range(groups):  # (x is shared by the groups: one product per group, written in place)

@@ -44,18 +44,24 @@ _OWN_MAX_MN = 2048 * 256
 # CODA_GEMM_X3=0 sends everything back to the library (A/B switch, and the reference point of the parity tests).
 _X3 = os.environ.get("CODA_GEMM_X3", "1") != "0"
 _X3_MIN_ROWS = 4096
+_X3_CHECK = os.environ.get("CODA_X3_CHECK", "0") == "1"
+_X3_CHECK_PREV = None
+_X3_FORCE = False     # tests: every shape the kernels take, not only the ones they win on
 
 
-def set_x3(on):
-    """Development / test switch (tools/bench_gemm_x3.py, tests): route eligible products through the x3 kernels."""
-    global _X3
+def set_x3(on, force=False):
+    """Development / test switch (tools/bench_gemm_x3.py, tests): route eligible products through the x3 kernels;
+    ``force``: also the shapes on which the library is faster."""
+    global _X3, _X3_FORCE
     _X3 = bool(on)
+    _X3_FORCE = bool(force)
 
 
 class _Planes:
-    __slots__ = ("base", "version", "epoch", "used", "nt", "nn")
+    __slots__ = ("base", "version", "epoch", "used", "nt", "nn", "declared")
 
 
+x3_calls = 0          # products that took the x3 route (diagnostics: tests, tools)
 _planes = {}          # (data_ptr, rows, cols, stride) of the BASE weight -> _Planes (holds the base: its storage stays alive)
 _planes_epoch = 0
 
@@ -66,13 +72,21 @@ def _weight_base(w):
     recycled by the allocator, and a cache keyed by address would serve another tensor's pieces)."""
     base = w._base if w._base is not None else w
     if not (base.requires_grad or isinstance(base, torch.nn.Parameter)) or not base.is_leaf:
+        # ... or a tensor a caller has DECLARED a weight for this step (declare_weight: the decoder's concatenated
+        # key / value in-projection rows): the entry holds the tensor, so a matching address is the same storage
+        e = _planes.get((w.data_ptr(), w.shape[0], w.shape[1], w.stride(0))) if w.dim() == 2 else None
+        if (e is not None and e.declared and e.base is not None and e.version == w._version
+                and e.epoch == _planes_epoch):
+            return e.base, 0, w.shape[0]
         return None
-    if base.dim() != 2 or base.stride(1) != 1 or base.dtype != torch.float32:
+    if base.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
         return None
     if base is w:
         return base, 0, w.shape[0]
-    if w.shape[1] != base.shape[1] or w.stride() != base.stride():
-        return None
+    if base.dim() != 2 or base.stride(1) != 1 or w.shape[1] != base.shape[1] or w.stride() != base.stride():
+        # another 2-D view of a parameter (a 1 x 1 convolution's weight flattened to (Cout, Cin)): the view itself is
+        # the cached matrix (it keeps the parameter's storage alive and shares its version counter)
+        return (w, 0, w.shape[0]) if w.stride(0) >= w.shape[1] else None
     off = (w.data_ptr() - base.data_ptr()) // 4
     if off % base.stride(0):
         return None
@@ -97,7 +111,7 @@ def _weight_planes(base):
         r, c = base.shape
         e.nt = torch.empty((3, r, c), dtype=torch.bfloat16, device=base.device)
         e.nn = torch.empty((3, c, r), dtype=torch.bfloat16, device=base.device)
-        e.version, e.epoch, e.used, e.base = -1, -1, -1, None
+        e.version, e.epoch, e.used, e.base, e.declared = -1, -1, -1, None, False
         _planes[key] = e
     if e.version != base._version or e.epoch != _planes_epoch or e.base is None:
         e.base = base
@@ -108,6 +122,22 @@ def _weight_planes(base):
     return e
 
 
+def declare_weight(t):
+    """``t`` is a weight-like matrix assembled for THIS step from parameters (``torch.cat`` of the decoder layers'
+    key / value in-projection rows): split it now, both orientations, so that the products of this step's forward and
+    backward that use it (the very tensor, not a slice) take the x3 route.  The entry keeps ``t`` alive until the next
+    ``refresh_weight_planes`` (after the optimizer step) or until eight newer declarations have been made."""
+    if not (_X3 and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+            and t.shape[0] % 8 == 0 and t.shape[1] % 8 == 0 and t._base is None):
+        return t
+    e = _weight_planes(t)
+    e.declared = True
+    old = [k for k, v in _planes.items() if v.declared and v is not e]
+    for k in old[:-7]:
+        del _planes[k]
+    return t
+
+
 def refresh_weight_planes():
     """The weights have changed behind the version counters (this package's optimizer writes through raw pointers;
     so do checkpoint loaders that assign through ``p.data``): every cached set of pieces that was used since the last
@@ -116,7 +146,8 @@ def refresh_weight_planes():
     global _planes_epoch
     live = []
     for key, e in list(_planes.items()):
-        if e.used == _planes_epoch and e.base is not None and e.base.is_cuda:
+        # kept: used within the last few refreshes (a loop with two optimizers refreshes twice per step)
+        if e.used > _planes_epoch - 4 and e.base is not None and e.base.is_cuda and not e.declared:
             live.append(e)
         else:
             del _planes[key]
@@ -129,7 +160,6 @@ def refresh_weight_planes():
             _split_items(group)
         for e in group:
             e.version, e.epoch = e.base._version, _planes_epoch
-            e.used = _planes_epoch - 1   # "not yet used in the new epoch": dropped at the next refresh unless used
 
 
 try:  # torch optimizers bump the version counters themselves; the hook only turns ~25 one-weight launches into one
@@ -142,7 +172,11 @@ except Exception:  # pragma: no cover
 def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
     """The product through coda_gemm_x3_nt_f32 when it is one of the large token-wise ones with a weight as B;
     returns ``out`` or None ("not this route")."""
-    if transa or m < _X3_MIN_ROWS or m % 64 or n % 64 or k % 32 or a.stride(0) % 4 or a.data_ptr() % 16:
+    if transa or m < _X3_MIN_ROWS or m % 128 or n % 64 or k % 32 or a.stride(0) % 4 or a.data_ptr() % 16:
+        return None
+    if not _X3_FORCE and (m < 8192 or n < 256):
+        # measured (tools/bench_gemm_x3.py): with 128 or fewer output columns the 128-row tiles fill half the chip and
+        # the library's small-tile kernels win (16 384 x 128 x 256: 16.3 vs 14.3 us), likewise below 8192 rows
         return None
     wb = _weight_base(b)
     if wb is None:
@@ -160,6 +194,11 @@ def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
         return None
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if _X3_CHECK and accumulate:
+        global _X3_CHECK_PREV
+        _X3_CHECK_PREV = out.double().clone()
+    global x3_calls
+    x3_calls += 1
     st = _lib.load().coda_gemm_x3_nt_f32(m, n, k, a.data_ptr(), a.stride(0), w_ptr, ldw, rows * cols, out.data_ptr(),
                                          out.stride(0), bias.data_ptr() if bias is not None else None,
                                          1 if accumulate else 0, _lib.current_stream_handle())
@@ -167,14 +206,42 @@ def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
         return None
     if st != 0:
         raise RuntimeError(f"coda_gemm_x3_nt_f32 failed ({st}) for transb={transb} m={m} n={n} k={k}")
+    if _X3_CHECK:  # development: every x3 product against float64, next to the library's fp32 result
+        b2 = (b.t() if transb else b).double()
+        ref = a.double() @ b2
+        if bias is not None:
+            ref = ref + bias.double()
+        lib_out = torch.mm(a, b.t() if transb else b)
+        if bias is not None:
+            lib_out = lib_out + bias
+        got = out.double() - (_X3_CHECK_PREV if accumulate else 0.0)
+        den = float(ref.abs().max()) + 1e-300
+        e_x3 = float((got - ref).abs().max()) / den
+        e_lib = float((lib_out.double() - ref).abs().max()) / den
+        cs = ref.sum(0)
+        cden = float(cs.abs().max()) + 1e-300
+        c_x3 = float((got.sum(0) - cs).abs().max()) / cden
+        c_lib = float((lib_out.double().sum(0) - cs).abs().max()) / cden
+        print(f"x3check tb={transb} acc={int(bool(accumulate))} m={m} n={n} k={k} lda={a.stride(0)} ldc={out.stride(0)}: "
+              f"max err x3 {e_x3:.2e} lib {e_lib:.2e} | column sums x3 {c_x3:.2e} lib {c_lib:.2e}"
+              + ("   <<<<" if e_x3 > 3 * e_lib + 1e-7 or c_x3 > 3 * c_lib + 1e-7 else ""), flush=True)
     return out
+
+
+route_log = None      # tools/gemm_routes.py: a dict (route, transa, transb, m, n, k) -> calls, filled while not None
 
 
 def _run(transa, transb, m, n, k, a, b, out, bias, accumulate):
     if _X3:
         r = _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate)
         if r is not None:
+            if route_log is not None:
+                key = ("x3", transa, transb, m, n, k)
+                route_log[key] = route_log.get(key, 0) + 1
             return r
+    if route_log is not None:
+        key = ("lib/own", transa, transb, m, n, k)
+        route_log[key] = route_log.get(key, 0) + 1
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if _OWN_SMALL and not transa and m * n <= _OWN_MAX_MN and m % 64 == 0 and n % 64 == 0 and k % 128 == 0:

@@ -349,6 +349,8 @@ class FlatGradReducer:
         src = self.dist.get_global_rank(self.group, 0) if self.group is not None else 0
         for t in tensors:
             self.dist.broadcast(t.data, src=src, group=self.group)
+        from . import gemm
+        gemm.refresh_weight_planes()  # written through .data: the weight-piece cache cannot see it (gemm.py)
 
     @torch.no_grad()
     def _fire(self, seg):

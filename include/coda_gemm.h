@@ -96,7 +96,7 @@ int coda_grouped_gemm_tn_f32(const CodaTnProblem *problems, int count, void *str
  *   planes: plane q at w_planes + q * plane_stride, row r (of n) at + r * ldw, bf16 ELEMENTS.  y = x W^T + b takes the
  *   `nt` planes of W (n x k); dx = dy W takes the `nn` planes (k_in x n_out: again "row = output column") -- a row
  *   slice of W is a row slice of nt and a COLUMN slice of nn (ldw stays the full row length).
- *   Constraints: m, n multiples of 64, k a multiple of 32, lda a multiple of 4, ldw and plane_stride multiples of 8,
+ *   Constraints: m a multiple of 128, n of 64, k of 32, lda a multiple of 4, ldw and plane_stride multiples of 8,
  *   a and w_planes 16-byte aligned; CODA_ENOSPC otherwise ("not this kernel's shape": use coda_gemm_f32). */
 typedef struct CodaX3SplitItem {
   const float *src;

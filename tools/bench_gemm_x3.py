@@ -38,7 +38,7 @@ with torch.no_grad():
         gemm.set_x3(False)
         t_lib = timed(lambda: gemm._run(0, tb, m, n, k, a, w, out, None, False))
         ref = out.clone()
-        gemm.set_x3(True)
+        gemm.set_x3(True, force=True)
         t_x3 = timed(lambda: gemm._run(0, tb, m, n, k, a, w, out, None, False))
         diff = float((out - ref).abs().max() / ref.abs().max())
         fl = 2.0 * m * n * k
