@@ -168,6 +168,7 @@ SIGNATURES = {
     "coda_gemm_x3_split_f32": (_c_int, [_P, _c_int, _P]),
     "coda_gemm_x3_nt_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                      ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_int, _P]),
+    "coda_gemm_x3_tn_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_int, _P]),
     "coda_sgemm_relu_dropout_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                              _P, ctypes.c_longlong, _P, _c_float, ctypes.c_uint64, _P]),
     "coda_mha_get_mfma_dtype": (_c_int, []),

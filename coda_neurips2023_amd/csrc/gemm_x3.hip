@@ -303,6 +303,197 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
   }
 }
 
+// ---- the weight gradients: dW = dY^T X over the token rows, as partial sums per token slice -------------------------------
+// Both operands are activations (fp32, token-major: feature contiguous), the contraction runs over TOKENS.  The MFMA wants,
+// per lane, eight consecutive k (tokens) of one output row / column (feature) -- the transpose of how the data lie.  They
+// go to LDS as they are ([token][feature] bf16 per plane: the producers' stores stay whole-row and conflict-free) and the
+// fragments come out through ds_read_b64_tr_b16, the transposing LDS read: within a 16-lane group, lane c receives
+// element (c & 3) of the four 8-byte pieces addressed by lanes (c >> 2), 4 + (c >> 2), 8 + (c >> 2), 12 + (c >> 2)
+// (tools/tr_probe.hip), i.e. with lane i pointing at token k0 + (i >> 2), features f0 + 4 (i & 3) .. + 3, lane c gets
+// tokens k0 .. k0 + 3 of feature f0 + c: two such reads are one 32 x 16 MFMA operand.  Rows are 256 + 64 bytes apart so
+// that the four token rows of a read fall on different banks.
+//   part (slices, M, N) [slice s] = dY[s-th token range]^T X[same range],   dY (T x M), X (T x N), row strides lddy / ldx
+// The sum over the slices is the caller's (the grouped column-sum kernel that already closes the library path's chunks).
+// Same pipeline as x3_nt_pipe_kernel (producer / consumer waves, flat stage sequence over the workgroup's (slice, tile)
+// list, X / Y accumulators with alternating signs); both operands are split by the producers.
+struct X3TnParams {
+  const float *dy, *x;
+  float *part;
+  long long lddy, ldx;
+  int m, n;            // output rows (features of dY) and columns (features of X)
+  int slice_rows;      // tokens per slice (a multiple of 32)
+  int tiles_m, tiles_n, slices;
+};
+constexpr int kTnRow = 320;  // bytes per LDS token row: 128 features x 2 B + 64 B
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *plane, int token0, int feat0, int lane) {
+  // the 32 (features feat0 ..) x 16 (tokens token0 ..) operand of v_mfma_f32_32x32x16_bf16 from a [token][feature] image
+  const int g = lane >> 4, i = lane & 15;
+  const unsigned char *a0 = plane + (token0 + 8 * (g >> 1) + (i >> 2)) * kTnRow + (feat0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a0 + 4 * kTnRow));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int P>
+__global__ __launch_bounds__(kX3PipeThreads, 2) void x3_tn_pipe_kernel(const X3TnParams p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int IMG = kX3BK * kTnRow;              // one plane of one operand: 32 token rows
+  constexpr int BUF = 6 * IMG;                     // dY planes, then X planes
+  constexpr int NA = kX3BK * BM / 4 / 256;         // 4 float4 pieces per operand, producer thread and stage
+  constexpr int U = (P % 2 == 0) ? P : 2 * P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
+
+  const int lane = lane_id(), w = wave_id();
+  const bool consumer = w < 4;
+  const int nwg = static_cast<int>(gridDim.x), b = static_cast<int>(blockIdx.x);
+  const int tiles = p.tiles_m * p.tiles_n, total_tiles = tiles * p.slices;
+  const int my_tiles = total_tiles > b ? (total_tiles - b + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  const int nk = p.slice_rows / kX3BK;
+  // (slice, tile) of this workgroup's i-th item: consecutive workgroups share a token slice (its rows come from L2)
+  auto coords = [&](int i, int &row0, int &m0, int &n0, int &slice) {
+    const int t = b + i * nwg;
+    slice = t / tiles;
+    const int tt = t % tiles;
+    row0 = slice * p.slice_rows;
+    m0 = (tt / p.tiles_n) * BM;
+    n0 = (tt % p.tiles_n) * BN;
+  };
+  const int total = my_tiles * nk;
+
+  if (!consumer) {
+    const int tid = static_cast<int>(threadIdx.x) - 256;
+    int tok[NA], f4[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int i = tid + u * 256;
+      tok[u] = i >> 5;      // 32 float4 per 128-feature row
+      f4[u] = i & 31;
+    }
+    f32x4v ry[P][NA], rx[P][NA];
+    int f_i = 0, f_k = 0, f_row0, f_m0, f_n0, f_slice;
+    coords(0, f_row0, f_m0, f_n0, f_slice);
+#define X3T_FETCH(SLOT)                                                                                               \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NA; ++u) {                                                                  \
+      const size_t r_ = static_cast<size_t>(f_row0 + kX3BK * f_k + tok[u]);                                           \
+      ry[SLOT][u] = *reinterpret_cast<const f32x4v *>(p.dy + r_ * p.lddy + f_m0 + 4 * f4[u]);                         \
+      rx[SLOT][u] = *reinterpret_cast<const f32x4v *>(p.x + r_ * p.ldx + f_n0 + 4 * f4[u]);                           \
+    }                                                                                                                 \
+    if (f_k + 1 < nk) ++f_k;                                                                                          \
+    else if (f_i + 1 < my_tiles) {                                                                                    \
+      f_k = 0;                                                                                                        \
+      ++f_i;                                                                                                          \
+      coords(f_i, f_row0, f_m0, f_n0, f_slice);                                                                       \
+    }                                                                                                                 \
+  }
+    // sign pattern of the dY pieces: (-1)^(output row + 16-token block); a float4 holds output rows 4 f4 .. + 3
+    // (parities 0 1 0 1), its token block is tok >> 4 = (u >> 1) for every thread
+#define X3T_STORE(SLOT, BUFI)                                                                                         \
+  {                                                                                                                   \
+    unsigned char *sy_ = x3_smem + (BUFI) * BUF, *sx_ = sy_ + 3 * IMG;                                                \
+    _Pragma("unroll") for (int u = 0; u < NA; ++u) {                                                                  \
+      const u32x4v m_ = (u >> 1) ? u32x4v{0x80000000u, 0u, 0x80000000u, 0u} : u32x4v{0u, 0x80000000u, 0u, 0x80000000u}; \
+      const Pieces4 py = split4(__builtin_bit_cast(f32x4v, __builtin_bit_cast(u32x4v, ry[SLOT][u]) ^ m_));            \
+      const Pieces4 px = split4(rx[SLOT][u]);                                                                         \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                                 \
+        *reinterpret_cast<bf16x4 *>(sy_ + q * IMG + tok[u] * kTnRow + 8 * f4[u]) = py.p[q];                           \
+        *reinterpret_cast<bf16x4 *>(sx_ + q * IMG + tok[u] * kTnRow + 8 * f4[u]) = px.p[q];                           \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+#pragma unroll
+    for (int d = 0; d < P; ++d) X3T_FETCH(d);
+    X3T_STORE(0, 0);
+    X3T_FETCH(0);
+    __syncthreads();
+    for (int s = 0; s < total;) {
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        if (s >= total) break;
+        X3T_STORE((uu + 1) % P, (uu & 1) ^ 1);
+        X3T_FETCH((uu + 1) % P);
+        __syncthreads();
+        ++s;
+      }
+    }
+#undef X3T_FETCH
+#undef X3T_STORE
+    return;
+  }
+  // consumers
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (BN / 2);
+  f32x16 acc[TM][TN], acs[TM][TN];  // X and Y (see x3_nt_pipe_kernel)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acs[i][j][r] = 0.f;
+  int c_i = 0, c_k = 0, c_row0, c_m0, c_n0, c_slice;
+  coords(0, c_row0, c_m0, c_n0, c_slice);
+  __syncthreads();
+  for (int s = 0; s < total;) {
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      if (s >= total) break;
+      const unsigned char *sy = x3_smem + uu * BUF, *sx = sy + 3 * IMG;
+#pragma unroll
+      for (int kk = 0; kk < kX3BK / 16; ++kk) {
+        bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag(sy + q * IMG, 16 * kk, wm + 32 * i, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fb[j][q] = tr_frag(sx + q * IMG, 16 * kk, wn + 32 * j, lane);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+          constexpr int qa_of[6] = {2, 0, 1, 1, 0, 0};
+          constexpr int qb_of[6] = {0, 2, 1, 0, 1, 0};
+          const int qa = qa_of[t], qb = qb_of[t];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (kk & 1) acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acs[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+      if (c_k + 1 == nk) {
+        float *tile = p.part + (static_cast<size_t>(c_slice) * p.m + c_m0) * p.n + c_n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float *dst0 = tile + static_cast<size_t>(wm + 32 * i + 4 * half) * p.n + wn + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              dst0[static_cast<size_t>(crow_x3(r, 0)) * p.n] =
+                  (r & 1) ? acs[i][j][r] - acc[i][j][r] : acc[i][j][r] - acs[i][j][r];
+              acc[i][j][r] = acs[i][j][r] = 0.f;
+            }
+          }
+        c_k = 0;
+        ++c_i;
+        if (c_i < my_tiles) coords(c_i, c_row0, c_m0, c_n0, c_slice);
+      } else {
+        ++c_k;
+      }
+      __syncthreads();
+      ++s;
+    }
+  }
+}
+
 // ---- the weights' pieces: every weight of a step in one launch ---------------------------------------------------------
 constexpr int kSplitMaxItems = 48;
 struct X3SplitTable {
@@ -423,6 +614,29 @@ CODA_API int coda_gemm_x3_split_f32(const CodaX3SplitItem *items, int count, voi
     t.count = nb;
     hipLaunchKernelGGL(x3_split_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, t);
   }
+  return launch_status();
+}
+
+CODA_API int coda_gemm_x3_tn_f32(int rows, int m, int n, const float *dy, long long lddy, const float *x, long long ldx,
+                                 float *part, int slices, void *stream) {
+  using namespace coda;
+  if (rows < 0 || m < 0 || n < 0 || slices < 1) return CODA_EINVAL;
+  if (rows == 0 || m == 0 || n == 0) return CODA_OK;
+  if (!dy || !x || !part) return CODA_EINVAL;
+  if (m % 128 || n % 128 || rows % slices || (rows / slices) % kX3BK || lddy % 4 || ldx % 4 ||
+      (reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) % 16 || reinterpret_cast<uintptr_t>(part) % 4)
+    return CODA_ENOSPC;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_sticky_error();
+  X3TnParams p{dy, x, part, lddy, ldx, m, n, rows / slices, m / 128, n / 128, slices};
+  constexpr int P = 2;
+  constexpr size_t lds = 2 * 6 * kX3BK * kTnRow;
+  const long long tiles = static_cast<long long>(p.tiles_m) * p.tiles_n * slices;
+  const int nwg = static_cast<int>(tiles < 256 ? tiles : 256);
+  auto kern = x3_tn_pipe_kernel<P>;
+  const int st = raise_dynamic_lds(kern, lds);
+  if (st != CODA_OK) return st;
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nwg)), dim3(kX3PipeThreads), lds, s, p);
   return launch_status();
 }
 

@@ -123,6 +123,19 @@ def _split_k_tn(dz, a, defer=None, out=None):
     tensor (``out`` if given: (G,Co,Ci), contiguous) holds its values only after ``defer.flush()``."""
     g, t, co = dz.shape
     ci = a.shape[-1]
+    if defer is not None and t >= 2 * _SPLIT_ROWS:
+        # the x3 kernel's partial sums per token slice (gemm.x3_tn_partials), one launch per group
+        first = gemm.x3_tn_partials(dz[0], a[0])
+        if first is not None:
+            part = first if g == 1 else torch.empty((g,) + tuple(first.shape), dtype=torch.float32, device=dz.device)
+            if g > 1:
+                part[0].copy_(first)
+                for k in range(1, g):
+                    gemm.x3_tn_partials(dz[k], a[k], out=part[k])
+            if out is None:
+                out = torch.empty((g, co, ci), dtype=torch.float32, device=dz.device)
+            defer.add_colsum(part, out, first.shape[0], co * ci, g)
+            return out
     if t >= 2 * _SPLIT_ROWS and t % _SPLIT_ROWS == 0:
         nc = t // _SPLIT_ROWS
         part = torch.bmm(dz.view(g * nc, _SPLIT_ROWS, co).transpose(1, 2), a.view(g * nc, _SPLIT_ROWS, ci))

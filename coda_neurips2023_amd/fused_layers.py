@@ -52,7 +52,10 @@ def _colsum_into(out, x3, defer=None):
 def _tn_into(out, dy, x):
     """out (Co,Ci) <- dy^T x with the row reduction split into chunks for long inputs."""
     p = dy.shape[0]
-    if p >= _MIN_ROWS and p % _CHUNK == 0:
+    part = gemm.x3_tn_partials(dy, x) if p >= _MIN_ROWS else None
+    if part is not None:
+        torch.sum(part, 0, out=out)
+    elif p >= _MIN_ROWS and p % _CHUNK == 0:
         nc = p // _CHUNK
         part = torch.bmm(dy.view(nc, _CHUNK, -1).transpose(1, 2), x.view(nc, _CHUNK, -1))
         torch.sum(part, 0, out=out)

@@ -49,12 +49,14 @@ _X3_CHECK_PREV = None
 _X3_FORCE = False     # tests: every shape the kernels take, not only the ones they win on
 
 
-def set_x3(on, force=False):
+def set_x3(on, force=False, tn=None):
     """Development / test switch (tools/bench_gemm_x3.py, tests): route eligible products through the x3 kernels;
-    ``force``: also the shapes on which the library is faster."""
-    global _X3, _X3_FORCE
+    ``force``: also the shapes on which the library is faster; ``tn``: the weight-gradient kernel too."""
+    global _X3, _X3_FORCE, _X3_TN
     _X3 = bool(on)
     _X3_FORCE = bool(force)
+    if tn is not None:
+        _X3_TN = bool(tn)
 
 
 class _Planes:
@@ -228,6 +230,47 @@ def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
     return out
 
 
+# Weight gradients through coda_gemm_x3_tn_f32: OFF by default.  Stand-alone the kernel is 1.2-1.55x the library path
+# (row chunks as a batched GEMM + a sum) and 3-6x closer to float64, but inside the step it does not pay: same-box A/B
+# 555-558 scenes/s with it against 559-564 without (two rounds each) -- it needs 32-64 token slices to fill the chip where
+# the library's chunks need 8, so the grouped reduction over the partial sums costs 0.235 instead of 0.087 ms per step
+# and 16 MB of partials per 256 x 256 gradient go through HBM.  CODA_GEMM_X3_TN=1 switches it on (tests do).
+_X3_TN = os.environ.get("CODA_GEMM_X3_TN", "0") == "1"
+
+
+def x3_tn_partials(dy, x, out=None):
+    """dy (T, Co), x (T, Ci) -> partial weight gradients (slices, Co, Ci) with sum over dim 0 = dy^T x, through
+    coda_gemm_x3_tn_f32 (both operands split in the kernel, transposing LDS reads); None when the shape is not the
+    kernel's (the caller then takes the library path: row chunks as a batched GEMM).  ``out``: a (slices, Co, Ci)
+    buffer to fill -- its first dimension then decides the slice count."""
+    if not (_X3 and _X3_TN) or not _plain(dy, x) or dy.stride(1) != 1 or x.stride(1) != 1:
+        return None
+    t, co = dy.shape
+    ci = x.shape[1]
+    if t < 8192 or t % 32 or co % 128 or ci % 128 or (dy.stride(0) | x.stride(0)) % 4 or (dy.data_ptr() | x.data_ptr()) % 16:
+        return None
+    tiles = (co // 128) * (ci // 128)
+    if out is not None:
+        slices = out.shape[0]
+        if t % slices or (t // slices) % 32 or not out.is_contiguous():
+            return None
+    else:
+        slices = 1  # enough (slice, tile) items for every CU, slices of at least 256 tokens
+        while tiles * slices < 256 and (t // (2 * slices)) % 32 == 0 and t // (2 * slices) >= 256:
+            slices *= 2
+        out = torch.empty((slices, co, ci), dtype=torch.float32, device=dy.device)
+    st = _lib.load().coda_gemm_x3_tn_f32(t, co, ci, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0),
+                                         out.data_ptr(), slices, _lib.current_stream_handle())
+    if st == _lib.CODA_ENOSPC:
+        return None
+    if st != 0:
+        raise RuntimeError(f"coda_gemm_x3_tn_f32 failed ({st}) for rows={t} m={co} n={ci} slices={slices}")
+    if route_log is not None:
+        key = ("x3-tn", 1, 0, co, ci, t)
+        route_log[key] = route_log.get(key, 0) + 1
+    return out
+
+
 route_log = None      # tools/gemm_routes.py: a dict (route, transa, transb, m, n, k) -> calls, filled while not None
 
 
@@ -328,6 +371,11 @@ class DeferredWeightGrads:
         """out (Co, Ci) <- dy^T x with the row reduction split into `chunk`-row pieces: the batched product now, the
         sum over the pieces at flush() (one grouped launch for all sums of a node instead of one torch.sum each)."""
         p = dy.shape[0]
+        if out.is_contiguous() and p >= min_rows:
+            part = x3_tn_partials(dy, x)
+            if part is not None:
+                self.add_colsum(part, out, part.shape[0], out.numel())
+                return
         if (p >= min_rows and p % chunk == 0 and out.is_contiguous() and dy.is_contiguous() and x.is_contiguous()
                 and dy.dtype == torch.float32 and dy.is_cuda):
             nc = p // chunk

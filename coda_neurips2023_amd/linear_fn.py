@@ -24,6 +24,9 @@ def tn_gemm(dy, x):
     # stand-alone, tools/bench_long_tn.py, but 958 vs 979 scenes/s in the SA-only step -- 32 descriptor rows and
     # slices on the host per call -- so the batched library GEMM stays)
     if p >= _MIN_ROWS:
+        part = gemm.x3_tn_partials(dy, x) if p < (1 << 18) else None
+        if part is not None:
+            return part.sum(0)
         rows = _CHUNK if p % _CHUNK == 0 else 0
         if p >= (1 << 18) and p % 16384 == 0:
             rows = 16384

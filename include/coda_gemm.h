@@ -108,6 +108,14 @@ typedef struct CodaX3SplitItem {
 int coda_gemm_x3_split_f32(const CodaX3SplitItem *items, int count, void *stream);
 int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long lda, const void *w_planes, long long ldw,
                         long long plane_stride, float *c, long long ldc, const float *bias, int accumulate, void *stream);
+/* Weight gradients: part (slices x m x n, dense) [s] = dY_s^T X_s over the s-th of `slices` equal token ranges of
+ * dY (rows x m, row stride lddy) and X (rows x n, row stride ldx) -- `torch.mm(dy.t(), x)` of a linear layer over its
+ * 16 384 token rows as the library path computes it (row chunks as a batched GEMM, then a sum over the chunks), both
+ * operands split in the kernel.  The sum over the slices is the caller's (coda_tok_colsum_finalize_grouped_f32).
+ * Constraints: m, n multiples of 128, rows / slices a multiple of 32, lddy / ldx multiples of 4, 16-byte aligned
+ * operands; CODA_ENOSPC otherwise. */
+int coda_gemm_x3_tn_f32(int rows, int m, int n, const float *dy, long long lddy, const float *x, long long ldx,
+                        float *part, int slices, void *stream);
 
 #ifdef __cplusplus
 }

@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def x3_on():
-    saved = gemm._X3
-    gemm.set_x3(True, force=True)
+    saved = (gemm._X3, gemm._X3_TN)
+    gemm.set_x3(True, force=True, tn=True)
     yield
-    gemm.set_x3(saved)
+    gemm.set_x3(saved[0], tn=saved[1])
 
 
 def err(c, ref):
@@ -135,3 +135,37 @@ def test_shapes_outside_the_kernel_take_the_library(dev):
     with torch.no_grad():
         assert gemm._x3_route(0, 1, 4096, 72, 40, x, w, None, None, False) is None
         assert err(gemm.linear(x, w), x.double() @ w.double().t()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["normal", "range", "cancel"])
+@pytest.mark.parametrize("t,co,ci,pad", [(16384, 256, 256, 0), (16384, 128, 256, 0), (16384, 256, 128, 0),
+                                         (16384, 2048, 256, 64), (8192, 384, 128, 0), (16384, 768, 256, 0)])
+def test_weight_gradient_partials_against_float64(dev, kind, t, co, ci, pad):
+    """coda_gemm_x3_tn_f32: dW = dY^T X over the token rows as partial sums per token slice (both operands split in the
+    kernel, fragments through the transposing LDS read); the sum of the partials within 2x of the library's error."""
+    gen = torch.Generator().manual_seed(t + co + ci)
+    a, b = operands(kind, co, ci, t, gen, dev)        # a (co, t), b (t, ci): the product a @ b = dY^T X
+    dy_full = torch.zeros((t, co + pad), device=dev)
+    dy = dy_full[:, :co]
+    dy.copy_(a.t())
+    x = b.contiguous()
+    ref = dy.double().t() @ x.double()
+    native = err(torch.mm(dy.t(), x), ref)
+    part = gemm.x3_tn_partials(dy, x)
+    assert part is not None and part.shape[1:] == (co, ci)
+    got = part.double().sum(0)
+    e = float((got - ref).abs().max() / ref.abs().max())
+    assert e < 2.0 * native + 1e-7, (kind, e, native, part.shape)
+    again = gemm.x3_tn_partials(dy, x)
+    assert torch.equal(part, again)                   # deterministic
+    # a caller-provided buffer decides the slice count
+    buf = torch.full((16, co, ci), float("nan"), device=dev)
+    assert gemm.x3_tn_partials(dy, x, out=buf) is buf
+    assert float((buf.double().sum(0) - ref).abs().max() / ref.abs().max()) < 2.0 * native + 1e-7
+
+
+def test_weight_gradient_shapes_outside_the_kernel_are_declined(dev):
+    dy = torch.randn(16384, 192, device=dev)
+    x = torch.randn(16384, 256, device=dev)
+    assert gemm.x3_tn_partials(dy, x) is None
+    assert gemm.x3_tn_partials(dy[:4096, :128].contiguous(), x[:4096]) is None

@@ -44,3 +44,28 @@ with torch.no_grad():
         fl = 2.0 * m * n * k
         print(f"{lay} {m:6d} x {n:5d} x {k:6d}: library {t_lib:8.1f} us ({fl / t_lib / 1e6:6.1f} TF/s)   "
               f"x3 {t_x3:8.1f} us ({fl / t_x3 / 1e6:6.1f} TF/s)   {t_lib / t_x3:5.2f}x   max diff {diff:.1e}")
+
+
+gemm.set_x3(True, force=True, tn=True)
+# weight gradients: dW = dY^T X over 16 384 token rows -- the library path (row chunks as one batched GEMM + a sum) against
+# the x3 partial sums per token slice + the same sum
+with torch.no_grad():
+    for t, co, ci in [(16384, 256, 256), (16384, 768, 256), (16384, 128, 256), (16384, 256, 128), (16384, 2048, 256),
+                      (16384, 512, 512)]:
+        dy = torch.randn(t, co, generator=g).to(dev)
+        x = torch.randn(t, ci, generator=g).to(dev)
+
+        def lib():
+            return torch.bmm(dy.view(8, t // 8, co).transpose(1, 2), x.view(8, t // 8, ci)).sum(0)
+
+        def x3():
+            return gemm.x3_tn_partials(dy, x).sum(0)
+
+        ref = dy.double().t() @ x.double()
+        t_lib, t_x3 = timed(lib), timed(x3)
+        e_lib = float((lib().double() - ref).abs().max() / ref.abs().max())
+        e_x3 = float((x3().double() - ref).abs().max() / ref.abs().max())
+        fl = 2.0 * t * co * ci
+        print(f"tn {co:5d} x {ci:5d} x {t:6d}: library {t_lib:8.1f} us ({fl / t_lib / 1e6:6.1f} TF/s)   "
+              f"x3 {t_x3:8.1f} us ({fl / t_x3 / 1e6:6.1f} TF/s)   {t_lib / t_x3:5.2f}x   err vs f64: lib {e_lib:.1e} x3 {e_x3:.1e} "
+              f"slices {gemm.x3_tn_partials(dy, x).shape[0]}")

@@ -22,6 +22,7 @@ def cat(nm):
         return "GenericMLP batch-norm kernels (hip)"
     if "coda" in nm and any(k in nm for k in ("add_ln", "colsum", "bias_relu_dropout")):
         return "transformer token kernels (hip)"
+    if "coda" in nm and ("x3_nt" in nm or "x3_tn" in nm or "x3_split" in nm): return "own bf16x3 GEMMs, fp32-accurate (hip)"
     if "coda" in nm and ("sgemm" in nm or "grouped_tn" in nm or "gemm_tn" in nm): return "own fp32-MFMA GEMMs (hip)"
     if "coda" in nm and any(k in nm for k in ("giou", "hungarian", "box_decode", "box_loss", "align_loss", "nms", "box_point")):
         return "boxes / matcher / losses (hip)"
