@@ -20,6 +20,9 @@ from . import attention_core as _core
 from .linear_fn import _CHUNK, _MIN_ROWS
 
 
+_FWD_X3 = __import__("os").environ.get("CODA_ATTN_FWD_X3", "1") != "0"
+
+
 def _p(t):
     return t.data_ptr() if t is not None else None
 
@@ -193,8 +196,18 @@ class _MHA(torch.autograd.Function):
         seed, seed_dev = _core._next_seed() if p > 0.0 else (0, None)
         scale = 1.0 / (d ** 0.5)
         dt = _lib.opt("mfma_dtype")  # per-call MFMA operand type (this thread's option), kept for the backward
+        # Long unmasked sequences in fp32 mode (the encoder's 2048 x 2048): the FORWARD core runs its products as three
+        # bf16 pieces on the real matrix cores (mode 2 of include/coda_attention.h: fp32-level accuracy,
+        # tests/test_attention_x3_gpu.py; 258 against 352 us per layer, tools/bench_attn.py), the backward stays on the
+        # fp32 MFMA -- its kernels gain little in that mode (594 against 651 us), and a gradient is where the bf16 matrix
+        # core's rounding bias would matter (csrc/gemm_x3.hip).  CODA_ATTN_FWD_X3=0: fp32 MFMA forward too (A/B).
+        fwd_dt = dt
+        if (_FWD_X3 and mask_u8 is None and tgt_len >= 1024 and src_len >= 1024 and d == 64
+                and (dt == 0 or (dt < 0 and lib.coda_mha_get_mfma_dtype() == 0))):
+            fwd_dt = 2
         _lib.check(lib.coda_mha_fwd_opt_f32(_p(q), _p(k), _p(v), _p(mask_u8), _p(attn), _p(lse), bsz, nheads, tgt_len,
-                                            src_len, d, ldq, ldk, ldv, scale, float(p), seed, _p(seed_dev), dt, _stream()),
+                                            src_len, d, ldq, ldk, ldv, scale, float(p), seed, _p(seed_dev), fwd_dt,
+                                            _stream()),
                    "mha_fwd")
         out = gemm.linear(attn, w_out).view(tgt_len, bsz, e)
         ctx.meta = (tgt_len, src_len, bsz, e, nheads, ldq, ldk, ldv, scale, float(p), seed, seed_dev, same_qk, same_kv)
