@@ -315,6 +315,55 @@ def run_image_tower(dev, steps, warmup):
                          "frac": round(tf / 2500.0, 4), "traffic": None}}
 
 
+def run_alignment_extra(dev, reps=10):
+    """SURVEY.md 8a row a13 at the stage-2 class counts (232 / 1201 prompts, models/model_3detr.py:321): both alignment
+    terms of all 8 decoder layers (16 384 proposal rows x 512), forward + backward, on the matrix-core route (class logits
+    and their gradient as two dense bf16x3 products, align_loss._AlignLossGemm) and on the one-wave-per-row vector kernel
+    the headline's 10 classes use.  Flops = the two dense products, 4 * rows * ncls * 512."""
+    from coda_neurips2023_amd import align_loss
+    nl, b, nq, e = 8, B_PER_GPU, 256, 512
+    rows = nl * b * nq
+    gen = torch.Generator().manual_seed(5)
+    out = {}
+    for ncls in (232, 1201):
+        emb = torch.randn(nl, b, nq, e, generator=gen).to(dev).requires_grad_(True)
+        gt = torch.nn.functional.normalize(torch.randn(b, nq, e, generator=gen), dim=-1).to(dev)
+        wm = (torch.rand(b, nq, generator=gen) < 0.25).float().to(dev)
+        text = torch.nn.functional.normalize(torch.randn(ncls, e, generator=gen), dim=-1).to(dev).unsqueeze(0).expand(b, -1, -1)
+        labels = torch.randint(0, ncls, (nl, b, nq), generator=gen).to(dev)
+        conf = torch.rand(nl, b, nq, generator=gen).to(dev)
+        scale = torch.tensor(14.2857, device=dev)
+        res = {}
+        for route, thr in (("matrix_cores", 64), ("vector_rows", 1 << 30)):
+            saved = align_loss.GEMM_MIN_CLASSES
+            align_loss.GEMM_MIN_CLASSES = thr
+
+            def one():
+                emb.grad = None
+                l1, ce = align_loss.align_loss_sums(emb, gt, wm, text, scale, labels, conf)
+                (l1.sum() + ce.sum()).backward()
+
+            try:
+                for _ in range(2):
+                    one()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    one()
+                torch.cuda.synchronize()
+                res[route] = (time.perf_counter() - t0) / reps
+            finally:
+                align_loss.GEMM_MIN_CLASSES = saved
+        fl = 4.0 * rows * ncls * e
+        out[f"ncls_{ncls}"] = {"ms_matrix_cores": round(res["matrix_cores"] * 1e3, 4),
+                               "ms_vector_rows": round(res["vector_rows"] * 1e3, 4),
+                               "tflops_matrix_cores": round(fl / res["matrix_cores"] / 1e12, 1),
+                               "speedup": round(res["vector_rows"] / res["matrix_cores"], 2)}
+    out["what"] = ("both CLIP-space alignment terms of 8 layers x 8 scenes x 256 proposals, forward + backward (wall time per "
+                   "call incl. the row-wise kernels and the per-call split of the prompt matrix)")
+    return out
+
+
 def run_extra(kind, dev, steps, warmup):
     """The other single-GPU configurations of BASELINE.json next to the headline, so that the driver's default
     command times them too: configs[1] (set abstraction only) and the one-GPU share of configs[4] (40 000-point
@@ -461,6 +510,17 @@ def cpu_baseline(kind):
                       f"OpenMP over scenes) + torch-CPU layers on {cores} threads"}
 
 
+def _arithmetic_note():
+    from coda_neurips2023_amd import fused_layers, gemm
+    dense = ("dense projections with >= 8192 token rows (y = x W^T + b, dx = dy W): fp32 operands as three bf16 pieces, "
+             "six piece products on the bf16 matrix cores, fp32 accumulate (csrc/gemm_x3.hip)" if gemm._X3 else
+             "dense projections: library fp32 GEMMs")
+    wgrad = "weight gradients: bf16x3 kernel" if (gemm._X3 and gemm._X3_TN) else "weight gradients: library fp32 GEMMs"
+    attn = ("encoder self-attention forward: bf16x3 mode of the fused core; every attention backward and the decoder's "
+            "cores: fp32 MFMA" if fused_layers._FWD_X3 else "attention cores: fp32 MFMA")
+    return "; ".join((dense, wgrad, attn))
+
+
 def compact_line(out, dry=False):
     """The whole record goes to a file (CODA_BENCH_FULL, default gpurun_out/bench_full.json when that directory exists,
     else bench_full.json beside this script); stdout gets ONE line that stays under the 8 KB tail the driver keeps:
@@ -493,6 +553,8 @@ def compact_line(out, dry=False):
                     brief[name].setdefault("attention_bf16_us", {})[k] = round(v["avg_launch_ms"] * 1e3, 1)
                 if isinstance(e.get("roofline"), dict):
                     brief[name]["frac"] = e["roofline"].get("frac")
+                if name == "alignment_loss_stage2_classes":
+                    brief[name] = {k: v for k, v in e.items() if k != "what"}
             short["extra_configs"] = brief
         short["full_record"] = os.path.relpath(path, ROOT) if path else None
         return json.dumps(short)
@@ -1104,7 +1166,11 @@ def main():
                        "sampling": ("FPS + ball query of batch i+1 run on a side stream during step i (once per "
                                     "step, inside the timed region); padded group copies are computed once"
                                     if prefetch else "in line"),
-                       "library_gemms": "the libraries' own heuristics (no tuning table)"},
+                       "library_gemms": "the libraries' own heuristics (no tuning table)",
+                       # which arithmetic the products of the step run on ("dtype": "f32" = every tensor is fp32 and every
+                       # result is fp32-ACCURATE: the bf16x3 routes are closer to float64 than the fp32 library GEMM,
+                       # tests/test_gemm_x3_gpu.py, tools/x3_error.py)
+                       "arithmetic": _arithmetic_note()},
             "roofline": roofline,
             # host side of the timed region on rank 0: time until the last step was enqueued (close to the wall
             # time when the host is the bottleneck -- or when the GPU is and the launch queue fills up) and what
@@ -1137,6 +1203,7 @@ def main():
                                     "configs[4]_40k_512q_bf16_one_gpu": run_extra("model40k", dev, ex_steps, ex_warm),
                                     "scripts_variant_dec512_128q": run_extra("scripts", dev, ex_steps, ex_warm),
                                     "clip_image_tower": run_image_tower(dev, ex_steps, ex_warm),
+                                    "alignment_loss_stage2_classes": run_alignment_extra(dev),
                                     "configs[2]_with_image_branch": run_extra("distill", dev, ex_steps, ex_warm)}
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(kind)

@@ -103,6 +103,12 @@ SIGNATURES = {
                                          _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
     "coda_align_loss_bwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P, _P,
                                          _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P]),
+    "coda_align_rows_fwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _c_int,
+                                         _c_int, _c_int, _c_int, _P, _P, _P, _P]),
+    "coda_align_rows_bwd_f32": (_c_int, [_P, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _P, _P, _P,
+                                         _c_int, _c_int, _c_int, _c_int, _P, _P]),
+    "coda_align_ce_f32": (_c_int, [_P, ctypes.c_longlong, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong,
+                                   ctypes.c_longlong, _P]),
     # include/coda_box_ops.h
     "coda_generalized_box3d_iou_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     "coda_generalized_box3d_iou_devflag_f32": (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P, _c_int, _c_int, _P]),

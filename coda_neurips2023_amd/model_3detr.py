@@ -379,7 +379,9 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         if (not if_real_test) and (not if_cmp_class) and (not if_test):  # :1799-1817
             prompts = self.superset_text_features_fg_norm if self.if_clip_superset \
                 else self.text_features_fg_norm[:self.train_range_max, :]
-            outputs["text_features_clip"] = prompts.unsqueeze(0).repeat(bsz, 1, 1)
+            # (B, ncls, E) as a VIEW (the reference materialises B copies, models/model_3detr.py:1806: same values): the
+            # criterion can then see that all scenes share one prompt set and run the class logits as one dense product
+            outputs["text_features_clip"] = prompts.unsqueeze(0).expand(bsz, -1, -1)
             provider = self.region_embedding_provider
             if provider is not None:
                 if getattr(provider, "stage2", self.online_nms_update_save_novel_label_clip_driven_with_cate_confidence):

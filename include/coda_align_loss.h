@@ -43,6 +43,26 @@ int coda_align_loss_bwd_f32(const float *emb, long long ld_l, long long ld_b, lo
                             const float *g, int nl, int b, int nq, int e, int ncls, float *demb,
                             void *stream);
 
+/* ---- the same two terms at the stage-2 class counts (232 / 1201 prompts, models/model_3detr.py:321): the class logits
+ * and their gradient are DENSE PRODUCTS on the matrix cores (coda_gemm.h; the host side, align_loss.py, issues them), and
+ * these three entry points are the row-wise pieces around them.  Rows are ordered (l, b, q) as above.
+ *   coda_align_rows_fwd_f32: partial[row][0] = sum_c |e w - gt w|; stat[row] = (|e|, 1 / (|e| + 1e-32));
+ *                            ehat (rows x E, dense) = e / (|e| + 1e-32)                     -> logits = ehat . text^T
+ *   coda_align_ce_f32:       logits (rows, row stride ld; the first ncls of ncols columns are classes).  g == NULL:
+ *                            partial[row][1] = conf * CE(t * logits[row], label).  g (L,2) given: the row is overwritten
+ *                            with g[l][1] * conf * t * (softmax - onehot), zero in columns ncls .. ncols - 1
+ *                                                                                          -> dh = dlogits . text
+ *   coda_align_rows_bwd_f32: demb = g[l][0] * d l1 / d e + (dh / (n + eps) - e <dh, e> / (n (n + eps)^2)) */
+int coda_align_rows_fwd_f32(const float *emb, long long ld_l, long long ld_b, long long ld_q, const float *gt,
+                            const float *wmask, int nl, int b, int nq, int e, float *ehat, float *stat,
+                            float *partial, void *stream);
+int coda_align_rows_bwd_f32(const float *emb, long long ld_l, long long ld_b, long long ld_q, const float *gt,
+                            const float *wmask, const float *stat, const float *dh, const float *g, int nl, int b,
+                            int nq, int e, float *demb, void *stream);
+int coda_align_ce_f32(float *logits, long long ld, int ncls, int ncols, const float *logit_scale,
+                      const int64_t *labels, const float *conf, const float *g, float *partial, long long rows,
+                      long long rows_per_layer, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ def _crit(dev, ncls):
     return SetCriterion(None, cfg, {}, train_range_max=ncls).to(dev)
 
 
-def _case(dev, nl, b, nq, e, ncls, ngt, permuted, seed):
+def _case(dev, nl, b, nq, e, ncls, ngt, permuted, seed, shared=False):
     g = torch.Generator().manual_seed(seed)
     if permuted:  # the heads hand over a (layer, scene, query) VIEW of a (layer, query, scene) buffer
         emb = torch.randn(nl, nq, b, e, generator=g).to(dev).permute(0, 2, 1, 3)
@@ -36,6 +36,8 @@ def _case(dev, nl, b, nq, e, ncls, ngt, permuted, seed):
         "weak_box_cate_label": torch.randint(0, ncls, (b, nq), generator=g).to(dev),
         "weak_confidence_weight": (torch.rand(b, nq, generator=g) * (torch.rand(b, nq, generator=g) < 0.5)).to(dev),
     }
+    if shared:  # what model_3detr.py hands over: one prompt set, expanded over the scenes (stride 0)
+        targets["text_features_clip"] = targets["text_features_clip"][0].unsqueeze(0).expand(b, -1, -1)
     targets["gt_text_correlation_embedding_mask"][0, 0, 0] = 1.0  # an empty mask is 0/0 in the reference too
     assign = {"per_prop_gt_inds": torch.randint(0, ngt, (nl, b, nq), generator=g).to(dev),
               "proposal_matched_mask": (torch.rand(nl, b, nq, generator=g) < 0.2).float().to(dev)}
@@ -58,6 +60,35 @@ def test_fused_alignment_matches_torch(dev, nl, b, nq, e, ncls, permuted):
         w = torch.linspace(0.5, 1.5, nl, device=dev)
         ((l1 * w).sum() + 2.0 * (ce * w).sum()).backward()
         res[fused] = (l1.detach(), ce.detach(), emb.grad.detach().clone())
+    for i, what in enumerate(["l1", "ce", "d emb"]):
+        got, ref = res[True][i].double().cpu().numpy(), res[False][i].double().cpu().numpy()
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert err < 1e-3, f"{what}: {err:.3e}"
+
+
+@pytest.mark.parametrize("nl,b,nq,e,ncls", [(8, 8, 256, 512, 232), (8, 8, 256, 512, 1201), (2, 2, 64, 512, 100),
+                                            (8, 8, 256, 512, 64)])
+def test_gemm_route_at_the_stage2_class_counts(dev, nl, b, nq, e, ncls):
+    """ncls >= 64 with one prompt set for all scenes (232 / 1201 prompts, models/model_3detr.py:321): the class logits and
+    their gradient are dense products on the matrix cores (align_loss._AlignLossGemm: bf16x3 kernels at 16 384 rows, the
+    library below 8192) -- values and gradient against the torch formulation, 1e-3 relative."""
+    from coda_neurips2023_amd import align_loss, gemm
+    crit = _crit(dev, ncls)
+    names = ["loss_predicted_region_embed_l1", "loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi"]
+    res = {}
+    before = gemm.x3_calls
+    for fused in (True, False):
+        crit.fused_alignment = fused
+        emb, targets, assign = _case(dev, nl, b, nq, e, ncls, 7, True, seed=ncls, shared=True)
+        assert align_loss._shared_text(targets["text_features_clip"]) is not None
+        outs = {"text_correlation_embedding": emb}
+        l1 = crit.stacked_loss_predicted_region_embed_l1(outs, targets, assign)[names[0]]
+        ce = crit.stacked_loss_feat_seen_softmax_weakly_loss_with_novel_cate_confi(outs, targets, assign)[names[1]]
+        w = torch.linspace(0.5, 1.5, nl, device=dev)
+        ((l1 * w).sum() + 2.0 * (ce * w).sum()).backward()
+        res[fused] = (l1.detach(), ce.detach(), emb.grad.detach().clone())
+    if nl * b * nq >= 8192 and ncls > 128 and gemm._X3:
+        assert gemm.x3_calls - before >= 2   # both products of the fused evaluation took the matrix-core route
     for i, what in enumerate(["l1", "ce", "d emb"]):
         got, ref = res[True][i].double().cpu().numpy(), res[False][i].double().cpu().numpy()
         err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
