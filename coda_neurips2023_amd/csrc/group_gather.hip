@@ -81,25 +81,28 @@ int scatter_add_rows(const float *grad_out, const int32_t *idx, float *grad_poin
 // The adjoints above sum colliding gradients with hardware float atomics: like the reference's atomicAdd
 // (group_points_gpu.cu:46-67, sampling_gpu.cu:37-60) the result depends on the order the atomics happen in, i.e. it is
 // not reproducible from run to run.  Integer addition is associative: every addend is converted to 64-bit fixed point
-// at a scale taken from the tensor's largest magnitude (so that the worst-case sum of all e_count addends still fits),
+// at a scale taken from the largest magnitude of its (scene, channel) row (so that the worst-case sum of all e_count addends still fits),
 // accumulated with 64-bit integer atomics -- ANY order gives the same bits -- and converted back once.  The fixed-point
 // grid has 62 - ceil(log2(e_count + 1)) bits below the largest magnitude (47 at 32 768 entries per scene, never fewer
 // than 31): finer than the float32 roundings of a float accumulation.  Three passes (largest magnitude, scatter,
-// convert) and 8 bytes of workspace per output element.  A non-finite gradient anywhere makes the whole result NaN
+// convert) and 8 bytes of workspace per output element.  A non-finite gradient makes its (scene, channel) row NaN
 // (the float atomics would have poisoned only the targets it reaches; a training step is lost either way).
-struct DetHeader {
-  unsigned int absmax_bits;  // float bits of the largest |x| (non-negative floats order like their bit patterns)
-  unsigned int pad_[63];
-};
-static_assert(sizeof(DetHeader) == 256, "header = one aligned block in front of the accumulators");
+// One scale per (scene, channel) ROW of the output (round 6; until then one for the whole tensor: a channel or a scene
+// whose gradients sat more than ~2^-(62 - count_bits) below the global maximum rounded to zero, and one non-finite value
+// anywhere turned the entire result into NaN -- ADVICE r5).  The header holds the float bits of max |x| per row
+// (non-negative floats order like their bit patterns), padded to a 256-byte multiple in front of the accumulators.
+__host__ __device__ inline size_t det_header_bytes(size_t rows) { return (sizeof(unsigned int) * rows + 255) & ~static_cast<size_t>(255); }
 
-__global__ __launch_bounds__(kThreads) void det_absmax_kernel(const float *__restrict__ x, size_t total, DetHeader *hdr) {
+// grid (chunks of the row, rows)
+__global__ __launch_bounds__(kThreads) void det_absmax_kernel(const float *__restrict__ x, int e_count,
+                                                              unsigned int *__restrict__ row_max) {
+  const float *__restrict__ r = x + static_cast<size_t>(blockIdx.y) * e_count;
   unsigned int m = 0u;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * kThreads)
-    m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < e_count; i += gridDim.x * kThreads)
+    m = max(m, __float_as_uint(r[i]) & 0x7fffffffu);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), off)));
-  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0u) atomicMax(&hdr->absmax_bits, m);
+  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0u) atomicMax(&row_max[blockIdx.y], m);
 }
 // 2^k with  max |x| * 2^k < 2^(62 - count_bits):  k = 62 - count_bits - (exponent of max + 1)
 __device__ __forceinline__ double det_scale(unsigned int absmax_bits, int count_bits) {
@@ -108,14 +111,11 @@ __device__ __forceinline__ double det_scale(unsigned int absmax_bits, int count_
   return ldexp(1.0, 62 - count_bits - (e + 1));
 }
 __global__ __launch_bounds__(kThreads) void det_scatter_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
-                                                               const DetHeader *__restrict__ hdr,
+                                                               const unsigned int *__restrict__ row_max,
                                                                unsigned long long *__restrict__ acc, int c, int n, int e_count,
                                                                int count_bits) {
   const int e = blockIdx.x * kThreads + threadIdx.x;
   if (e >= e_count) return;
-  const unsigned int mb = hdr->absmax_bits;
-  if (mb >= 0x7f800000u) return;  // non-finite input: the convert pass writes NaN
-  const double scale = det_scale(mb, count_bits);
   const int bi = blockIdx.z;
   const int c0 = blockIdx.y * kCh;
   const int a = idx[static_cast<size_t>(bi) * e_count + e];
@@ -124,16 +124,18 @@ __global__ __launch_bounds__(kThreads) void det_scatter_kernel(const float *__re
 #pragma unroll
   for (int l = 0; l < kCh; ++l)
     if (c0 + l < c) {
-      const long long q = __double2ll_rn(static_cast<double>(src[static_cast<size_t>(l) * e_count]) * scale);
+      const unsigned int mb = row_max[static_cast<size_t>(bi) * c + c0 + l];
+      if (mb >= 0x7f800000u) continue;  // a non-finite value in this row: the convert pass writes NaN into the row
+      const long long q = __double2ll_rn(static_cast<double>(src[static_cast<size_t>(l) * e_count]) * det_scale(mb, count_bits));
       if (q != 0) atomicAdd(dst + static_cast<size_t>(l) * n, static_cast<unsigned long long>(q));  // two's complement
     }
 }
 __global__ __launch_bounds__(kThreads) void det_convert_kernel(const unsigned long long *__restrict__ acc,
-                                                               const DetHeader *__restrict__ hdr, float *__restrict__ out,
-                                                               size_t total, int count_bits) {
+                                                               const unsigned int *__restrict__ row_max, float *__restrict__ out,
+                                                               size_t total, int n, int count_bits) {
   const size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= total) return;
-  const unsigned int mb = hdr->absmax_bits;
+  const unsigned int mb = row_max[i / n];
   if (mb >= 0x7f800000u) {
     out[i] = __uint_as_float(0x7fc00000u);
     return;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kThreads) void det_convert_kernel(const unsigned lo
 }
 
 size_t det_workspace_bytes(int b, int c, int n) {
-  return sizeof(DetHeader) + sizeof(unsigned long long) * static_cast<size_t>(b) * c * n;
+  return det_header_bytes(static_cast<size_t>(b) * c) + sizeof(unsigned long long) * static_cast<size_t>(b) * c * n;
 }
 
 int scatter_add_rows_det(const float *grad_out, const int32_t *idx, float *grad_points, int b, int c, int n, long long e_count,
@@ -155,21 +157,23 @@ int scatter_add_rows_det(const float *grad_out, const int32_t *idx, float *grad_
   }
   if (!workspace || workspace_bytes < det_workspace_bytes(b, c, n) || (reinterpret_cast<uintptr_t>(workspace) & 7) != 0)
     return CODA_ENOSPC;
-  DetHeader *hdr = static_cast<DetHeader *>(workspace);
-  unsigned long long *acc = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + sizeof(DetHeader));
+  const size_t rows = static_cast<size_t>(b) * c;
+  unsigned int *row_max = static_cast<unsigned int *>(workspace);
+  unsigned long long *acc = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + det_header_bytes(rows));
   const hipError_t e = hipMemsetAsync(workspace, 0, det_workspace_bytes(b, c, n), s);
   if (e != hipSuccess) return static_cast<int>(e);
   int count_bits = 1;
   while ((1LL << count_bits) <= e_count) ++count_bits;  // ceil(log2(e_count + 1))
-  const size_t in_total = static_cast<size_t>(b) * c * static_cast<size_t>(e_count);
   clear_sticky_error();
-  const unsigned int rblocks = static_cast<unsigned int>(std::min<size_t>((in_total + kThreads - 1) / kThreads, 4096));
-  hipLaunchKernelGGL(det_absmax_kernel, dim3(rblocks), dim3(kThreads), 0, s, grad_out, in_total, hdr);
+  if (rows > 65535) return CODA_EINVAL;  // (grid.y; far beyond any (scene, channel) count of the path)
+  const unsigned int chunks = static_cast<unsigned int>(std::min<long long>((e_count + kThreads - 1) / kThreads, 64));
+  hipLaunchKernelGGL(det_absmax_kernel, dim3(chunks, static_cast<unsigned int>(rows)), dim3(kThreads), 0, s, grad_out,
+                     static_cast<int>(e_count), row_max);
   dim3 grid(ceil_div(static_cast<int>(e_count), kThreads), ceil_div(c, kCh), b);
-  hipLaunchKernelGGL(det_scatter_kernel, grid, dim3(kThreads), 0, s, grad_out, idx, hdr, acc, c, n, static_cast<int>(e_count),
+  hipLaunchKernelGGL(det_scatter_kernel, grid, dim3(kThreads), 0, s, grad_out, idx, row_max, acc, c, n, static_cast<int>(e_count),
                      count_bits);
   hipLaunchKernelGGL(det_convert_kernel, dim3(static_cast<unsigned int>((out_total + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                     acc, hdr, grad_points, out_total, count_bits);
+                     acc, row_max, grad_points, out_total, n, count_bits);
   return launch_status();
 }
 

@@ -144,11 +144,13 @@ int coda_gather_points_grad_f32(const float *grad_out, const int32_t *idx,
 /* Deterministic forms of the two scatter-add adjoints (gather_points_grad here, group_points_grad below): the same
  * sums, but reproducible bit for bit from run to run.  The float atomics of the plain entry points -- and of the
  * reference, sampling_gpu.cu:37-60 / group_points_gpu.cu:46-67 -- add colliding gradients in whatever order the
- * hardware serves them.  Here every addend goes to 64-bit fixed point at a scale taken from the tensor's largest
- * magnitude (62 - ceil(log2(entries + 1)) bits below it: 47 at 32 768 entries per scene, never fewer than 31, i.e. finer
- * than float32), is accumulated with integer atomics (associative: any order, same bits) and converted back once.
- * `workspace`: device memory, 8-byte aligned, >= coda_scatter_add_det_workspace_bytes(b, c, n) (8 bytes per output
- * element + 256); CODA_ENOSPC otherwise.  A non-finite gradient anywhere makes the whole result NaN.
+ * hardware serves them.  Here every addend goes to 64-bit fixed point at a scale taken from the largest magnitude of
+ * its own (scene, channel) ROW (62 - ceil(log2(entries + 1)) bits below it: 47 at 32 768 entries per scene, never
+ * fewer than 31, i.e. finer than float32 -- per row since round 6, so channels of very different gradient size keep
+ * their own relative accuracy), is accumulated with integer atomics (associative: any order, same bits) and
+ * converted back once.  `workspace`: device memory, 8-byte aligned, >= coda_scatter_add_det_workspace_bytes(b, c, n)
+ * (8 bytes per output element + a 4-byte word per row, rounded up to 256); CODA_ENOSPC otherwise.  A non-finite
+ * gradient makes its (scene, channel) row NaN and leaves the other rows untouched.
  * The Python binding uses these by default (CODA_SCATTER=atomic: the plain ones).                                  */
 size_t coda_scatter_add_det_workspace_bytes(int b, int c, int n);
 int coda_gather_points_grad_det_f32(const float *grad_out, const int32_t *idx,
