@@ -767,6 +767,31 @@ def main():
     for i in range(args.warmup):
         one_step(i)
 
+    # Settle: a fresh box can run the first seconds of a process with a host side ~1.4x slower than its steady state
+    # (lazy loading of the libraries' code objects, page-ins: seen on 1 of 14 boxes in round 6 -- 413 instead of 557
+    # scenes/s in the first timed region of the process, every later leg of the same process at its normal rate, kernel
+    # times identical).  After the W warm-up steps, untimed blocks of 5 steps run until a block is within 3 % of the best
+    # block so far (at least two blocks, at most 80 = ~6 s); the count goes into the line (host.settle_steps).  The timed
+    # region below is unchanged: exactly K steps between barriers + synchronize.
+    settle_steps = 0
+    if not dry and kind == "model" and os.environ.get("CODA_BENCH_SETTLE", "1") != "0":
+        best = None
+        for _blk in range(80):  # (a count, not a clock: with several ranks every rank must run the same number of blocks)
+            sync()
+            t_blk = time.perf_counter()
+            for i in range(5):
+                one_step(args.warmup + settle_steps + i)
+            sync()
+            blk = (time.perf_counter() - t_blk) / 5
+            settle_steps += 5
+            if world > 1:  # every rank must take the same decision
+                t = torch.tensor([blk], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                blk = float(t.item())
+            if best is not None and blk <= best * 1.03 and settle_steps >= 10:
+                break
+            best = blk if best is None else min(best, blk)
+
     # the set-abstraction stage (and its side-stream sampling) is enqueued eagerly in both modes
     timing = _ext.enable_kernel_timing(["query_and_group_xyz", "ball_query", "furthest_point_sampling"])
     # every rank records (same overhead on all ranks); rank 0 reports
@@ -1175,7 +1200,7 @@ def main():
             # host side of the timed region on rank 0: time until the last step was enqueued (close to the wall
             # time when the host is the bottleneck -- or when the GPU is and the launch queue fills up) and what
             # Python's garbage collector took of it
-            "host": {"enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
+            "host": {"enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4), "settle_steps": settle_steps,
                      "gc_passes": gc_stat["n"], "gc_ms_per_step": round(gc_stat["ms"] / args.steps, 4)},
             "kernels_ms": {"furthest_point_sampling_20000_to_2048": round(fps_ms, 4) if fps_ms else None},
         }
