@@ -101,6 +101,12 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
 
   const int lane = lane_id(), w = wave_id();
   const bool consumer = w < 4;                     // wave-uniform
+  if (p.dbg & 8) {  // A/B: the consumers' instruction stream in front of the producers' at issue
+    if (consumer) __builtin_amdgcn_s_setprio(1);
+  }
+  if (p.dbg & 16) {
+    if (!consumer) __builtin_amdgcn_s_setprio(1);
+  }
   const int nwg = static_cast<int>(gridDim.x), b = static_cast<int>(blockIdx.x);
   // this workgroup's tiles: with the XCD map, XCD x owns the row blocks tm = x (mod 8) and its nwg / 8 workgroups take
   // that list's tiles (n fastest) round-robin, so the tiles_n tiles of a row block run on one L2 at about the same time
@@ -560,7 +566,6 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const X3SplitTable t) {
 
 template <int BN>
 int launch_x3_pipe(X3NtParams p, hipStream_t s) {
-  constexpr int P = 3;
   constexpr size_t lds = 2 * (3 * 128 * kX3Row + 3 * BN * kX3Row);
   p.tiles_m = p.m / 128;
   p.tiles_n = p.n / BN;
@@ -579,7 +584,8 @@ int launch_x3_pipe(X3NtParams p, hipStream_t s) {
   }
   int nwg = tiles < cus ? tiles : cus;
   p.xcd_map = (p.tiles_m % 8 == 0 && nwg % 8 == 0 && nwg >= 8) ? 1 : 0;
-  auto kern = x3_nt_pipe_kernel<BN, P>;
+// (prefetch depths 2 / 3 / 4 measure the same, CODA_X3_DBG=8 -- the consumer waves at priority 1 -- 0 .. -4 %: round 6)
+  auto kern = x3_nt_pipe_kernel<BN, 3>;
   const int st = raise_dynamic_lds(kern, lds);
   if (st != CODA_OK) return st;
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nwg)), dim3(kX3PipeThreads), lds, s, p, tiles, p.k / kX3BK);
