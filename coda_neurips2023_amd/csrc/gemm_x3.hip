@@ -133,25 +133,30 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
   if (!consumer) {
     // ================================================= producers =================================================
     const int tid = static_cast<int>(threadIdx.x) - 256;
+    // Which tile row a lane block stages: consecutive blocks of a store instruction's lane group (8 lanes per row for the
+    // activation pieces, 4 for the weight pieces) take rows FOUR apart, not adjacent ones -- with 80-byte rows, rows r and
+    // r + 1 overlap in four of the 32 write banks (PMC: a third of the LDS cycles of the kernel were bank conflicts, all
+    // from these stores), rows r and r + 4 are 320 bytes = exactly half a bank period apart.
+    auto spread = [](int t) { return (t & ~7) | ((t & 1) << 2) | ((t >> 1) & 3); };
     int a_row[NA], a_c4[NA], w_q[NW], w_row[NW], w_c[NW];
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int i = tid + u * 256;
-      a_row[u] = i >> 3;
+      a_row[u] = spread(i >> 3);
       a_c4[u] = i & 7;
     }
 #pragma unroll
     for (int u = 0; u < NW; ++u) {
       const int i = tid + u * 256, rem = i % (BN * 4);
       w_q[u] = i / (BN * 4);
-      w_row[u] = rem >> 2;
+      w_row[u] = spread(rem >> 2);
       w_c[u] = rem & 3;
     }
     f32x4v ra[P][NA];
     u32x4v rw[P][NW];
     // SIGN PATTERN (see the consumers): the activation pieces of row r, 16-k block b go to LDS multiplied by
     // (-1)^(r + b).  Row and block parity are the same for all of a thread's pieces: one constant mask.
-    const unsigned int flip = ((((tid >> 3) ^ ((tid & 7) >> 2)) & 1) != 0) ? 0x80000000u : 0u;
+    const unsigned int flip = (((spread(tid >> 3) ^ ((tid & 7) >> 2)) & 1) != 0) ? 0x80000000u : 0u;
     // fetch stream: (tile f_i, k-step f_k); past the end it keeps re-reading the last stage (unconditional loads keep
     // the compiler's counted waits exact; the extra stages come from L2)
     int f_i = 0, f_k = 0, f_m0, f_n0;
