@@ -169,6 +169,10 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
         ahead = getattr(self, "_queries_ahead", None)
         self._queries_ahead = None
         if ahead is not None and ahead[0] is encoder_xyz and ahead[1].shape[1] == self.num_queries:
+            if len(ahead) > 2:  # sampled on the side stream during this very forward (run_pre_encoder)
+                cur = torch.cuda.current_stream(encoder_xyz.device)
+                cur.wait_event(ahead[2])
+                ahead[1].record_stream(cur)
             query_inds = ahead[1].long()  # sampled next to the pre-encoder's own sampling (prefetch_sampling)
         else:
             query_inds = furthest_point_sample(encoder_xyz, self.num_queries).long()
@@ -217,6 +221,29 @@ class Model3DETRPredictedBoxDistillationHead(nn.Module):
             if "query_inds" in prepared:
                 self._queries_ahead = (prepared["new_xyz"], prepared["query_inds"])
             return self.pre_encoder(prepared["xyz"], features, prepared=prepared)
+        if (features is None and xyz.is_cuda and hasattr(self.pre_encoder, "prepare")
+                and type(self.encoder).__name__ == "TransformerEncoder"
+                and os.environ.get("CODA_PREFETCH_QUERIES", "1") != "0"):
+            # No caller-side prefetch (an unchanged engine.py): the front runs in line, and the object queries -- a
+            # sampling of the pre-encoder's CENTRES, 0.15-0.24 ms of one-workgroup-per-scene work -- go to the sampling
+            # side stream as soon as the centres exist, under the shared MLP and the encoder instead of between encoder
+            # and decoder.  Same kernels, same values.
+            with torch.no_grad():  # (parameter-free; the cloud itself carries no gradient)
+                front = self.pre_encoder.prepare(xyz) if not xyz.requires_grad else None
+            if front is not None:
+                main = torch.cuda.current_stream(xyz.device)
+                side = getattr(self, "_query_stream", None)
+                if side is None or side.device != xyz.device:
+                    side = self._query_stream = torch.cuda.Stream(
+                        device=xyz.device, priority=int(os.environ.get("CODA_PREFETCH_PRIORITY", "-1")))
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    q_inds = furthest_point_sample(front["new_xyz"], self.num_queries)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                front["new_xyz"].record_stream(side)
+                self._queries_ahead = (front["new_xyz"], q_inds, done)
+                return self.pre_encoder(front["xyz"], features, prepared=front)
         return self.pre_encoder(xyz, features)
 
     def run_encoder(self, point_clouds, pre_encoded=None):
