@@ -10,6 +10,7 @@ if [ "$1" = "tests" ]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1; tail -2 gpurun_out/final_smoke.log
 fi
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
+cp gpurun_out/bench_full.json gpurun_out/final_bench_with_extras_full.json
 python bench.py --prefetch off --no-cpu-baseline --no-extras > gpurun_out/final_bench_noprefetch.json 2>> gpurun_out/final_bench.err
 python bench.py --workload sa --no-cpu-baseline > gpurun_out/final_bench_sa.json 2>> gpurun_out/final_bench.err
 # the multi-GPU wrapping forced onto the one rank (SyncBatchNorm conversion, RCCL group of 1, gradient all-reduce executed,
@@ -32,7 +33,12 @@ timeout 300 python tools/sa_prof.py > gpurun_out/final_sa_prof.txt 2>&1
 bash tools/pmc_sa.sh > /dev/null 2>&1
 bash tools/pmc_attn.sh > gpurun_out/final_pmc_attn_hbm.txt 2>&1
 bash tools/pmc_attn_mfma.sh > gpurun_out/final_pmc_attn_mfma.txt 2>&1
+bash tools/pmc_x3.sh > /dev/null 2>&1
 fi
+cp gpurun_out/bench_full.json gpurun_out/final_bench_full.json 2>/dev/null
+python tools/bench_gemm_x3.py > gpurun_out/final_bench_gemm_x3.txt 2>&1
+python tools/x3_bias.py > gpurun_out/final_x3_bias.txt 2>&1
+python tools/x3_error.py > gpurun_out/final_x3_error.txt 2>&1
 python - <<'PY'
 import json
 for f in ("final_bench", "final_bench_noprefetch", "final_bench_sa", "final_bench_force_ddp", "final_prof_bench"):
