@@ -74,7 +74,7 @@ ATTN_UNITS_NOTE = {"fwd": "4 algorithmic (QK^T, PV)",
 # WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
 # HBM bytes per launch of the encoder's dK/dV kernel from PMC passes (FETCH_SIZE x2 + WRITE_SIZE): with the dS workspace
 # route of round 4 (the kernel also streams dS = 8 x 4 x 2048 x 2048 floats = 537 MB out) / the two-kernel form of round 3
-ATTN_DKV_TRAFFIC_DS = int(44360.2 * 2 * 1024) + int(565560.2 * 1024)  # profiles/r05_pmc_attention_hbm.md; algorithmic: 84 MB in + 570 MB out
+ATTN_DKV_TRAFFIC_DS = int(44498.9 * 2 * 1024) + int(565525.9 * 1024)  # profiles/r06_pmc_attention_hbm.md (r05: 44360.2 / 565560.2); algorithmic: 84 MB in + 570 MB out
 ATTN_DKV_TRAFFIC = 94_247_117 + 45_362_074      # profiles/r03_pmc_attention_hbm.md
 
 
@@ -1060,7 +1060,7 @@ def main():
             # HBM bytes per launch from PMC (separate FETCH_SIZE / WRITE_SIZE passes), not collected in this run
             via_ds = ("dqg", 2048, 2048) in attn_ms_all
             roofline["traffic"] = ATTN_DKV_TRAFFIC_DS if via_ds else ATTN_DKV_TRAFFIC
-            roofline["traffic_source"] = ("profiles/r05_pmc_attention_hbm.md" if via_ds else "profiles/r03_pmc_attention_hbm.md") + \
+            roofline["traffic_source"] = ("profiles/r06_pmc_attention_hbm.md" if via_ds else "profiles/r03_pmc_attention_hbm.md") + \
                 " (PMC, separate FETCH_SIZE / WRITE_SIZE passes)"
             if via_ds:
                 roofline["traffic_algorithmic"] = 5 * 16_777_216 + 536_870_912 + 2 * 16_777_216  # Q K V dO O in; dS dK dV out
