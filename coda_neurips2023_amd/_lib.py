@@ -172,8 +172,8 @@ SIGNATURES = {
     "coda_sgemm_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
                                 ctypes.c_longlong, _P, _c_int, _P]),
     "coda_gemm_x3_split_f32": (_c_int, [_P, _c_int, _P]),
-    "coda_gemm_x3_nt_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
-                                     ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_int, _P]),
+    "coda_gemm_x3_nt_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, _c_int, _c_int, _c_int, _P,
+                                     ctypes.c_longlong, _P, _c_int, _P]),
     "coda_gemm_x3_tn_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_int, _P]),
     "coda_sgemm_relu_dropout_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                              _P, ctypes.c_longlong, _P, _c_float, ctypes.c_uint64, _P]),

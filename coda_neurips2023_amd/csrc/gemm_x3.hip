@@ -47,10 +47,12 @@ constexpr int kX3Row = 80;       // bytes per LDS row: 32 bf16 + 16 B pad
 
 struct X3NtParams {
   const float *a;
-  const __bf16 *w;     // plane q at w + q * wplane, row r at + r * ldw (elements)
+  const __bf16 *w;     // TILED planes (x3_split_kernel): block (row tile of 128, k stage of 32) = 3 planes x 128 x 32
   const float *bias;
   float *c;
-  long long lda, ldw, wplane, ldc;
+  long long lda, ldc;
+  int w_kt_total;      // k stages of the whole plane set (its column count / 32)
+  int w_row0, w_kt0;   // first output column (a multiple of BN) and first k stage of this product inside the plane set
   int m, n, k;
   int accumulate;
   int tiles_m, tiles_n;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
     // r + 1 overlap in four of the 32 write banks (PMC: a third of the LDS cycles of the kernel were bank conflicts, all
     // from these stores), rows r and r + 4 are 320 bytes = exactly half a bank period apart.
     auto spread = [](int t) { return (t & ~7) | ((t & 1) << 2) | ((t >> 1) & 3); };
-    int a_row[NA], a_c4[NA], w_q[NW], w_row[NW], w_c[NW];
+    int a_row[NA], a_c4[NA], w_q[NW], w_row[NW], w_c[NW], w_goff[NW];
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int i = tid + u * 256;
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
       w_q[u] = i / (BN * 4);
       w_row[u] = spread(rem >> 2);
       w_c[u] = rem & 3;
+      w_goff[u] = w_q[u] * 4096 + w_row[u] * 32 + 8 * w_c[u];  // elements inside the 3 x 128 x 32 block
     }
     f32x4v ra[P][NA];
     u32x4v rw[P][NW];
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
       ra[SLOT][u] = *reinterpret_cast<const f32x4v *>(p.a + static_cast<size_t>(f_m0 + a_row[u]) * p.lda +            \
                                                       kX3BK * f_k + 4 * a_c4[u]);                                     \
     _Pragma("unroll") for (int u = 0; u < NW; ++u)                                                                    \
-      rw[SLOT][u] = *reinterpret_cast<const u32x4v *>(p.w + static_cast<size_t>(w_q[u]) * p.wplane +                  \
-                                                      static_cast<size_t>(f_n0 + w_row[u]) * p.ldw + kX3BK * f_k +    \
-                                                      8 * w_c[u]);                                                    \
+      rw[SLOT][u] = *reinterpret_cast<const u32x4v *>(                                                                \
+          p.w + (static_cast<size_t>((p.w_row0 + f_n0) >> 7) * p.w_kt_total + p.w_kt0 + f_k) * (3 * 4096) +          \
+          (((p.w_row0 + f_n0) & 64) << 5) + w_goff[u]);                                                               \
     if (f_k + 1 < nk) ++f_k;                                                                                          \
     else if (f_i + 1 < my_tiles) {                                                                                    \
       f_k = 0;                                                                                                        \
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(kX3PipeThreads, 2) void x3_nt_pipe_kernel(const X3N
         // stage s - 1), then the freed register set takes stage s + 1 + P.  (Past the end the last stage is stored
         // again: harmless.)
         if (!(p.dbg & 1)) {
-          X3P_STORE((uu + 1) % P, (uu & 1) ^ 1);
-          X3P_FETCH((uu + 1) % P);
+          if (!(p.dbg & 32)) X3P_STORE((uu + 1) % P, (uu & 1) ^ 1);
+          if (!(p.dbg & 64)) X3P_FETCH((uu + 1) % P);
         }
         __syncthreads();
         ++s;
@@ -542,7 +545,14 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const X3SplitTable t) {
     x -= static_cast<float>(o[1]);
     o[2] = static_cast<__bf16>(x);
   };
-  const size_t plane = static_cast<size_t>(rows) * cols;
+  // TILED plane sets (what x3_nt_pipe_kernel stages): a matrix of R output columns x C contraction indices is stored as
+  // blocks [R / 128][C / 32] of 3 planes x 128 rows x 32 k bf16 = 24 KB each, so that a stage's weight operand is ONE
+  // contiguous run (whole cache lines, sequential 16-byte loads) instead of 128 x 3 row pieces of 64 bytes.
+  // nt: R = rows, C = cols (needs cols % 32 == 0); nn: the transpose, R = cols, C = rows (needs rows % 32 == 0); rows past
+  // R in the last row tile stay as the caller zeroed them.
+  auto tiled = [](int r, int c, int kt_total, int plane) -> size_t {
+    return ((static_cast<size_t>(r >> 7) * kt_total + (c >> 5)) * 3 + plane) * 4096 + (r & 127) * 32 + (c & 31);
+  };
   if (t.nt[it]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const X3SplitTable t) {
         __bf16 o[3];
         pieces(s[ty + 8 * q][tx], o);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t.nt[it][k * plane + static_cast<size_t>(r) * cols + c] = o[k];
+        for (int k = 0; k < 3; ++k) t.nt[it][tiled(r, c, cols >> 5, k)] = o[k];
       }
     }
   }
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(256) void x3_split_kernel(const X3SplitTable t) {
         __bf16 o[3];
         pieces(s[tx][ty + 8 * q], o);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t.nn[it][k * plane + static_cast<size_t>(c) * rows + r] = o[k];
+        for (int k = 0; k < 3; ++k) t.nn[it][tiled(c, r, rows >> 5, k)] = o[k];
       }
     }
   }
@@ -612,6 +622,7 @@ CODA_API int coda_gemm_x3_split_f32(const CodaX3SplitItem *items, int count, voi
     for (int i = 0; i < nb; ++i) {
       const CodaX3SplitItem &it = items[base + i];
       if (!it.src || it.rows <= 0 || it.cols <= 0 || it.ld < it.cols || (!it.nt && !it.nn)) return CODA_EINVAL;
+      if ((it.nt && it.cols % 32) || (it.nn && it.rows % 32)) return CODA_EINVAL;  // the tiled layout's k stages
       t.src[i] = it.src;
       t.nt[i] = static_cast<__bf16 *>(it.nt);
       t.nn[i] = static_cast<__bf16 *>(it.nn);
@@ -651,21 +662,23 @@ CODA_API int coda_gemm_x3_tn_f32(int rows, int m, int n, const float *dy, long l
   return launch_status();
 }
 
-CODA_API int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long lda, const void *w_planes, long long ldw,
-                                 long long plane_stride, float *c, long long ldc, const float *bias, int accumulate,
+CODA_API int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long lda, const void *w_tiled, int w_cols,
+                                 int w_row0, int w_col0, float *c, long long ldc, const float *bias, int accumulate,
                                  void *stream) {
   using namespace coda;
   if (m < 0 || n < 0 || k < 0) return CODA_EINVAL;
   if (m == 0 || n == 0) return CODA_OK;
-  if (!a || !w_planes || !c || k == 0) return CODA_EINVAL;
+  if (!a || !w_tiled || !c || k == 0 || w_cols <= 0 || w_row0 < 0 || w_col0 < 0) return CODA_EINVAL;
   // shapes / alignments this kernel takes (everything else: coda_gemm_f32)
-  if (m % 128 || n % 64 || k % kX3BK || lda % 4 || ldw % 8 || plane_stride % 8 ||
-      (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_planes)) % 16 ||
+  const int bn = (n % 128 == 0 && w_row0 % 128 == 0) ? 128 : 64;
+  if (m % 128 || n % 64 || k % kX3BK || lda % 4 || w_cols % kX3BK || w_col0 % kX3BK || w_col0 + k > w_cols || w_row0 % bn ||
+      (reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w_tiled)) % 16 ||
       reinterpret_cast<uintptr_t>(c) % 4)
     return CODA_ENOSPC;
   hipStream_t s = static_cast<hipStream_t>(stream);
   clear_sticky_error();
   static const int dbg = [] { const char *e = getenv("CODA_X3_DBG"); return e ? atoi(e) : 0; }();
-  X3NtParams p{a, static_cast<const __bf16 *>(w_planes), bias, c, lda, ldw, plane_stride, ldc, m, n, k, accumulate, 0, 0, 0, dbg};
-  return (n % 128 == 0) ? launch_x3_pipe<128>(p, s) : launch_x3_pipe<64>(p, s);
+  X3NtParams p{a, static_cast<const __bf16 *>(w_tiled), bias, c, lda, ldc, w_cols / kX3BK, w_row0, w_col0 / kX3BK,
+               m, n, k, accumulate, 0, 0, 0, dbg};
+  return bn == 128 ? launch_x3_pipe<128>(p, s) : launch_x3_pipe<64>(p, s);
 }

@@ -100,7 +100,8 @@ def _split_items(entries):
     table = np.zeros((len(entries), 5), dtype=np.int64)  # the CodaX3SplitItem layout: src, nt, nn, (rows, cols), ld
     for i, e in enumerate(entries):
         r, c = e.base.shape
-        table[i] = (e.base.data_ptr(), e.nt.data_ptr(), e.nn.data_ptr(), r | (c << 32), e.base.stride(0))
+        table[i] = (e.base.data_ptr(), e.nt.data_ptr() if e.nt is not None else 0,
+                    e.nn.data_ptr() if e.nn is not None else 0, r | (c << 32), e.base.stride(0))
     st = _lib.load().coda_gemm_x3_split_f32(table.ctypes.data, len(entries), _lib.current_stream_handle())
     _lib.check(st, "coda_gemm_x3_split_f32")
 
@@ -111,8 +112,10 @@ def _weight_planes(base):
     if e is None or e.base.device != base.device:
         e = _Planes()
         r, c = base.shape
-        e.nt = torch.empty((3, r, c), dtype=torch.bfloat16, device=base.device)
-        e.nn = torch.empty((3, c, r), dtype=torch.bfloat16, device=base.device)
+        # tiled plane sets (include/coda_gemm.h): rows padded to the 128-row tile, zero-filled once (the split kernel
+        # writes the real rows only); an orientation whose contraction length is not a multiple of 32 has none
+        e.nt = torch.zeros(3 * (-(-r // 128) * 128) * c, dtype=torch.bfloat16, device=base.device) if c % 32 == 0 else None
+        e.nn = torch.zeros(3 * (-(-c // 128) * 128) * r, dtype=torch.bfloat16, device=base.device) if r % 32 == 0 else None
         e.version, e.epoch, e.used, e.base, e.declared = -1, -1, -1, None, False
         _planes[key] = e
     if e.version != base._version or e.epoch != _planes_epoch or e.base is None:
@@ -130,7 +133,7 @@ def declare_weight(t):
     backward that use it (the very tensor, not a slice) take the x3 route.  The entry keeps ``t`` alive until the next
     ``refresh_weight_planes`` (after the optimizer step) or until eight newer declarations have been made."""
     if not (_X3 and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
-            and t.shape[0] % 8 == 0 and t.shape[1] % 8 == 0 and t._base is None):
+            and (t.shape[0] % 32 == 0 or t.shape[1] % 32 == 0) and t._base is None):
         return t
     e = _weight_planes(t)
     e.declared = True
@@ -184,15 +187,15 @@ def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
     if wb is None:
         return None
     base, r0, nrows = wb
-    if base.shape[0] % 8 or base.shape[1] % 8:
+    rows, cols = base.shape
+    if (rows % 32 and cols % 32) or r0 % 64:
         return None
     e = _weight_planes(base)
-    rows, cols = base.shape
-    if transb:   # y = x W^T: W (n x k) = rows r0.. of the base -> a row slice of nt
-        w_ptr, ldw = e.nt.data_ptr() + 2 * r0 * cols, cols
-    else:        # dx = dy W: W (k x n) = rows r0.. of the base -> a column slice of nn ([cols][rows])
-        w_ptr, ldw = e.nn.data_ptr() + 2 * r0, rows
-    if w_ptr % 16:
+    if transb:   # y = x W^T: W (n x k) = rows r0 .. of the base: output columns r0 .. of the nt set, whole contraction
+        tiled, w_cols, w_row0, w_col0 = e.nt, cols, r0, 0
+    else:        # dx = dy W: W (k x n) = rows r0 .. of the base: the nn set's contraction range r0 .. r0 + k
+        tiled, w_cols, w_row0, w_col0 = e.nn, rows, 0, r0
+    if tiled is None or (e.nt is None and e.nn is None):
         return None
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
@@ -201,8 +204,8 @@ def _x3_route(transa, transb, m, n, k, a, b, out, bias, accumulate):
         _X3_CHECK_PREV = out.double().clone()
     global x3_calls
     x3_calls += 1
-    st = _lib.load().coda_gemm_x3_nt_f32(m, n, k, a.data_ptr(), a.stride(0), w_ptr, ldw, rows * cols, out.data_ptr(),
-                                         out.stride(0), bias.data_ptr() if bias is not None else None,
+    st = _lib.load().coda_gemm_x3_nt_f32(m, n, k, a.data_ptr(), a.stride(0), tiled.data_ptr(), w_cols, w_row0, w_col0,
+                                         out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None,
                                          1 if accumulate else 0, _lib.current_stream_handle())
     if st == _lib.CODA_ENOSPC:
         return None

@@ -87,17 +87,21 @@ int coda_grouped_gemm_tn_f32(const CodaTnProblem *problems, int count, void *str
  * carried as three bf16 pieces (x = hi + mid + lo exactly) and the six piece products of order <= 2 accumulated in
  * fp32: error against float64 within 2x of the native fp32 GEMM (tests/test_gemm_x3_gpu.py), 6/16 of its matrix time.
  *
- * The WEIGHT operand is split ahead of time, once per optimizer step:
- *   coda_gemm_x3_split_f32: for every item, src (rows x cols fp32, row stride ld) -> nt = three bf16 planes
- *   [3][rows][cols] and / or nn = three bf16 planes of the TRANSPOSE [3][cols][rows] (either may be NULL).  `items` is
- *   HOST memory read during the call; all items go in one launch (48 per launch).
+ * The WEIGHT operand is split ahead of time, once per optimizer step, into TILED plane sets: a matrix of R output
+ * columns x C contraction indices is stored as blocks [ceil(R / 128)][C / 32] of 3 planes x 128 rows x 32 k bf16 (24 KB,
+ * contiguous: a stage's weight operand is one sequential run of whole cache lines); rows past R stay as the caller zeroed
+ * them.  Size: 3 * ceil(R / 128) * 128 * C bf16.
+ *   coda_gemm_x3_split_f32: for every item, src (rows x cols fp32, row stride ld) -> nt = the tiled set of src itself
+ *   (R = rows, C = cols; needs cols % 32 == 0) and / or nn = the tiled set of its TRANSPOSE (R = cols, C = rows; needs
+ *   rows % 32 == 0); either may be NULL.  `items` is HOST memory read during the call; 48 items per launch.
  * The product:
- *   coda_gemm_x3_nt_f32: C (m x n, row stride ldc) [+]= A (m x k fp32, row stride lda) . W^T [+ bias], W given as its
- *   planes: plane q at w_planes + q * plane_stride, row r (of n) at + r * ldw, bf16 ELEMENTS.  y = x W^T + b takes the
- *   `nt` planes of W (n x k); dx = dy W takes the `nn` planes (k_in x n_out: again "row = output column") -- a row
- *   slice of W is a row slice of nt and a COLUMN slice of nn (ldw stays the full row length).
- *   Constraints: m a multiple of 128, n of 64, k of 32, lda a multiple of 4, ldw and plane_stride multiples of 8,
- *   a and w_planes 16-byte aligned; CODA_ENOSPC otherwise ("not this kernel's shape": use coda_gemm_f32). */
+ *   coda_gemm_x3_nt_f32: C (m x n, row stride ldc) [+]= A (m x k fp32, row stride lda) . W^T [+ bias], W = rows
+ *   w_row0 .. w_row0 + n - 1, columns w_col0 .. w_col0 + k - 1 of the matrix whose tiled set `w_tiled` is (w_cols = that
+ *   matrix's column count).  y = x W^T + b takes the `nt` set of W (n x k); dx = dy W takes the `nn` set (rows = dx's
+ *   columns, contraction over W's rows) -- a row slice [r0, r0 + n') of a packed weight is w_row0 = r0 in nt and
+ *   w_col0 = r0, k = n' in nn.
+ *   Constraints: m a multiple of 128, n of 64, k and w_col0 of 32, w_row0 of 64 (of 128 for the 128-wide tiles), lda
+ *   a multiple of 4, a and w_tiled 16-byte aligned; CODA_ENOSPC otherwise ("not this kernel's shape": use coda_gemm_f32). */
 typedef struct CodaX3SplitItem {
   const float *src;
   void *nt;
@@ -106,8 +110,8 @@ typedef struct CodaX3SplitItem {
   long long ld;
 } CodaX3SplitItem;
 int coda_gemm_x3_split_f32(const CodaX3SplitItem *items, int count, void *stream);
-int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long lda, const void *w_planes, long long ldw,
-                        long long plane_stride, float *c, long long ldc, const float *bias, int accumulate, void *stream);
+int coda_gemm_x3_nt_f32(int m, int n, int k, const float *a, long long lda, const void *w_tiled, int w_cols, int w_row0,
+                        int w_col0, float *c, long long ldc, const float *bias, int accumulate, void *stream);
 /* Weight gradients: part (slices x m x n, dense) [s] = dY_s^T X_s over the s-th of `slices` equal token ranges of
  * dY (rows x m, row stride lddy) and X (rows x n, row stride ldx) -- `torch.mm(dy.t(), x)` of a linear layer over its
  * 16 384 token rows as the library path computes it (row chunks as a batched GEMM, then a sum over the chunks), both

@@ -75,8 +75,8 @@ def test_packed_weights_bias_accumulate_and_output_slices(dev):
             gemm.linear(x, w_in[j * e:(j + 1) * e], bias[j * e:(j + 1) * e], out=out[:, j * e:(j + 1) * e])
         ref = x.double() @ w_in.double().t() + bias.double()
         assert err(full, ref) < 1e-6 and err(out, ref) < 1e-6
-        assert len(gemm._planes) >= 1 and all(v.nt.shape == (3, 3 * e, k) for v in gemm._planes.values()
-                                              if v.base is w_in)  # ONE set of pieces serves the slices
+        assert sum(1 for v in gemm._planes.values() if v.base is w_in) == 1   # ONE set of pieces serves the slices
+        assert all(v.nt.numel() == 3 * 3 * e * k for v in gemm._planes.values() if v.base is w_in)
         # dx = dq Wq + dk Wk + dv Wv: mm with accumulate on row slices (= column slices of the transposed pieces)
         dq, dk, dv = (torch.randn(m, e, generator=gen).to(dev) for _ in range(3))
         dx = gemm.mm(dq, w_in[:e])
