@@ -599,7 +599,11 @@ int launch_x3_pipe(X3NtParams p, hipStream_t s) {
   }
   int nwg = tiles < cus ? tiles : cus;
   p.xcd_map = (p.tiles_m % 8 == 0 && nwg % 8 == 0 && nwg >= 8) ? 1 : 0;
-// (prefetch depths 2 / 3 / 4 measure the same, CODA_X3_DBG=8 -- the consumer waves at priority 1 -- 0 .. -4 %: round 6)
+// (prefetch depths 2 / 3 / 4 measure the same, CODA_X3_DBG=8 -- the consumer waves at priority 1 -- 0 .. -4 %: round 6.
+  // hipcc waits vmcnt(9) .. vmcnt(0) in front of a stage's LDS stores, i.e. it drains every load in flight and the
+  // register ring is one stage deep whatever P; with the loads as inline-asm statements and a hand-counted
+  // `s_waitcnt vmcnt((P - 1) * 10)` the ring really is P deep -- and the kernel exactly as fast: the producers are bound by
+  // load THROUGHPUT (40 KB per stage and CU), not by latency.  Kept compiler-visible.)
   auto kern = x3_nt_pipe_kernel<BN, 3>;
   const int st = raise_dynamic_lds(kern, lds);
   if (st != CODA_OK) return st;
