@@ -63,13 +63,17 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_m
 # dK/dV kernel S = QK^T (recomputed), dP = dO V^T, dV = P^T dO, dK = dS^T Q; dQ kernel S, dP, dQ = dS K.
 # SURVEY.md 8d counts the whole backward as 8 (+4 "if recomputed") = the dV, dK, dP, dQ products plus
 # one recomputation; the two-kernel split executes 14.
-ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2}  # dqg: dQ = dS K alone (dS from the dK/dV kernel's workspace)
+# dqg: dQ = dS K alone (dS from the dK/dV kernel's workspace); bwdf: the decoder cross-attention's one-kernel backward
+# (S, dP, dV, dK, dQ partial tiles: 10); dqr / delta: its partial-tile sum and rowsum(dO * O) -- no MFMA flops, their time counts
+ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2, "bwdf": 10, "dqr": 0, "delta": 0}
 # of those, the units SURVEY 8d's ALGORITHMIC count credits (backward = 8: dV, dP, dK, dQ; recomputing S is extra work)
-ATTN_FLOPS_ALG = {"fwd": 4, "dkv": 6, "dq": 2, "dqg": 2}
+ATTN_FLOPS_ALG = {"fwd": 4, "dkv": 6, "dq": 2, "dqg": 2, "bwdf": 8, "dqr": 0, "delta": 0}
 ATTN_UNITS_NOTE = {"fwd": "4 algorithmic (QK^T, PV)",
                    "dkv": "6 algorithmic (dP, dV, dK) + 2 recomputed (S = QK^T)",
                    "dq": "2 algorithmic (dQ = dS K) + 4 recomputed (S, dP)",
-                   "dqg": "2 algorithmic (dQ = dS K, dS read from the dK/dV kernel's workspace)"}
+                   "dqg": "2 algorithmic (dQ = dS K, dS read from the dK/dV kernel's workspace)",
+                   "bwdf": "8 algorithmic (dP, dV, dK, dQ) + 2 recomputed (S = QK^T), one kernel",
+                   "dqr": "no MFMA work: the key blocks' partial dQ tiles summed in fixed order"}
 # HBM bytes per launch of the 2048x2048 dK/dV kernel from PMC: FETCH_SIZE 55 374 KB x 2 (gfx950 correction) +
 # WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
 # HBM bytes per launch of the encoder's dK/dV kernel from PMC passes (FETCH_SIZE x2 + WRITE_SIZE): with the dS workspace
@@ -449,7 +453,7 @@ def run_extra(kind, dev, steps, warmup):
         # by K/V delivery, not by the matrix cores
         kern = {}
         for (k, l, s_len), samples in sorted(attn_ms.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
-            if k == "delta":
+            if k in ("delta", "dqr"):
                 continue
             ms = sum(samples) / len(samples)
             tf = ATTN_FLOPS[k] * l * s_len * 256 * B_PER_GPU / (ms * 1e-3) / 1e12
@@ -1037,7 +1041,7 @@ def main():
             flops = ATTN_FLOPS[k] * l * s_len * 256 * B_PER_GPU  # 4 heads x 64 = 256 model channels
             tf = flops / (ms * 1e-3) / 1e12
             names = {"fwd": "mha_fwd_kernel", "dkv": "mha_bwd_dkv_kernel", "dq": "mha_bwd_dq_kernel",
-                     "dqg": "mha_bwd_dq_gemm_kernel"}
+                     "dqg": "mha_bwd_dq_gemm_kernel", "bwdf": "mha_bwd_fused_kernel", "dqr": "mha_dq_reduce_kernel"}
             return {"kernel": f"{names[k]} (queries {l} x keys {s_len}, {B_PER_GPU} scenes x 4 heads x 64, "
                               f"dropout 0.1)",
                     "timing": timing_note, "bound": "mfma", "achieved": round(tf, 2),
@@ -1076,11 +1080,13 @@ def main():
             roofline["frac_whole_backward_algorithmic"] = round(8 * unit, 4)
             note = "HIP events around each launch, `steps` extra steps right after the timed region"
             for key in sorted(attn_ms_all, key=lambda k: (-k[1] * k[2], k[0])):
-                if key[0] != "delta" and key != dom:
+                if key[0] not in ("delta", "dqr") and key != dom:
                     others.append(attn_entry(key, attn_ms_all[key], note))
             # the six decoder-shaped kernels together (north_star: >= 50 % of the MFMA peak on decoder attention):
             # sum of the flops of one launch of each / sum of their event-timed durations
-            dec_keys = [k for k in attn_ms_all if k[0] != "delta" and k[1] == 256 and k[2] in (256, 2048)]
+            # (every launch of the two shapes counts, the stand-alone rowsum(dO * O) and the partial-tile sum of the
+            # one-kernel backward included: they are part of the time, not of the flops)
+            dec_keys = [k for k in attn_ms_all if k[1] == 256 and k[2] in (256, 2048)]
             if dec_keys:
                 fl = sum(ATTN_FLOPS[k[0]] * k[1] * k[2] * 256 * B_PER_GPU for k in dec_keys)
                 ms = sum(sum(attn_ms_all[k]) / len(attn_ms_all[k]) for k in dec_keys)
@@ -1089,8 +1095,9 @@ def main():
                 # the forward.  Both fractions are reported; the north-star bar is read on the algorithmic one.
                 shapes = sorted({(k[1], k[2]) for k in dec_keys})
                 fl_alg = sum(16 * l * s_len * 256 * B_PER_GPU for l, s_len in shapes)
-                others.append({"kernel": "decoder_aggregate: cross-attention (256 x 2048) and self-attention (256 x 256) "
-                                         "forward + dQ + dK/dV, one launch of each",
+                others.append({"kernel": "decoder_aggregate: cross-attention (256 x 2048) and self-attention (256 x 256), "
+                                         "forward + whole backward, one launch of each kernel: "
+                                         + ", ".join(f"{k[0]}_{k[1]}x{k[2]}" for k in sorted(dec_keys, key=lambda k: (-k[2], k[0]))),
                                "timing": note, "bound": "mfma", "achieved": round(fl_alg / (ms * 1e-3) / 1e12, 2),
                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(fl_alg / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
@@ -1098,7 +1105,7 @@ def main():
                                "frac_executed": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                                "flops_algorithmic": fl_alg, "flops_executed": fl,
                                "flops_formula": "algorithmic: 16 * Lq * Lk * 256 * scenes per shape (SURVEY 8d: fwd 4, bwd 8 "
-                                                "+ 4 recomputed); executed: fwd 4 + dK/dV 8 + dQ 6",
+                                                "+ 4 recomputed); executed: fwd 4 + (dK/dV 8 + dQ 6 | one-kernel backward 10)",
                                "sum_launch_ms": round(ms, 5), "kernels": len(dec_keys)})
             # the set-abstraction MLP's hand-written fp32-MFMA GEMM kernels (csrc/sa_mfma.hip): 2 * rows * Cin * Cout
             # flops per launch over the packed (de-duplicated) rows of the step's 8 scenes

@@ -182,7 +182,8 @@ def attention(q, k, v, mask, scale, dropout_p, need_weights):
 
 
 # ---- measurement aid (bench.py): per-kernel HIP-event timing inside the C library ----------------
-TIMING_KINDS = ("fwd", "delta", "dkv", "dq", "dqg")  # dqg: dQ as the dS K GEMM (coda_mha_bwd_ws_f32)
+# dqg: dQ as the dS K GEMM (coda_mha_bwd_ws_f32); bwdf: dK, dV and partial dQ tiles in one kernel; dqr: their sum
+TIMING_KINDS = ("fwd", "delta", "dkv", "dq", "dqg", "bwdf", "dqr")
 
 
 def backward_workspace(b, h, l, s, d, dev, dt):

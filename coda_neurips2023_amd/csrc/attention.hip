@@ -823,6 +823,219 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   }
 }
 
+// ---- the whole backward of a short query sequence against a long key sequence in ONE kernel (round 6) -------------
+// The decoder's cross-attention (256 queries x 2048 keys): the two-kernel form recomputes S in both kernels and dP in
+// the second one, 14 units of L * S * d per head for 8 algorithmic.  Here the dK/dV kernel's own dS also yields dQ:
+// 10 units.  A workgroup = KW waves x 32 keys walks the query tiles like mha_bwd_dkv_kernel (S un-transposed: lane =
+// key, registers = queries, the A-operand layout of dV and dK).  dQ = dS K contracts over KEYS, which sit in lanes:
+//  * every wave writes its 32 x 32 dS tile TRANSPOSED into one shared LDS tile [query][KW * 32 keys];
+//  * after a barrier the workgroup's dQ tile (32 queries x 64 components over its KW * 32 keys) is formed with
+//    v_mfma_f32_16x16x4_f32: wave w owns components 16 w .. 16 w + 15 of both 16-query halves (8 accumulator
+//    registers), A = dS^T rows and B = K^T rows as ds_read_b128 (K^T of the workgroup's keys: written once, [64][keys]);
+//    nothing is summed across waves;
+//  * the tile goes to a partial-sum workspace [head][key block][query tile][2048] in accumulator order (every store
+//    instruction one contiguous 256 bytes); mha_dq_reduce_kernel sums the key blocks in FIXED order, scales and writes
+//    dQ: deterministic, no atomics, no waiting among workgroups.
+// One Q / dO tile in LDS (the next one is in flight in registers during the stage), two LDS-only barriers per stage:
+// 68 KB, two workgroups per CU.  Plain problems only (no mask, L % 32 == 0, S % (32 KW) == 0, head width 64).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KW>
+__global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdParams p) {
+  constexpr int D = 64, HD = 32, NT = 2, LS = D + 4, THREADS = KW * kWave, KB = KW * kTile, TS = KB + 4;
+  constexpr int NLD = kTile * D / 4 / THREADS;
+  static_assert(KW == 4, "component split of the dQ tile: four waves x 16 components");
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *s_q = s_dyn;                // [32][68]
+  float *s_do = s_q + kTile * LS;    // [32][68]
+  float *s_lse = s_do + kTile * LS;  // [32]
+  float *s_delta = s_lse + kTile;    // [32]
+  float *s_kt = s_delta + kTile;     // [64][KB + 4]: K^T of the workgroup's keys
+  float *s_ds = s_kt + D * TS;       // [32][KB + 4]: dS^T of the stage
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int k0 = (th.tile * KW + w) * kTile;
+  const int mykey = k0 + l31;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  float kf[HD], vf[HD];  // B operands: K[mykey][half*HD + c], V[mykey][half*HD + c]
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 a = *reinterpret_cast<const float4 *>(kbase + static_cast<size_t>(mykey) * kstride + half * HD + c);
+    const float4 b4 = *reinterpret_cast<const float4 *>(vbase + static_cast<size_t>(mykey) * vstride + half * HD + c);
+    kf[c] = a.x; kf[c + 1] = a.y; kf[c + 2] = a.z; kf[c + 3] = a.w;
+    vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c) s_kt[(half * HD + c) * TS + w * kTile + l31] = kf[c];
+  f32x16 dk[NT], dv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  float4 rq[NLD], rg[NLD];
+  float r_lse = 0.f, r_delta = 0.f;
+  auto fetch_rows = [&](int qb) {
+    if (tid < kTile) {
+      r_lse = p.lse[static_cast<size_t>(bh) * p.l + qb + tid] * kLog2e;  // log2 units
+      r_delta = p.delta[static_cast<size_t>(bh) * p.l + qb + tid];
+    }
+  };
+  fetch_tile<D, THREADS, kTile>(rq, qbase, qstride, 0, p.l, tid);
+  fetch_tile<D, THREADS, kTile>(rg, p.dout + head_off, rstride, 0, p.l, tid);
+  fetch_rows(0);
+  store_tile<D, THREADS, kTile>(s_q, rq, tid);
+  store_tile<D, THREADS, kTile>(s_do, rg, tid);
+  if (tid < kTile) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
+  lds_only_barrier();
+
+  const int nqt = p.l / kTile;
+  const int l15 = lane & 15, g = lane >> 4;
+  // this workgroup's partial dQ tiles: [bh][key block][query tile][(w, query half, register)][lane]
+  float *part = p.ds + (static_cast<size_t>(bh) * gridDim.x + th.tile) * nqt * (kTile * D) + (w * 8) * kWave + lane;
+  const float *a_row = s_ds + l15 * TS + g * 32, *b_row = s_kt + (16 * w + l15) * TS + g * 32;
+  const float sscale = p.scale * kLog2e;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int q0 = qt * kTile;
+    const bool more = qt + 1 < nqt;
+    if (more) {  // next stage: loads in flight during this stage's MFMAs
+      fetch_tile<D, THREADS, kTile>(rq, qbase, qstride, q0 + kTile, p.l, tid);
+      fetch_tile<D, THREADS, kTile>(rg, p.dout + head_off, rstride, q0 + kTile, p.l, tid);
+      fetch_rows(q0 + kTile);
+    }
+    // S[q][key] and dP[q][key]: A = Q / dO rows (lane = query), B = K / V rows (lane = key)
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 qa = *reinterpret_cast<const float4 *>(s_q + l31 * LS + half * HD + c);
+      const float4 ga = *reinterpret_cast<const float4 *>(s_do + l31 * LS + half * HD + c);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kf[c], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vf[c], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kf[c + 1], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vf[c + 1], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kf[c + 2], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vf[c + 2], pacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kf[c + 3], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vf[c + 3], pacc, 0, 0, 0);
+    }
+    // lane: key = mykey, register r: query q0 + crow(r, half); the soft-max backward of mha_bwd_dkv_kernel's plain path
+    float pd[16], ds[16];
+    {
+      const int par = l31 & 1;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float keep0 = 1.f, keep1 = 1.f;
+        if (use_drop) {
+          const uint32_t mine = drop_hash(dconst, q0 + crow(r, half) + par, p.s, mykey);
+          const uint32_t other = __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+          keep0 = drop_keep(par ? other : mine, mykey, p.thresh16) ? p.inv_keep : 0.f;
+          keep1 = drop_keep(par ? mine : other, mykey, p.thresh16) ? p.inv_keep : 0.f;
+        }
+        const int qi = crow(r, half);
+        const f32x2 lse2 = {s_lse[qi], s_lse[qi + 1]}, del2 = {s_delta[qi], s_delta[qi + 1]};
+        const f32x2 keep2 = {keep0, keep1}, s2 = {sacc[r], sacc[r + 1]}, dp2 = {pacc[r], pacc[r + 1]};
+        const f32x2 arg = __builtin_elementwise_fma(s2, f32x2{sscale, sscale}, -lse2);
+        const f32x2 prob = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+        const f32x2 pdv = prob * keep2;
+        const f32x2 dsv = prob * __builtin_elementwise_fma(dp2, keep2, -del2);  // * scale: on the dK rows / in the dQ sum
+        pd[r] = pdv[0]; pd[r + 1] = pdv[1];
+        ds[r] = dsv[0]; ds[r + 1] = dsv[1];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_ds[crow(r, half) * TS + w * kTile + l31] = ds[r];
+    // dV[key][dv] += sum_q Pd[q][key] dO[q][dv],  dK[key][c] += sum_q dS[q][key] Q[q][c]  (A: lane = key, k = query)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = crow(r, half);
+      const float2 g2 = *reinterpret_cast<const float2 *>(s_do + qi * LS + NT * l31);
+      const float2 q2 = *reinterpret_cast<const float2 *>(s_q + qi * LS + NT * l31);
+      dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.x, dv[0], 0, 0, 0);
+      dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.y, dv[1], 0, 0, 0);
+      dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.x, dk[0], 0, 0, 0);
+      dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.y, dk[1], 0, 0, 0);
+    }
+    lds_only_barrier();  // dS^T complete; every wave is done with the Q / dO tile
+    if (more) {
+      store_tile<D, THREADS, kTile>(s_q, rq, tid);
+      store_tile<D, THREADS, kTile>(s_do, rg, tid);
+      if (tid < kTile) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
+    }
+    // dQ tile: rows = queries (two halves of 16), columns = components 16 w + l15, contraction over the KB keys;
+    // k-slot g of step (j, e) <-> key 32 g + 4 j + e
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KB / 16; ++j) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(a_row + 4 * j);
+      const float4 a1 = *reinterpret_cast<const float4 *>(a_row + 16 * TS + 4 * j);
+      const float4 bb = *reinterpret_cast<const float4 *>(b_row + 4 * j);
+      dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bb.x, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bb.x, dq1, 0, 0, 0);
+      dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bb.y, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bb.y, dq1, 0, 0, 0);
+      dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bb.z, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bb.z, dq1, 0, 0, 0);
+      dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bb.w, dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bb.w, dq1, 0, 0, 0);
+    }
+    {
+      float *pt = part + static_cast<size_t>(qt) * (kTile * D);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pt[r * kWave] = dq0[r];
+        pt[(4 + r) * kWave] = dq1[r];
+      }
+    }
+    lds_only_barrier();  // next Q / dO tile visible; dS^T free again
+  }
+
+  // dk[t][r]: row i = crow(r, half) = key within the tile, column j = l31 <-> component NT*l31 + t
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = k0 + crow(r, half);
+    float *dkrow = p.dk + (static_cast<size_t>(key) * p.b + bi) * p.lddk + hi * D + NT * l31;
+    float *dvrow = p.dv + (static_cast<size_t>(key) * p.b + bi) * p.lddv + hi * D + NT * l31;
+    *reinterpret_cast<float2 *>(dkrow) = make_float2(dk[0][r] * p.scale, dk[1][r] * p.scale);
+    *reinterpret_cast<float2 *>(dvrow) = make_float2(dv[0][r], dv[1][r]);
+  }
+}
+
+// dQ = scale * (sum over the key blocks, in order) of mha_bwd_fused_kernel's partial tiles.  One workgroup per
+// (query tile, head); a thread owns four consecutive lanes' values of one (wave, half, register) row = four
+// consecutive components of one query.
+__global__ __launch_bounds__(256) void mha_dq_reduce_kernel(MhaBwdParams p, int nkb) {
+  constexpr int D = 64, TILE = kTile * D;
+  const int qt = blockIdx.x, bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h, nqt = gridDim.x;
+  const float *part = p.ds + (static_cast<size_t>(bh) * nkb * nqt + qt) * TILE;
+#pragma unroll
+  for (int i = 0; i < TILE / 4 / 256; ++i) {
+    const int e = 4 * (threadIdx.x + 256 * i);  // element of the tile: ((w * 2 + qh) * 4 + r) * 64 + lane
+    float4 acc = *reinterpret_cast<const float4 *>(part + e);
+    for (int kb = 1; kb < nkb; ++kb) {
+      const float4 v = *reinterpret_cast<const float4 *>(part + static_cast<size_t>(kb) * nqt * TILE + e);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int ln = e & 63, r = (e >> 6) & 3, qh = (e >> 8) & 1, w = e >> 9;
+    const int qq = qt * kTile + 16 * qh + 4 * (ln >> 4) + r, c = 16 * w + (ln & 15);
+    float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + c;
+    *reinterpret_cast<float4 *>(row) = make_float4(acc.x * p.scale, acc.y * p.scale, acc.z * p.scale, acc.w * p.scale);
+  }
+}
+
 // delta = rowsum(dO * O) of this lane's query inside the dQ kernel (fuse_delta): the lane holds its half of the dO row
 // already; the other half comes from lane ^ 32.  Written once per query for the dK/dV kernel that runs behind this one
 // -- a launch (6.5 us, 19 per step) less than the stand-alone mha_delta_kernel.
@@ -1632,6 +1845,14 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   return st != CODA_OK ? st : launch_status();
 }
 
+// problems the one-kernel backward takes: head width 64, whole tiles, at most 1024 queries against at least 1024 keys
+bool fused_bwd_takes(int b, int h, int l, int s, int d) {
+  return b > 0 && h > 0 && d == 64 && l >= kTile && l < 1024 && l % kTile == 0 && s >= 1024 && s % (4 * kTile) == 0;
+}
+size_t fused_bwd_ws_bytes(int b, int h, int l, int s) {  // partial dQ tiles: one (l x 64) per key block of 128
+  return sizeof(float) * static_cast<size_t>(b) * h * (s / (4 * kTile)) * l * 64;
+}
+
 template <int D>
 int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   clear_sticky_error();
@@ -1640,7 +1861,12 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   static const bool fuse_ok = [] { const char *e = getenv("CODA_ATTN_FUSE_DELTA"); return !e || atoi(e) != 0; }();
   const bool ds_route = D == 64 && p.ds != nullptr && mfma_dtype() == 0 && p.mask == nullptr && p.l >= 1024 && p.s >= 1024 &&
                         p.l % kTile == 0 && p.s % kTile == 0 && (p.parts & 6) == 6;
-  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7 && !ds_route;
+  // one kernel for dK, dV and the partial dQ tiles + a reduction (mha_bwd_fused_kernel): short query sequences against
+  // long key sequences -- the decoder's cross-attention (CODA_ATTN_FUSED_BWD=0: the two-kernel form, A/B)
+  static const bool fused_ok = [] { const char *e = getenv("CODA_ATTN_FUSED_BWD"); return !e || atoi(e) != 0; }();
+  const bool fused_route = fused_ok && !ds_route && fused_bwd_takes(p.b, p.h, p.l, p.s, D) && p.ds != nullptr &&
+                           mfma_dtype() == 0 && p.mask == nullptr && (p.parts & 6) == 6;
+  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7 && !ds_route && !fused_route;
   if ((p.parts & 1) && !fuse) {
     KernelTimer timer(1, p.l, p.s, s);
     mha_launch((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
@@ -1678,6 +1904,25 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
     if (st != CODA_OK) return st;
   }
   if (!(rest.parts & 6)) return launch_status();
+  if constexpr (D == 64) {
+    if (fused_route) {
+      constexpr int KW = 4;
+      constexpr size_t lds = sizeof(float) * (2 * kTile * (D + 4) + 2 * kTile + (D + kTile) * (KW * kTile + 4));
+      const int nkb = p.s / (KW * kTile);
+      {
+        KernelTimer timer(5, p.l, p.s, s);  // kind 5: dK, dV and the partial dQ tiles (10 L S d flops per head)
+        auto kern = mha_bwd_fused_kernel<KW>;
+        int st = set_lds(kern, lds);
+        if (st != CODA_OK) return st;
+        mha_launch(kern, dim3(nkb, p.b * p.h), dim3(KW * kWave), lds, s, p);
+      }
+      {
+        KernelTimer timer(6, p.l, p.s, s);  // kind 6: the key blocks' partial dQ tiles summed in order
+        mha_launch(mha_dq_reduce_kernel, dim3(p.l / kTile, p.b * p.h), dim3(256), 0, s, p, nkb);
+      }
+      return launch_status();
+    }
+  }
   const bool gen = p.mask != nullptr || (p.l % kTile) != 0 || (p.s % kTile) != 0;
   return gen ? launch_bwd_g<D, true>(rest, s) : launch_bwd_g<D, false>(rest, s);
 }
@@ -1752,8 +1997,8 @@ CODA_API int coda_mha_bwd_parts_f32(const float *q, const float *k, const float 
   p.xcd_map = xcd_mapped();
   {  // optional dS workspace of coda_mha_bwd_ws_f32 (per-call options, common.hip.h)
     const CallOptions &o = call_options();
-    const size_t need = sizeof(float) * static_cast<size_t>(b) * h * l * s;
-    if (o.attn_ds_ws && o.attn_ds_bytes >= need && (reinterpret_cast<uintptr_t>(o.attn_ds_ws) & 15) == 0)
+    const size_t need = coda_mha_bwd_ws_bytes(b, h, l, s, d);  // 0: this problem uses none
+    if (need && o.attn_ds_ws && o.attn_ds_bytes >= need && (reinterpret_cast<uintptr_t>(o.attn_ds_ws) & 15) == 0)
       p.ds = static_cast<float *>(o.attn_ds_ws);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1762,6 +2007,9 @@ CODA_API int coda_mha_bwd_parts_f32(const float *q, const float *k, const float 
 
 CODA_API size_t coda_mha_bwd_ws_bytes(int b, int h, int l, int s, int d) {
   // the dS route applies to long unmasked sequences at head width 64 (the encoder's self-attention); 0 = not used
+  // ... and the one-kernel backward of short query sequences against long key sequences (the decoder's cross-attention)
+  // keeps the key blocks' partial dQ tiles there
+  if (coda::fused_bwd_takes(b, h, l, s, d)) return coda::fused_bwd_ws_bytes(b, h, l, s);
   if (b <= 0 || h <= 0 || d != 64 || l < 1024 || s < 1024 || l % 32 != 0 || s % 32 != 0) return 0;
   return sizeof(float) * static_cast<size_t>(b) * h * l * s;
 }

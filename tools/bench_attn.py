@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 from coda_neurips2023_amd import attention_core as core  # noqa: E402
 
 dev = torch.device("cuda:0")
-FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2}  # executed MFMA flops per (l * s * d * b * h); dqg: dQ = dS K alone
+# executed MFMA flops per (l * s * d * b * h); dqg: dQ = dS K alone; bwdf: S, dP, dV, dK, dQ in one kernel
+FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2, "bwdf": 10}
 
 
 def run(l, s, b=8, h=4, d=64, p=0.1, reps=20):
@@ -33,7 +34,7 @@ def run(l, s, b=8, h=4, d=64, p=0.1, reps=20):
     rec = core.collect_kernel_timing()
     core.disable_kernel_timing()
     line = f"L={l:5d} S={s:5d} d={d:3d} p={p}:"
-    for kind in ("fwd", "delta", "dkv", "dq", "dqg"):
+    for kind in core.TIMING_KINDS:
         if (kind, l, s) not in rec:   # delta: formed inside the dQ kernel on the fp32 path
             continue
         ms = sorted(rec[(kind, l, s)])
