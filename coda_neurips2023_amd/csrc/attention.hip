@@ -836,9 +836,24 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 //  * the tile goes to a partial-sum workspace [head][key block][query tile][2048] in accumulator order (every store
 //    instruction one contiguous 256 bytes); mha_dq_reduce_kernel sums the key blocks in FIXED order, scales and writes
 //    dQ: deterministic, no atomics, no waiting among workgroups.
-// One Q / dO tile in LDS (the next one is in flight in registers during the stage), two LDS-only barriers per stage:
-// 68 KB, two workgroups per CU.  Plain problems only (no mask, L % 32 == 0, S % (32 KW) == 0, head width 64).
+// One Q / dO tile in LDS (the next one is in flight in registers during the stage's second half; delta = rowsum(dO * O)
+// is formed on its way into LDS), two LDS-only barriers per stage: 68 KB, two workgroups per CU.  Plain problems only (no mask, L % 32 == 0, S % (32 KW) == 0, head width 64).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// -DCODA_ATTN_PROF (tools/attn_phase_probe.py): shader-clock stamps of wave 0 of every workgroup of the short one-kernel
+// backward, written over `delta` (which that kernel does not use): [workgroup][16] clocks since the kernel's first stamp.
+#ifdef CODA_ATTN_PROF
+#define CODA_PROF_STAMP(i)                                                                                   \
+  do {                                                                                                       \
+    __builtin_amdgcn_s_waitcnt(0);                                                                           \
+    const long long t_now = clock64();                                                                       \
+    if ((i) == 0) prof_t0 = t_now;                                                                           \
+    if (threadIdx.x == 0)                                                                                    \
+      p.delta[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] = static_cast<float>(t_now - prof_t0); \
+  } while (0)
+#else
+#define CODA_PROF_STAMP(i)
+#endif
 
 template <int KW>
 __global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdParams p) {
@@ -885,20 +900,39 @@ __global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdPara
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
 
-  float4 rq[NLD], rg[NLD];
-  float r_lse = 0.f, r_delta = 0.f;
-  auto fetch_rows = [&](int qb) {
-    if (tid < kTile) {
-      r_lse = p.lse[static_cast<size_t>(bh) * p.l + qb + tid] * kLog2e;  // log2 units
-      r_delta = p.delta[static_cast<size_t>(bh) * p.l + qb + tid];
+  // Q / dO / O rows of the next stage in registers; delta[row] = sum(dO * O) is formed when they go to LDS (the 16
+  // threads that copy a row each hold four products): no launch for it
+  float4 rq[NLD], rg[NLD], ro[NLD];
+  float r_lse = 0.f;
+  // (thread: rows tid / 16 and tid / 16 + 16 of the tile -- a uniform base + the thread's own 32-bit offset)
+  const uint32_t qoff = static_cast<uint32_t>(tid / (D / 4)) * static_cast<uint32_t>(qstride) + (tid % (D / 4)) * 4;
+  const uint32_t roff = static_cast<uint32_t>(tid / (D / 4)) * static_cast<uint32_t>(rstride) + (tid % (D / 4)) * 4;
+  auto fetch_stage = [&](int qb) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int row0 = qb + j * (THREADS / (D / 4));
+      rq[j] = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(row0) * qstride + qoff);
+      rg[j] = *reinterpret_cast<const float4 *>(p.dout + head_off + static_cast<size_t>(row0) * rstride + roff);
+      ro[j] = *reinterpret_cast<const float4 *>(p.out + head_off + static_cast<size_t>(row0) * rstride + roff);
     }
+    if (tid < kTile) r_lse = p.lse[static_cast<size_t>(bh) * p.l + qb + tid] * kLog2e;  // log2 units
   };
-  fetch_tile<D, THREADS, kTile>(rq, qbase, qstride, 0, p.l, tid);
-  fetch_tile<D, THREADS, kTile>(rg, p.dout + head_off, rstride, 0, p.l, tid);
-  fetch_rows(0);
-  store_tile<D, THREADS, kTile>(s_q, rq, tid);
-  store_tile<D, THREADS, kTile>(s_do, rg, tid);
-  if (tid < kTile) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
+  auto store_stage = [&]() {
+    store_tile<D, THREADS, kTile>(s_q, rq, tid);
+    store_tile<D, THREADS, kTile>(s_do, rg, tid);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      float part_d = rg[j].x * ro[j].x + rg[j].y * ro[j].y + rg[j].z * ro[j].z + rg[j].w * ro[j].w;
+      part_d += __shfl_xor(part_d, 1, kWave);
+      part_d += __shfl_xor(part_d, 2, kWave);
+      part_d += __shfl_xor(part_d, 4, kWave);
+      part_d += __shfl_xor(part_d, 8, kWave);
+      if (tid % (D / 4) == 0) s_delta[(tid + j * THREADS) / (D / 4)] = part_d;
+    }
+    if (tid < kTile) s_lse[tid] = r_lse;
+  };
+  fetch_stage(0);
+  store_stage();
   lds_only_barrier();
 
   const int nqt = p.l / kTile;
@@ -910,11 +944,6 @@ __global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdPara
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * kTile;
     const bool more = qt + 1 < nqt;
-    if (more) {  // next stage: loads in flight during this stage's MFMAs
-      fetch_tile<D, THREADS, kTile>(rq, qbase, qstride, q0 + kTile, p.l, tid);
-      fetch_tile<D, THREADS, kTile>(rg, p.dout + head_off, rstride, q0 + kTile, p.l, tid);
-      fetch_rows(q0 + kTile);
-    }
     // S[q][key] and dP[q][key]: A = Q / dO rows (lane = query), B = K / V rows (lane = key)
     f32x16 sacc, pacc;
 #pragma unroll
@@ -958,6 +987,10 @@ __global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdPara
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_ds[crow(r, half) * TS + w * kTile + l31] = ds[r];
+    // next stage: its loads are in flight during the 64 MFMAs below (issued here, not at the top of the stage: the
+    // soft-max above is where the registers are short)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) fetch_stage(q0 + kTile);
     // dV[key][dv] += sum_q Pd[q][key] dO[q][dv],  dK[key][c] += sum_q dS[q][key] Q[q][c]  (A: lane = key, k = query)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -970,11 +1003,7 @@ __global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdPara
       dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.y, dk[1], 0, 0, 0);
     }
     lds_only_barrier();  // dS^T complete; every wave is done with the Q / dO tile
-    if (more) {
-      store_tile<D, THREADS, kTile>(s_q, rq, tid);
-      store_tile<D, THREADS, kTile>(s_do, rg, tid);
-      if (tid < kTile) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
-    }
+    if (more) store_stage();
     // dQ tile: rows = queries (two halves of 16), columns = components 16 w + l15, contraction over the KB keys;
     // k-slot g of step (j, e) <-> key 32 g + 4 j + e
     f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
@@ -1014,25 +1043,279 @@ __global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_fused_kernel(MhaBwdPara
   }
 }
 
-// dQ = scale * (sum over the key blocks, in order) of mha_bwd_fused_kernel's partial tiles.  One workgroup per
-// (query tile, head); a thread owns four consecutive lanes' values of one (wave, half, register) row = four
-// consecutive components of one query.
+// The same for SHORT key sequences (the decoder's 256 queries attending to themselves): a workgroup owns ONE key tile and
+// its KW waves split the query tiles like mha_bwd_dkv_kernel<QSPLIT> (wave w takes tile w of the KW staged per step), so
+// a wave's dQ tile over the workgroup's 32 keys is nobody else's: dS goes transposed into the wave's own (spent) Q tile
+// in LDS, dQ = dS K is 32 v_mfma_f32_32x32x2_f32 (A = dS^T rows as ds_read_b128, B = the key tile's rows from LDS), the
+// partial tiles [head][key tile][query tile][2048] are summed by mha_dq_reduce_kernel<1>.  delta = rowsum(dO * O) is
+// formed while the Q / dO tiles are staged (the 16 threads that copy a row each hold four products): no launch for it.
+// The per-wave partial dK / dV are summed through LDS at the end as in the two-kernel form.
+template <int KW>
+__global__ __launch_bounds__(KW * kWave, 1) void mha_bwd_fused_short_kernel(MhaBwdParams p) {
+  constexpr int D = 64, HD = 32, NT = 2, LS = D + 4, THREADS = KW * kWave, QT = KW, TS = kTile + 4;
+  static_assert(KW == 8, "the closing sum of the partial dK / dV gives each of eight waves eight registers");
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *s_q = s_dyn;                     // [QT * 32][68]; tile w becomes wave w's dS^T [32][36] once dK has read it
+  float *s_do = s_q + QT * kTile * LS;    // [QT * 32][68]
+  float *s_lse = s_do + QT * kTile * LS;  // [QT * 32]
+  float *s_delta = s_lse + QT * kTile;    // [QT * 32]
+  float *s_k = s_delta + QT * kTile;      // [32][68]: the key tile -- B operand of S and of dQ
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int k0 = th.tile * kTile, mykey = k0 + l31;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+#ifdef CODA_ATTN_PROF
+  long long prof_t0 = 0;
+#endif
+  CODA_PROF_STAMP(0);
+  float vf[HD];  // B operand of dP: V[mykey][half*HD + c]  (K's rows come from s_k)
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 b4 = *reinterpret_cast<const float4 *>(vbase + static_cast<size_t>(mykey) * vstride + half * HD + c);
+    vf[c] = b4.x; vf[c + 1] = b4.y; vf[c + 2] = b4.z; vf[c + 3] = b4.w;
+  }
+  static_assert(THREADS == kTile * (D / 4), "one float4 of the key tile per thread");
+  const float4 k4 = *reinterpret_cast<const float4 *>(kbase + static_cast<size_t>(k0 + tid / (D / 4)) * kstride + (tid % (D / 4)) * 4);
+  f32x16 dk[NT], dv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  CODA_PROF_STAMP(1);
+  const int nqt = p.l / kTile;
+  float *part = p.ds + (static_cast<size_t>(bh) * gridDim.x + th.tile) * nqt * (kTile * D) + lane;
+  const float sscale = p.scale * kLog2e;
+  const uint32_t qoff = static_cast<uint32_t>(tid / (D / 4)) * static_cast<uint32_t>(qstride) + (tid % (D / 4)) * 4;
+  const uint32_t roff = static_cast<uint32_t>(tid / (D / 4)) * static_cast<uint32_t>(rstride) + (tid % (D / 4)) * 4;
+  for (int qbase0 = 0; qbase0 < p.l; qbase0 += kTile * QT) {
+    if (qbase0) lds_only_barrier();  // every wave is done with the previous step's tiles (its stores stay in flight)
+    // stage QT query tiles of Q and dO; delta[row] = sum(dO * O) from the 16 threads that copy the row
+    // two batches of 12 loads per thread (one batch of 24 spills); the first one is in flight together with the K / V
+    // loads above: the key tile goes to LDS once that batch has been issued
+    constexpr int NJ = QT * kTile * (D / 4) / THREADS / 2;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      float4 q4[NJ], g4[NJ], o4[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {  // rows 32 (jb NJ + j) + tid / 16 of the step: a uniform base + the thread's own offset
+        const int row0 = qbase0 + (jb * NJ + j) * (THREADS / (D / 4));
+        q4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g4[j] = q4[j];
+        o4[j] = q4[j];
+        if (row0 < p.l) {  // whole tiles: uniform
+          q4[j] = *reinterpret_cast<const float4 *>(qbase + static_cast<size_t>(row0) * qstride + qoff);
+          g4[j] = *reinterpret_cast<const float4 *>(p.dout + head_off + static_cast<size_t>(row0) * rstride + roff);
+          o4[j] = *reinterpret_cast<const float4 *>(p.out + head_off + static_cast<size_t>(row0) * rstride + roff);
+        }
+      }
+      if (jb == 0 && qbase0 == 0) *reinterpret_cast<float4 *>(s_k + (tid / (D / 4)) * LS + (tid % (D / 4)) * 4) = k4;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int i = tid + (jb * NJ + j) * THREADS, row = i / (D / 4), c4 = i % (D / 4);
+        *reinterpret_cast<float4 *>(s_q + row * LS + c4 * 4) = q4[j];
+        *reinterpret_cast<float4 *>(s_do + row * LS + c4 * 4) = g4[j];
+        float part_d = g4[j].x * o4[j].x + g4[j].y * o4[j].y + g4[j].z * o4[j].z + g4[j].w * o4[j].w;
+        part_d += __shfl_xor(part_d, 1, kWave);
+        part_d += __shfl_xor(part_d, 2, kWave);
+        part_d += __shfl_xor(part_d, 4, kWave);
+        part_d += __shfl_xor(part_d, 8, kWave);
+        if (c4 == 0) s_delta[row] = part_d;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the second batch's loads stay behind the first batch's stores (registers)
+    }
+    CODA_PROF_STAMP(2);
+    if (tid < kTile * QT) {
+      const int qq = qbase0 + tid;
+      s_lse[tid] = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] * kLog2e : 0.f;
+    }
+    lds_only_barrier();
+    CODA_PROF_STAMP(3);
+    const int q0 = qbase0 + w * kTile;
+    if (q0 < p.l) {
+      float *tq = s_q + w * kTile * LS;
+      const float *tdo = s_do + w * kTile * LS, *t_lse = s_lse + w * kTile, *t_delta = s_delta + w * kTile;
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        const float4 qa = *reinterpret_cast<const float4 *>(tq + l31 * LS + half * HD + c);
+        const float4 ga = *reinterpret_cast<const float4 *>(tdo + l31 * LS + half * HD + c);
+        const float4 ka = *reinterpret_cast<const float4 *>(s_k + l31 * LS + half * HD + c);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, ka.x, sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.x, vf[c], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, ka.y, sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.y, vf[c + 1], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, ka.z, sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.z, vf[c + 2], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, ka.w, sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga.w, vf[c + 3], pacc, 0, 0, 0);
+      }
+      CODA_PROF_STAMP(4);
+      float pd[16], ds[16];
+      {
+        const int par = l31 & 1;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float keep0 = 1.f, keep1 = 1.f;
+          if (use_drop) {
+            const uint32_t mine = drop_hash(dconst, q0 + crow(r, half) + par, p.s, mykey);
+            const uint32_t other = __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+            keep0 = drop_keep(par ? other : mine, mykey, p.thresh16) ? p.inv_keep : 0.f;
+            keep1 = drop_keep(par ? mine : other, mykey, p.thresh16) ? p.inv_keep : 0.f;
+          }
+          const int qi = crow(r, half);
+          const f32x2 lse2 = {t_lse[qi], t_lse[qi + 1]}, del2 = {t_delta[qi], t_delta[qi + 1]};
+          const f32x2 keep2 = {keep0, keep1}, s2 = {sacc[r], sacc[r + 1]}, dp2 = {pacc[r], pacc[r + 1]};
+          const f32x2 arg = __builtin_elementwise_fma(s2, f32x2{sscale, sscale}, -lse2);
+          const f32x2 prob = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+          const f32x2 pdv = prob * keep2;
+          const f32x2 dsv = prob * __builtin_elementwise_fma(dp2, keep2, -del2);
+          pd[r] = pdv[0]; pd[r + 1] = pdv[1];
+          ds[r] = dsv[0]; ds[r + 1] = dsv[1];
+        }
+      }
+      CODA_PROF_STAMP(5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = crow(r, half);
+        const float2 g2 = *reinterpret_cast<const float2 *>(tdo + qi * LS + NT * l31);
+        const float2 q2 = *reinterpret_cast<const float2 *>(tq + qi * LS + NT * l31);
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.x, dv[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.y, dv[1], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.x, dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.y, dk[1], 0, 0, 0);
+      }
+      CODA_PROF_STAMP(6);
+      // dS^T into the wave's own Q tile (every read of it has been issued; LDS operations of a wave complete in order)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tq[crow(r, half) * TS + l31] = ds[r];
+      // dQ[q][c] = sum_key dS[q][key] K[key][c]: A = dS^T rows (lane = query), k-slot (kk, half) <-> key 16 half + kk
+      f32x16 dq[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(tq + l31 * TS + 16 * half + kk);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 b2 = *reinterpret_cast<const float2 *>(s_k + (16 * half + kk + i) * LS + NT * l31);
+          dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b2.x, dq[0], 0, 0, 0);
+          dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b2.y, dq[1], 0, 0, 0);
+        }
+      }
+      CODA_PROF_STAMP(7);
+      float *pt = part + static_cast<size_t>(q0 / kTile) * (kTile * D);  // [t][r][lane]
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pt[(t * 16 + r) * kWave] = dq[t][r];
+    }
+  }
+
+  CODA_PROF_STAMP(8);
+  // the waves' partial dK / dV: [wave][t * 16 + r | 32 + t * 16 + r][64 lanes] through LDS; wave w then owns dK (w < 4) or
+  // dV (w >= 4), registers r = 4 (w & 3) .. + 3 of both column tiles, and adds the eight partials in wave order
+  lds_only_barrier();
+  {
+    float *slot = s_dyn + static_cast<size_t>(w) * (2 * NT * 16) * kWave + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        slot[(t * 16 + r) * kWave] = dk[t][r];
+        slot[((NT + t) * 16 + r) * kWave] = dv[t][r];
+      }
+  }
+  lds_only_barrier();
+  CODA_PROF_STAMP(9);
+  {
+    const int which = w >> 2, r0 = 4 * (w & 3);
+    const float mul = which ? 1.f : p.scale;
+    float *obase = which ? p.dv : p.dk;
+    const int ldo = which ? p.lddv : p.lddk;
+#pragma unroll
+    for (int r = r0; r < r0 + 4; ++r) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < KW; ++ww) {
+        const float *sl = s_dyn + static_cast<size_t>(ww) * (2 * NT * 16) * kWave + (which * NT * 16 + r) * kWave + lane;
+        a0 += sl[0];
+        a1 += sl[16 * kWave];
+      }
+      const int key = k0 + crow(r, half);
+      float *orow = obase + (static_cast<size_t>(key) * p.b + bi) * ldo + hi * D + NT * l31;
+      *reinterpret_cast<float2 *>(orow) = make_float2(a0 * mul, a1 * mul);
+    }
+  }
+  CODA_PROF_STAMP(10);
+}
+
+// dQ = scale * (sum over the key blocks, in order) of the one-kernel backward's partial tiles.  One workgroup per
+// (query tile, head).  LAYOUT 0 (mha_bwd_fused_kernel): element ((w * 2 + qh) * 4 + r) * 64 + lane = query 16 qh +
+// 4 (lane >> 4) + r, component 16 w + (lane & 15); a thread owns four consecutive lanes = four consecutive components.
+// LAYOUT 1 (mha_bwd_fused_short_kernel): element (t * 16 + r) * 64 + lane = query crow(r, lane >> 5), component
+// 2 (lane & 31) + t; a thread owns both t of one (r, lane).
+template <int LAYOUT>
 __global__ __launch_bounds__(256) void mha_dq_reduce_kernel(MhaBwdParams p, int nkb) {
   constexpr int D = 64, TILE = kTile * D;
   const int qt = blockIdx.x, bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h, nqt = gridDim.x;
   const float *part = p.ds + (static_cast<size_t>(bh) * nkb * nqt + qt) * TILE;
+  const size_t kbs = static_cast<size_t>(nqt) * TILE;
+  if constexpr (LAYOUT == 0) {
 #pragma unroll
-  for (int i = 0; i < TILE / 4 / 256; ++i) {
-    const int e = 4 * (threadIdx.x + 256 * i);  // element of the tile: ((w * 2 + qh) * 4 + r) * 64 + lane
-    float4 acc = *reinterpret_cast<const float4 *>(part + e);
-    for (int kb = 1; kb < nkb; ++kb) {
-      const float4 v = *reinterpret_cast<const float4 *>(part + static_cast<size_t>(kb) * nqt * TILE + e);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int i = 0; i < TILE / 4 / 256; ++i) {
+      const int e = 4 * (threadIdx.x + 256 * i);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kb = 0; kb < nkb; kb += 8) {  // eight loads in flight, summed in key-block order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = kb + u < nkb ? *reinterpret_cast<const float4 *>(part + (kb + u) * kbs + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      const int ln = e & 63, r = (e >> 6) & 3, qh = (e >> 8) & 1, w = e >> 9;
+      const int qq = qt * kTile + 16 * qh + 4 * (ln >> 4) + r, c = 16 * w + (ln & 15);
+      float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + c;
+      *reinterpret_cast<float4 *>(row) = make_float4(acc.x * p.scale, acc.y * p.scale, acc.z * p.scale, acc.w * p.scale);
     }
-    const int ln = e & 63, r = (e >> 6) & 3, qh = (e >> 8) & 1, w = e >> 9;
-    const int qq = qt * kTile + 16 * qh + 4 * (ln >> 4) + r, c = 16 * w + (ln & 15);
-    float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + c;
-    *reinterpret_cast<float4 *>(row) = make_float4(acc.x * p.scale, acc.y * p.scale, acc.z * p.scale, acc.w * p.scale);
+  } else {
+#pragma unroll
+    for (int i = 0; i < TILE / 2 / 256; ++i) {
+      const int e = threadIdx.x + 256 * i;  // (r, lane)
+      float a0 = 0.f, a1 = 0.f;
+      for (int kb = 0; kb < nkb; kb += 8) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v0[u] = kb + u < nkb ? part[(kb + u) * kbs + e] : 0.f;
+          v1[u] = kb + u < nkb ? part[(kb + u) * kbs + 16 * 64 + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a0 += v0[u]; a1 += v1[u]; }
+      }
+      const int ln = e & 63, r = e >> 6;
+      const int qq = qt * kTile + crow(r, ln >> 5);
+      float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + 2 * (ln & 31);
+      *reinterpret_cast<float2 *>(row) = make_float2(a0 * p.scale, a1 * p.scale);
+    }
   }
 }
 
@@ -1849,8 +2132,12 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
 bool fused_bwd_takes(int b, int h, int l, int s, int d) {
   return b > 0 && h > 0 && d == 64 && l >= kTile && l < 1024 && l % kTile == 0 && s >= 1024 && s % (4 * kTile) == 0;
 }
-size_t fused_bwd_ws_bytes(int b, int h, int l, int s) {  // partial dQ tiles: one (l x 64) per key block of 128
-  return sizeof(float) * static_cast<size_t>(b) * h * (s / (4 * kTile)) * l * 64;
+// ... and its short-key-sequence form (mha_bwd_fused_short_kernel): whole tiles, both sequences below 1024
+bool fused_short_bwd_takes(int b, int h, int l, int s, int d) {
+  return b > 0 && h > 0 && d == 64 && l >= kTile && l < 1024 && l % kTile == 0 && s >= kTile && s < 1024 && s % kTile == 0;
+}
+size_t fused_bwd_ws_bytes(int b, int h, int l, int s, bool short_keys) {  // partial dQ tiles: one (l x 64) per key block
+  return sizeof(float) * static_cast<size_t>(b) * h * (s / (short_keys ? kTile : 4 * kTile)) * l * 64;
 }
 
 template <int D>
@@ -1864,10 +2151,11 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
   // one kernel for dK, dV and the partial dQ tiles + a reduction (mha_bwd_fused_kernel): short query sequences against
   // long key sequences -- the decoder's cross-attention (CODA_ATTN_FUSED_BWD=0: the two-kernel form, A/B)
   static const bool fused_ok = [] { const char *e = getenv("CODA_ATTN_FUSED_BWD"); return !e || atoi(e) != 0; }();
-  const bool fused_route = fused_ok && !ds_route && fused_bwd_takes(p.b, p.h, p.l, p.s, D) && p.ds != nullptr &&
-                           mfma_dtype() == 0 && p.mask == nullptr && (p.parts & 6) == 6;
-  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7 && !ds_route && !fused_route;
-  if ((p.parts & 1) && !fuse) {
+  const bool fused_any = fused_ok && !ds_route && p.ds != nullptr && mfma_dtype() == 0 && p.mask == nullptr;
+  const bool fused_route = fused_any && fused_bwd_takes(p.b, p.h, p.l, p.s, D) && (p.parts & 6) == 6;
+  const bool fused_short = fused_any && fused_short_bwd_takes(p.b, p.h, p.l, p.s, D) && (p.parts & 7) == 7;
+  const bool fuse = fuse_ok && mfma_dtype() == 0 && (p.parts & 7) == 7 && !ds_route && !fused_route && !fused_short;
+  if ((p.parts & 1) && !fuse && !fused_short && !fused_route) {  // (the one-kernel forms sum dO * O themselves)
     KernelTimer timer(1, p.l, p.s, s);
     mha_launch((mha_delta_kernel<D>), dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s, p);
   }
@@ -1918,7 +2206,24 @@ int launch_bwd(const MhaBwdParams &p, hipStream_t s) {
       }
       {
         KernelTimer timer(6, p.l, p.s, s);  // kind 6: the key blocks' partial dQ tiles summed in order
-        mha_launch(mha_dq_reduce_kernel, dim3(p.l / kTile, p.b * p.h), dim3(256), 0, s, p, nkb);
+        mha_launch(mha_dq_reduce_kernel<0>, dim3(p.l / kTile, p.b * p.h), dim3(256), 0, s, p, nkb);
+      }
+      return launch_status();
+    }
+    if (fused_short) {  // delta is formed inside
+      constexpr int KW = 8;
+      constexpr size_t lds = sizeof(float) * (2 * KW * kTile * (D + 4) + 2 * KW * kTile + kTile * (D + 4));
+      const int nkb = p.s / kTile;
+      {
+        KernelTimer timer(5, p.l, p.s, s);
+        auto kern = mha_bwd_fused_short_kernel<KW>;
+        int st = set_lds(kern, lds);
+        if (st != CODA_OK) return st;
+        mha_launch(kern, dim3(nkb, p.b * p.h), dim3(KW * kWave), lds, s, p);
+      }
+      {
+        KernelTimer timer(6, p.l, p.s, s);
+        mha_launch(mha_dq_reduce_kernel<1>, dim3(p.l / kTile, p.b * p.h), dim3(256), 0, s, p, nkb);
       }
       return launch_status();
     }
@@ -2009,7 +2314,8 @@ CODA_API size_t coda_mha_bwd_ws_bytes(int b, int h, int l, int s, int d) {
   // the dS route applies to long unmasked sequences at head width 64 (the encoder's self-attention); 0 = not used
   // ... and the one-kernel backward of short query sequences against long key sequences (the decoder's cross-attention)
   // keeps the key blocks' partial dQ tiles there
-  if (coda::fused_bwd_takes(b, h, l, s, d)) return coda::fused_bwd_ws_bytes(b, h, l, s);
+  if (coda::fused_bwd_takes(b, h, l, s, d)) return coda::fused_bwd_ws_bytes(b, h, l, s, false);
+  if (coda::fused_short_bwd_takes(b, h, l, s, d)) return coda::fused_bwd_ws_bytes(b, h, l, s, true);
   if (b <= 0 || h <= 0 || d != 64 || l < 1024 || s < 1024 || l % 32 != 0 || s % 32 != 0) return 0;
   return sizeof(float) * static_cast<size_t>(b) * h * l * s;
 }

@@ -174,8 +174,8 @@ def test_kernel_timing_records_every_launch(dev):
         rec = attention_core.collect_kernel_timing()
     finally:
         attention_core.disable_kernel_timing()
-    # (no "delta" record on the fp32 path: the dQ kernel forms rowsum(dO * O) itself)
-    assert sorted(rec) == [(kind, 256, 256) for kind in sorted(attention_core.TIMING_KINDS) if kind not in ("delta", "dqg", "bwdf", "dqr")]
+    # (no "delta" record: the one-kernel backward of short sequences forms rowsum(dO * O) itself)
+    assert sorted(rec) == [(kind, 256, 256) for kind in ("bwdf", "dqr", "fwd")]
     for samples in rec.values():
         assert len(samples) == 3 and all(0.0 < ms < 50.0 for ms in samples)
     assert attention_core.collect_kernel_timing() == {}  # disabling dropped the records
@@ -266,7 +266,7 @@ def test_backward_through_the_ds_workspace_equals_the_two_kernel_form(dev, monke
         return out.detach(), torch.autograd.grad((out * gw).sum(), leaves)
 
     assert _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, d) == 4 * b * h * l * s
-    assert _lib.load().coda_mha_bwd_ws_bytes(b, h, 256, 256, d) == 0 and _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, 128) == 0
+    assert _lib.load().coda_mha_bwd_ws_bytes(b, h, 100, 77, d) == 0 and _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, 128) == 0
     o1, g1 = grads("1")
     o0, g0 = grads("0")
     assert torch.equal(o1, o0)
@@ -279,9 +279,12 @@ def test_backward_through_the_ds_workspace_equals_the_two_kernel_form(dev, monke
 
 
 @pytest.mark.parametrize("l,s,b,p", [(256, 2048, 8, 0.1), (256, 2048, 2, 0.0), (512, 2048, 8, 0.1), (32, 1024, 3, 0.3),
-                                     (992, 1152, 1, 0.1)])
+                                     (992, 1152, 1, 0.1),
+                                     # short key sequences (the decoder's self-attention): mha_bwd_fused_short_kernel
+                                     (256, 256, 8, 0.1), (256, 256, 2, 0.0), (512, 512, 8, 0.1), (96, 64, 3, 0.3),
+                                     (32, 32, 1, 0.0), (160, 992, 1, 0.1)])
 def test_one_kernel_backward_equals_the_two_kernel_form(dev, monkeypatch, l, s, b, p):
-    """mha_bwd_fused_kernel (short query sequences against >= 1024 keys, the decoder's cross-attention): dK, dV and the
+    """mha_bwd_fused_kernel / mha_bwd_fused_short_kernel (fewer than 1024 queries; the decoder's cross- and self-attention): dK, dV and the
     key blocks' partial dQ tiles from ONE evaluation of S and dP (10 instead of 14 units of L S d flops), the partial
     tiles summed in fixed order by mha_dq_reduce_kernel.  Same dropout mask; the gradients equal the two-kernel form's
     (no workspace: CODA_ATTN_DS=0) up to fp32 summation order, the torch reference within 1e-3, and repeated calls are
@@ -297,14 +300,14 @@ def test_one_kernel_backward_equals_the_two_kernel_form(dev, monkeypatch, l, s, 
         out, _ = attention_core.attention(q, k, v, None, scale, p, False)
         return out.detach(), torch.autograd.grad((out * gw).sum(), leaves)
 
-    assert _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, d) == 4 * b * h * (s // 128) * l * 64
+    assert _lib.load().coda_mha_bwd_ws_bytes(b, h, l, s, d) == 4 * b * h * (s // (128 if s >= 1024 else 32)) * l * 64
     attention_core.enable_kernel_timing(0)
     try:
         o1, g1 = grads("1")
         kinds = sorted(k[0] for k in attention_core.collect_kernel_timing())
     finally:
         attention_core.disable_kernel_timing()
-    assert kinds == ["bwdf", "delta", "dqr", "fwd"], kinds  # the route under test really ran
+    assert kinds == ["bwdf", "dqr", "fwd"], kinds  # the route under test really ran (rowsum(dO * O) is formed inside)
     o0, g0 = grads("0")
     assert torch.equal(o1, o0)
     for a, r in zip(g1, g0):
