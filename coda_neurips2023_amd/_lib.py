@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoda_hip.so")
+# (CODA_LIB_PATH: another build of the same library for A/B runs of development variants -- tools/ab_prio.sh; never a
+# different implementation: there is none)
+LIB_PATH = os.environ.get("CODA_LIB_PATH") or os.path.join(_HERE, "libcoda_hip.so")
 
 CODA_OK = 0
 CODA_EINVAL = -1

@@ -107,7 +107,15 @@ int coda_mha_get_mfma_dtype(void);
  * leaves dS = P (dP - delta)
  * in the workspace, (B, H, L, S) floats, and dQ = scale dS K is a plain GEMM -- the backward then executes S, dP, dV,
  * dK, dQ once each (10 L S d flops per head) instead of recomputing S and dP in a second kernel (14).  Same results
- * as the two-kernel form up to the summation order of dQ.  The workspace is scratch: nothing is kept in it. */
+ * as the two-kernel form up to the summation order of dQ.  The workspace is scratch: nothing is kept in it.
+ *
+ * Short query sequences (round 6; l < 1024, whole 32-row tiles, head width 64, no mask, fp32 MFMA operands -- the
+ * decoder's cross-attention, s >= 1024 and a multiple of 128, and its self-attention, s < 1024): ONE kernel forms dK, dV
+ * and, from the same dS, the dQ tile of every (key block, query tile) pair; the workspace holds those partial tiles,
+ * (B, H, key blocks of 128 | 32 keys, L, 64) floats, and a second small kernel adds the key blocks in FIXED order and
+ * scales: 10 L S d flops per head instead of 14, rowsum(dO * O) formed inside (`delta` is not written on this route),
+ * no atomics and no waiting among workgroups, results bit-identical from call to call.  Without a workspace these
+ * problems run the two-kernel form.  CODA_ATTN_FUSED_BWD=0 switches the route off (A/B). */
 size_t coda_mha_bwd_ws_bytes(int b, int h, int l, int s, int d);
 int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const uint8_t *mask, const float *out,
                         const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta, int b,
@@ -122,7 +130,8 @@ int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const ui
  * measured the launch gap and two marker packets, +3 us on a 10-20 us kernel).
  * coda_mha_timing_enable(min_len < 0) disables; every call drops the records taken so far.
  * coda_mha_timing_collect synchronises the recorded events and writes up to `cap` records
- * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ, 4 dQ as the dS K GEMM; the call's l and s; milliseconds); returns the
+ * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ, 4 dQ as the dS K GEMM, 5 the one-kernel backward, 6 the sum of its partial dQ
+ * tiles; the call's l and s; milliseconds); returns the
  * number written, CODA_EINVAL, or -(1000 + hipError_t) if an event query failed. */
 int coda_mha_timing_enable(int min_len);
 int coda_mha_timing_collect(int *kind, int *l, int *s, float *ms, int cap);

@@ -49,8 +49,9 @@ typedef struct CodaDecoderStack {
   float *ws;               /* saved activations: coda_decoder_stack_ws_floats() floats, written by fwd, read by bwd */
   int ld_kv;               /* row stride of k_all / v_all / dk_all / dv_all in floats (0: nl * E) */
   int mfma_dtype;          /* MFMA operand type of the attention core (coda_attention.h): -1 library default, 0 fp32, 1 bf16, 2 bf16x3 */
-  float *attn_ws;          /* backward only, optional: dS workspace of the attention core (coda_mha_bwd_ws_bytes of the
-                              cross-attention problem; shared by the layers), NULL = the two-kernel backward */
+  float *attn_ws;          /* backward only, optional: workspace of the attention core's backward (coda_mha_bwd_ws_bytes of
+                              the cross-attention problem -- the partial dQ tiles of the one-kernel backward; the
+                              self-attention's need is smaller; shared by the layers), NULL = the two-kernel backward */
   size_t attn_ws_bytes;
 } CodaDecoderStack;
 
