@@ -78,7 +78,7 @@ ATTN_UNITS_NOTE = {"fwd": "4 algorithmic (QK^T, PV)",
 # WRITE_SIZE 49 272 KB, separate rocprofv3 --pmc passes (profiles/r01_pmc_attention_hbm.md); algorithmic 101.2 MB
 # HBM bytes per launch of the encoder's dK/dV kernel from PMC passes (FETCH_SIZE x2 + WRITE_SIZE): with the dS workspace
 # route of round 4 (the kernel also streams dS = 8 x 4 x 2048 x 2048 floats = 537 MB out) / the two-kernel form of round 3
-ATTN_DKV_TRAFFIC_DS = int(44498.9 * 2 * 1024) + int(565525.9 * 1024)  # profiles/r06_pmc_attention_hbm.md (r05: 44360.2 / 565560.2); algorithmic: 84 MB in + 570 MB out
+ATTN_DKV_TRAFFIC_DS = int(45656.3 * 2 * 1024) + int(565421.8 * 1024)  # profiles/r06_pmc_attention_hbm.md (r05: 44360.2 / 565560.2); algorithmic: 84 MB in + 570 MB out
 ATTN_DKV_TRAFFIC = 94_247_117 + 45_362_074      # profiles/r03_pmc_attention_hbm.md
 
 
@@ -741,7 +741,13 @@ def main():
 
     finite = DeferredFiniteCheck(dev) if not dry else None
 
+    host_spin = float(os.environ.get("CODA_BENCH_HOST_SPIN_US", "0")) * 1e-6  # dev probe: is the step host-bound?
+
     def one_step_eager(i):
+        if host_spin:
+            t_end = time.perf_counter() + host_spin
+            while time.perf_counter() < t_end:
+                pass
         if prefetch:
             # the data pipeline knows the next batch: its furthest point sampling (8 workgroups,
             # ~3.4 ms of dependent rounds) runs on a side stream while this step computes
