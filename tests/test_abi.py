@@ -49,6 +49,16 @@ def test_workspace_queries_run_without_gpu():
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 20000, 2048) == 8 * 20000 * 16  # sorted records
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 100000, 2048) == 8 * 100000 * 4
     assert lib.coda_ball_query_workspace_bytes(8, 20000, 2048, 64) >= 0
+    # attention backward (include/coda_attention.h): dS for the encoder's long sequences, the key blocks' partial dQ tiles
+    # for the decoder's short query sequences (blocks of 128 keys from 1024 keys on, of 32 below), nothing otherwise
+    ws = lib.coda_mha_bwd_ws_bytes
+    assert ws(8, 4, 2048, 2048, 64) == 4 * 8 * 4 * 2048 * 2048
+    assert ws(8, 4, 256, 2048, 64) == 4 * 8 * 4 * (2048 // 128) * 256 * 64
+    assert ws(8, 4, 256, 256, 64) == 4 * 8 * 4 * (256 // 32) * 256 * 64
+    assert ws(8, 4, 512, 2048, 64) == 4 * 8 * 4 * 16 * 512 * 64
+    for b, h, l, s, d in [(8, 4, 256, 2048, 128), (8, 4, 100, 2048, 64), (8, 4, 256, 1100, 64), (8, 4, 256, 77, 64),
+                          (0, 4, 256, 256, 64), (8, 4, 1024, 256, 64)]:
+        assert ws(b, h, l, s, d) == 0, (b, h, l, s, d)
 
 
 def test_python_signatures_have_the_arity_of_the_header():
