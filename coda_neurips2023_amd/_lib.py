@@ -181,6 +181,7 @@ SIGNATURES = {
                                              _P, ctypes.c_longlong, _P, _c_float, ctypes.c_uint64, _P]),
     "coda_mha_get_mfma_dtype": (_c_int, []),
     "coda_mha_timing_enable": (_c_int, [_c_int]),
+    "coda_mha_timing_enable_kinds": (_c_int, [_c_int, ctypes.c_uint]),
     "coda_mha_timing_collect": (_c_int, [_P, _P, _P, _P, _c_int]),
 }
 

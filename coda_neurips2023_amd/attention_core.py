@@ -198,10 +198,16 @@ def backward_workspace(b, h, l, s, d, dev, dt):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=dev), nbytes
 
 
-def enable_kernel_timing(min_len=0):
+def enable_kernel_timing(min_len=0, kinds=None):
     """Bracket every attention kernel of problems with l, s >= min_len with HIP events on its launch
-    stream (coda_mha_timing_enable); drops earlier records."""
-    _lib.check(_lib.load().coda_mha_timing_enable(int(min_len)), "coda_mha_timing_enable")
+    stream (coda_mha_timing_enable); drops earlier records.  kinds: names from TIMING_KINDS to record (default all)."""
+    if kinds is None:
+        _lib.check(_lib.load().coda_mha_timing_enable(int(min_len)), "coda_mha_timing_enable")
+        return
+    mask = 0
+    for k in kinds:
+        mask |= 1 << TIMING_KINDS.index(k)
+    _lib.check(_lib.load().coda_mha_timing_enable_kinds(int(min_len), mask), "coda_mha_timing_enable_kinds")
 
 
 def disable_kernel_timing():

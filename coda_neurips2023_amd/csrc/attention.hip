@@ -823,6 +823,235 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
   }
 }
 
+// ---- dK / dV with S and dP on the bf16 matrix cores at fp32 accuracy (round 6) ------------------------------------
+// Of the 8 units of L * S * d this kernel executes per head, the two that only FEED the soft-max backward -- S = Q K^T
+// (recomputed) and dP = dO V^T -- have both operands in memory: tiles that are staged once per workgroup and stage
+// (Q, dO) or once per wave (K, V).  Those operands are split into three bf16 pieces (x = hi + mid + lo exactly, as in
+// gemm_x3.hip) where they are staged, and S / dP become six piece products each on v_mfma_f32_32x32x16_bf16, fp32
+// accumulation: 24 MFMAs of 32 cycles per 32 x 32 tile instead of 32 MFMAs of 64 cycles -- 1536 instead of 4096 matrix
+// cycles per stage for the pair.  dV = Pd^T dO and dK = dS^T Q stay on the fp32 MFMA: their A operands are the
+// probabilities themselves, one split per ELEMENT, which is what holds the all-bf16x3 backward of attention_bf16.hip.
+//  * K / V pieces of the wave's 32 keys: hi and mid in 2 x 32 registers per lane (as many as the fp32 fragments they
+//    replace), the lo pieces -- one product in six -- in LDS, each lane reading back what it wrote (with all three in
+//    registers the kernel spilled 54 of them).
+//  * Q / dO pieces: [piece][query][64 bf16], rows 144 B apart (conflict-free ds_read_b128), written by the threads that
+//    stage the fp32 tile (16 elements of each per thread and stage); the fp32 tiles stay, as dV / dK's B operands.
+//  * The bf16 matrix core's accumulate truncates toward -inf (gemm_x3.hip, tools/x3_bias.py): a relative 1e-9 at k = 64,
+//    but of ONE sign.  The staged Q / dO pieces carry the sign (-1)^query, so S and dP arrive as (-1)^query * value -- a
+//    register's query parity is the parity of its index, the sign folds into constants of the soft-max backward -- and
+//    the drift alternates from one query row to the next: sums over queries (dK, dV) and over tokens (every weight
+//    gradient behind dQ) see noise, not a drift.
+//  * One stage = one query tile; everything in LDS is single-buffered (45 KB), the next tile waits in registers:
+//    barrier -- store (split) -- barrier per stage, the second workgroup of the CU fills the SIMDs meanwhile.
+// Plain problems only (no mask, whole tiles), head width 64; WDS as in mha_bwd_dkv_kernel.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct Bf3x4 {
+  bf16x4 p[3];
+};
+// x = hi + mid + lo exactly (round-to-nearest-even conversions; both residuals are exact in fp32)
+__device__ __forceinline__ Bf3x4 split3(f32x4 x) {
+  Bf3x4 r;
+  r.p[0] = __builtin_convertvector(x, bf16x4);
+  x = x - __builtin_convertvector(r.p[0], f32x4);
+  r.p[1] = __builtin_convertvector(x, bf16x4);
+  x = x - __builtin_convertvector(r.p[1], f32x4);
+  r.p[2] = __builtin_convertvector(x, bf16x4);
+  return r;
+}
+
+constexpr int kPieceRow = 144;                 // bytes: 64 bf16 + 16
+constexpr int kPiecePlane = kTile * kPieceRow;  // one piece of one 32 x 64 tile
+constexpr size_t kDkvX3Lds = sizeof(float) * (2 * kTile * 68 + 2 * kTile) + 6 * kPiecePlane + 2 * 4 * 4096;  // + K / V lo pieces of 4 waves: 76.25 KB, two workgroups per CU
+
+template <int KW, bool WDS>
+__global__ __launch_bounds__(KW * kWave, 2) void mha_bwd_dkv_x3_kernel(MhaBwdParams p) {
+  constexpr int D = 64, NT = 2, LS = D + 4, THREADS = KW * kWave;
+  constexpr int NLD = kTile * D / 4 / THREADS;  // float4 per thread and tile
+  static_assert(NLD >= 1 && kTile * D / 4 % THREADS == 0, "tile must divide over the threads");
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *s_q = s_dyn;
+  float *s_do = s_q + kTile * LS;
+  float *s_lse = s_do + kTile * LS;
+  float *s_delta = s_lse + kTile;
+  unsigned char *s_qp = reinterpret_cast<unsigned char *>(s_delta + kTile);  // three planes
+  unsigned char *s_gp = s_qp + 3 * kPiecePlane;
+
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const int aoff = l31 * kPieceRow + 16 * half;  // bytes: this lane's fragment of k block 0 in a piece plane
+  unsigned char *s_klo = s_gp + 3 * kPiecePlane + w * 8192 + 16 * lane;  // this wave's K / V lo pieces [k block][lane], this lane's
+  unsigned char *s_vlo = s_klo + 4096;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int k0 = (th.tile * KW + w) * kTile;
+  const int mykey = k0 + l31;
+  const bool wave_active = k0 < p.s;
+  const size_t rstride = static_cast<size_t>(p.b) * p.h * D;
+  const size_t head_off = (static_cast<size_t>(bi) * p.h + hi) * D;
+  const bool use_drop = p.thresh16 != 0u;
+  const uint32_t dconst = use_drop ? drop_const(effective_seed(p.seed, p.seed_dev), static_cast<uint32_t>(bh)) : 0u;
+  const size_t qstride = static_cast<size_t>(p.b) * p.ldq, kstride = static_cast<size_t>(p.b) * p.ldk,
+               vstride = static_cast<size_t>(p.b) * p.ldv;
+  const float *qbase = p.q + static_cast<size_t>(bi) * p.ldq + hi * D;
+  const float *kbase = p.k + static_cast<size_t>(bi) * p.ldk + hi * D;
+  const float *vbase = p.v + static_cast<size_t>(bi) * p.ldv + hi * D;
+
+  // B operands of S and dP: the pieces of K[mykey][16 j + 8 half + (0..7)], V likewise, j = 16-k block
+  bf16x8 kp[2][4], vp[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    if (mykey < p.s) {
+      const float *kr = kbase + static_cast<size_t>(mykey) * kstride + 16 * j + 8 * half;
+      const float *vr = vbase + static_cast<size_t>(mykey) * vstride + 16 * j + 8 * half;
+      a0 = *reinterpret_cast<const f32x4 *>(kr); a1 = *reinterpret_cast<const f32x4 *>(kr + 4);
+      b0 = *reinterpret_cast<const f32x4 *>(vr); b1 = *reinterpret_cast<const f32x4 *>(vr + 4);
+    }
+    const Bf3x4 ka = split3(a0), kb = split3(a1), va = split3(b0), vb = split3(b1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      kp[q][j] = __builtin_shufflevector(ka.p[q], kb.p[q], 0, 1, 2, 3, 4, 5, 6, 7);
+      vp[q][j] = __builtin_shufflevector(va.p[q], vb.p[q], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    *reinterpret_cast<bf16x8 *>(s_klo + 1024 * j) = __builtin_shufflevector(ka.p[2], kb.p[2], 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8 *>(s_vlo + 1024 * j) = __builtin_shufflevector(va.p[2], vb.p[2], 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  f32x16 dk[NT], dv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  float4 rq[NLD], rg[NLD];
+  float r_lse = 0.f, r_delta = 0.f;
+  auto fetch = [&](int qb) {
+    fetch_tile<D, THREADS, kTile>(rq, qbase, qstride, qb, p.l, tid);
+    fetch_tile<D, THREADS, kTile>(rg, p.dout + head_off, rstride, qb, p.l, tid);
+    if (tid < kTile) {
+      const int qq = qb + tid;
+      r_lse = qq < p.l ? p.lse[static_cast<size_t>(bh) * p.l + qq] * kLog2e : 0.f;  // log2 units
+      r_delta = qq < p.l ? p.delta[static_cast<size_t>(bh) * p.l + qq] : 0.f;
+    }
+  };
+  auto store = [&]() {
+    store_tile<D, THREADS, kTile>(s_q, rq, tid);
+    store_tile<D, THREADS, kTile>(s_do, rg, tid);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int i = tid + j * THREADS;
+      const int row = i / (D / 4), c4 = i % (D / 4);
+      const float sg = (row & 1) ? -1.f : 1.f;
+      const Bf3x4 pq = split3(f32x4{rq[j].x * sg, rq[j].y * sg, rq[j].z * sg, rq[j].w * sg});
+      const Bf3x4 pg = split3(f32x4{rg[j].x * sg, rg[j].y * sg, rg[j].z * sg, rg[j].w * sg});
+      const int off = row * kPieceRow + c4 * 8;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        *reinterpret_cast<bf16x4 *>(s_qp + q * kPiecePlane + off) = pq.p[q];
+        *reinterpret_cast<bf16x4 *>(s_gp + q * kPiecePlane + off) = pg.p[q];
+      }
+    }
+    if (tid < kTile) { s_lse[tid] = r_lse; s_delta[tid] = r_delta; }
+  };
+  fetch(0);
+  store();
+  lds_only_barrier();
+
+  const float sscale = p.scale * kLog2e;
+  for (int q0 = 0; q0 < p.l; q0 += kTile) {
+    const bool more = q0 + kTile < p.l;
+    if (more) fetch(q0 + kTile);  // in flight during this stage
+    if (wave_active) {
+      // (-1)^query * S[q][key] and (-1)^query * dP[q][key]: A = Q / dO piece rows (lane = query), B = K / V pieces (lane = key)
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 aq[3], ag[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          aq[q] = *reinterpret_cast<const bf16x8 *>(s_qp + q * kPiecePlane + aoff + 32 * j);
+          ag[q] = *reinterpret_cast<const bf16x8 *>(s_gp + q * kPiecePlane + aoff + 32 * j);
+        }
+        // the six products of order <= 2, small ones first
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[1], kp[1][j], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[1], vp[1][j], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], *reinterpret_cast<const bf16x8 *>(s_klo + 1024 * j), sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[0], *reinterpret_cast<const bf16x8 *>(s_vlo + 1024 * j), pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[2], kp[0][j], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[2], vp[0][j], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], kp[1][j], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[0], vp[1][j], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[1], kp[0][j], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[1], vp[0][j], pacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], kp[0][j], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag[0], vp[0][j], pacc, 0, 0, 0);
+      }
+      // lane: key = mykey, register r: query q0 + crow(r, half), whose parity is r & 1 (the staged sign)
+      float pd[16], ds[16];
+      const int par = l31 & 1;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float keep0 = 1.f, keep1 = 1.f;
+        if (use_drop) {  // one hash word per pair of adjacent keys (see mha_bwd_dkv_kernel)
+          const uint32_t mine = drop_hash(dconst, q0 + crow(r, half) + par, p.s, mykey);
+          const uint32_t other = __builtin_amdgcn_mov_dpp(mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+          keep0 = drop_keep(par ? other : mine, mykey, p.thresh16) ? p.inv_keep : 0.f;
+          keep1 = drop_keep(par ? mine : other, mykey, p.thresh16) ? p.inv_keep : 0.f;
+        }
+        const int qi = crow(r, half);
+        const f32x2 lse2 = {s_lse[qi], s_lse[qi + 1]}, del2 = {s_delta[qi], s_delta[qi + 1]};
+        const f32x2 keep2 = {keep0, keep1}, keeps2 = {keep0, -keep1};
+        const f32x2 s2 = {sacc[r], sacc[r + 1]}, dp2 = {pacc[r], pacc[r + 1]};
+        const f32x2 arg = __builtin_elementwise_fma(s2, f32x2{sscale, -sscale}, -lse2);
+        const f32x2 prob = {fast_exp2(arg[0]), fast_exp2(arg[1])};
+        const f32x2 pdv = prob * keep2;
+        const f32x2 dsv = prob * __builtin_elementwise_fma(dp2, keeps2, -del2);  // * scale: once, on the dK rows
+        pd[r] = pdv[0]; pd[r + 1] = pdv[1];
+        ds[r] = dsv[0]; ds[r + 1] = dsv[1];
+      }
+      if (WDS) {  // lane = key: the 32 lanes of a half-wave write 128 contiguous bytes of one query's row
+        float *dsb = p.ds + (static_cast<size_t>(bh) * p.l + q0) * p.s + k0;  // wave-uniform base, 32-bit lane offsets
+        const uint32_t off0 = static_cast<uint32_t>(4 * half) * static_cast<uint32_t>(p.s) + static_cast<uint32_t>(l31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_nontemporal_store(ds[r], dsb + off0 + static_cast<uint32_t>((r & 3) + 8 * (r >> 2)) * static_cast<uint32_t>(p.s));
+      }
+      // dV[key][c] += sum_q Pd[q][key] dO[q][c], dK[key][c] += sum_q dS[q][key] Q[q][c]  (A: lane = key, k = query)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = crow(r, half);
+        const float2 g2 = *reinterpret_cast<const float2 *>(s_do + qi * LS + NT * l31);
+        const float2 q2 = *reinterpret_cast<const float2 *>(s_q + qi * LS + NT * l31);
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.x, dv[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd[r], g2.y, dv[1], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.x, dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[r], q2.y, dk[1], 0, 0, 0);
+      }
+    }
+    lds_only_barrier();  // every wave is done with this stage's tiles
+    if (more) store();
+    lds_only_barrier();
+  }
+  // dk[t][r]: row i = crow(r, half) = key within the tile, column j = l31 <-> component NT*l31 + t
+  if (wave_active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + crow(r, half);
+      if (key < p.s) {
+        float *dkrow = p.dk + (static_cast<size_t>(key) * p.b + bi) * p.lddk + hi * D + NT * l31;
+        float *dvrow = p.dv + (static_cast<size_t>(key) * p.b + bi) * p.lddv + hi * D + NT * l31;
+        *reinterpret_cast<float2 *>(dkrow) = make_float2(dk[0][r] * p.scale, dk[1][r] * p.scale);
+        *reinterpret_cast<float2 *>(dvrow) = make_float2(dv[0][r], dv[1][r]);
+      }
+    }
+  }
+}
+
 // ---- the whole backward of a short query sequence against a long key sequence in ONE kernel (round 6) -------------
 // The decoder's cross-attention (256 queries x 2048 keys): the two-kernel form recomputes S in both kernels and dP in
 // the second one, 14 units of L * S * d per head for 8 algorithmic.  Here the dK/dV kernel's own dS also yields dQ:
@@ -838,7 +1067,6 @@ __global__ __launch_bounds__(KW * kWave, ((D == 64 && !QSPLIT) ? 2 : 1)) void mh
 //    dQ: deterministic, no atomics, no waiting among workgroups.
 // One Q / dO tile in LDS (the next one is in flight in registers during the stage's second half; delta = rowsum(dO * O)
 // is formed on its way into LDS), two LDS-only barriers per stage: 68 KB, two workgroups per CU.  Plain problems only (no mask, L % 32 == 0, S % (32 KW) == 0, head width 64).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // -DCODA_ATTN_PROF (tools/attn_phase_probe.py): shader-clock stamps of wave 0 of every workgroup of the short one-kernel
 // backward, written over `delta` (which that kernel does not use): [workgroup][16] clocks since the kernel's first stamp.
@@ -1791,6 +2019,7 @@ struct TimingRecord {
   hipEvent_t e0, e1;
 };
 int g_timing_min_len = -1;  // < 0: off
+unsigned g_timing_kinds = ~0u;  // bit k: kernels of kind k are recorded (coda_mha_timing_enable_kinds)
 std::vector<TimingRecord> g_timing;
 constexpr size_t kTimingCap = 16384;
 
@@ -1894,7 +2123,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_gemm_kernel(MhaBwdParams p)
 struct KernelTimer {
   bool armed = false;
   KernelTimer(int kind, int l, int s, hipStream_t) {
-    if (g_timing_min_len < 0 || l < g_timing_min_len || s < g_timing_min_len || g_timing.size() >= kTimingCap)
+    if (g_timing_min_len < 0 || l < g_timing_min_len || s < g_timing_min_len || g_timing.size() >= kTimingCap ||
+        !((g_timing_kinds >> kind) & 1u))
       return;
     TimingRecord r{kind, l, s, nullptr, nullptr};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
@@ -2032,7 +2262,22 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   auto run_dkv = [&]() -> int {
   if (!(p.parts & 2)) return CODA_OK;
   KernelTimer timer(2, p.l, p.s, s);
-  if (via_ds) {
+  // S and dP on the bf16 matrix cores at fp32 accuracy (mha_bwd_dkv_x3_kernel; CODA_ATTN_DKV_X3=0: all four products
+  // on the fp32 MFMA, A/B)
+  static const bool dkv_x3 = [] { const char *e = getenv("CODA_ATTN_DKV_X3"); return !e || atoi(e) != 0; }();
+  if (D == 64 && !GEN && dkv_x3 && p.s >= 1024 && p.l >= 1024 && double_buffered()) {
+    if (via_ds) {
+      auto kern = mha_bwd_dkv_x3_kernel<4, true>;
+      int st = set_lds(kern, kDkvX3Lds);
+      if (st != CODA_OK) return st;
+      mha_launch(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), kDkvX3Lds, s, p);
+    } else {
+      auto kern = mha_bwd_dkv_x3_kernel<4, false>;
+      int st = set_lds(kern, kDkvX3Lds);
+      if (st != CODA_OK) return st;
+      mha_launch(kern, dim3(ceil_div(p.s, kTile * 4), p.b * p.h), dim3(256), kDkvX3Lds, s, p);
+    }
+  } else if (via_ds) {
     auto kern = mha_bwd_dkv_kernel<D, 4, false, false, true, D == 64>;
     const size_t lds = 2 * (kTileBytes + kRowBytes);
     int st = set_lds(kern, lds);
@@ -2367,6 +2612,15 @@ CODA_API int coda_mha_timing_enable(int min_len) {
   using namespace coda;
   timing_clear();
   g_timing_min_len = min_len;
+  g_timing_kinds = ~0u;
+  return CODA_OK;
+}
+
+CODA_API int coda_mha_timing_enable_kinds(int min_len, unsigned kind_mask) {
+  using namespace coda;
+  timing_clear();
+  g_timing_min_len = min_len;
+  g_timing_kinds = kind_mask;
   return CODA_OK;
 }
 

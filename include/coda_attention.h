@@ -132,8 +132,13 @@ int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const ui
  * coda_mha_timing_collect synchronises the recorded events and writes up to `cap` records
  * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ, 4 dQ as the dS K GEMM, 5 the one-kernel backward, 6 the sum of its partial dQ
  * tiles; the call's l and s; milliseconds); returns the
- * number written, CODA_EINVAL, or -(1000 + hipError_t) if an event query failed. */
+ * number written, CODA_EINVAL, or -(1000 + hipError_t) if an event query failed.
+ * coda_mha_timing_enable_kinds additionally restricts the records to the kinds whose bit is set in `kind_mask`
+ * (bit k = kind k above).  A dispatch that carries events is not free for its NEIGHBOURS: the queue runs it with a
+ * completion signal of its own, and the kernel trace shows 5-9 us of idle queue before and after it (round 6:
+ * twelve timed launches per step cost the headline 1.5 %), so bench.py's timed region records the dominant kernel only. */
 int coda_mha_timing_enable(int min_len);
+int coda_mha_timing_enable_kinds(int min_len, unsigned kind_mask);
 int coda_mha_timing_collect(int *kind, int *l, int *s, float *ms, int cap);
 
 #ifdef __cplusplus
