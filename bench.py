@@ -65,9 +65,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_m
 # one recomputation; the two-kernel split executes 14.
 # dqg: dQ = dS K alone (dS from the dK/dV kernel's workspace); bwdf: the decoder cross-attention's one-kernel backward
 # (S, dP, dV, dK, dQ partial tiles: 10); dqr / delta: its partial-tile sum and rowsum(dO * O) -- no MFMA flops, their time counts
-ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2, "bwdf": 10, "dqr": 0, "delta": 0}
+ATTN_FLOPS = {"fwd": 4, "dkv": 8, "dq": 6, "dqg": 2, "bwdf": 10, "dqr": 0, "delta": 0, "ktp": 0}
 # of those, the units SURVEY 8d's ALGORITHMIC count credits (backward = 8: dV, dP, dK, dQ; recomputing S is extra work)
-ATTN_FLOPS_ALG = {"fwd": 4, "dkv": 6, "dq": 2, "dqg": 2, "bwdf": 8, "dqr": 0, "delta": 0}
+ATTN_FLOPS_ALG = {"fwd": 4, "dkv": 6, "dq": 2, "dqg": 2, "bwdf": 8, "dqr": 0, "delta": 0, "ktp": 0}
 ATTN_UNITS_NOTE = {"fwd": "4 algorithmic (QK^T, PV)",
                    "dkv": "6 algorithmic (dP, dV, dK) + 2 recomputed (S = QK^T)",
                    "dq": "2 algorithmic (dQ = dS K) + 4 recomputed (S, dP)",
@@ -453,7 +453,7 @@ def run_extra(kind, dev, steps, warmup):
         # by K/V delivery, not by the matrix cores
         kern = {}
         for (k, l, s_len), samples in sorted(attn_ms.items(), key=lambda kv: (-kv[0][1] * kv[0][2], kv[0][0])):
-            if k in ("delta", "dqr"):
+            if k in ("delta", "dqr", "ktp"):
                 continue
             ms = sum(samples) / len(samples)
             tf = ATTN_FLOPS[k] * l * s_len * 256 * B_PER_GPU / (ms * 1e-3) / 1e12
@@ -1121,9 +1121,10 @@ def main():
             # the part sustains 2.16 GHz under matrix load (tools/mfma_lds_probe.hip): what the nominal-clock peak becomes
             roofline["frac_of_sustained_clock_peak"] = round(roofline["achieved"] / (MFMA_F32_PEAK_TFLOPS * 2.16 / 2.4), 4)
             # (dK/dV from the timed region; delta and dQ from the extra steps when the timed region recorded dK/dV only)
-            src = {k: (attn_ms if (k, 2048, 2048) in attn_ms else attn_ms_all) for k in ("delta", "dkv", "dq", "dqg")}
+            bwd_kinds = ("delta", "dkv", "dq", "dqg", "ktp")
+            src = {k: (attn_ms if (k, 2048, 2048) in attn_ms else attn_ms_all) for k in bwd_kinds}
             t_bwd = sum(sum(src[k][(k, 2048, 2048)]) / len(src[k][(k, 2048, 2048)])
-                        for k in ("delta", "dkv", "dq", "dqg") if (k, 2048, 2048) in src[k])
+                        for k in bwd_kinds if (k, 2048, 2048) in src[k])
             # the encoder layer's whole attention backward (delta + dK/dV + dQ launches): what it EXECUTES (dK/dV 8 + dQ
             # GEMM 2 = 10 units of Lq * Lk * d through the dS workspace, 14 in the two-kernel form) and SURVEY 8d's
             # algorithmic 8.  (Rounds 4-5 printed `frac_whole_backward_8d` with 12 units credited -- more than either.)
@@ -1132,7 +1133,7 @@ def main():
             roofline["frac_whole_backward_algorithmic"] = round(8 * unit, 4)
             note = "HIP events around each launch, `steps` extra steps right after the timed region"
             for key in sorted(attn_ms_all, key=lambda k: (-k[1] * k[2], k[0])):
-                if key[0] not in ("delta", "dqr") and key != dom:
+                if key[0] not in ("delta", "dqr", "ktp") and key != dom:
                     others.append(attn_entry(key, attn_ms_all[key], note))
             # the six decoder-shaped kernels together (north_star: >= 50 % of the MFMA peak on decoder attention):
             # sum of the flops of one launch of each / sum of their event-timed durations

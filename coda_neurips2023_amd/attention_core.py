@@ -182,8 +182,9 @@ def attention(q, k, v, mask, scale, dropout_p, need_weights):
 
 
 # ---- measurement aid (bench.py): per-kernel HIP-event timing inside the C library ----------------
-# dqg: dQ as the dS K GEMM (coda_mha_bwd_ws_f32); bwdf: dK, dV and partial dQ tiles in one kernel; dqr: their sum
-TIMING_KINDS = ("fwd", "delta", "dkv", "dq", "dqg", "bwdf", "dqr")
+# dqg: dQ as the dS K GEMM (coda_mha_bwd_ws_f32); bwdf: dK, dV and partial dQ tiles in one kernel; dqr: their sum;
+# ktp: the bf16 K^T pieces of the bf16x3 dS K GEMM
+TIMING_KINDS = ("fwd", "delta", "dkv", "dq", "dqg", "bwdf", "dqr", "ktp")
 
 
 def backward_workspace(b, h, l, s, d, dev, dt):

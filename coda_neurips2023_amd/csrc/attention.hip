@@ -2120,6 +2120,128 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_gemm_kernel(MhaBwdParams p)
 }
 
 
+// ---- dQ = scale * dS K on the bf16 matrix cores at fp32 accuracy (round 6) ------------------------------------------
+// The dS K GEMM above reads its 537 MB once and runs at 60 % of the fp32 MFMA peak: neither bound.  With both operands
+// in three bf16 pieces the matrix work is 6/16 of that and the kernel becomes the HBM stream it should be.
+//  * K^T pieces are made ONCE per call by mha_kt_pieces_kernel: [head][chunk of 64 keys][piece][component][key slot],
+//    24 KB per chunk in one run -- the B operand wants 8 consecutive keys of one component per lane.  Inside a 16-key
+//    block the slots are ordered (keys 0-3, 8-11 | 4-7, 12-15) so that the two halves of the wave read ADJACENT 16-byte
+//    pieces of a dS row with each load instruction.  The pieces of the odd 16-key blocks are stored NEGATED.
+//  * dS fragments come straight from memory, two chunks ahead, and are split by the wave that multiplies them (every
+//    element of dS is used by one wave only: nothing to share through LDS).
+//  * Two accumulator sets: X takes the even 16-key blocks, Y the (negated) odd ones, dQ = scale * (X - Y) -- the bf16
+//    matrix core's accumulate truncates toward -inf (gemm_x3.hip): both sets carry the same drift and the difference
+//    keeps only its fluctuation.
+// A workgroup = 4 waves x 32 queries; K^T chunks double-buffered in LDS (rows 144 B apart), one LDS-only barrier per chunk.
+constexpr int kDqChunkBytes = 3 * 64 * 64 * 2;    // one K^T piece chunk in memory
+constexpr int kDqLdsBuf = 3 * 64 * kPieceRow;     // ... in LDS
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mha_kt_pieces_kernel(MhaBwdParams p, __bf16 *ktp) {
+  const int c = blockIdx.x, bh = blockIdx.y, bi = bh / p.h, hi = bh % p.h;
+  const int tid = threadIdx.x, key = tid & 63, kk = key & 15, jb = key >> 4;
+  const int slot = 16 * jb + 8 * ((kk >> 2) & 1) + (kk & 3) + 4 * (kk >> 3);
+  const float sg = (jb & 1) ? -1.f : 1.f;
+  const float *krow = p.k + (static_cast<size_t>(c * 64 + key) * p.b + bi) * p.ldk + hi * 64;
+  __bf16 *dst = ktp + (static_cast<size_t>(bh) * gridDim.x + c) * (3 * 64 * 64) + slot;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d4 = (tid >> 6) + 4 * i;
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(krow + 4 * d4);
+    const Bf3x4 sp = split3(x * sg);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(q * 64 + 4 * d4 + e) * 64] = sp.p[q][e];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(MhaBwdParams p, const unsigned char *ktp) {
+  constexpr int D = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_kt[];
+  const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const int half = lane >> 5, l31 = lane & 31;
+  const TileHead th = tile_head(p.xcd_map);
+  const int bh = th.bh, bi = bh / p.h, hi = bh % p.h;
+  const int q0 = (th.tile * 4 + w) * kTile;
+  const bool wave_active = q0 < p.l;
+  const int nch = p.s / 64;
+  const float *arow = p.ds + (static_cast<size_t>(bh) * p.l + (wave_active ? q0 + l31 : 0)) * p.s + 4 * half;
+  const unsigned char *kt = ktp + static_cast<size_t>(bh) * nch * kDqChunkBytes + 16 * tid;
+
+  f32x16 X[2], Y[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { X[t][r] = 0.f; Y[t][r] = 0.f; }
+
+  u32x4 rb[6];
+  f32x4 ra0[8], ra1[8];
+  auto fetch_b = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rb[i] = *reinterpret_cast<const u32x4 *>(kt + static_cast<size_t>(c) * kDqChunkBytes + 4096 * i);
+  };
+  auto fetch_a = [&](f32x4 (&ra)[8], int c) {  // block j: keys 16 j + 4 half + (0..3) and 16 j + 8 + 4 half + (0..3)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      ra[j] = (wave_active && c < nch) ? *reinterpret_cast<const f32x4 *>(arow + 64 * c + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  fetch_b(0);
+  fetch_a(ra0, 0);
+  fetch_a(ra1, 1);
+  const int boff = l31 * kPieceRow + 16 * half;  // this lane's B fragment: component l31 (+ 32 t), k block 0
+  for (int c = 0; c < nch; ++c) {
+    unsigned char *sb = s_kt + (c & 1) * kDqLdsBuf;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int e = tid + 256 * i;
+      *reinterpret_cast<u32x4 *>(sb + (e >> 3) * kPieceRow + (e & 7) * 16) = rb[i];
+    }
+    f32x4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = ra0[j]; ra0[j] = ra1[j]; }
+    lds_only_barrier();  // LDS only: the loads in flight stay in flight (two buffers: slower waves may still read the other one)
+    if (c + 1 < nch) fetch_b(c + 1);
+    fetch_a(ra1, c + 2);  // (past the end: predicated off)
+    if (wave_active) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Bf3x4 lo = split3(a[2 * j]), hi4 = split3(a[2 * j + 1]);
+        bf16x8 pa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pa[q] = __builtin_shufflevector(lo.p[q], hi4.p[q], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bf16x8 fb[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            fb[q] = *reinterpret_cast<const bf16x8 *>(sb + (q * 64 + 32 * t) * kPieceRow + boff + 32 * j);
+          f32x16 acc = (j & 1) ? Y[t] : X[t];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], fb[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], fb[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], fb[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[0], acc, 0, 0, 0);
+          if (j & 1) Y[t] = acc; else X[t] = acc;
+        }
+      }
+    }
+  }
+  if (wave_active) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + crow(r, half);
+      if (qq < p.l) {
+        float *row = p.dq + (static_cast<size_t>(qq) * p.b + bi) * p.lddq + hi * D + l31;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) row[32 * t] = (X[t][r] - Y[t][r]) * p.scale;
+      }
+    }
+  }
+}
+
+
 struct KernelTimer {
   bool armed = false;
   KernelTimer(int kind, int l, int s, hipStream_t) {
@@ -2247,6 +2369,16 @@ int launch_fwd(const MhaParams &p, hipStream_t s) {
   return gen ? launch_fwd_g<D, true>(p, s) : launch_fwd_g<D, false>(p, s);
 }
 
+// dQ of the dS route on the bf16x3 kernel (CODA_ATTN_DQ_X3=0: the fp32-MFMA GEMM, A/B); its K^T pieces live behind the
+// dS workspace (coda_mha_bwd_ws_bytes accounts for them)
+bool dq_x3_route(int s_len) {
+  static const bool on = [] { const char *e = getenv("CODA_ATTN_DQ_X3"); return !e || atoi(e) != 0; }();
+  return on && s_len % 64 == 0;
+}
+size_t dq_x3_ws_bytes(int b, int h, int s_len) {
+  return dq_x3_route(s_len) ? static_cast<size_t>(b) * h * (s_len / 64) * kDqChunkBytes : 0;
+}
+
 template <int D, bool GEN>
 int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   constexpr size_t kTileBytes = sizeof(float) * 2 * kTile * (D + 4);  // one Q + one dO (or K + V) tile
@@ -2307,6 +2439,20 @@ int launch_bwd_g(const MhaBwdParams &p, hipStream_t s) {
   auto run_dq = [&]() -> int {
   if (!(p.parts & 4)) return CODA_OK;
   if constexpr (D == 64) {
+    if (via_ds && dq_x3_route(p.s)) {  // bf16x3: K^T pieces behind the dS workspace, then the GEMM as an HBM stream
+      unsigned char *ktp = reinterpret_cast<unsigned char *>(p.ds + static_cast<size_t>(p.b) * p.h * p.l * p.s);
+      {
+        KernelTimer timer(7, p.l, p.s, s);  // kind 7: K^T pieces
+        mha_launch(mha_kt_pieces_kernel, dim3(p.s / 64, p.b * p.h), dim3(256), 0, s, p, reinterpret_cast<__bf16 *>(ktp));
+      }
+      KernelTimer timer(4, p.l, p.s, s);
+      auto kern = mha_bwd_dq_x3_kernel;
+      int st = set_lds(kern, 2 * kDqLdsBuf);
+      if (st != CODA_OK) return st;
+      mha_launch(kern, dim3(ceil_div(p.l, kTile * 4), p.b * p.h), dim3(256), 2 * kDqLdsBuf, s, p,
+                 static_cast<const unsigned char *>(ktp));
+      return CODA_OK;
+    }
     if (via_ds) {
       KernelTimer timer(4, p.l, p.s, s);  // kind 4: the dS K GEMM (2 L S d flops per head)
       // 64-key chunks: two workgroups per CU (181 registers); 128-key chunks with one measured slower (0.31 vs 0.25 ms)
@@ -2565,7 +2711,7 @@ CODA_API size_t coda_mha_bwd_ws_bytes(int b, int h, int l, int s, int d) {
   if (coda::fused_bwd_takes(b, h, l, s, d)) return coda::fused_bwd_ws_bytes(b, h, l, s, false);
   if (coda::fused_short_bwd_takes(b, h, l, s, d)) return coda::fused_bwd_ws_bytes(b, h, l, s, true);
   if (b <= 0 || h <= 0 || d != 64 || l < 1024 || s < 1024 || l % 32 != 0 || s % 32 != 0) return 0;
-  return sizeof(float) * static_cast<size_t>(b) * h * l * s;
+  return sizeof(float) * static_cast<size_t>(b) * h * l * s + coda::dq_x3_ws_bytes(b, h, s);  // dS + the K^T pieces of dQ
 }
 
 CODA_API int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const uint8_t *mask, const float *out,

@@ -40,6 +40,8 @@ def _call(name, *args):
 
 # measurement aid (bench.py's roofline figures of the MFMA kernels): HIP events on the launch stream around each call
 _TIMING = None
+# dev probe: workgroups of the two forward MFMA launches (0: the library's 2 per CU); see DESIGN.md section 7, round 6
+_FWD_BLOCKS = int(os.environ.get("CODA_SA_FWD_BLOCKS", "0"))
 
 
 def enable_kernel_timing():
@@ -370,7 +372,7 @@ class _MfmaMlpPool(torch.autograd.Function):
         c1, c2, c3 = (w.shape[0] for w in ws)
         world = [dist.get_world_size(bn.process_group) if _is_sync(bn) else 1 for bn in bns]
         n_rows = groups * nsample  # rows the statistics are taken over (copies included)
-        nblk = lib.coda_sa_mfma_blocks(0)
+        nblk = _FWD_BLOCKS or lib.coda_sa_mfma_blocks(0)
         f32 = dict(dtype=torch.float32, device=dev)
         s1, s2, s3 = sums[:2 * c1], sums[2 * c1:2 * (c1 + c2)], sums[2 * (c1 + c2):]
 

@@ -108,6 +108,11 @@ int coda_mha_get_mfma_dtype(void);
  * in the workspace, (B, H, L, S) floats, and dQ = scale dS K is a plain GEMM -- the backward then executes S, dP, dV,
  * dK, dQ once each (10 L S d flops per head) instead of recomputing S and dP in a second kernel (14).  Same results
  * as the two-kernel form up to the summation order of dQ.  The workspace is scratch: nothing is kept in it.
+ * Round 6: of those five products, S and dP (inside the dK/dV kernel: both operands are staged tiles) and the dS K GEMM
+ * run on the bf16 matrix cores with every operand in three bf16 pieces (x = hi + mid + lo exactly, six piece products,
+ * fp32 accumulation; errors below the fp32 MFMA's own, drift of the bf16 accumulate cancelled by alternating signs);
+ * the GEMM's K^T pieces take another 24 KB per head and 64 keys behind dS (when s is a multiple of 64), which
+ * coda_mha_bwd_ws_bytes includes.  CODA_ATTN_DKV_X3=0 / CODA_ATTN_DQ_X3=0: the fp32-MFMA forms (A/B).
  *
  * Short query sequences (round 6; l < 1024, whole 32-row tiles, head width 64, no mask, fp32 MFMA operands -- the
  * decoder's cross-attention, s >= 1024 and a multiple of 128, and its self-attention, s < 1024): ONE kernel forms dK, dV
@@ -131,7 +136,7 @@ int coda_mha_bwd_ws_f32(const float *q, const float *k, const float *v, const ui
  * coda_mha_timing_enable(min_len < 0) disables; every call drops the records taken so far.
  * coda_mha_timing_collect synchronises the recorded events and writes up to `cap` records
  * (kind: 0 forward, 1 delta, 2 dK/dV, 3 dQ, 4 dQ as the dS K GEMM, 5 the one-kernel backward, 6 the sum of its partial dQ
- * tiles; the call's l and s; milliseconds); returns the
+ * tiles, 7 the bf16 K^T pieces of the bf16x3 dS K GEMM; the call's l and s; milliseconds); returns the
  * number written, CODA_EINVAL, or -(1000 + hipError_t) if an event query failed.
  * coda_mha_timing_enable_kinds additionally restricts the records to the kinds whose bit is set in `kind_mask`
  * (bit k = kind k above).  A dispatch that carries events is not free for its NEIGHBOURS: the queue runs it with a

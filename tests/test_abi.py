@@ -49,10 +49,11 @@ def test_workspace_queries_run_without_gpu():
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 20000, 2048) == 8 * 20000 * 16  # sorted records
     assert lib.coda_furthest_point_sampling_workspace_bytes(8, 100000, 2048) == 8 * 100000 * 4
     assert lib.coda_ball_query_workspace_bytes(8, 20000, 2048, 64) >= 0
-    # attention backward (include/coda_attention.h): dS for the encoder's long sequences, the key blocks' partial dQ tiles
+    # attention backward (include/coda_attention.h): dS (+ the bf16 K^T pieces of the dQ GEMM, 24 KB per head and 64 keys) for
+    # the encoder's long sequences, the key blocks' partial dQ tiles
     # for the decoder's short query sequences (blocks of 128 keys from 1024 keys on, of 32 below), nothing otherwise
     ws = lib.coda_mha_bwd_ws_bytes
-    assert ws(8, 4, 2048, 2048, 64) == 4 * 8 * 4 * 2048 * 2048
+    assert ws(8, 4, 2048, 2048, 64) == 4 * 8 * 4 * 2048 * 2048 + 8 * 4 * (2048 // 64) * 24576  # dS + the K^T pieces of dQ
     assert ws(8, 4, 256, 2048, 64) == 4 * 8 * 4 * (2048 // 128) * 256 * 64
     assert ws(8, 4, 256, 256, 64) == 4 * 8 * 4 * (256 // 32) * 256 * 64
     assert ws(8, 4, 512, 2048, 64) == 4 * 8 * 4 * 16 * 512 * 64
