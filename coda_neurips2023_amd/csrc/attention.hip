@@ -2176,33 +2176,33 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(MhaBwdParams p, c
     for (int r = 0; r < 16; ++r) { X[t][r] = 0.f; Y[t][r] = 0.f; }
 
   u32x4 rb[6];
-  f32x4 ra0[8], ra1[8];
+  f32x4 r0[8], r1[8], r2[8];  // dS fragments of three consecutive chunks; the loop is unrolled three times so that the
+                              // sets rotate by NAME (a copy of a set would have to wait for its loads)
   auto fetch_b = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) rb[i] = *reinterpret_cast<const u32x4 *>(kt + static_cast<size_t>(c) * kDqChunkBytes + 4096 * i);
   };
-  auto fetch_a = [&](f32x4 (&ra)[8], int c) {  // block j: keys 16 j + 4 half + (0..3) and 16 j + 8 + 4 half + (0..3)
+  // block j: keys 16 j + 4 half + (0..3) and 16 j + 8 + 4 half + (0..3).  Unconditional loads (past the end: the last
+  // chunk again, unused; an idle wave reads row 0): with a predicate per load hipcc turns every one into a branch and
+  // its wait counts drain ALL loads in flight at the top of each iteration -- the two-chunks-ahead prefetch was one
+  auto fetch_a = [&](f32x4 (&ra)[8], int c) {
+    const float *src = arow + 64 * (c < nch ? c : nch - 1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      ra[j] = (wave_active && c < nch) ? *reinterpret_cast<const f32x4 *>(arow + 64 * c + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) ra[j] = *reinterpret_cast<const f32x4 *>(src + 8 * j);
   };
-  fetch_b(0);
-  fetch_a(ra0, 0);
-  fetch_a(ra1, 1);
   const int boff = l31 * kPieceRow + 16 * half;  // this lane's B fragment: component l31 (+ 32 t), k block 0
-  for (int c = 0; c < nch; ++c) {
+  // one chunk: K^T pieces of chunk c (in rb) to LDS, barrier, loads of chunk c + 1 (K^T) and c + 2 (dS, into the set
+  // the previous step has consumed), then 48 MFMAs on this chunk's dS fragments
+  auto step = [&](int c, f32x4 (&a)[8], f32x4 (&nxt)[8]) {
     unsigned char *sb = s_kt + (c & 1) * kDqLdsBuf;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int e = tid + 256 * i;
       *reinterpret_cast<u32x4 *>(sb + (e >> 3) * kPieceRow + (e & 7) * 16) = rb[i];
     }
-    f32x4 a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a[j] = ra0[j]; ra0[j] = ra1[j]; }
     lds_only_barrier();  // LDS only: the loads in flight stay in flight (two buffers: slower waves may still read the other one)
-    if (c + 1 < nch) fetch_b(c + 1);
-    fetch_a(ra1, c + 2);  // (past the end: predicated off)
+    fetch_b(c + 1 < nch ? c + 1 : c);
+    fetch_a(nxt, c + 2);
     if (wave_active) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -2227,7 +2227,18 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(MhaBwdParams p, c
         }
       }
     }
+  };
+  fetch_b(0);
+  fetch_a(r0, 0);
+  fetch_a(r1, 1);
+  int c = 0;
+  for (; c + 3 <= nch; c += 3) {  // (unrolled six times -- one drain of the loads per six chunks at the loop header instead of per three -- measured the same)
+    step(c, r0, r2);
+    step(c + 1, r1, r0);
+    step(c + 2, r2, r1);
   }
+  if (c < nch) { step(c, r0, r2); ++c; }
+  if (c < nch) step(c, r1, r0);
   if (wave_active) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -42,6 +42,7 @@ def _call(name, *args):
 _TIMING = None
 # dev probe: workgroups of the two forward MFMA launches (0: the library's 2 per CU); see DESIGN.md section 7, round 6
 _FWD_BLOCKS = int(os.environ.get("CODA_SA_FWD_BLOCKS", "0"))
+_LEAVE_SAMPLING_CUS = os.environ.get("CODA_SA_LEAVE_SAMPLING_CUS", "1") != "0"  # A/B
 
 
 def enable_kernel_timing():
@@ -373,6 +374,13 @@ class _MfmaMlpPool(torch.autograd.Function):
         world = [dist.get_world_size(bn.process_group) if _is_sync(bn) else 1 for bn in bns]
         n_rows = groups * nsample  # rows the statistics are taken over (copies included)
         nblk = _FWD_BLOCKS or lib.coda_sa_mfma_blocks(0)
+        if not _FWD_BLOCKS and _LEAVE_SAMPLING_CUS:
+            # the next batch's sampling front may be running on the side stream and holds whole CUs: two workgroups for
+            # each FREE CU (any count is correct -- the kernels split the rows evenly over their grid)
+            from .pointnet2_utils import sampling_busy_cus
+            busy = sampling_busy_cus()
+            if busy:
+                nblk = max(nblk // 2, nblk - 2 * busy)
         f32 = dict(dtype=torch.float32, device=dev)
         s1, s2, s3 = sums[:2 * c1], sums[2 * c1:2 * (c1 + c2)], sums[2 * (c1 + c2):]
 
