@@ -1085,6 +1085,19 @@ def main():
             if bq_alone_ms else None,
         }
 
+        # Round 6: the long-sequence backward (l, s >= 1024, whole tiles, head width 64: the encoder's launches) runs
+        # part of its products on the bf16 matrix cores with three-piece operands -- six bf16 products per fp32 product,
+        # 2500 / 6 = 416.7 TFLOP/s-equivalent.  Units of (Lq * Lk * 256 * scenes * 2 flops) on that pipe per kind:
+        x3_dkv = os.environ.get("CODA_ATTN_DKV_X3", "1") != "0"
+        x3_dq = any(k[0] == "ktp" for k in attn_ms_all) or any(k[0] == "ktp" for k in attn_ms)
+        x3_fwd = os.environ.get("CODA_ATTN_FWD_X3", "1") != "0"  # the encoder's forward: the fused core's three-piece mode
+        MFMA_X3_PEAK = MFMA_BF16_PEAK_TFLOPS / 6.0
+
+        def x3_units(k, l, s_len):
+            if l < 1024 or s_len < 1024 or l % 32 or s_len % 32:
+                return 0
+            return {"dkv": 4 if x3_dkv else 0, "dqg": 2 if x3_dq else 0, "fwd": 4 if x3_fwd else 0}.get(k, 0)
+
         def attn_entry(key, samples, timing_note):
             k, l, s_len = key
             ms = sum(samples) / len(samples)
@@ -1092,15 +1105,40 @@ def main():
             tf = flops / (ms * 1e-3) / 1e12
             names = {"fwd": "mha_fwd_kernel", "dkv": "mha_bwd_dkv_kernel", "dq": "mha_bwd_dq_kernel",
                      "dqg": "mha_bwd_dq_gemm_kernel", "bwdf": "mha_bwd_fused_kernel", "dqr": "mha_dq_reduce_kernel"}
-            return {"kernel": f"{names[k]} (queries {l} x keys {s_len}, {B_PER_GPU} scenes x 4 heads x 64, "
-                              f"dropout 0.1)",
-                    "timing": timing_note, "bound": "mfma", "achieved": round(tf, 2),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                    "traffic": None, "flops_per_launch": flops,
-                    "flops_formula": f"{ATTN_FLOPS[k]} * Lq * Lk * 256 * scenes = EXECUTED MFMA flops: " + ATTN_UNITS_NOTE[k],
-                    # the same launch on SURVEY 8d's algorithmic count (recomputed products not credited)
-                    "frac_algorithmic": round(tf * ATTN_FLOPS_ALG[k] / ATTN_FLOPS[k] / MFMA_F32_PEAK_TFLOPS, 4),
-                    "avg_launch_ms": round(ms, 5), "launches": len(samples)}
+            ux = x3_units(k, l, s_len)
+            name = names[k]
+            # the peak a launch is priced against: its products on the fp32 MFMA at 157.3 TFLOP/s, those on the
+            # three-piece bf16 path at 416.7 TFLOP/s-equivalent -- the harmonic blend by units (all-fp32 launches: 157.3)
+            peak = ATTN_FLOPS[k] / ((ATTN_FLOPS[k] - ux) / MFMA_F32_PEAK_TFLOPS + ux / MFMA_X3_PEAK) if ATTN_FLOPS[k] else MFMA_F32_PEAK_TFLOPS
+            e = {"kernel": f"{name} (queries {l} x keys {s_len}, {B_PER_GPU} scenes x 4 heads x 64, "
+                           f"dropout 0.1)",
+                 "timing": timing_note, "bound": "mfma", "achieved": round(tf, 2),
+                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                 "traffic": None, "flops_per_launch": flops,
+                 "flops_formula": f"{ATTN_FLOPS[k]} * Lq * Lk * 256 * scenes = EXECUTED MFMA flops (fp32-equivalent): " + ATTN_UNITS_NOTE[k],
+                 # the same launch on SURVEY 8d's algorithmic count (recomputed products not credited)
+                 "frac_algorithmic": round(tf * ATTN_FLOPS_ALG[k] / ATTN_FLOPS[k] / peak, 4),
+                 "avg_launch_ms": round(ms, 5), "launches": len(samples)}
+            if ux:
+                pipes = {"dkv": "S and dP (4 units: both operands are staged tiles) on v_mfma_f32_32x32x16_bf16 with "
+                                "three-piece operands, dV and dK (4 units) on the fp32 MFMA",
+                         "dqg": "the whole product on v_mfma_f32_32x32x16_bf16 with three-piece operands; the launch "
+                                "streams dS (537 MB) once: see hbm_frac",
+                         "fwd": "both products on v_mfma_f32_32x32x16_bf16 with three-piece operands (the probabilities are "
+                                "split per element: the soft-max + split vector work bounds this launch, DESIGN.md section 4)"}[k]
+                e["kernel"] = e["kernel"].replace(name, {"dkv": "mha_bwd_dkv_x3_kernel", "dqg": "mha_bwd_dq_x3_kernel",
+                                                         "fwd": "mha_fwd_bf16_kernel<three pieces>"}[k])
+                e["peak_note"] = (f"{ux} of {ATTN_FLOPS[k]} units at 2500 / 6 = 416.7 TFLOP/s-equivalent (six bf16 piece "
+                                  f"products per fp32 product), the rest at the fp32 MFMA's 157.3: {pipes}.  Rounds 1-5 "
+                                  "priced this launch against 157.3 alone (frac_of_fp32_mfma_peak keeps that reading; it is "
+                                  "not bounded by 1 any more)")
+                e["frac_of_fp32_mfma_peak"] = round(tf / MFMA_F32_PEAK_TFLOPS, 4)
+                e["arithmetic"] = "fp32-accurate: operands split exactly into three bf16 pieces, fp32 accumulation"
+            if k == "dqg":
+                by = 4 * B_PER_GPU * 4 * l * s_len
+                e["hbm_bytes_algorithmic"] = by + 2 * B_PER_GPU * s_len * 256 * 4
+                e["hbm_frac"] = round(e["hbm_bytes_algorithmic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            return e
 
         roofline, others = bq_roofline, []
         dom = ("dkv", 2048, 2048)
@@ -1119,7 +1157,7 @@ def main():
             if via_ds:
                 roofline["traffic_algorithmic"] = 5 * 16_777_216 + 536_870_912 + 2 * 16_777_216  # Q K V dO O in; dS dK dV out
             # the part sustains 2.16 GHz under matrix load (tools/mfma_lds_probe.hip): what the nominal-clock peak becomes
-            roofline["frac_of_sustained_clock_peak"] = round(roofline["achieved"] / (MFMA_F32_PEAK_TFLOPS * 2.16 / 2.4), 4)
+            roofline["frac_of_sustained_clock_peak"] = round(roofline["achieved"] / (roofline["peak"] * 2.16 / 2.4), 4)
             # (dK/dV from the timed region; delta and dQ from the extra steps when the timed region recorded dK/dV only)
             bwd_kinds = ("delta", "dkv", "dq", "dqg", "ktp")
             src = {k: (attn_ms if (k, 2048, 2048) in attn_ms else attn_ms_all) for k in bwd_kinds}
@@ -1128,9 +1166,15 @@ def main():
             # the encoder layer's whole attention backward (delta + dK/dV + dQ launches): what it EXECUTES (dK/dV 8 + dQ
             # GEMM 2 = 10 units of Lq * Lk * d through the dS workspace, 14 in the two-kernel form) and SURVEY 8d's
             # algorithmic 8.  (Rounds 4-5 printed `frac_whole_backward_8d` with 12 units credited -- more than either.)
-            unit = 2048 * 2048 * 256 * B_PER_GPU / (t_bwd * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
-            roofline["frac_whole_backward_executed"] = round((10 if via_ds else 14) * unit, 4)
+            # priced like the single launches: the units on the three-piece bf16 path at 416.7, the others at 157.3
+            n_exec = 10 if via_ds else 14
+            n_x3 = (x3_units("dkv", 2048, 2048) + x3_units("dqg", 2048, 2048)) if via_ds else 0
+            peak_bwd = n_exec / ((n_exec - n_x3) / MFMA_F32_PEAK_TFLOPS + n_x3 / MFMA_X3_PEAK)
+            unit = 2048 * 2048 * 256 * B_PER_GPU / (t_bwd * 1e-3) / 1e12 / peak_bwd
+            roofline["frac_whole_backward_executed"] = round(n_exec * unit, 4)
             roofline["frac_whole_backward_algorithmic"] = round(8 * unit, 4)
+            roofline["whole_backward_peak_tflops"] = round(peak_bwd, 1)
+            roofline["whole_backward_ms"] = round(t_bwd, 5)
             note = "HIP events around each launch, `steps` extra steps right after the timed region"
             for key in sorted(attn_ms_all, key=lambda k: (-k[1] * k[2], k[0])):
                 if key[0] not in ("delta", "dqr", "ktp") and key != dom:

@@ -198,9 +198,12 @@ class _MHA(torch.autograd.Function):
         dt = _lib.opt("mfma_dtype")  # per-call MFMA operand type (this thread's option), kept for the backward
         # Long unmasked sequences in fp32 mode (the encoder's 2048 x 2048): the FORWARD core runs its products as three
         # bf16 pieces on the real matrix cores (mode 2 of include/coda_attention.h: fp32-level accuracy,
-        # tests/test_attention_x3_gpu.py; 258 against 352 us per layer, tools/bench_attn.py), the backward stays on the
-        # fp32 MFMA -- its kernels gain little in that mode (594 against 651 us), and a gradient is where the bf16 matrix
-        # core's rounding bias would matter (csrc/gemm_x3.hip).  CODA_ATTN_FWD_X3=0: fp32 MFMA forward too (A/B).
+        # tests/test_attention_x3_gpu.py; 258 against 352 us per layer, tools/bench_attn.py).  The backward is NOT run
+        # in that mode as a whole (594 against 651 us: the probabilities would be split per element); since round 6 its
+        # own kernels put the products whose operands are staged tiles -- S, dP, dQ = dS K -- on the bf16 matrix cores
+        # and keep dV / dK on the fp32 MFMA (csrc/attention.hip, mha_bwd_dkv_x3_kernel / mha_bwd_dq_x3_kernel: 567 + 150
+        # against 644 + 185 us), with alternating signs against the bf16 accumulate's drift (csrc/gemm_x3.hip).
+        # CODA_ATTN_FWD_X3=0: fp32 MFMA forward too (A/B).
         fwd_dt = dt
         if (_FWD_X3 and mask_u8 is None and tgt_len >= 1024 and src_len >= 1024 and d == 64
                 and (dt == 0 or (dt < 0 and lib.coda_mha_get_mfma_dtype() == 0))):

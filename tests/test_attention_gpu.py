@@ -320,3 +320,39 @@ def test_one_kernel_backward_equals_the_two_kernel_form(dev, monkeypatch, l, s, 
         _, again = grads("1")
         for a, r in zip(again, g1):
             assert torch.equal(a, r)
+
+
+def test_long_backward_on_the_bf16_matrix_cores_is_fp32_accurate(dev):
+    """Round 6: the encoder-shaped backward (l, s >= 1024) forms S, dP (mha_bwd_dkv_x3_kernel) and dQ = dS K
+    (mha_bwd_dq_x3_kernel) from three-piece bf16 operands.  Against the same attention in FLOAT64: every gradient is at
+    least as close as a plain fp32 torch evaluation is allowed to be (2x its own distance), and so are the sums over
+    the token axis -- the reductions every bias / LayerNorm gradient behind the attention performs, where a rounding
+    DRIFT of one sign (the bf16 matrix core's accumulate truncates toward -inf; the kernels alternate signs against it)
+    would collect 2048-fold."""
+    l = s = 2048
+    b, h, d = 1, 4, 64
+    leaves, q, k, v = make_qkv(dev, l, s, b, h, d, False, seed=2026)
+    scale = d ** -0.5
+    g = torch.Generator().manual_seed(5)
+    gw = (torch.randn(l, b, h, d, generator=g) + 0.25).to(dev)  # a non-zero mean: sums over tokens do not cancel by luck
+    out, _ = attention_core.attention(q, k, v, None, scale, 0.0, False)
+    ours = torch.autograd.grad((out * gw).sum(), leaves)
+
+    def torch_grads(dt):
+        q2, k2, v2 = (t.detach().to(dt).requires_grad_(True) for t in (q, k, v))
+        sc = torch.einsum("lbhd,sbhd->bhls", q2, k2) * scale
+        o = torch.einsum("bhls,sbhd->lbhd", torch.softmax(sc, -1), v2)
+        return torch.autograd.grad((o * gw.to(dt)).sum(), (q2, k2, v2))
+
+    ref64 = torch_grads(torch.float64)
+    ref32 = torch_grads(torch.float32)
+    for name, a, r32, r64 in zip("qkv", ours, ref32, ref64):
+        scale64 = float(r64.abs().max())
+        e_ours = float((a.double() - r64).abs().max()) / scale64
+        e_32 = float((r32.double() - r64).abs().max()) / scale64
+        assert e_ours <= 2.0 * e_32 + 1e-7, (name, e_ours, e_32)
+        col64 = r64.sum(0)
+        cscale = float(col64.abs().max())
+        c_ours = float((a.double().sum(0) - col64).abs().max()) / cscale
+        c_32 = float((r32.double().sum(0) - col64).abs().max()) / cscale
+        assert c_ours <= 2.0 * c_32 + 1e-6, (name, "sum over tokens", c_ours, c_32)
