@@ -28,6 +28,7 @@ python $R/tools/prof_summary.py $(find $R/gpurun_out/final_prof -name run_kernel
 python $R/tools/trace_by_grid.py $(find $R/gpurun_out/final_prof -name run_kernel_trace.csv) _kernel > $R/gpurun_out/final_prof/all_by_grid.csv
 find $R/gpurun_out/final_prof -name run_kernel_trace.csv -delete   # tens of MB; the stats file is what gets committed
 cd $R
+export PMC_TAG=r06
 if [ -z "$SKIP_PMC" ]; then   # (SKIP_PMC=1: the counter passes, when the kernels they look at have not changed)
 timeout 300 python tools/sa_prof.py > gpurun_out/final_sa_prof.txt 2>&1
 bash tools/pmc_sa.sh > /dev/null 2>&1
