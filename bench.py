@@ -36,6 +36,8 @@ import os
 import sys
 import time
 
+T_PROCESS_START = time.perf_counter()  # (value_unchanged's two readings carry their time since process start)
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -946,23 +948,28 @@ def main():
             clip2()
             opt2.step()
 
-        for i in range(3):
-            plain_step(i)
-        if world > 1:
-            dist.barrier()
-        sync()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            plain_step(i)
-        sync()
-        if world > 1:
-            dist.barrier()
-        sync()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
+        def time_unchanged():
+            for i in range(3):
+                plain_step(i)
+            if world > 1:
+                dist.barrier()
+            sync()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                plain_step(i)
+            sync()
+            if world > 1:
+                dist.barrier()
+            sync()
+            dt = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
+
+        dt2 = time_unchanged()
+        unchanged_at_s = time.perf_counter() - T_PROCESS_START
         unchanged = {"value": round(world * B_PER_GPU * args.steps / dt2, 3), "unit": "scenes/s",
                      "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                      "what": "the same step through the reference's unchanged call sequence (engine.py:136-164): "
@@ -970,7 +977,6 @@ def main():
                              "blocking loss.item() finite check / backward / torch clip_grad_norm_ + torch AdamW, no "
                              "sampling prefetch" + (", SyncBatchNorm + torch DistributedDataParallel (main.py:993-996)"
                                                     if world > 1 else "")}
-        del opt2
 
     # Multi-GPU diagnostics (rank 0 reports, every rank takes part): the collectives of a step timed in isolation with
     # HIP events -- the two segments of the flat gradient all-reduce and one SyncBatchNorm statistics all-reduce --
@@ -1345,6 +1351,24 @@ def main():
                                     "configs[2]_with_image_branch": run_extra("distill", dev, ex_steps, ex_warm)}
         if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(kind)
+        if (world == 1 and not dry and unchanged is not None and ("extra_configs" in out or "cpu_baseline" in out)
+                and os.environ.get("CODA_BENCH_UNCHANGED_REPEAT", "1") != "0"):
+            # The unchanged caller once more, at the END of the run (same loop, same step count).  Its host side is the
+            # heavier one (torch's optimizer and clip, a blocking .item() per step: host time adds to GPU time), so a box
+            # that is still busy with its own start-up shows here first: the first process on a fresh box read 348-358
+            # scenes/s where every later process of the same box read 491-498 (tools/ab_default.sh; the headline leg
+            # waits such a phase out with its slack probe, this leg cannot -- it is host-serialised by construction).
+            # Both readings stay in the record with their time since process start; the steady-state figure is the
+            # larger one.
+            dt3 = time_unchanged()
+            again = round(world * B_PER_GPU * args.steps / dt3, 3)
+            unchanged["readings"] = [{"value": unchanged["value"], "at_s": round(unchanged_at_s, 1)},
+                                     {"value": again, "at_s": round(time.perf_counter() - T_PROCESS_START, 1)}]
+            if again > unchanged["value"]:
+                unchanged["value"] = again
+                unchanged["ms_per_step"] = round(dt3 / args.steps * 1e3, 4)
+            out["config"]["value_unchanged"] = out["value_unchanged"] = unchanged["value"]
+            out["ms_per_step_unchanged"] = unchanged["ms_per_step"]
         if dry:
             out.update(metric="dry run (control flow only)", data="none", dtype="f32")
         line = compact_line(out, dry)
