@@ -92,6 +92,10 @@ SIGNATURES = {
     "coda_tok_add_ln_bwd_blocks": (_c_int, [ctypes.c_longlong, _c_int]),
     "coda_tok_add_ln_bwd_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_float,
                                          ctypes.c_uint64, _P, _P, _P, _P, _P, _P]),
+    "coda_tok_add_ln_fwd2_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_float,
+                                          _c_float, ctypes.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "coda_tok_add_ln_bwd2_f32": (_c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_int, _c_float,
+                                          ctypes.c_uint64, _P, _c_int, _P, _P, _c_int, _P, _P, _P, _P, _P]),
     "coda_tok_colsum_finalize_f32": (_c_int, [_P, _c_int, _c_int, _P, _P]),
     "coda_tok_colsum_blocks": (_c_int, [ctypes.c_longlong, _c_int]),
     "coda_tok_colsum_f32": (_c_int, [_P, _c_int, ctypes.c_longlong, _c_int, _P, _P, _P]),

@@ -7,6 +7,8 @@
 #include "coda_token_ops.h"
 #include "common.hip.h"
 
+#include <cstdlib>
+
 #include <vector>
 
 namespace coda {
@@ -78,6 +80,12 @@ int dgrad(int m, int k, int nprime, const float *dy, long long lddy, const float
   return gemm_auto(0, m, k, nprime, dy, lddy, w, ldw, dx, k, nullptr, accumulate, s);
 }
 
+// CODA_DEC_LN2=0: the layer-output norm and the next layer's norm1 as separate launches, forward and backward (A/B)
+inline bool fuse_ln2() {
+  static const bool on = [] { const char *e = getenv("CODA_DEC_LN2"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 #define CODA_TRY(expr)           \
   do {                           \
     const int st__ = (expr);     \
@@ -131,9 +139,11 @@ CODA_API int coda_decoder_stack_fwd_f32(const CodaDecoderStack *a, void *stream)
                 *in2 = P[8], *ib2 = P[9], *ow2 = P[10], *ob2 = P[11], *g3 = P[12], *b3n = P[13], *w1 = P[14], *fb1 = P[15],
                 *w2 = P[16], *fb2 = P[17];
     float *W = a->ws + lw.total * l;
-    // 1. y1 = LN1(res), y1p = y1 + query_pos
-    CODA_TRY(coda_tok_add_ln_fwd_f32(res, nullptr, nullptr, a->query_pos, g1, b1n, R, E, a->eps, 0.f, 0, nullptr, nullptr,
-                                     W + lw.y1, W + lw.y1p, W + lw.mean1, W + lw.rstd1, stream));
+    // 1. y1 = LN1(res), y1p = y1 + query_pos -- for l > 0 already written by the layer below (step 7: the decoder's norm
+    //    and this norm1 normalise the same s4 with the same mean / rstd; CODA_DEC_LN2=0: one launch each, A/B)
+    if (l == 0 || !fuse_ln2())
+      CODA_TRY(coda_tok_add_ln_fwd_f32(res, nullptr, nullptr, a->query_pos, g1, b1n, R, E, a->eps, 0.f, 0, nullptr, nullptr,
+                                       W + lw.y1, W + lw.y1p, W + lw.mean1, W + lw.rstd1, stream));
     // 2. self-attention: [q|k] from y1p, v from y1
     CODA_TRY(linear(R, 2 * E, E, W + lw.y1p, in1, E, ib1, W + lw.qk, 2 * E, stream));
     CODA_TRY(linear(R, E, E, W + lw.y1, in1 + static_cast<size_t>(2) * E * E, E, ib1 + 2 * E, W + lw.v1, E, stream));
@@ -165,10 +175,19 @@ CODA_API int coda_decoder_stack_fwd_f32(const CodaDecoderStack *a, void *stream)
       }
     }
     CODA_TRY(linear(R, E, F, W + lw.h, w2, F, nullptr, o, E, stream));
-    // 7. s4 = s3 + drop(o + fb2); the layer's output = decoder.norm(s4)
-    CODA_TRY(coda_tok_add_ln_fwd_f32(o, fb2, W + lw.s3, nullptr, a->norm_g, a->norm_b, R, E, a->eps, a->p3,
-                                     op_seed(a->seed, l, 5), nullptr, W + lw.s4, a->outs + d.RE * l, nullptr, W + lw.mean4,
-                                     W + lw.rstd4, stream));
+    // 7. s4 = s3 + drop(o + fb2); the layer's output = decoder.norm(s4) -- and, in the same pass, the next layer's
+    //    y1 = norm1(s4), y1p = y1 + query_pos
+    if (l + 1 < d.nl && fuse_ln2()) {
+      const float *const *Pn = a->params + 18 * (l + 1);
+      float *Wn = a->ws + lw.total * (l + 1);
+      CODA_TRY(coda_tok_add_ln_fwd2_f32(o, fb2, W + lw.s3, nullptr, a->norm_g, a->norm_b, Pn[0], Pn[1], a->query_pos, R, E,
+                                        a->eps, a->p3, op_seed(a->seed, l, 5), nullptr, W + lw.s4, a->outs + d.RE * l, nullptr,
+                                        Wn + lw.y1, Wn + lw.y1p, W + lw.mean4, W + lw.rstd4, stream));
+    } else {
+      CODA_TRY(coda_tok_add_ln_fwd_f32(o, fb2, W + lw.s3, nullptr, a->norm_g, a->norm_b, R, E, a->eps, a->p3,
+                                       op_seed(a->seed, l, 5), nullptr, W + lw.s4, a->outs + d.RE * l, nullptr, W + lw.mean4,
+                                       W + lw.rstd4, stream));
+    }
     res = W + lw.s4;
   }
   return CODA_OK;
@@ -259,9 +278,21 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
     float *S = sums + static_cast<size_t>(12) * E * l;  // [c1 | c3 | c5 | cn] x 3E
     // 7'. decoder.norm + residual + dropout of the layer output
     float *d_o = a->p3 > 0.f ? B + lb.d_o : ds3;  // dx == dres without dropout
-    CODA_TRY(coda_tok_add_ln_bwd_f32(dstack + d.RE * l, nullptr, ds_next, W + lw.s4, W + lw.mean4, W + lw.rstd4, a->norm_g, R, E,
-                                     a->p3, op_seed(a->seed, l, 5), nullptr, ds3, a->p3 > 0.f ? B + lb.d_o : nullptr,
-                                     B + lb.p_cn, nullptr, stream));
+    if (l + 1 < d.nl && fuse_ln2()) {
+      // ... together with norm1 of the layer above (same s4, mean, rstd; upstream dv1 through y1, dqk through y1p, the
+      // stream's own gradient ds1) and the positional embedding's gradient of that layer (dqk through y1p, dxq through
+      // y2p): what were three launches at the end of the previous iteration (LN1 backward, add3) and this one
+      const float *g1n = (a->params + 18 * (l + 1))[0];
+      float *Bn = bwd_ws + lb.total * (l + 1);
+      CODA_TRY(coda_tok_add_ln_bwd2_f32(dstack + d.RE * l, nullptr, dv1, dqk, ds1, W + lw.s4, W + lw.mean4, W + lw.rstd4,
+                                        a->norm_g, g1n, R, E, a->p3, op_seed(a->seed, l, 5), nullptr, 2, dxq, d_query_pos,
+                                        l + 1 == d.nl - 1 ? 1 : 0, ds3, a->p3 > 0.f ? B + lb.d_o : nullptr, B + lb.p_cn,
+                                        Bn + lb.p_c1, stream));
+    } else {
+      CODA_TRY(coda_tok_add_ln_bwd_f32(dstack + d.RE * l, nullptr, ds_next, W + lw.s4, W + lw.mean4, W + lw.rstd4, a->norm_g, R,
+                                       E, a->p3, op_seed(a->seed, l, 5), nullptr, ds3, a->p3 > 0.f ? B + lb.d_o : nullptr,
+                                       B + lb.p_cn, nullptr, stream));
+    }
     if (!(a->p3 > 0.f)) {  // the deferred weight gradient needs a buffer that survives the loop
       CODA_TRY(static_cast<int>(hipMemcpyAsync(B + lb.d_o, ds3, sizeof(float) * d.RE, hipMemcpyDeviceToDevice,
                                                static_cast<hipStream_t>(stream))));
@@ -323,13 +354,20 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
     CODA_TRY(dgrad(R, E, E, dqkv + 2 * d.RE, E, in1 + static_cast<size_t>(2) * E * E, E, dv1, 0, stream));
     // 1'. LN1: the block's input WAS the stream, so its gradient is d(stream) + d(LayerNorm path)
     float *out_ds = l == 0 ? d_tgt : dsn[l & 1];
-    CODA_TRY(coda_tok_add_ln_bwd_f32(dv1, dqk, ds1, res_in, W + lw.mean1, W + lw.rstd1, g1, R, E, 0.f, 0, nullptr, out_ds, nullptr,
-                                     B + lb.p_c1, nullptr, stream));
+    if (!fuse_ln2()) {
+      CODA_TRY(coda_tok_add_ln_bwd_f32(dv1, dqk, ds1, res_in, W + lw.mean1, W + lw.rstd1, g1, R, E, 0.f, 0, nullptr, out_ds,
+                                       nullptr, B + lb.p_c1, nullptr, stream));
+      // query_pos receives dqk (through y1p) and dxq (through y2p)
+      const size_t n4 = d.RE / 4;
+      hipLaunchKernelGGL(add3_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0,
+                         static_cast<hipStream_t>(stream), d_query_pos, dqk, dxq, n4, l == d.nl - 1 ? 1 : 0);
+    } else if (l == 0) {
+      // the first layer's norm1 has no layer below to share a launch with; the positional gradient rides along
+      CODA_TRY(coda_tok_add_ln_bwd2_f32(dv1, dqk, nullptr, nullptr, ds1, res_in, W + lw.mean1, W + lw.rstd1, g1, nullptr, R, E,
+                                        0.f, 0, nullptr, 1, dxq, d_query_pos, d.nl == 1 ? 1 : 0, out_ds, nullptr, B + lb.p_c1,
+                                        nullptr, stream));
+    }  // (l > 0: norm1's backward runs at the top of the next iteration, with the layer below's output norm)
     add_cs(B + lb.p_c1, S, bl, 3 * E, 1);               // [d norm1.weight | .bias | unused]
-    // query_pos receives dqk (through y1p) and dxq (through y2p)
-    const size_t n4 = d.RE / 4;
-    hipLaunchKernelGGL(add3_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), d_query_pos, dqk, dxq, n4, l == d.nl - 1 ? 1 : 0);
     ds_next = out_ds;
   }
   if (tn_status != CODA_OK) return tn_status;

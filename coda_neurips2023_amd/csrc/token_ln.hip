@@ -47,6 +47,9 @@ struct LnFwd {
   int c;
   float eps;
   Drop dr;
+  // second head (coda_tok_add_ln_fwd2_f32): y2 = LayerNorm(s) * gamma2 + beta2 of the SAME s (same mean / rstd), yp2 = y2 + pos2
+  const float *gamma2 = nullptr, *beta2 = nullptr, *pos2 = nullptr;
+  float *y2_out = nullptr, *yp2_out = nullptr;
 };
 
 template <int NV>
@@ -102,6 +105,16 @@ __global__ __launch_bounds__(kThreads) void add_ln_fwd_kernel(LnFwd p) {
         y.w = (s[k].w - mu) * rs * g.w + b.w;
         st4(p.y_out + base + ch, y);
         if (p.yp_out) st4(p.yp_out + base + ch, add4(y, ld4(p.pos + base + ch)));
+        if (p.gamma2) {
+          const float4 g2 = ld4(p.gamma2 + ch), b2 = ld4(p.beta2 + ch);
+          float4 y2;
+          y2.x = (s[k].x - mu) * rs * g2.x + b2.x;
+          y2.y = (s[k].y - mu) * rs * g2.y + b2.y;
+          y2.z = (s[k].z - mu) * rs * g2.z + b2.z;
+          y2.w = (s[k].w - mu) * rs * g2.w + b2.w;
+          st4(p.y2_out + base + ch, y2);
+          if (p.yp2_out) st4(p.yp2_out + base + ch, add4(y2, ld4(p.pos2 + base + ch)));
+        }
       }
   }
 }
@@ -112,11 +125,20 @@ struct LnBwd {
   long long rows;
   int c;
   Drop dr;
+  // second head (coda_tok_add_ln_bwd2_f32): a second LayerNorm of the same s with its own affine map and upstream
+  // gradient dy2 (+ dyp2); its [sum d2 * xhat | sum d2 | 0] partials go to partials2
+  const float *dy2 = nullptr, *dyp2 = nullptr, *gamma2 = nullptr;
+  float *partials2 = nullptr;
+  // positional-embedding gradient folded in: dpos_acc (+)= dpos_src + dpos_extra (dpos_src = this call's dyp or dyp2)
+  const float *dpos_src = nullptr, *dpos_extra = nullptr;
+  float *dpos_acc = nullptr;
+  int dpos_init = 0;
 };
 
 constexpr int bwd_waves(int nv) { return 16 / nv; }
 
-template <int NV>
+// DUAL: the second head of LnBwd (two LayerNorms of one s: the decoder's layer-output norm and the next layer's norm1)
+template <int NV, bool DUAL = false>
 __global__ __launch_bounds__(bwd_waves(NV) * kWave) void add_ln_bwd_kernel(LnBwd p) {
   constexpr int kWavesPerBlock = bwd_waves(NV);  // (shadows the forward's 4)
   __shared__ float4 s_acc[kWavesPerBlock][3][NV][kWave];
@@ -126,11 +148,16 @@ __global__ __launch_bounds__(bwd_waves(NV) * kWave) void add_ln_bwd_kernel(LnBwd
   const bool has_ln = p.gamma != nullptr;
   bool on[NV];
   float4 gam[NV], a_g[NV], a_b[NV], a_x[NV];
+  float4 gam2[DUAL ? NV : 1], a_g2[DUAL ? NV : 1], a_b2[DUAL ? NV : 1];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     on[k] = 256 * k + 4 * lane < p.c;
     gam[k] = (has_ln && on[k]) ? ld4(p.gamma + 256 * k + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
     a_g[k] = a_b[k] = a_x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DUAL) {
+      gam2[k] = on[k] ? ld4(p.gamma2 + 256 * k + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+      a_g2[k] = a_b2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   for (long long r = static_cast<long long>(blockIdx.x) * kWavesPerBlock + w; r < p.rows;
        r += static_cast<long long>(gridDim.x) * kWavesPerBlock) {
@@ -153,6 +180,20 @@ __global__ __launch_bounds__(bwd_waves(NV) * kWave) void add_ln_bwd_kernel(LnBwd
           a_b[k] = add4(a_b[k], d);
           a_g[k].x += d.x * xh[k].x; a_g[k].y += d.y * xh[k].y; a_g[k].z += d.z * xh[k].z; a_g[k].w += d.w * xh[k].w;
           g[k] = make_float4(d.x * gam[k].x, d.y * gam[k].y, d.z * gam[k].z, d.w * gam[k].w);
+          if (DUAL) {
+            float4 d2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.dy2) d2 = ld4(p.dy2 + base + ch);
+            if (p.dyp2) d2 = add4(d2, ld4(p.dyp2 + base + ch));
+            a_b2[k] = add4(a_b2[k], d2);
+            a_g2[k].x += d2.x * xh[k].x; a_g2[k].y += d2.y * xh[k].y; a_g2[k].z += d2.z * xh[k].z; a_g2[k].w += d2.w * xh[k].w;
+            g[k].x += d2.x * gam2[k].x; g[k].y += d2.y * gam2[k].y; g[k].z += d2.z * gam2[k].z; g[k].w += d2.w * gam2[k].w;
+          }
+          if (p.dpos_acc) {  // the positional embedding's gradient: what came in through y + pos (+ a second such tensor)
+            float4 e = ld4(p.dpos_src + base + ch);
+            if (p.dpos_extra) e = add4(e, ld4(p.dpos_extra + base + ch));
+            if (!p.dpos_init) e = add4(e, ld4(p.dpos_acc + base + ch));
+            st4(p.dpos_acc + base + ch, e);
+          }
           c1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
           c2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
         }
@@ -197,6 +238,29 @@ __global__ __launch_bounds__(bwd_waves(NV) * kWave) void add_ln_bwd_kernel(LnBwd
         for (int q = 1; q < kWavesPerBlock; ++q) t = add4(t, s_acc[q][w][k][lane]);
         st4(dst + 256 * k + 4 * lane, t);
       }
+  }
+  if (DUAL) {  // the second head's two accumulators through the same LDS; its third partial row is zero
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      s_acc[w][0][k][lane] = a_g2[k];
+      s_acc[w][1][k][lane] = a_b2[k];
+    }
+    __syncthreads();
+    if (w < 3) {
+      float *dst = p.partials2 + (static_cast<size_t>(blockIdx.x) * 3 + w) * p.c;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        if (on[k]) {
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (w < 2) {
+            t = s_acc[0][w][k][lane];
+#pragma unroll
+            for (int q = 1; q < kWavesPerBlock; ++q) t = add4(t, s_acc[q][w][k][lane]);
+          }
+          st4(dst + 256 * k + 4 * lane, t);
+        }
+    }
   }
 }
 
@@ -443,6 +507,68 @@ CODA_API int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const fl
   if (sums_out)  // second launch of the same call: fixed-order reduction of the per-block partials
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((3 * c + 63) / 64, 1), dim3(1024), 0, s, partials, blocks, 3 * c,
                        sums_out);
+  return launch_status();
+}
+
+CODA_API int coda_tok_add_ln_fwd2_f32(const float *x, const float *bias, const float *res, const float *pos,
+                                      const float *gamma, const float *beta, const float *gamma2, const float *beta2,
+                                      const float *pos2, long long rows, int c, float eps, float dropout_p, uint64_t seed,
+                                      const uint64_t *seed_dev, float *s_out, float *y_out, float *yp_out, float *y2_out,
+                                      float *yp2_out, float *mean, float *rstd, void *stream) {
+  if (rows < 0 || bad_ln_c(c) || bad_p(dropout_p)) return CODA_EINVAL;
+  if (rows == 0) return CODA_OK;
+  if (!x || !gamma || !beta || !y_out || !mean || !rstd || !gamma2 || !beta2 || !y2_out) return CODA_EINVAL;
+  const bool changes = bias || res || dropout_p > 0.f;
+  if (changes && !s_out) return CODA_EINVAL;
+  if ((pos != nullptr) != (yp_out != nullptr) || (pos2 != nullptr) != (yp2_out != nullptr)) return CODA_EINVAL;
+  LnFwd p{x, bias, res, pos, gamma, beta, s_out, y_out, yp_out, mean, rstd, rows, c, eps,
+          make_drop(dropout_p, seed, seed_dev)};
+  p.gamma2 = gamma2; p.beta2 = beta2; p.pos2 = pos2; p.y2_out = y2_out; p.yp2_out = yp2_out;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(ln_blocks(rows));
+  clear_sticky_error();
+  if (c <= 256) hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, dim3(kThreads), 0, s, p);
+  else if (c <= 512) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, dim3(kThreads), 0, s, p);
+  else hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, dim3(kThreads), 0, s, p);
+  return launch_status();
+}
+
+CODA_API int coda_tok_add_ln_bwd2_f32(const float *dy, const float *dyp, const float *dy2, const float *dyp2,
+                                      const float *ds, const float *s_in, const float *mean, const float *rstd,
+                                      const float *gamma, const float *gamma2, long long rows, int c, float dropout_p,
+                                      uint64_t seed, const uint64_t *seed_dev, int dpos_from, const float *dpos_extra,
+                                      float *dpos_acc, int dpos_init, float *dres_out, float *dx_out, float *partials,
+                                      float *partials2, void *stream) {
+  if (rows < 0 || bad_ln_c(c) || bad_p(dropout_p) || !partials || !gamma) return CODA_EINVAL;
+  if (!s_in || !mean || !rstd || (!dy && !dyp)) return CODA_EINVAL;
+  if (gamma2 && ((!dy2 && !dyp2) || !partials2)) return CODA_EINVAL;
+  if (!gamma2 && (dy2 || dyp2)) return CODA_EINVAL;
+  if (!dres_out && !dx_out) return CODA_EINVAL;
+  if (dpos_from < 0 || dpos_from > 2 || (dpos_from == 0) != (dpos_acc == nullptr)) return CODA_EINVAL;
+  const float *dpos_src = dpos_from == 1 ? dyp : (dpos_from == 2 ? dyp2 : nullptr);
+  if (dpos_from != 0 && !dpos_src) return CODA_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int blocks = ln_bwd_blocks(rows, c);
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(partials, 0, sizeof(float) * 3 * c * blocks, s);
+    if (e == hipSuccess && partials2) e = hipMemsetAsync(partials2, 0, sizeof(float) * 3 * c * blocks, s);
+    return e == hipSuccess ? CODA_OK : static_cast<int>(e);
+  }
+  LnBwd p{dy, dyp, ds, s_in, mean, rstd, gamma, dres_out, dx_out, partials, rows, c,
+          make_drop(dropout_p, seed, seed_dev)};
+  p.dy2 = dy2; p.dyp2 = dyp2; p.gamma2 = gamma2; p.partials2 = partials2;
+  p.dpos_src = dpos_src; p.dpos_extra = dpos_extra; p.dpos_acc = dpos_acc; p.dpos_init = dpos_init;
+  const dim3 grid(blocks);
+  clear_sticky_error();
+  if (gamma2) {
+    if (c <= 256) hipLaunchKernelGGL((add_ln_bwd_kernel<1, true>), grid, dim3(bwd_waves(1) * kWave), 0, s, p);
+    else if (c <= 512) hipLaunchKernelGGL((add_ln_bwd_kernel<2, true>), grid, dim3(bwd_waves(2) * kWave), 0, s, p);
+    else hipLaunchKernelGGL((add_ln_bwd_kernel<4, true>), grid, dim3(bwd_waves(4) * kWave), 0, s, p);
+  } else {
+    if (c <= 256) hipLaunchKernelGGL(add_ln_bwd_kernel<1>, grid, dim3(bwd_waves(1) * kWave), 0, s, p);
+    else if (c <= 512) hipLaunchKernelGGL(add_ln_bwd_kernel<2>, grid, dim3(bwd_waves(2) * kWave), 0, s, p);
+    else hipLaunchKernelGGL(add_ln_bwd_kernel<4>, grid, dim3(bwd_waves(4) * kWave), 0, s, p);
+  }
   return launch_status();
 }
 

@@ -115,6 +115,27 @@ int coda_tok_add_ln_bwd_f32(const float *dy, const float *dyp, const float *ds, 
                             float *dres_out, float *dx_out, float *partials, float *sums_out,
                             void *stream);
 
+/* Two LayerNorms of ONE residual stream (round 6: the decoder's layer-output norm and the next layer's norm1 normalise the
+ * same s with the same mean / rstd and differ only in their affine maps -- models/transformer.py:213-240 calls them
+ * back to back).  Forward: the first kernel's (s, y, yp, mean, rstd) plus y2 = LayerNorm(s) * gamma2 + beta2 and
+ * yp2 = y2 + pos2.  Backward: head 1 (dy, dyp, gamma) and head 2 (dy2, dyp2, gamma2; gamma2 == NULL: one head) enter the
+ * SAME correction terms -- dres = rstd (g - mean(g) - xhat mean(g xhat)) + ds with g = d gamma + d2 gamma2 --, head 2's
+ * [sum d2 xhat | sum d2 | 0] partials go to partials2 (same (blocks, 3, C) layout).  dpos_from = 1 / 2: the gradient of the
+ * positional embedding that entered through yp / yp2 is accumulated on the way, dpos_acc (=, when dpos_init, else +=)
+ * dyp|dyp2 + dpos_extra (dpos_extra optional); 0: none. */
+int coda_tok_add_ln_fwd2_f32(const float *x, const float *bias, const float *res, const float *pos,
+                             const float *gamma, const float *beta, const float *gamma2,
+                             const float *beta2, const float *pos2, long long rows, int c, float eps,
+                             float dropout_p, uint64_t seed, const uint64_t *seed_dev, float *s_out,
+                             float *y_out, float *yp_out, float *y2_out, float *yp2_out, float *mean,
+                             float *rstd, void *stream);
+int coda_tok_add_ln_bwd2_f32(const float *dy, const float *dyp, const float *dy2, const float *dyp2,
+                             const float *ds, const float *s_in, const float *mean, const float *rstd,
+                             const float *gamma, const float *gamma2, long long rows, int c,
+                             float dropout_p, uint64_t seed, const uint64_t *seed_dev, int dpos_from,
+                             const float *dpos_extra, float *dpos_acc, int dpos_init, float *dres_out,
+                             float *dx_out, float *partials, float *partials2, void *stream);
+
 /* out[j] = sum_b partials[b][j], j < n (n = 3*C above) */
 int coda_tok_colsum_finalize_f32(const float *partials, int blocks, int n, float *out, void *stream);
 

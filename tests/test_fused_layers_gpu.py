@@ -199,3 +199,64 @@ def test_fused_decoder_equals_module_path(dev, monkeypatch, nodes):
     _close(gq_f, gq_m, "query_pos gradient")
     for k in gp_m:
         _close(gp_f[k], gp_m[k], f"grad {k}")
+
+
+@pytest.mark.parametrize("rows,c,p", [(2048, 256, 0.0), (2048, 256, 0.1), (300, 512, 0.0), (37, 100, 0.0), (17, 1024, 0.0)])
+def test_two_layer_norms_of_one_stream(dev, rows, c, p):
+    """coda_tok_add_ln_fwd2_f32 / _bwd2_f32 (the decoder's layer-output norm + the next layer's norm1 in one pass, with
+    the positional embedding's gradient folded in) against float64 torch: s = res + drop(x + bias); y = LN_a(s);
+    y2 = LN_b(s); yp2 = y2 + pos."""
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(rows + c)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)  # noqa: E731
+    x, res, pos = rnd(rows, c), 3 * rnd(rows, c), rnd(rows, c)
+    bias, ga, ba, gb, bb = rnd(c), 1 + 0.3 * rnd(c), rnd(c), 1 + 0.3 * rnd(c), rnd(c)
+    s = torch.empty(rows, c, device=dev); y = torch.empty_like(s); y2 = torch.empty_like(s); yp2 = torch.empty_like(s)
+    mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    st = _lib.current_stream_handle()
+    _lib.check(lib.coda_tok_add_ln_fwd2_f32(P(x), P(bias), P(res), None, P(ga), P(ba), P(gb), P(bb), P(pos), rows, c, 1e-5, p,
+                                            99, None, P(s), P(y), None, P(y2), P(yp2), P(mean), P(rstd), st), "fwd2")
+    # the single-head kernel on the same inputs: identical s (same dropout mask), y, mean, rstd
+    s1 = torch.empty_like(s); y1 = torch.empty_like(s); m1 = torch.empty_like(mean); r1 = torch.empty_like(rstd)
+    _lib.check(lib.coda_tok_add_ln_fwd_f32(P(x), P(bias), P(res), None, P(ga), P(ba), rows, c, 1e-5, p, 99, None, P(s1), P(y1),
+                                           None, P(m1), P(r1), st), "fwd")
+    assert torch.equal(s, s1) and torch.equal(y, y1) and torch.equal(mean, m1) and torch.equal(rstd, r1)
+    keep = ((s - res) != 0).double() if p > 0 else None  # the mask, read off the result (x + bias is never exactly 0)
+    d64 = lambda t: t.double().requires_grad_(True)  # noqa: E731
+    x64, b64, r64, p64, ga64, ba64, gb64, bb64 = map(d64, (x, bias, res, pos, ga, ba, gb, bb))
+    v64 = x64 + b64
+    if keep is not None:
+        v64 = v64 * keep / (1.0 - p)
+    s64 = r64 + v64
+    ya64 = F.layer_norm(s64, (c,), ga64, ba64, 1e-5)
+    yb64 = F.layer_norm(s64, (c,), gb64, bb64, 1e-5)
+    _close(s, s64, "s"); _close(y, ya64, "y"); _close(y2, yb64, "y2"); _close(yp2, yb64 + p64, "yp2")
+    # backward: upstream dy (through y), dy2 (through y2), dyp2 (through yp2), ds (the stream's own), + an extra tensor
+    # and a running total for the positional gradient
+    dy, dy2, dyp2, ds, extra, acc0 = rnd(rows, c), rnd(rows, c), rnd(rows, c), rnd(rows, c), rnd(rows, c), rnd(rows, c)
+    (ya64 * dy.double()).sum().backward(retain_graph=True)
+    (yb64 * dy2.double() + (yb64 + p64) * dyp2.double() + s64 * ds.double()).sum().backward()
+    blocks = lib.coda_tok_add_ln_bwd_blocks(rows, c)
+    pa = torch.full((blocks, 3, c), float("nan"), device=dev); pb = torch.full((blocks, 3, c), float("nan"), device=dev)
+    dres = torch.empty_like(s); dx = torch.empty_like(s)
+    for init in (1, 0):
+        acc = acc0.clone()
+        _lib.check(lib.coda_tok_add_ln_bwd2_f32(P(dy), None, P(dy2), P(dyp2), P(ds), P(s), P(mean), P(rstd), P(ga), P(gb), rows, c,
+                                                p, 99, None, 2, P(extra), P(acc), init, P(dres), P(dx), P(pa), P(pb), st), "bwd2")
+        want = dyp2.double() + extra.double() + (0 if init else acc0.double())
+        _close(acc, want, f"dpos (init {init})", 1e-6)
+    _close(dres, r64.grad, "dres"); _close(dx, x64.grad, "dx")
+    sa, sb = pa.sum(0), pb.sum(0)
+    _close(sa[0], ga64.grad, "dgamma a"); _close(sa[1], ba64.grad, "dbeta a"); _close(sa[2], b64.grad, "dbias")
+    _close(sb[0], gb64.grad, "dgamma b"); _close(sb[1], bb64.grad, "dbeta b")
+    assert float(sb[2].abs().max()) == 0.0
+    # one head + the positional fold (the first decoder layer's norm1): equals the plain backward bit for bit
+    pc = torch.empty_like(pa); pd = torch.empty_like(pa); dres1 = torch.empty_like(s); dres2 = torch.empty_like(s)
+    acc = torch.empty_like(s)
+    _lib.check(lib.coda_tok_add_ln_bwd2_f32(P(dy2), P(dyp2), None, None, P(ds), P(s), P(mean), P(rstd), P(gb), None, rows, c, 0.0,
+                                            0, None, 1, P(extra), P(acc), 1, P(dres1), None, P(pc), None, st), "bwd2 one head")
+    _lib.check(lib.coda_tok_add_ln_bwd_f32(P(dy2), P(dyp2), P(ds), P(s), P(mean), P(rstd), P(gb), rows, c, 0.0, 0, None, P(dres2),
+                                           None, P(pd), None, st), "bwd")
+    assert torch.equal(dres1, dres2) and torch.equal(pc, pd) and torch.equal(acc, dyp2 + extra)
