@@ -86,6 +86,12 @@ inline bool fuse_ln2() {
   return on;
 }
 
+// CODA_DEC_QKV_ROWS=0: the self-attention's dq, dk, dv as three separate (R, E) matrices (A/B)
+inline bool qkv_rows() {
+  static const bool on = [] { const char *e = getenv("CODA_DEC_QKV_ROWS"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 #define CODA_TRY(expr)           \
   do {                           \
     const int st__ = (expr);     \
@@ -208,7 +214,8 @@ LayerBwd layer_bwd(const Dims &d) {
   const size_t bc = static_cast<size_t>(coda_tok_colsum_blocks(static_cast<long long>(d.R), d.e));
   w.d_o = take(d.RE); w.dh0 = take(d.RF); w.da2 = take(d.RE); w.dq = take(d.RE); w.da1 = take(d.RE); w.dqkv = take(3 * d.RE);
   w.p_cn = take(bl * 3 * d.e); w.p_c5 = take(bl * 3 * d.e); w.p_c3 = take(bl * 3 * d.e); w.p_c1 = take(bl * 3 * d.e);
-  w.p_ffn = take(bf * d.f); w.p_dq = take(bc * d.e); w.p_dqkv = take(3 * bc * d.e);
+  const size_t bc3 = static_cast<size_t>(coda_tok_colsum_blocks(static_cast<long long>(d.R), 3 * d.e));  // (R, 3E) as one matrix
+  w.p_ffn = take(bf * d.f); w.p_dq = take(bc * d.e); w.p_dqkv = take(3 * (bc > bc3 ? bc : bc3) * d.e);
   w.total = o;
   return w;
 }
@@ -257,12 +264,15 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
   // the grouped kernel's shape constraints; otherwise every weight gradient is a library call on the spot
   const bool grouped = R % 8 == 0 && E % 64 == 0 && F % 64 == 0;
   int tn_status = CODA_OK;
-  auto add_tn = [&](float *out, long long ldout, const float *dy, int m, const float *x, int n) {
+  auto add_tn_ld = [&](float *out, long long ldout, const float *dy, int m, long long lddy, const float *x, int n) {
     if (grouped) {
-      tn.push_back(CodaTnProblem{dy, x, out, R, m, n, m, n, ldout});
+      tn.push_back(CodaTnProblem{dy, x, out, R, m, n, lddy, n, ldout});
     } else if (tn_status == CODA_OK) {
-      tn_status = coda_gemm_f32(1, 0, m, n, R, dy, m, x, n, out, ldout, nullptr, 0, stream);
+      tn_status = coda_gemm_f32(1, 0, m, n, R, dy, lddy, x, n, out, ldout, nullptr, 0, stream);
     }
+  };
+  auto add_tn = [&](float *out, long long ldout, const float *dy, int m, const float *x, int n) {
+    add_tn_ld(out, ldout, dy, m, m, x, n);
   };
   auto add_cs = [&](const float *partials, float *out, int blocks, int n, int groups) {
     cs.push_back(CodaColsumItem{partials, out, blocks, n, groups, 0});
@@ -341,17 +351,32 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
     add_tn(G[4], E, da1, E, W + lw.attn1, E);                                     // d out_proj.weight
     CODA_TRY(dgrad(R, E, E, da1, E, ow1, E, dattn, 0, stream));
     float *dqkv = B + lb.dqkv;
-    CODA_TRY(coda_mha_bwd_f32(W + lw.qk, W + lw.qk + E, W + lw.v1, nullptr, W + lw.attn1, W + lw.lse1, dattn, dqkv, dqkv + d.RE,
-                              dqkv + 2 * d.RE, delta, d.b, d.h, d.nq, d.nq, hd, 2 * E, 2 * E, E, 0, 0, 0, scale, a->p_attn,
-                              op_seed(a->seed, l, 0), nullptr, stream));
-    CODA_TRY(coda_tok_colsum_f32(dqkv, 3, R, E, B + lb.p_dqkv, nullptr, stream));
-    add_cs(B + lb.p_dqkv, G[3], bc, E, 3);                                        // d in_proj_bias (3E)
-    add_tn(G[2], E, dqkv, E, W + lw.y1p, E);
-    add_tn(G[2] + static_cast<size_t>(E) * E, E, dqkv + d.RE, E, W + lw.y1p, E);
-    add_tn(G[2] + static_cast<size_t>(2) * E * E, E, dqkv + 2 * d.RE, E, W + lw.y1, E);
-    CODA_TRY(dgrad(R, E, E, dqkv, E, in1, E, dqk, 0, stream));
-    CODA_TRY(dgrad(R, E, E, dqkv + d.RE, E, in1 + static_cast<size_t>(E) * E, E, dqk, 1, stream));
-    CODA_TRY(dgrad(R, E, E, dqkv + 2 * d.RE, E, in1 + static_cast<size_t>(2) * E * E, E, dv1, 0, stream));
+    if (qkv_rows()) {
+      // dq | dk | dv as the columns of ONE (R, 3E) matrix (the attention kernels take row strides): the in_proj bias
+      // gradient is one column sum over 3E columns, and d y1p = [dq | dk] in_proj_weight[:2E] ONE product over K = 2E
+      // instead of two accumulating ones
+      CODA_TRY(coda_mha_bwd_f32(W + lw.qk, W + lw.qk + E, W + lw.v1, nullptr, W + lw.attn1, W + lw.lse1, dattn, dqkv, dqkv + E,
+                                dqkv + 2 * E, delta, d.b, d.h, d.nq, d.nq, hd, 2 * E, 2 * E, E, 3 * E, 3 * E, 3 * E, scale,
+                                a->p_attn, op_seed(a->seed, l, 0), nullptr, stream));
+      CODA_TRY(coda_tok_colsum_f32(dqkv, 1, R, 3 * E, B + lb.p_dqkv, nullptr, stream));
+      add_cs(B + lb.p_dqkv, G[3], coda_tok_colsum_blocks(R, 3 * E), 3 * E, 1);     // d in_proj_bias (3E)
+      add_tn_ld(G[2], E, dqkv, 2 * E, 3 * E, W + lw.y1p, E);                      // rows of q and k: [dq | dk]^T y1p
+      add_tn_ld(G[2] + static_cast<size_t>(2) * E * E, E, dqkv + 2 * E, E, 3 * E, W + lw.y1, E);
+      CODA_TRY(dgrad(R, E, 2 * E, dqkv, 3 * E, in1, E, dqk, 0, stream));
+      CODA_TRY(dgrad(R, E, E, dqkv + 2 * E, 3 * E, in1 + static_cast<size_t>(2) * E * E, E, dv1, 0, stream));
+    } else {
+      CODA_TRY(coda_mha_bwd_f32(W + lw.qk, W + lw.qk + E, W + lw.v1, nullptr, W + lw.attn1, W + lw.lse1, dattn, dqkv,
+                                dqkv + d.RE, dqkv + 2 * d.RE, delta, d.b, d.h, d.nq, d.nq, hd, 2 * E, 2 * E, E, 0, 0, 0, scale,
+                                a->p_attn, op_seed(a->seed, l, 0), nullptr, stream));
+      CODA_TRY(coda_tok_colsum_f32(dqkv, 3, R, E, B + lb.p_dqkv, nullptr, stream));
+      add_cs(B + lb.p_dqkv, G[3], bc, E, 3);                                      // d in_proj_bias (3E)
+      add_tn(G[2], E, dqkv, E, W + lw.y1p, E);
+      add_tn(G[2] + static_cast<size_t>(E) * E, E, dqkv + d.RE, E, W + lw.y1p, E);
+      add_tn(G[2] + static_cast<size_t>(2) * E * E, E, dqkv + 2 * d.RE, E, W + lw.y1, E);
+      CODA_TRY(dgrad(R, E, E, dqkv, E, in1, E, dqk, 0, stream));
+      CODA_TRY(dgrad(R, E, E, dqkv + d.RE, E, in1 + static_cast<size_t>(E) * E, E, dqk, 1, stream));
+      CODA_TRY(dgrad(R, E, E, dqkv + 2 * d.RE, E, in1 + static_cast<size_t>(2) * E * E, E, dv1, 0, stream));
+    }
     // 1'. LN1: the block's input WAS the stream, so its gradient is d(stream) + d(LayerNorm path)
     float *out_ds = l == 0 ? d_tgt : dsn[l & 1];
     if (!fuse_ln2()) {
