@@ -87,9 +87,10 @@ inline bool fuse_ln2() {
 }
 
 // CODA_DEC_QKV_ROWS=0: the self-attention's dq, dk, dv as three separate (R, E) matrices (A/B)
-inline bool qkv_rows() {
-  static const bool on = [] { const char *e = getenv("CODA_DEC_QKV_ROWS"); return !e || atoi(e) != 0; }();
-  return on;
+// (3E columns must fit the column-sum kernel: E <= 341, i.e. the 256-wide decoder; the 512-wide one keeps three matrices)
+inline bool qkv_rows(int e) {
+  static const bool on = [] { const char *v = getenv("CODA_DEC_QKV_ROWS"); return !v || atoi(v) != 0; }();
+  return on && 3 * e <= 1024;
 }
 
 #define CODA_TRY(expr)           \
@@ -214,7 +215,7 @@ LayerBwd layer_bwd(const Dims &d) {
   const size_t bc = static_cast<size_t>(coda_tok_colsum_blocks(static_cast<long long>(d.R), d.e));
   w.d_o = take(d.RE); w.dh0 = take(d.RF); w.da2 = take(d.RE); w.dq = take(d.RE); w.da1 = take(d.RE); w.dqkv = take(3 * d.RE);
   w.p_cn = take(bl * 3 * d.e); w.p_c5 = take(bl * 3 * d.e); w.p_c3 = take(bl * 3 * d.e); w.p_c1 = take(bl * 3 * d.e);
-  const size_t bc3 = static_cast<size_t>(coda_tok_colsum_blocks(static_cast<long long>(d.R), 3 * d.e));  // (R, 3E) as one matrix
+  const size_t bc3 = qkv_rows(d.e) ? static_cast<size_t>(coda_tok_colsum_blocks(static_cast<long long>(d.R), 3 * d.e)) : 0;  // (R, 3E) as one matrix
   w.p_ffn = take(bf * d.f); w.p_dq = take(bc * d.e); w.p_dqkv = take(3 * (bc > bc3 ? bc : bc3) * d.e);
   w.total = o;
   return w;
@@ -351,7 +352,7 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
     add_tn(G[4], E, da1, E, W + lw.attn1, E);                                     // d out_proj.weight
     CODA_TRY(dgrad(R, E, E, da1, E, ow1, E, dattn, 0, stream));
     float *dqkv = B + lb.dqkv;
-    if (qkv_rows()) {
+    if (qkv_rows(E)) {
       // dq | dk | dv as the columns of ONE (R, 3E) matrix (the attention kernels take row strides): the in_proj bias
       // gradient is one column sum over 3E columns, and d y1p = [dq | dk] in_proj_weight[:2E] ONE product over K = 2E
       // instead of two accumulating ones
