@@ -183,6 +183,9 @@ SIGNATURES = {
     "coda_gemm_x3_tn_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _c_int, _P]),
     "coda_sgemm_relu_dropout_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong,
                                              _P, ctypes.c_longlong, _P, _c_float, ctypes.c_uint64, _P]),
+    "coda_sgemm_relu_dropout_bwd_blocks": (_c_int, [_c_int]),
+    "coda_sgemm_relu_dropout_bwd_f32": (_c_int, [_c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P,
+                                                 _c_float, _P, _P, _P]),
     "coda_mha_get_mfma_dtype": (_c_int, []),
     "coda_mha_timing_enable": (_c_int, [_c_int]),
     "coda_mha_timing_enable_kinds": (_c_int, [_c_int, ctypes.c_uint]),

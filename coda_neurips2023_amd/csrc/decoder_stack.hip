@@ -86,6 +86,12 @@ inline bool fuse_ln2() {
   return on;
 }
 
+// CODA_DEC_FFN_BWD=0: the feed-forward's activation backward as its own pass behind the product (A/B)
+inline bool ffn_bwd_epilogue() {
+  static const bool on = [] { const char *v = getenv("CODA_DEC_FFN_BWD"); return !v || atoi(v) != 0; }();
+  return on;
+}
+
 // CODA_DEC_QKV_ROWS=0: the self-attention's dq, dk, dv as three separate (R, E) matrices (A/B)
 // (3E columns must fit the column-sum kernel: E <= 341, i.e. the 256-wide decoder; the 512-wide one keeps three matrices)
 inline bool qkv_rows(int e) {
@@ -216,7 +222,8 @@ LayerBwd layer_bwd(const Dims &d) {
   w.d_o = take(d.RE); w.dh0 = take(d.RF); w.da2 = take(d.RE); w.dq = take(d.RE); w.da1 = take(d.RE); w.dqkv = take(3 * d.RE);
   w.p_cn = take(bl * 3 * d.e); w.p_c5 = take(bl * 3 * d.e); w.p_c3 = take(bl * 3 * d.e); w.p_c1 = take(bl * 3 * d.e);
   const size_t bc3 = qkv_rows(d.e) ? static_cast<size_t>(coda_tok_colsum_blocks(static_cast<long long>(d.R), 3 * d.e)) : 0;  // (R, 3E) as one matrix
-  w.p_ffn = take(bf * d.f); w.p_dq = take(bc * d.e); w.p_dqkv = take(3 * (bc > bc3 ? bc : bc3) * d.e);
+  w.p_ffn = take((bf > static_cast<size_t>(d.R / 32) ? bf : static_cast<size_t>(d.R / 32)) * d.f);  // (own product's epilogue: a partial per 32 rows)
+  w.p_dq = take(bc * d.e); w.p_dqkv = take(3 * (bc > bc3 ? bc : bc3) * d.e);
   w.total = o;
   return w;
 }
@@ -311,9 +318,20 @@ CODA_API int coda_decoder_stack_bwd_f32(const CodaDecoderStack *a, const float *
     }
     add_cs(B + lb.p_cn, S + 9 * E, bl, 3 * E, 1);       // [d decoder.norm.weight | .bias | d linear2.bias]
     // 6'. feed-forward
-    CODA_TRY(dgrad(R, F, E, d_o, E, w2, F, dh, 0, stream));                      // dh = do W2
-    CODA_TRY(coda_tok_bias_relu_dropout_bwd_f32(dh, W + lw.h, R, F, a->p_ffn, B + lb.dh0, B + lb.p_ffn, nullptr, stream));
-    add_cs(B + lb.p_ffn, G[15], bf, F, 1);                                        // d linear1.bias
+    {  // dh0 = relu-dropout backward of dh = do W2, with the bias gradient's partials: one launch where the own kernel
+       // takes the shape (the activation's backward in its epilogue), else the product and the element-wise pass
+      int st = ffn_bwd_epilogue() ? coda_sgemm_relu_dropout_bwd_f32(R, F, E, d_o, E, w2, F, W + lw.h, a->p_ffn, B + lb.dh0,
+                                                                    B + lb.p_ffn, stream)
+                                  : CODA_ENOSPC;
+      if (st == CODA_ENOSPC) {
+        CODA_TRY(dgrad(R, F, E, d_o, E, w2, F, dh, 0, stream));                  // dh = do W2
+        CODA_TRY(coda_tok_bias_relu_dropout_bwd_f32(dh, W + lw.h, R, F, a->p_ffn, B + lb.dh0, B + lb.p_ffn, nullptr, stream));
+        add_cs(B + lb.p_ffn, G[15], bf, F, 1);                                    // d linear1.bias
+      } else {
+        CODA_TRY(st);
+        add_cs(B + lb.p_ffn, G[15], coda_sgemm_relu_dropout_bwd_blocks(R), F, 1);
+      }
+    }
     add_tn(G[16], F, d_o, E, W + lw.h, F);                                        // d linear2.weight (E,F) = do^T h
     add_tn(G[14], E, B + lb.dh0, F, W + lw.y3, E);                                // d linear1.weight (F,E) = dh0^T y3
     CODA_TRY(dgrad(R, E, F, B + lb.dh0, F, w1, E, dy3, 0, stream));               // dy3 = dh0 W1

@@ -113,10 +113,16 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_kernel(const float *__restri
 // EPI = 1: C = dropout(relu(A . op(B) + bias)) -- the feed-forward's first layer with the element-wise pass that
 // followed it (token_ln.hip: bias_relu_dropout_fwd_kernel) in the epilogue; same counter hash of (seed, row * n + col),
 // so the masks are those of the stand-alone kernel.
+// EPI = 2: C = relu-dropout BACKWARD of the product, dz = (act > 0 ? A . op(B) * inv_keep : 0) with `act` the saved
+// activation (token_ln.hip: bias_relu_dropout_bwd_kernel, a dropped or clamped element has act == 0 either way), plus the
+// column sums of dz over the workgroup's 32 rows -> partials[m0 / 32][col] (the bias gradient's per-block partials: the
+// caller reduces the m / 32 rows in fixed order, coda_tok_colsum_finalize_grouped_f32).
 struct ReluDrop {
   uint32_t thresh24, seed;
   float inv_keep;
   int n;
+  const float *act = nullptr;
+  float *partials = nullptr;
 };
 template <bool BT, int EPI = 0>
 __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *__restrict__ a, long long lda,
@@ -182,11 +188,17 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
   if (w > 0) return;
   const int col = n0 + l31;
   const float bval = bias ? bias[col] : 0.f;
+  float colsum = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     float *p = c + static_cast<size_t>(m0 + crow_nn(r, half)) * ldc + col;
     float v = ((acc[r] + s_part[0][r][lane]) + (s_part[1][r][lane] + s_part[2][r][lane])) + bval;
     if (accumulate) v += *p;
+    if (EPI == 2) {
+      const float av = epi.act[static_cast<size_t>(m0 + crow_nn(r, half)) * epi.n + col];
+      v = av > 0.f ? v * epi.inv_keep : 0.f;
+      colsum += v;
+    }
     if (EPI == 1) {
       v = fmaxf(v, 0.f);
       if (epi.thresh24) {
@@ -195,6 +207,10 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
       }
     }
     *p = v;
+  }
+  if (EPI == 2) {
+    colsum += __shfl_xor(colsum, 32, kWave);  // the two halves hold the two sets of 16 rows of a column
+    if (half == 0) epi.partials[static_cast<size_t>(m0 / 32) * epi.n + col] = colsum;
   }
 }
 
@@ -247,5 +263,29 @@ CODA_API int coda_sgemm_relu_dropout_f32(int transb, int m, int n, int k, const 
   const dim3 sgrid(static_cast<unsigned>((m / 32) * nt));
   if (transb) hipLaunchKernelGGL((sgemm_splitk_kernel<true, 1>), sgrid, dim3(kThreadsNN), 0, s, a, lda, b, ldb, c, ldc, bias, nt, k, 0, epi);
   else hipLaunchKernelGGL((sgemm_splitk_kernel<false, 1>), sgrid, dim3(kThreadsNN), 0, s, a, lda, b, ldb, c, ldc, bias, nt, k, 0, epi);
+  return launch_status();
+}
+
+CODA_API int coda_sgemm_relu_dropout_bwd_blocks(int m) { return m > 0 ? m / 32 : 0; }
+
+CODA_API int coda_sgemm_relu_dropout_bwd_f32(int m, int n, int k, const float *da, long long ldda, const float *w,
+                                             long long ldw, const float *act, float dropout_p, float *dz,
+                                             float *partials, void *stream) {
+  using namespace coda;
+  if (m < 0 || n < 0 || k < 0 || !(dropout_p >= 0.f) || dropout_p >= 1.f) return CODA_EINVAL;
+  if (m == 0 || n == 0) return CODA_OK;
+  if (!da || !w || !act || !dz || !partials || k == 0) return CODA_EINVAL;
+  if (ldda < k || ldw < n) return CODA_EINVAL;
+  // the launch-sized split-K kernel only (wave 0's epilogue owns whole sums and the tile's 32 rows)
+  if (m % 64 || n % 64 || k % 128 || (ldda | ldw) % 4 || (reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(w)) % 16 ||
+      static_cast<long long>(m) * n > 2048ll * 1024)
+    return CODA_ENOSPC;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_sticky_error();
+  ReluDrop epi{0u, 0u, 1.0f / (1.0f - dropout_p), n, act, partials};
+  const int nt = n / 32;
+  const dim3 sgrid(static_cast<unsigned>((m / 32) * nt));
+  hipLaunchKernelGGL((sgemm_splitk_kernel<false, 2>), sgrid, dim3(kThreadsNN), 0, s, da, ldda, w, ldw, dz, static_cast<long long>(n),
+                     nullptr, nt, k, 0, epi);
   return launch_status();
 }

@@ -66,6 +66,17 @@ int coda_sgemm_relu_dropout_f32(int transb, int m, int n, int k, const float *a,
                                 long long ldb, float *c, long long ldc, const float *bias, float dropout_p,
                                 uint64_t seed, void *stream);
 
+/* The backward of that layer's activation in the epilogue of the product that feeds it (round 6): dz (m x n, dense) =
+ * relu-dropout backward of da (m x k) . w (k x n) -- dz = product / (1 - p) where the saved activation act (m x n,
+ * dense; zero where clamped or dropped) is positive, else 0 -- and partials (m / 32, n) = the column sums of dz over
+ * each 32-row tile (the bias gradient: reduce the coda_sgemm_relu_dropout_bwd_blocks(m) rows in fixed order, e.g.
+ * with coda_tok_colsum_finalize_grouped_f32).  One launch where the feed-forward's backward ran a product and
+ * coda_tok_bias_relu_dropout_bwd_f32.  Launch-sized problems only (as above); CODA_ENOSPC otherwise. */
+int coda_sgemm_relu_dropout_bwd_blocks(int m);
+int coda_sgemm_relu_dropout_bwd_f32(int m, int n, int k, const float *da, long long ldda, const float *w,
+                                    long long ldw, const float *act, float dropout_p, float *dz,
+                                    float *partials, void *stream);
+
 /* Many weight gradients in one launch: out_p (m x n, row stride ldout) = dy_p^T x_p for every problem of the
  * array (dy_p rows x m, x_p rows x n; replaces one `torch.mm(dy.t(), x)` per linear layer, models/transformer.py's
  * decoder layers as autograd differentiates them).  `problems` is HOST memory, read during the call (the

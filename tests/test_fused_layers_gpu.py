@@ -260,3 +260,29 @@ def test_two_layer_norms_of_one_stream(dev, rows, c, p):
     _lib.check(lib.coda_tok_add_ln_bwd_f32(P(dy2), P(dyp2), P(ds), P(s), P(mean), P(rstd), P(gb), rows, c, 0.0, 0, None, P(dres2),
                                            None, P(pd), None, st), "bwd")
     assert torch.equal(dres1, dres2) and torch.equal(pc, pd) and torch.equal(acc, dyp2 + extra)
+
+
+@pytest.mark.parametrize("m,n,k,p", [(2048, 256, 256, 0.1), (2048, 128, 256, 0.0), (256, 512, 128, 0.3), (1024, 64, 384, 0.1)])
+def test_ffn_activation_backward_in_the_product_epilogue(dev, m, n, k, p):
+    """coda_sgemm_relu_dropout_bwd_f32 = the product da . w followed by coda_tok_bias_relu_dropout_bwd_f32, in one launch:
+    dz against float64, the bias gradient's partials against the column sums of dz."""
+    from coda_neurips2023_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    da = torch.randn(m, k, generator=g).to(dev)
+    w = (torch.randn(k, n, generator=g) / k ** 0.5).to(dev)
+    act = torch.relu(torch.randn(m, n, generator=g)).to(dev)
+    act = act * (torch.rand(m, n, generator=g).to(dev) >= p) / (1.0 - p) if p > 0 else act
+    blocks = lib.coda_sgemm_relu_dropout_bwd_blocks(m)
+    assert blocks == m // 32
+    dz = torch.full((m, n), float("nan"), device=dev)
+    parts = torch.full((blocks, n), float("nan"), device=dev)
+    _lib.check(lib.coda_sgemm_relu_dropout_bwd_f32(m, n, k, da.data_ptr(), k, w.data_ptr(), n, act.data_ptr(), p, dz.data_ptr(),
+                                                   parts.data_ptr(), _lib.current_stream_handle()), "sgemm_relu_dropout_bwd")
+    ref = (da.double() @ w.double()) / (1.0 - p) * (act > 0)
+    _close(dz, ref, "dz", 1e-5)
+    assert torch.equal(dz == 0, ~(act > 0) | (ref == 0).to(dz.device))
+    _close(parts.double().sum(0), dz.double().sum(0), "dbias", 1e-5)
+    _close(parts.view(blocks, n), dz.view(blocks, 32, n).sum(1), "partials", 1e-5)
+    assert lib.coda_sgemm_relu_dropout_bwd_f32(100, n, k, da.data_ptr(), k, w.data_ptr(), n, act.data_ptr(), p, dz.data_ptr(),
+                                               parts.data_ptr(), _lib.current_stream_handle()) == _lib.CODA_ENOSPC
