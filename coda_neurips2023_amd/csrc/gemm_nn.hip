@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
                                                                  float *__restrict__ c, long long ldc,
                                                                  const float *__restrict__ bias, int n_tiles, int k,
                                                                  int accumulate, ReluDrop epi = ReluDrop{0u, 0u, 1.f, 0}) {
-  __shared__ float s_part[3][16][kWave];
+  __shared__ float s_part[4][16][kWave];
   const int lane = lane_id(), w = wave_id();
   const int half = lane >> 5, l31 = lane & 31;
   const int m0 = (static_cast<int>(blockIdx.x) / n_tiles) * 32, n0 = (static_cast<int>(blockIdx.x) % n_tiles) * 32;
@@ -180,19 +180,20 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
     __builtin_amdgcn_sched_barrier(0);
     mfma(0);
   }
-  if (w > 0) {
+  // Every wave posts its partial tile; wave w then finishes registers 4 w .. 4 w + 3 (rows 8 w + 4 half .. + 3 of the tile):
+  // the epilogue -- bias, activation (backward), 16 row stores -- used to be wave 0's alone, a quarter of the launch's
+  // duration at 2048 x 256 x 256, with the other three waves gone.  Same order of additions as before.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_part[w - 1][r][lane] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) s_part[w][r][lane] = acc[r];
   __syncthreads();
-  if (w > 0) return;
   const int col = n0 + l31;
   const float bval = bias ? bias[col] : 0.f;
   float colsum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * w + q;
     float *p = c + static_cast<size_t>(m0 + crow_nn(r, half)) * ldc + col;
-    float v = ((acc[r] + s_part[0][r][lane]) + (s_part[1][r][lane] + s_part[2][r][lane])) + bval;
+    float v = ((s_part[0][r][lane] + s_part[1][r][lane]) + (s_part[2][r][lane] + s_part[3][r][lane])) + bval;
     if (accumulate) v += *p;
     if (EPI == 2) {
       const float av = epi.act[static_cast<size_t>(m0 + crow_nn(r, half)) * epi.n + col];
@@ -208,9 +209,14 @@ __global__ __launch_bounds__(kThreadsNN) void sgemm_splitk_kernel(const float *_
     }
     *p = v;
   }
-  if (EPI == 2) {
-    colsum += __shfl_xor(colsum, 32, kWave);  // the two halves hold the two sets of 16 rows of a column
-    if (half == 0) epi.partials[static_cast<size_t>(m0 / 32) * epi.n + col] = colsum;
+  if (EPI == 2) {  // the tile's column sums: the waves' 8-row sums meet in LDS (fixed order)
+    colsum += __shfl_xor(colsum, 32, kWave);
+    __syncthreads();  // (every wave has read what it needed of s_part)
+    if (half == 0) s_part[0][w][l31] = colsum;
+    __syncthreads();
+    if (w == 0 && half == 0)
+      epi.partials[static_cast<size_t>(m0 / 32) * epi.n + col] =
+          (s_part[0][0][l31] + s_part[0][1][l31]) + (s_part[0][2][l31] + s_part[0][3][l31]);
   }
 }
 
